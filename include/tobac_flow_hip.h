@@ -1,0 +1,150 @@
+/* tobac_flow_hip.h -- C ABI of the MI355X (gfx950) hot path of tobac-flow.
+ *
+ * One shared library, libtobac_flow_hip.so, built from the .hip sources in tobac_flow_amd/csrc/.  Every entry
+ * point is `extern "C"`, takes plain pointers and sizes, never retains a pointer past return
+ * and never allocates device memory behind the caller's back: scratch comes from a caller
+ * supplied workspace whose size is given by the matching *_workspace_bytes() query.
+ *
+ * All data pointers are DEVICE pointers (HBM) unless the name ends in `_host`.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous with respect to
+ * the host unless stated otherwise.
+ *
+ * Return value: 0 on success, a negative TF_E* code on failure; tf_last_error() returns a
+ * thread-local message.  The Python host layer (tobac_flow_amd/) validates arguments first and
+ * raises the same exception types as the reference (ValueError / AssertionError / ...).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * /root/reference/).  How a maintainer binds them from the reference is shown in INTEGRATION.md.
+ */
+#ifndef TOBAC_FLOW_HIP_H
+#define TOBAC_FLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TF_OK 0
+#define TF_EINVAL (-1)   /* bad argument (shape, enum, null pointer)          */
+#define TF_ENOMEM (-2)   /* workspace too small                               */
+#define TF_EHIP (-3)     /* a HIP runtime call or kernel launch failed        */
+#define TF_ENOCONV (-4)  /* an iterative kernel hit its sweep limit           */
+
+/* interpolation of the semi-Lagrangian gathers: cv2.INTER_NEAREST / _LINEAR / _CUBIC as selected
+ * by tobac_flow/convolve.py:47-54 and tobac_flow/utils/flow_utils.py:22-34 */
+#define TF_INTERP_NEAREST 0
+#define TF_INTERP_LINEAR 1
+#define TF_INTERP_CUBIC 2
+
+/* element types of `data` / `out` arguments */
+#define TF_F32 0
+#define TF_F64 1
+#define TF_I32 2
+
+/* reductions over the gathered (n_struct, H, W) stack, i.e. the `func` argument of
+ * tobac_flow/convolve.py:248-348 for the callables the reference itself passes */
+#define TF_FUNC_STACK 0        /* func=None: return the whole stack (n_struct, T, H, W)            */
+#define TF_FUNC_SOBEL 1        /* sobel.py:66-86  _sobel_func                                      */
+#define TF_FUNC_SOBEL_UPHILL 2 /* sobel.py:32-46  _sobel_func_uphill                               */
+#define TF_FUNC_SOBEL_DOWNHILL 3 /* sobel.py:49-63 _sobel_func_downhill                            */
+#define TF_FUNC_NANMEAN 4      /* detection.py:53-55,190-195  lambda x: np.nanmean(x, 0)           */
+#define TF_FUNC_DIFF 5         /* flow.py:180-184  centred semi-Lagrangian time difference         */
+#define TF_FUNC_ANY 6          /* detection.py:313-320  partial(np.any, axis=0) on int32           */
+#define TF_FUNC_NANMAX 7       /* detection.py:57-59 (commented-out variant kept for completeness) */
+
+int tf_version(void);
+const char *tf_last_error(void);
+/* number of visible HIP devices, or a negative TF_E* code; never initialises a context */
+int tf_device_count(void);
+
+/* ---- a3: to_8bit(linear_norm(data[i:i+2]), 0, 1) --------------------------------------------
+ * replaces tobac_flow/utils/normalisation_utils.py:10-33 (to_8bit) composed with :59-72
+ * (linear_norm) exactly as tobac_flow/flow.py:411-414 calls them: joint nanmin/nanmax over the
+ * frame pair, scale to [0,1], clip, *255, non-finite -> 127 then patched from the other frame,
+ * truncate to uint8.  ws: >= tf_to8bit_workspace_bytes() bytes. */
+size_t tf_to8bit_workspace_bytes(int64_t H, int64_t W);
+int tf_to8bit_pair(const float *frame0, const float *frame1, int64_t H, int64_t W,
+                   uint8_t *out0, uint8_t *out1, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- a5: dense Farnebaeck flow for one frame pair, BOTH directions ---------------------------
+ * replaces cv2.optflow.createOptFlow_Farneback().calc(prev, next, None) and
+ * .calc(next, prev, None) as issued by tobac_flow/flow.py:511,516 (model factory
+ * tobac_flow/utils/flow_utils.py:52-53; OpenCV defaults numLevels=5, pyrScale=0.5, winSize=13,
+ * numIters=10, polyN=5, polySigma=1.1, flags=0).  The two directions share the Gaussian pyramid
+ * and the polynomial expansion of both images.  flow_fwd / flow_bwd: (H, W, 2) float, (dx, dy).
+ * Either output may be NULL to skip that direction. */
+typedef struct {
+    int num_levels;     /* 5   */
+    double pyr_scale;   /* 0.5 */
+    int win_size;       /* 13  */
+    int num_iters;      /* 10  */
+    int poly_n;         /* 5   */
+    double poly_sigma;  /* 1.1 */
+} tf_farneback_params;
+void tf_farneback_default_params(tf_farneback_params *p);
+size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_params *p);
+int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H, int64_t W,
+                      const tf_farneback_params *p, float *flow_fwd, float *flow_bwd,
+                      void *ws, size_t ws_bytes, void *stream);
+
+/* ---- a6: forward/backward consistency smoothing ----------------------------------------------
+ * replaces tobac_flow/flow.py:530-568 smooth_flow_step (4 x cv2.remap via
+ * tobac_flow/utils/flow_utils.py:80-99 + np.nanmean).  Outputs must not alias inputs. */
+int tf_smooth_flow_step(const float *fwd, const float *bwd, int64_t H, int64_t W, int interp,
+                        float *fwd_out, float *bwd_out, void *stream);
+
+/* single-image warp: tobac_flow/utils/flow_utils.py:80-99 warp_flow (BORDER_CONSTANT NaN) */
+int tf_warp_flow(const float *img, const float *flow, int64_t H, int64_t W, int interp,
+                 float *out, void *stream);
+
+/* ---- a2 tail: end-frame mirroring and clipping -------------------------------------------------
+ * tobac_flow/flow.py:425-426 (forward[-1] = -backward[-1]; backward[0] = -forward[0]) and
+ * tobac_flow/flow.py:60-61 (clip both to [-max_value, max_value]); in place. */
+int tf_flow_finalize(float *fwd, float *bwd, int64_t T, int64_t H, int64_t W, float max_value,
+                     void *stream);
+
+/* ---- a8-a13: semi-Lagrangian convolve / sobel / diff ------------------------------------------
+ * replaces tobac_flow/convolve.py:248-348 convolve (with :8-86 warp_flow, :89-144
+ * convolve_same_step, :147-245 convolve_step fused into one gather), tobac_flow/sobel.py:89-143
+ * and tobac_flow/flow.py:159-191.
+ *   data      (T, H, W), data_type TF_F32 or TF_I32 (TF_I32 requires TF_INTERP_NEAREST)
+ *   fwd, bwd  (T, H, W, 2) float
+ *   structure 27 bytes, (3,3,3) C order, non-zero = tap present
+ *   fill      value for out-of-image taps and, when func != STACK, for output pixels whose
+ *             input is NaN (convolve.py:346-347)
+ *   out       func == STACK: (n_struct, T, H, W); otherwise (T, H, W); element type out_type
+ *             (TF_F64 reproduces Flow.sobel's dtype=None behaviour, flow.py:193-199)
+ *   t0, t1    only frames t0 <= t < t1 are written (frames t0-1 and t1 are still read as
+ *             neighbours) so that a time series can be sharded without a halo copy. */
+int tf_convolve(const void *data, int data_type, int64_t T, int64_t H, int64_t W,
+                const float *fwd, const float *bwd, const uint8_t *structure_host,
+                int interp, double fill, int func, void *out, int out_type,
+                int64_t t0, int64_t t1, void *stream);
+
+/* ---- a14/a15: semi-Lagrangian marker-controlled watershed -------------------------------------
+ * replaces tobac_flow/watershed.py:17-168 (wrapper) and tobac_flow/_watershed.pyx:222-344
+ * (watershed_raveled, the reference's only native kernel; compactness = 0, wsl = False).
+ *   field    (T, H, W) float32            image values (watershed.py:64-65 coercion is the caller's)
+ *   markers  (T, H, W) int32, non-zero = seed (negative allowed)
+ *   mask     (T, H, W) int8 or NULL (= all ones)
+ *   fwd, bwd (T, H, W, 2) float; rounded half-to-even to integer pixel offsets (watershed.py:121-141)
+ *   nbr_host n_nbr x 3 int8 (dt, dy, dx) neighbour list IN THE REFERENCE'S ORDER
+ *            (skimage _offsets_to_raveled_neighbors, watershed.py:114-116)
+ *   chain_depth  number of tie-break levels of the pop-order key (>= 1; 3 is exact for tie-free
+ *            fields and for the plateau structure of detect_anvils)
+ *   labels   (T, H, W) int32 out
+ * No padding is needed: out-of-volume neighbours are rejected by coordinate tests, which is what
+ * the reference's zero-padded mask achieves (watershed.py:111-113).
+ * stats_host (optional, 8 x int64): sweeps per phase etc.  This call synchronises the stream. */
+size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int chain_depth);
+int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
+                 const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                 const int8_t *nbr_host, int n_nbr, int chain_depth, int32_t *labels,
+                 void *ws, size_t ws_bytes, int64_t *stats_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,298 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+
+Integer / label work is compared bit-exactly; float32 / float64 stencils that follow the oracle's
+operation order are compared bit-exactly too (the library is built with -ffp-contract=off);
+Farnebaeck is compared within the north-star tolerance of 1e-4 px.
+"""
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+from helpers import blob_sequence, rand_field, rand_flow, seeds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import tobac_flow_amd.flow as flow
+    return flow
+
+
+def _eq(a, b):
+    """bit-exact including NaN positions"""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    nan = np.isnan(a) if a.dtype.kind == "f" else np.zeros(a.shape, bool)
+    nanb = np.isnan(b) if b.dtype.kind == "f" else np.zeros(b.shape, bool)
+    assert np.array_equal(nan, nanb), f"NaN masks differ at {int((nan != nanb).sum())} px"
+    bad = (a != b) & ~nan
+    assert not bad.any(), f"{int(bad.sum())} px differ, max abs {np.nanmax(np.abs(a[bad].astype(np.float64) - b[bad]))}"
+
+
+# ----------------------------------------------------------------------------- convolve / sobel
+@pytest.mark.parametrize("method", ["nearest", "linear", "cubic"])
+@pytest.mark.parametrize("direction", [None, "uphill", "downhill"])
+@pytest.mark.parametrize("dtype", [None, np.float32])
+def test_sobel_matches_oracle(tf, method, direction, dtype):
+    from oracle import np_ops
+    rng = np.random.default_rng(7)
+    shape = (4, 37, 53)
+    data = rand_field(rng, shape, nan_frac=0.01)
+    fwd, bwd = rand_flow(rng, shape, 1.5), rand_flow(rng, shape, 1.5)
+    got = tf.Flow(fwd, bwd).sobel(data, method=method, dtype=dtype, direction=direction)
+    want = np_ops.sobel(data, fwd, bwd, method=method, dtype=dtype, direction=direction)
+    _eq(got, want)
+
+
+def test_sobel_reference_known_answer(tf):
+    """reference tests/test_detection.py:36-60 (zero flow, T = 1, cubic, uphill)"""
+    field = np.zeros([1, 5, 5], np.float32)
+    field[:, 3:] = 1
+    z = np.zeros([1, 5, 5, 2], np.float32)
+    edges = tf.Flow(z, z).sobel(field, direction="uphill", method="cubic")
+    assert edges.dtype == np.float64
+    assert np.all(edges[:, 2] > 0) and np.all(edges[:, :2] == 0) and np.all(edges[:, 3:] == 0)
+
+
+@pytest.mark.parametrize("method", ["nearest", "linear", "cubic"])
+def test_convolve_stack_nanmean_diff(tf, method):
+    from oracle import np_ops
+    rng = np.random.default_rng(11)
+    shape = (5, 33, 41)
+    data = rand_field(rng, shape, nan_frac=0.02)
+    fwd, bwd = rand_flow(rng, shape, 2.0), rand_flow(rng, shape, 2.0)
+    fl = tf.Flow(fwd, bwd)
+    for conn in (1, 2):
+        st = ndi.generate_binary_structure(3, conn)
+        _eq(fl.convolve(data, structure=st, method=method), np_ops.convolve(data, fwd, bwd, st, method))
+    import tobac_flow_amd.detection as det
+    s_struct = ndi.generate_binary_structure(3, 1)
+    s_struct[0] = 0
+    s_struct[2] = 0
+    got = fl.convolve(data, structure=s_struct, func=det._nanmean0, method=method)
+    want = np_ops.convolve(data, fwd, bwd, s_struct, method, func=lambda x: np.nanmean(x, 0))
+    _eq(got, want)
+    t_struct = np.zeros([3, 3, 3])
+    t_struct[:, 1, 1] = 1
+    got = fl.convolve(data, structure=t_struct, func=det._nanmean0, method=method)
+    with np.errstate(all="ignore"):
+        want = np_ops.convolve(data, fwd, bwd, t_struct, method, func=lambda x: np.nanmean(x, 0))
+    _eq(got, want)
+    _eq(fl.diff(data, method=method), np_ops.diff(data, fwd, bwd, method))
+
+
+def test_convolve_python_callable_fallback(tf):
+    from oracle import np_ops
+    rng = np.random.default_rng(12)
+    shape = (4, 20, 24)
+    data = rand_field(rng, shape)
+    fwd, bwd = rand_flow(rng, shape, 1.0), rand_flow(rng, shape, 1.0)
+    f = lambda x: np.nanmax(x, 0)  # noqa: E731  (not a tagged function -> host reduction)
+    with np.errstate(all="ignore"):
+        _eq(tf.Flow(fwd, bwd).convolve(data, func=f), np_ops.convolve(data, fwd, bwd, func=f))
+
+
+def test_convolve_int_labels_nearest_and_any(tf):
+    from functools import partial
+    from oracle import np_ops
+    rng = np.random.default_rng(13)
+    shape = (4, 30, 36)
+    labels = ndi.label(rand_field(rng, shape) > 0.05)[0].astype(np.int32)
+    fwd, bwd = rand_flow(rng, shape, 2.0), rand_flow(rng, shape, 2.0)
+    fl = tf.Flow(fwd, bwd)
+    st = ndi.generate_binary_structure(3, 1) * np.array([1, 0, 1])[:, None, None]
+    got = fl.convolve(labels, method="nearest", dtype=np.int32, structure=st, fill_value=0)
+    want = np_ops.convolve(labels, fwd, bwd, st, "nearest", np.int32, 0)
+    _eq(got, want)
+    t_struct = np.zeros([3, 3, 3], bool)
+    t_struct[:, 1, 1] = True
+    m = (labels > 0).astype(int)
+    got = fl.convolve(m, structure=t_struct, method="nearest", fill_value=False, dtype=np.int32,
+                      func=partial(np.any, axis=0))
+    want = np_ops.convolve(m.astype(np.int32), fwd, bwd, t_struct, "nearest", np.int32, False,
+                           func=partial(np.any, axis=0))
+    _eq(got, want)
+
+
+# ----------------------------------------------------------------------------- warp / smoothing / to_8bit
+def test_warp_flow_reference_known_answers(tf):
+    """reference tests/test_flow.py:94-161"""
+    arr = np.arange(15, dtype=np.float32).reshape(3, 5)
+    fl = np.zeros(arr.shape + (2,), np.float32)
+    w = tf.warp_flow(arr, fl)
+    ok = ~np.isnan(w)
+    assert np.all(w[ok] == arr[ok])
+    fl[..., 0] = 0.5
+    w = tf.warp_flow(arr, fl)[:, :-1]
+    ok = ~np.isnan(w)
+    assert np.all(w[ok] == ((arr[:, 1:] + arr[:, :-1])[ok] * 0.5))
+
+
+@pytest.mark.parametrize("method", ["nearest", "linear", "cubic"])
+def test_warp_and_smooth_match_oracle(tf, method):
+    from oracle import np_ops
+    rng = np.random.default_rng(3)
+    img = rand_field(rng, (1, 45, 57))[0]
+    f, b = rand_flow(rng, (1, 45, 57), 2.0)[0], rand_flow(rng, (1, 45, 57), 2.0)[0]
+    _eq(tf.warp_flow(img, f, method), np_ops.warp_flow_single(img, f, method))
+    gf, gb = tf.smooth_flow_step(f, b, method)
+    wf, wb = np_ops.smooth_flow_step(f, b, method)
+    _eq(gf, wf)
+    _eq(gb, wb)
+
+
+def test_smooth_flow_reference_known_answers(tf):
+    """reference tests/test_flow.py:165-194"""
+    z, one = np.zeros([3, 5, 2], np.float32), np.ones([3, 5, 2], np.float32)
+    assert np.all(np.stack(list(tf.smooth_flow_step(z, z))) == 0)
+    f, b = tf.smooth_flow_step(one, -one)
+    assert np.all(f == 1) and np.all(b == -1)
+    f, b = tf.smooth_flow_step(one, z)
+    assert np.all(f[:1, :3] == 0.5) and np.all(b[:2, :4] == -0.5)
+
+
+def test_to8bit_pair_matches_oracle(tf):
+    from oracle import np_ops
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.utils.normalisation_utils import to_8bit_pair_dev
+    rng = np.random.default_rng(5)
+    for case in range(4):
+        pair = blob_sequence(rng, 2, 67, 91)
+        if case == 1:
+            pair[0, 10:20, 30:50] = np.nan
+            pair[1, 15:30, 40:45] = np.nan
+        if case == 2:
+            pair[:] = 250.0
+        if case == 3:
+            pair[:] = np.nan
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = np_ops.to_8bit(np_ops.linear_norm(pair.copy()), 0, 1)
+        a, b = to_8bit_pair_dev(_lib.to_dev(pair[0]), _lib.to_dev(pair[1]))
+        _eq(a.cpu().numpy(), want[0])
+        _eq(b.cpu().numpy(), want[1])
+
+
+# ----------------------------------------------------------------------------- Farnebaeck
+def _oracle_farneback(a, b):
+    import ctypes
+    from oracle import _lib as ol
+    L = ol.lib()
+    h, w = a.shape
+    out = np.zeros((h, w, 2), np.float32)
+    L.oracle_farneback.restype = ctypes.c_int
+    L.oracle_farneback(ol.ptr(np.ascontiguousarray(a), ctypes.c_uint8), ol.ptr(np.ascontiguousarray(b), ctypes.c_uint8),
+                       h, w, ol.ptr(out, ctypes.c_float), 5, ctypes.c_double(0.5), 13, 10, 5, ctypes.c_double(1.1))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(96, 128), (150, 250), (333, 517)])
+def test_farneback_matches_oracle(tf, shape):
+    from oracle import np_ops
+    rng = np.random.default_rng(shape[0])
+    seq = blob_sequence(rng, 2, *shape, n_blobs=8)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p8 = np_ops.to_8bit(np_ops.linear_norm(seq.copy()), 0, 1)
+    model = tf.select_of_model("Farneback")
+    f, b = tf.calculate_flow_frame(p8[0], p8[1], model)
+    wf, wb = _oracle_farneback(p8[0], p8[1]), _oracle_farneback(p8[1], p8[0])
+    assert f.dtype == np.float32 and f.shape == shape + (2,)
+    assert np.max(np.abs(f - wf)) <= 1e-4, np.max(np.abs(f - wf))
+    assert np.max(np.abs(b - wb)) <= 1e-4, np.max(np.abs(b - wb))
+
+
+def test_farneback_recovers_translation(tf):
+    rng = np.random.default_rng(0)
+    img = ndi.gaussian_filter(rng.normal(size=(200, 260)), 4)
+    img = ((img - img.min()) / (img.max() - img.min()) * 255).astype(np.uint8)
+    f, b = tf.calculate_flow_frame(img, np.roll(img, (2, -3), (0, 1)), tf.select_of_model("Farneback"))
+    c = f[50:150, 60:200].mean((0, 1))
+    assert abs(c[0] + 3) < 0.05 and abs(c[1] - 2) < 0.05
+    c = b[50:150, 60:200].mean((0, 1))
+    assert abs(c[0] - 3) < 0.05 and abs(c[1] + 2) < 0.05
+
+
+def test_create_flow_matches_oracle_pipeline(tf):
+    from oracle import np_ops
+    import warnings
+    rng = np.random.default_rng(21)
+    seq = blob_sequence(rng, 4, 120, 160, n_blobs=6)
+    seq[1, 30:40, 50:70] = np.nan
+    fl = tf.create_flow(seq, model="Farneback", smoothing_passes=1, interp_method="cubic")
+    T = seq.shape[0]
+    fw = np.full(seq.shape + (2,), np.nan, np.float32)
+    bw = np.full(seq.shape + (2,), np.nan, np.float32)
+    for i in range(T - 1):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            p8 = np_ops.to_8bit(np_ops.linear_norm(seq[i:i + 2].copy()), 0, 1)
+        f, b = _oracle_farneback(p8[0], p8[1]), _oracle_farneback(p8[1], p8[0])
+        f, b = np_ops.smooth_flow_step(f, b, "cubic")
+        fw[i], bw[i + 1] = f, b
+    fw[-1] = -bw[-1]
+    bw[0] = -fw[0]
+    fw, bw = np.clip(fw, -20, 20), np.clip(bw, -20, 20)
+    assert fl.shape == seq.shape
+    assert np.nanmax(np.abs(fl.forward_flow - fw)) <= 2e-4
+    assert np.nanmax(np.abs(fl.backward_flow - bw)) <= 2e-4
+    assert np.array_equal(np.isnan(fl.forward_flow), np.isnan(fw))
+
+
+# ----------------------------------------------------------------------------- watershed
+EXACT_VS_REFERENCE = ["A_cont_c1", "B_cont_mask_c2", "B_cont_mask_c3", "D_anvil_like_c1", "F_zero_flow_c1", "G_big_flow_c1"]
+
+
+@pytest.mark.parametrize("name", EXACT_VS_REFERENCE)
+def test_watershed_golden_bit_exact(tf, golden_ws, name):
+    c = golden_ws[name]
+    got = tf.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], mask=c.get("mask"), connectivity=int(c["conn"]))
+    assert got.dtype == np.int32
+    assert np.array_equal(got, c["labels"]), f"{int((got != c['labels']).sum())} px differ from the reference"
+
+
+@pytest.mark.parametrize("name,depth,max_vs_ref", [("C_quant4_c1", 3, 21), ("C_quant32_c1", 6, 0), ("E_const_plateau_c1", 3, 37)])
+def test_watershed_tie_heavy_goldens(tf, golden_ws, name, depth, max_vs_ref):
+    """Tie-heavy inputs: the HIP flood equals the oracle under the idealised marker order
+    (value, age, push sequence) bit for bit; against the reference itself the only differences are
+    where equal-valued markers (age 0) compete, which the reference resolves by heap-internal order."""
+    from oracle import ws_oracle
+    c = golden_ws[name]
+    conn = int(c["conn"])
+    got = tf.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], mask=c.get("mask"), connectivity=conn,
+                       chain_depth=depth)
+    ideal = ws_oracle.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn, tie_mode=1)
+    assert np.array_equal(got, ideal), f"{int((got != ideal).sum())} px differ from the idealised-order oracle"
+    assert int((got != c["labels"]).sum()) <= max_vs_ref
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_watershed_random_vs_oracle(tf, seed):
+    from oracle import ws_oracle
+    rng = np.random.default_rng(100 + seed)
+    shape = (int(rng.integers(1, 7)), int(rng.integers(20, 60)), int(rng.integers(20, 70)))
+    field = rand_field(rng, shape)
+    if seed % 3 == 2:
+        field[rng.random(shape) < 0.02] = np.inf
+    markers = seeds(rng, shape, int(rng.integers(1, 15)))
+    mask = None if seed % 2 == 0 else ndi.gaussian_filter(rng.normal(size=shape), (0, 2, 2)) > -0.03
+    fwd, bwd = rand_flow(rng, shape, 2.5), rand_flow(rng, shape, 2.5)
+    conn = [1, 2, 3][seed % 3]
+    got = tf.watershed(fwd, bwd, field, markers, mask=mask, connectivity=conn)
+    want = ws_oracle.watershed(fwd, bwd, field, markers, mask, conn)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} px differ"
+
+
+def test_watershed_errors(tf):
+    z = np.zeros((2, 5, 5, 2), np.float32)
+    f = np.zeros((2, 5, 5), np.float32)
+    with pytest.raises(ValueError):
+        tf.watershed(z, z, f, np.zeros((2, 5, 4), np.int32))
+    with pytest.raises(ValueError):
+        tf.watershed(z, z, f, np.zeros((2, 5, 5), np.int32), mask=np.ones((1, 5, 5), bool))
+    out = tf.watershed(z, z, f, np.zeros((2, 5, 5), np.int32))       # no markers: nothing flooded
+    assert out.dtype == np.int32 and not out.any()

@@ -1,0 +1,158 @@
+"""ctypes binding of libtobac_flow_hip.so (include/tobac_flow_hip.h) + device-buffer plumbing.
+
+The HIP library is the product path: if it is missing the import of any compute entry point
+fails loudly -- there is no CPU fallback.  PyTorch is used for device memory and streams only.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "csrc", "libtobac_flow_hip.so")
+
+INTERP = {"nearest": 0, "linear": 1, "cubic": 2}
+TF_F32, TF_F64, TF_I32 = 0, 1, 2
+FUNC_STACK, FUNC_SOBEL, FUNC_SOBEL_UPHILL, FUNC_SOBEL_DOWNHILL, FUNC_NANMEAN, FUNC_DIFF, FUNC_ANY, FUNC_NANMAX = range(8)
+
+
+class FarnebackParams(ctypes.Structure):
+    _fields_ = [("num_levels", ctypes.c_int), ("pyr_scale", ctypes.c_double), ("win_size", ctypes.c_int),
+                ("num_iters", ctypes.c_int), ("poly_n", ctypes.c_int), ("poly_sigma", ctypes.c_double)]
+
+
+_lib = None
+
+_c = ctypes
+_P = ctypes.c_void_p
+_PROTOS = {
+    "tf_version": (_c.c_int, []),
+    "tf_last_error": (_c.c_char_p, []),
+    "tf_device_count": (_c.c_int, []),
+    "tf_to8bit_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    "tf_to8bit_pair": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_size_t, _P]),
+    "tf_farneback_default_params": (None, [_c.POINTER(FarnebackParams)]),
+    "tf_farneback_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams)]),
+    "tf_farneback_pair": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _P, _P, _P,
+                                     _c.c_size_t, _P]),
+    "tf_smooth_flow_step": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P, _P]),
+    "tf_warp_flow": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P]),
+    "tf_flow_finalize": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float, _P]),
+    "tf_convolve": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int,
+                               _c.c_double, _c.c_int, _P, _c.c_int, _c.c_int64, _c.c_int64, _P]),
+    "tf_watershed_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int]),
+    "tf_watershed": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int,
+                                _P, _P, _c.c_size_t, _P, _P]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+def lib_path():
+    return _SO
+
+
+def lib():
+    """Load the HIP library (once). Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise ImportError(
+                f"{_SO} not found: build it with `make -C tobac_flow_amd/csrc` (or __graft_entry__.build()). "
+                "tobac_flow_amd has no CPU fallback.")
+        L = ctypes.CDLL(_SO)
+        for name, (res, args) in _PROTOS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+class TobacFlowHipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = lib().tf_last_error().decode(errors="replace")
+    if rc == -2:
+        raise MemoryError(f"{what}: {msg}")
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}")
+    raise TobacFlowHipError(f"{what} failed (code {rc}): {msg}")
+
+
+# ---- device plumbing (torch) ---------------------------------------------------------------------
+_torch = None
+
+
+def torch():
+    global _torch
+    if _torch is None:
+        import torch as _t
+        _torch = _t
+    return _torch
+
+
+def device():
+    t = torch()
+    if not t.cuda.is_available():
+        raise TobacFlowHipError("no HIP device visible: tobac_flow_amd computes on an MI355X only (no CPU fallback)")
+    lib()
+    return t.device("cuda", t.cuda.current_device())
+
+
+def is_tensor(x):
+    return _torch is not None and isinstance(x, _torch.Tensor) or (type(x).__module__.startswith("torch"))
+
+
+def to_dev(x, dtype=None):
+    """numpy array / torch tensor -> contiguous torch tensor on the current HIP device."""
+    t = torch()
+    dev = device()
+    if isinstance(x, t.Tensor):
+        y = x.to(dev)
+    else:
+        a = np.asarray(x)
+        if a.dtype == np.bool_:
+            a = a.astype(np.uint8)
+        if not a.flags.c_contiguous:
+            a = np.ascontiguousarray(a)
+        y = t.from_numpy(a).to(dev)
+    if dtype is not None and y.dtype != dtype:
+        y = y.to(dtype)
+    return y.contiguous()
+
+
+def ptr(tensor):
+    return ctypes.c_void_p(tensor.data_ptr()) if tensor is not None else None
+
+
+def stream_ptr():
+    t = torch()
+    return ctypes.c_void_p(t.cuda.current_stream().cuda_stream)
+
+
+def empty(shape, dtype):
+    t = torch()
+    return t.empty(shape, dtype=dtype, device=device())
+
+
+_WS = {}
+
+
+def workspace(nbytes, tag="default"):
+    """Grow-only scratch buffer per tag (uint8 tensor)."""
+    t = torch()
+    cur = _WS.get(tag)
+    if cur is None or cur.numel() < nbytes or cur.device != device():
+        _WS[tag] = None
+        cur = t.empty(int(nbytes), dtype=t.uint8, device=device())
+        _WS[tag] = cur
+    return cur
+
+
+def release_workspaces():
+    _WS.clear()

@@ -1,0 +1,380 @@
+// Semi-Lagrangian gather operators for gfx950:
+//   tf_convolve  -- /root/reference/tobac_flow/convolve.py:248-348 (+ :8-86, :89-144, :147-245)
+//                   with the reductions the reference passes as `func` fused in:
+//                   sobel.py:32-86, flow.py:180-184 (diff), detection.py nanmean / any
+//   tf_warp_flow -- /root/reference/tobac_flow/utils/flow_utils.py:80-99
+//   tf_smooth_flow_step -- /root/reference/tobac_flow/flow.py:530-568
+//   tf_flow_finalize    -- /root/reference/tobac_flow/flow.py:425-426, :60-61
+//
+// One thread per output pixel; a 64 x 4 workgroup covers 64 consecutive columns of 4 rows so
+// that the field loads of the 3x3 same-step taps and of the (flow-displaced, locally coherent)
+// t-1 / t+1 taps coalesce and hit L1/L2.  The 27-row [n_struct, H, W] float64 temporary of the
+// reference is never materialised: each tap is reduced as soon as it is gathered.  HBM traffic
+// per pixel is the algorithmic 4 (field, each frame reused by 3 outputs through L2/MALL) + 16
+// (two flow vectors) + 4 or 8 (output) bytes.
+#include "remap_dev.h"
+#include <type_traits>
+
+struct ConvTaps {
+    int nb, ns, nf;        // taps taken from t-1 (backward flow), t, t+1 (forward flow)
+    int8_t ox[27], oy[27]; // (x, y) offset of every tap, in the reference's stack order
+    int8_t wx[27], wy[27], wt[27]; // Sobel weights per stack slot (full 27-tap structure only)
+};
+
+template <typename TS> struct StackTraits;
+template <> struct StackTraits<float> { typedef float In; };
+template <> struct StackTraits<double> { typedef float In; };
+template <> struct StackTraits<int32_t> { typedef int32_t In; };
+
+template <typename TO> __device__ __forceinline__ void store_out(void *out, int out_type, int64_t idx, TO v) {
+    if (out_type == TF_F32) ((float *)out)[idx] = (float)v;
+    else if (out_type == TF_F64) ((double *)out)[idx] = (double)v;
+    else ((int32_t *)out)[idx] = (int32_t)v;
+}
+
+template <typename T> __device__ __forceinline__ bool is_nan_t(T v) { return v != v; }
+template <> __device__ __forceinline__ bool is_nan_t<int32_t>(int32_t) { return false; }
+
+// gather one tap of the stack (slot i) for output pixel (x, y) of frame t
+template <int METHOD, typename TS>
+__device__ __forceinline__ TS gather_tap(const typename StackTraits<TS>::In *__restrict__ data,
+                                         const float *__restrict__ fwd, const float *__restrict__ bwd,
+                                         int64_t T, int H, int W, int64_t t, int y, int x,
+                                         const ConvTaps &tp, int i, typename StackTraits<TS>::In fillv,
+                                         float fbx, float fby, float ffx, float ffy)
+{
+    typedef typename StackTraits<TS>::In In;
+    const int ox = tp.ox[i], oy = tp.oy[i];
+    const int64_t plane = (int64_t)H * W;
+    if (i >= tp.nb && i < tp.nb + tp.ns) {                 // same step: integer gather, OOB -> fill
+        int xx = x + ox, yy = y + oy;
+        if (xx < 0 || yy < 0 || xx >= W || yy >= H) return (TS)fillv;
+        return (TS)data[t * plane + (int64_t)yy * W + xx];
+    }
+    const bool prev = i < tp.nb;
+    const int64_t tt = prev ? t - 1 : t + 1;
+    if (tt < 0 || tt >= T) return (TS)fillv;             // all-fill neighbour frame (convolve.py:307-314)
+    const float mx = tf_loc(prev ? fbx : ffx, ox, x), my = tf_loc(prev ? fby : ffy, oy, y);
+    const In *img = data + tt * plane;
+    if constexpr (std::is_same<In, int32_t>::value) {
+        return (TS)tf_remap_nearest<int32_t>(img, H, W, mx, my, fillv);
+    } else {
+        return (TS)tf_remap<METHOD>(img, H, W, mx, my, fillv);
+    }
+}
+
+template <int METHOD, typename TS>
+__global__ void __launch_bounds__(256)
+k_convolve(const typename StackTraits<TS>::In *__restrict__ data, const float *__restrict__ fwd,
+           const float *__restrict__ bwd, int64_t T, int H, int W, ConvTaps tp, double fill, int func,
+           void *__restrict__ out, int out_type, int64_t t0)
+{
+    typedef typename StackTraits<TS>::In In;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = t0 + blockIdx.z;
+    if (x >= W || y >= H) return;
+    const int64_t plane = (int64_t)H * W, pix = t * plane + (int64_t)y * W + x;
+    const In fillv = (In)fill;
+    const int n = tp.nb + tp.ns + tp.nf;
+    float fbx = 0, fby = 0, ffx = 0, ffy = 0;
+    if (tp.nb) { float2 f = ((const float2 *)bwd)[pix]; fbx = f.x; fby = f.y; }
+    if (tp.nf) { float2 f = ((const float2 *)fwd)[pix]; ffx = f.x; ffy = f.y; }
+    const In centre = data[pix];
+
+    if (func == TF_FUNC_STACK) {
+        for (int i = 0; i < n; i++) {
+            TS v = gather_tap<METHOD, TS>(data, fwd, bwd, T, H, W, t, y, x, tp, i, fillv, fbx, fby, ffx, ffy);
+            store_out<TS>(out, out_type, (int64_t)i * T * plane + pix, v);
+        }
+        return;
+    }
+    if (func >= TF_FUNC_SOBEL && func <= TF_FUNC_SOBEL_DOWNHILL) {
+        // sobel.py:32-86: x = stack - stack[13] (in the STACK dtype), optional fmax/fmin with 0,
+        // three nansum(x * w) in float64 in stack order, sqrt(gx^2 + gy^2 + gt^2)
+        if constexpr (!std::is_same<TS, int32_t>::value) {
+            const TS c = (TS)centre;
+            double gx = 0, gy = 0, gt = 0;
+            for (int i = 0; i < n; i++) {
+                TS v = gather_tap<METHOD, TS>(data, fwd, bwd, T, H, W, t, y, x, tp, i, fillv, fbx, fby, ffx, ffy);
+                TS d = v - c;
+                if (func == TF_FUNC_SOBEL_UPHILL) d = (d != d) ? (TS)0 : (d > (TS)0 ? d : (TS)0);
+                else if (func == TF_FUNC_SOBEL_DOWNHILL) d = (d != d) ? (TS)0 : (d < (TS)0 ? d : (TS)0);
+                const double dd = (double)d;
+                double px = dd * (double)tp.wx[i], py = dd * (double)tp.wy[i], pt = dd * (double)tp.wt[i];
+                if (px == px) gx += px;
+                if (py == py) gy += py;
+                if (pt == pt) gt += pt;
+            }
+            double m = gx * gx;
+            m += gy * gy;
+            m += gt * gt;
+            double r = sqrt(m);
+            if (is_nan_t(centre)) r = fill;
+            store_out<double>(out, out_type, pix, r);
+        }
+        return;
+    }
+    if (func == TF_FUNC_NANMEAN || func == TF_FUNC_NANMAX) {
+        if constexpr (!std::is_same<TS, int32_t>::value) {
+            TS s = 0; int cnt = 0; TS mx = 0; bool any = false;
+            for (int i = 0; i < n; i++) {
+                TS v = gather_tap<METHOD, TS>(data, fwd, bwd, T, H, W, t, y, x, tp, i, fillv, fbx, fby, ffx, ffy);
+                if (v == v) { s += v; cnt++; mx = (!any || v > mx) ? v : mx; any = true; }
+            }
+            double r;
+            if (func == TF_FUNC_NANMEAN) r = (double)s / (double)cnt;      // 0/0 -> NaN like np.nanmean
+            else r = any ? (double)mx : (double)NAN;
+            if (is_nan_t(centre)) r = fill;
+            store_out<double>(out, out_type, pix, r);
+        }
+        return;
+    }
+    if (func == TF_FUNC_DIFF) {
+        // flow.py:180-184 with a (prev, same, next) 3-tap structure
+        if constexpr (!std::is_same<TS, int32_t>::value) {
+            TS x0 = gather_tap<METHOD, TS>(data, fwd, bwd, T, H, W, t, y, x, tp, 0, fillv, fbx, fby, ffx, ffy);
+            TS x1 = gather_tap<METHOD, TS>(data, fwd, bwd, T, H, W, t, y, x, tp, 1, fillv, fbx, fby, ffx, ffy);
+            TS x2 = gather_tap<METHOD, TS>(data, fwd, bwd, T, H, W, t, y, x, tp, 2, fillv, fbx, fby, ffx, ffy);
+            TS a = x2 - x1, b = x1 - x0;
+            TS s = (a == a ? a : (TS)0) + (b == b ? b : (TS)0);
+            int cnt = (isfinite((double)x2) ? 1 : 0) + (isfinite((double)x0) ? 1 : 0);
+            double r = (double)s / (double)(cnt > 1 ? cnt : 1);
+            if (is_nan_t(centre)) r = fill;
+            store_out<double>(out, out_type, pix, r);
+        }
+        return;
+    }
+    if (func == TF_FUNC_ANY) {
+        bool any = false;
+        for (int i = 0; i < n; i++) {
+            TS v = gather_tap<METHOD, TS>(data, fwd, bwd, T, H, W, t, y, x, tp, i, fillv, fbx, fby, ffx, ffy);
+            any = any || (v != (TS)0);                       // NaN counts as True, like np.any
+        }
+        double r = any ? 1.0 : 0.0;
+        if (is_nan_t(centre)) r = fill;
+        store_out<double>(out, out_type, pix, r);
+        return;
+    }
+}
+
+static int build_taps(const uint8_t *structure, ConvTaps &tp) {
+    // stack order = plane 0 taps (C order) | plane 1 | plane 2; offsets as (x, y) = (col-1, row-1)
+    // (convolve.py:212,224,234: np.where(structure[k])[..., ::-1] - centre)
+    int k = 0;
+    tp.nb = tp.ns = tp.nf = 0;
+    for (int p = 0; p < 3; p++)
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++)
+                if (structure[p * 9 + r * 3 + c]) {
+                    tp.ox[k] = (int8_t)(c - 1); tp.oy[k] = (int8_t)(r - 1);
+                    // sobel.py:7-29: S[t,y,x] = a[t] a[y] d[x]; transpose([1,2,0]) -> d along y;
+                    // transpose([2,0,1]) -> d along t  (a = [1,2,1], d = [-1,0,1])
+                    static const int a[3] = {1, 2, 1}, d[3] = {-1, 0, 1};
+                    tp.wx[k] = (int8_t)(a[p] * a[r] * d[c]);
+                    tp.wy[k] = (int8_t)(a[c] * a[p] * d[r]);
+                    tp.wt[k] = (int8_t)(a[r] * a[c] * d[p]);
+                    k++;
+                    if (p == 0) tp.nb++; else if (p == 1) tp.ns++; else tp.nf++;
+                }
+    return k;
+}
+
+template <typename TS>
+static int launch_convolve(const void *data, int64_t T, int H, int W, const float *fwd, const float *bwd,
+                           const ConvTaps &tp, int interp, double fill, int func, void *out, int out_type,
+                           int64_t t0, int64_t t1, hipStream_t s)
+{
+    typedef typename StackTraits<TS>::In In;
+    dim3 block(64, 4, 1), grid((W + 63) / 64, (H + 3) / 4, (unsigned)(t1 - t0));
+    const In *d = (const In *)data;
+    switch (interp) {
+    case TF_INTERP_NEAREST:
+        hipLaunchKernelGGL((k_convolve<TF_INTERP_NEAREST, TS>), grid, block, 0, s, d, fwd, bwd, T, H, W, tp, fill, func, out, out_type, t0); break;
+    case TF_INTERP_LINEAR:
+        hipLaunchKernelGGL((k_convolve<TF_INTERP_LINEAR, TS>), grid, block, 0, s, d, fwd, bwd, T, H, W, tp, fill, func, out, out_type, t0); break;
+    default:
+        hipLaunchKernelGGL((k_convolve<TF_INTERP_CUBIC, TS>), grid, block, 0, s, d, fwd, bwd, T, H, W, tp, fill, func, out, out_type, t0); break;
+    }
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+extern "C" int tf_convolve(const void *data, int data_type, int64_t T, int64_t H, int64_t W,
+                           const float *fwd, const float *bwd, const uint8_t *structure_host,
+                           int interp, double fill, int func, void *out, int out_type,
+                           int64_t t0, int64_t t1, void *stream)
+{
+    TF_REQUIRE(data && fwd && bwd && structure_host && out, "tf_convolve: null pointer");
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_convolve: bad shape");
+    TF_REQUIRE(interp >= TF_INTERP_NEAREST && interp <= TF_INTERP_CUBIC, "tf_convolve: bad interp");
+    TF_REQUIRE(func >= TF_FUNC_STACK && func <= TF_FUNC_NANMAX, "tf_convolve: bad func");
+    TF_REQUIRE(data_type == TF_F32 || data_type == TF_I32, "tf_convolve: data_type must be f32 or i32");
+    TF_REQUIRE(out_type >= TF_F32 && out_type <= TF_I32, "tf_convolve: bad out_type");
+    TF_REQUIRE(data_type != TF_I32 || interp == TF_INTERP_NEAREST, "tf_convolve: int32 data needs nearest");
+    TF_REQUIRE(t0 >= 0 && t1 <= T && t0 <= t1, "tf_convolve: bad frame range");
+    if (t0 == t1) return TF_OK;
+    ConvTaps tp;
+    int n = build_taps(structure_host, tp);
+    TF_REQUIRE(n > 0, "tf_convolve: empty structure");
+    if (func == TF_FUNC_DIFF)
+        TF_REQUIRE(tp.nb == 1 && tp.ns == 1 && tp.nf == 1, "tf_convolve: DIFF needs one tap per time plane");
+    if (func >= TF_FUNC_SOBEL && func <= TF_FUNC_SOBEL_DOWNHILL)
+        TF_REQUIRE(n == 27, "tf_convolve: SOBEL needs the full 27-tap structure");
+    hipStream_t s = (hipStream_t)stream;
+    if (data_type == TF_I32) {
+        TF_REQUIRE(func == TF_FUNC_STACK || func == TF_FUNC_ANY, "tf_convolve: int32 data supports STACK / ANY");
+        return launch_convolve<int32_t>(data, T, (int)H, (int)W, fwd, bwd, tp, interp, fill, func, out, out_type, t0, t1, s);
+    }
+    // the stack dtype is the reference's `dtype` argument: float32 unless the output is float64
+    if (out_type == TF_F64)
+        return launch_convolve<double>(data, T, (int)H, (int)W, fwd, bwd, tp, interp, fill, func, out, out_type, t0, t1, s);
+    return launch_convolve<float>(data, T, (int)H, (int)W, fwd, bwd, tp, interp, fill, func, out, out_type, t0, t1, s);
+}
+
+// ---- single-image warp and forward/backward smoothing -----------------------------------------
+template <int METHOD>
+__global__ void __launch_bounds__(256)
+k_warp(const float *__restrict__ img, const float *__restrict__ flow, int H, int W, float *__restrict__ out)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int64_t pix = (int64_t)y * W + x;
+    float2 f = ((const float2 *)flow)[pix];
+    out[pix] = tf_remap<METHOD>(img, H, W, tf_loc(f.x, 0, x), tf_loc(f.y, 0, y), NAN);
+}
+
+// strided component sampler: flow images are interleaved (H, W, 2); the reference warps the two
+// components as separate (H, W) images (flow.py:545-546) -- identical arithmetic, stride 2 here.
+template <int METHOD>
+__device__ __forceinline__ float sample_component(const float *__restrict__ f2, int comp, int H, int W, float mx, float my)
+{
+    // re-implementation of tf_remap on a stride-2 image
+    const float cval = NAN;
+    auto at = [&](int yy, int xx) { return f2[((int64_t)yy * W + xx) * 2 + comp]; };
+    if (METHOD == TF_INTERP_NEAREST) {
+        int sx = tf_sat_short(tf_cvround(mx)), sy = tf_sat_short(tf_cvround(my));
+        return ((unsigned)sx < (unsigned)W && (unsigned)sy < (unsigned)H) ? at(sy, sx) : cval;
+    }
+    int fx = tf_cvround(mx * 32.f), fy = tf_cvround(my * 32.f);
+    int sx = tf_sat_short(fx >> 5), sy = tf_sat_short(fy >> 5);
+    if (METHOD == TF_INTERP_LINEAR) {
+        float ax = (float)(fx & 31) * (1.f / 32.f), ay = (float)(fy & 31) * (1.f / 32.f);
+        float w0 = (1.f - ay) * (1.f - ax), w1 = (1.f - ay) * ax, w2 = ay * (1.f - ax), w3 = ay * ax;
+        int w1lim = W - 1 > 0 ? W - 1 : 0, h1lim = H - 1 > 0 ? H - 1 : 0;
+        if ((unsigned)sx < (unsigned)w1lim && (unsigned)sy < (unsigned)h1lim)
+            return at(sy, sx) * w0 + at(sy, sx + 1) * w1 + at(sy + 1, sx) * w2 + at(sy + 1, sx + 1) * w3;
+        if (sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0) return cval;
+        bool okx0 = sx >= 0 && sx < W, okx1 = sx + 1 >= 0 && sx + 1 < W, oky0 = sy >= 0 && sy < H, oky1 = sy + 1 >= 0 && sy + 1 < H;
+        float v0 = (okx0 && oky0) ? at(sy, sx) : cval, v1 = (okx1 && oky0) ? at(sy, sx + 1) : cval;
+        float v2 = (okx0 && oky1) ? at(sy + 1, sx) : cval, v3 = (okx1 && oky1) ? at(sy + 1, sx + 1) : cval;
+        return v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+    }
+    float cx[4], cy[4];
+    tf_cubic_coeffs((float)(fx & 31) * (1.f / 32.f), cx);
+    tf_cubic_coeffs((float)(fy & 31) * (1.f / 32.f), cy);
+    int bx = sx - 1, by = sy - 1;
+    int w1lim = W - 3 > 0 ? W - 3 : 0, h1lim = H - 3 > 0 ? H - 3 : 0;
+    if ((unsigned)bx < (unsigned)w1lim && (unsigned)by < (unsigned)h1lim) {
+        float sum = at(by, bx) * (cy[0] * cx[0]) + at(by, bx + 1) * (cy[0] * cx[1]) + at(by, bx + 2) * (cy[0] * cx[2]) + at(by, bx + 3) * (cy[0] * cx[3]);
+#pragma unroll
+        for (int i = 1; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) sum = sum + at(by + i, bx + j) * (cy[i] * cx[j]);
+        return sum;
+    }
+    if (bx >= W || bx + 4 <= 0 || by >= H || by + 4 <= 0) return cval;
+    float sum = cval * 1.f;
+    for (int i = 0; i < 4; i++) {
+        int yi = by + i;
+        if (yi < 0 || yi >= H) continue;
+        for (int j = 0; j < 4; j++) {
+            int xj = bx + j;
+            if (xj >= 0 && xj < W) sum += (at(yi, xj) - cval) * (cy[i] * cx[j]);
+        }
+    }
+    return sum;
+}
+
+__device__ __forceinline__ float nanmean2(float a, float b) {
+    // np.nanmean([a, b], 0) in float32: nansum / count (0/0 -> NaN)
+    float s = (a == a ? a : 0.f) + (b == b ? b : 0.f);
+    int cnt = (a == a) + (b == b);
+    return (float)((double)s / (double)cnt);
+}
+
+template <int METHOD>
+__global__ void __launch_bounds__(256)
+k_smooth(const float *__restrict__ fwd, const float *__restrict__ bwd, int H, int W,
+         float *__restrict__ fo, float *__restrict__ bo)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int64_t pix = (int64_t)y * W + x;
+    const float2 f = ((const float2 *)fwd)[pix], b = ((const float2 *)bwd)[pix];
+    const float fmx = tf_loc(f.x, 0, x), fmy = tf_loc(f.y, 0, y);
+    const float bmx = tf_loc(b.x, 0, x), bmy = tf_loc(b.y, 0, y);
+    float2 r;
+    r.x = nanmean2(f.x, -sample_component<METHOD>(bwd, 0, H, W, fmx, fmy));
+    r.y = nanmean2(f.y, -sample_component<METHOD>(bwd, 1, H, W, fmx, fmy));
+    ((float2 *)fo)[pix] = r;
+    r.x = nanmean2(b.x, -sample_component<METHOD>(fwd, 0, H, W, bmx, bmy));
+    r.y = nanmean2(b.y, -sample_component<METHOD>(fwd, 1, H, W, bmx, bmy));
+    ((float2 *)bo)[pix] = r;
+}
+
+extern "C" int tf_warp_flow(const float *img, const float *flow, int64_t H, int64_t W, int interp,
+                            float *out, void *stream)
+{
+    TF_REQUIRE(img && flow && out, "tf_warp_flow: null pointer");
+    TF_REQUIRE(H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_warp_flow: bad shape");
+    TF_REQUIRE(interp >= 0 && interp <= 2, "tf_warp_flow: bad interp");
+    dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (interp == 0) hipLaunchKernelGGL(k_warp<0>, grid, block, 0, s, img, flow, (int)H, (int)W, out);
+    else if (interp == 1) hipLaunchKernelGGL(k_warp<1>, grid, block, 0, s, img, flow, (int)H, (int)W, out);
+    else hipLaunchKernelGGL(k_warp<2>, grid, block, 0, s, img, flow, (int)H, (int)W, out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+extern "C" int tf_smooth_flow_step(const float *fwd, const float *bwd, int64_t H, int64_t W, int interp,
+                                   float *fwd_out, float *bwd_out, void *stream)
+{
+    TF_REQUIRE(fwd && bwd && fwd_out && bwd_out, "tf_smooth_flow_step: null pointer");
+    TF_REQUIRE(fwd_out != fwd && fwd_out != bwd && bwd_out != fwd && bwd_out != bwd, "tf_smooth_flow_step: outputs alias inputs");
+    TF_REQUIRE(H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_smooth_flow_step: bad shape");
+    TF_REQUIRE(interp >= 0 && interp <= 2, "tf_smooth_flow_step: bad interp");
+    dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (interp == 0) hipLaunchKernelGGL(k_smooth<0>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
+    else if (interp == 1) hipLaunchKernelGGL(k_smooth<1>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
+    else hipLaunchKernelGGL(k_smooth<2>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+__global__ void k_flow_finalize(float *__restrict__ fwd, float *__restrict__ bwd, int64_t T, int64_t plane2, float maxv)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index inside one (H, W, 2) frame
+    const int64_t t = blockIdx.y;
+    if (i >= plane2) return;
+    const int64_t idx = t * plane2 + i;
+    float f = fwd[idx], b = bwd[idx];
+    if (t == T - 1) f = -b;                       // flow.py:425  forward[-1] = -backward[-1]
+    if (t == 0) b = -f;                           // flow.py:426  backward[0] = -forward[0] (after :425)
+    // np.minimum(np.maximum(v, -max), max): NaN propagates
+    f = (f != f) ? f : fminf(fmaxf(f, -maxv), maxv);
+    b = (b != b) ? b : fminf(fmaxf(b, -maxv), maxv);
+    fwd[idx] = f; bwd[idx] = b;
+}
+
+extern "C" int tf_flow_finalize(float *fwd, float *bwd, int64_t T, int64_t H, int64_t W, float max_value, void *stream)
+{
+    TF_REQUIRE(fwd && bwd, "tf_flow_finalize: null pointer");
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && T < 65536, "tf_flow_finalize: bad shape");
+    const int64_t plane2 = H * W * 2;
+    dim3 block(256), grid((unsigned)((plane2 + 255) / 256), (unsigned)T);
+    hipLaunchKernelGGL(k_flow_finalize, grid, block, 0, (hipStream_t)stream, fwd, bwd, T, plane2, max_value);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}

@@ -1,0 +1,408 @@
+// Pyramidal Farnebaeck dense optical flow for one frame pair, both directions, on gfx950.
+//
+// Replaces cv2.optflow.createOptFlow_Farneback().calc(prev, next, None) / .calc(next, prev, None)
+// as issued by /root/reference/tobac_flow/flow.py:511,516 (factory
+// /root/reference/tobac_flow/utils/flow_utils.py:52-53).  Algorithm = OpenCV's
+// modules/video/src/optflowgf.cpp with its defaults:
+//   per level k (coarse -> fine):  u8 -> f32, GaussianBlur of the FULL-RES image (REFLECT_101),
+//   INTER_LINEAR resize to the level size, polynomial expansion (n = 5, sigma = 1.1) -> 5-channel R,
+//   flow init (zeros | upsampled previous level * 2), UpdateMatrices, then numIters x
+//   [13x13 box filter of M in double -> per-pixel 2x2 solve -> flow ; UpdateMatrices].
+//
+// MI355X design notes
+//   * both directions share the Gaussian pyramid and the polynomial expansion of the two images;
+//   * R and M are PLANAR (5 planes) so that every stencil/gather load is lane-contiguous;
+//   * the box filter + solve runs on LDS tiles (64 x 16 outputs, 6-pixel halo), one channel at
+//     a time, column sums then row sums in double -- the clamped-window form of OpenCV's
+//     replicate-border running sums; nothing wider than the 5 float planes of M touches HBM;
+//   * all of these are HBM/L2-bound stencils: no MFMA.
+#include "tf_common.h"
+#include <math.h>
+#include <float.h>
+
+#define FB_MAX_KSIZE 255
+#define FB_MAX_POLY_N 8
+
+__device__ __forceinline__ int fb_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+
+// ---- Gaussian blur (cv::GaussianBlur on CV_32F: row pass then symmetric column pass) -----------
+struct FbKernel { int ksize; float k[FB_MAX_KSIZE]; };
+
+template <typename TIn>
+__global__ void __launch_bounds__(256)
+k_fb_blur_rows(const TIn *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int ksize = kk.ksize, r = ksize >> 1;
+    const float *k = kk.k;
+    const TIn *S = src + (int64_t)y * W;
+    float s;
+    if (ksize == 3) {
+        s = (float)S[x] * k[1] + ((float)S[fb_reflect101(x - 1, W)] + (float)S[fb_reflect101(x + 1, W)]) * k[0];
+    } else if (ksize == 5) {
+        s = (float)S[x] * k[2] + ((float)S[fb_reflect101(x - 1, W)] + (float)S[fb_reflect101(x + 1, W)]) * k[1]
+          + ((float)S[fb_reflect101(x - 2, W)] + (float)S[fb_reflect101(x + 2, W)]) * k[0];
+    } else {
+        s = k[0] * (float)S[fb_reflect101(x - r, W)];
+        if (x - r >= 0 && x + r < W) { for (int i = 1; i < ksize; i++) s += k[i] * (float)S[x - r + i]; }
+        else { for (int i = 1; i < ksize; i++) s += k[i] * (float)S[fb_reflect101(x - r + i, W)]; }
+    }
+    dst[(int64_t)y * W + x] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_fb_blur_cols(const float *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int r = kk.ksize >> 1;
+    const float *k = kk.k;
+    float s = k[r] * src[(int64_t)y * W + x];
+    if (y - r >= 0 && y + r < H) {
+        for (int i = 1; i <= r; i++) s += k[r + i] * (src[(int64_t)(y + i) * W + x] + src[(int64_t)(y - i) * W + x]);
+    } else {
+        for (int i = 1; i <= r; i++)
+            s += k[r + i] * (src[(int64_t)fb_reflect101(y + i, H) * W + x] + src[(int64_t)fb_reflect101(y - i, H) * W + x]);
+    }
+    dst[(int64_t)y * W + x] = s;
+}
+
+// ---- cv::resize INTER_LINEAR (cn interleaved channels), optional post-scale ---------------------
+__global__ void __launch_bounds__(256)
+k_fb_resize_linear(const float *__restrict__ src, int sh, int sw, int cn, float *__restrict__ dst, int dh, int dw,
+                   double scale_x, double scale_y, float post)
+{
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = tf_cvfloor(fx); fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = tf_cvfloor(fy); fy -= sy;
+    const int sy0 = tf_clampi(sy, 0, sh - 1), sy1 = tf_clampi(sy + 1, 0, sh - 1);
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+    const float ax0 = 1.f - fx, ax1 = fx, ay0 = 1.f - fy, ay1 = fy;
+    for (int c = 0; c < cn; c++) {
+        float r0 = src[((int64_t)sy0 * sw + sx) * cn + c] * ax0 + src[((int64_t)sy0 * sw + sx1) * cn + c] * ax1;
+        float r1 = src[((int64_t)sy1 * sw + sx) * cn + c] * ax0 + src[((int64_t)sy1 * sw + sx1) * cn + c] * ax1;
+        float v = r0 * ay0 + r1 * ay1;
+        dst[((int64_t)dy * dw + dx) * cn + c] = post == 1.f ? v : v * post;
+    }
+}
+
+// exact 2x decimation: OpenCV switches INTER_LINEAR to the INTER_AREA fast path
+__global__ void __launch_bounds__(256)
+k_fb_resize_area2(const float *__restrict__ src, int sw, float *__restrict__ dst, int dh, int dw)
+{
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    const float *S = src + (int64_t)(2 * dy) * sw + 2 * dx;
+    float sum = 0;
+    sum += S[0] + S[1] + S[sw] + S[sw + 1];
+    dst[(int64_t)dy * dw + dx] = sum * 0.25f;
+}
+
+// ---- polynomial expansion ------------------------------------------------------------------------
+struct FbPoly { int n; float g[FB_MAX_POLY_N + 1], xg[FB_MAX_POLY_N + 1], xxg[FB_MAX_POLY_N + 1]; double ig11, ig03, ig33, ig55; };
+
+// vertical pass: t0 = sum g (I_up + I_dn), t1 = sum xg (I_dn - I_up), t2 = sum xxg (I_up + I_dn); rows replicate
+__global__ void __launch_bounds__(256)
+k_fb_poly_v(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restrict__ t0, float *__restrict__ t1, float *__restrict__ t2)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    float r0 = I[(int64_t)y * W + x] * pp.g[0], r1 = 0.f, r2 = 0.f;
+    for (int k = 1; k <= pp.n; k++) {
+        const float s0 = I[(int64_t)(y - k > 0 ? y - k : 0) * W + x];
+        const float s1 = I[(int64_t)(y + k < H - 1 ? y + k : H - 1) * W + x];
+        const float p = s0 + s1;
+        r0 = r0 + pp.g[k] * p;
+        r1 = r1 + pp.xg[k] * (s1 - s0);
+        r2 = r2 + pp.xxg[k] * p;
+    }
+    const int64_t o = (int64_t)y * W + x;
+    t0[o] = r0; t1[o] = r1; t2[o] = r2;
+}
+
+// horizontal pass (double accumulators, columns replicate) -> planar R[5]
+__global__ void __launch_bounds__(256)
+k_fb_poly_h(const float *__restrict__ t0, const float *__restrict__ t1, const float *__restrict__ t2, int H, int W, FbPoly pp,
+            float *__restrict__ R, int64_t plane)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const float *a = t0 + (int64_t)y * W, *b = t1 + (int64_t)y * W, *c = t2 + (int64_t)y * W;
+    float g0 = pp.g[0];
+    double b1 = a[x] * g0, b2 = 0, b3 = b[x] * g0, b4 = 0, b5 = c[x] * g0, b6 = 0;
+    for (int k = 1; k <= pp.n; k++) {
+        const int xp = x + k < W - 1 ? x + k : W - 1, xm = x - k > 0 ? x - k : 0;
+        const double tg = a[xp] + a[xm];
+        g0 = pp.g[k];
+        b1 += tg * g0; b4 += tg * pp.xxg[k];
+        b2 += (a[xp] - a[xm]) * pp.xg[k];
+        b3 += (b[xp] + b[xm]) * g0;
+        b6 += (b[xp] - b[xm]) * pp.xg[k];
+        b5 += (c[xp] + c[xm]) * g0;
+    }
+    const int64_t o = (int64_t)y * W + x;
+    R[o] = (float)(b3 * pp.ig11);
+    R[plane + o] = (float)(b2 * pp.ig11);
+    R[2 * plane + o] = (float)(b1 * pp.ig03 + b5 * pp.ig33);
+    R[3 * plane + o] = (float)(b1 * pp.ig03 + b4 * pp.ig33);
+    R[4 * plane + o] = (float)(b6 * pp.ig55);
+}
+
+// ---- FarnebackUpdateMatrices ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1, const float *__restrict__ flow,
+                     int H, int W, int64_t plane, float *__restrict__ M)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+    const int64_t o = (int64_t)y * W + x;
+    const float2 fl = ((const float2 *)flow)[o];
+    const float dx = fl.x, dy = fl.y;
+    float fx = x + dx, fy = y + dy;
+    const int x1 = tf_cvfloor(fx), y1 = tf_cvfloor(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1; fy -= y1;
+    if ((unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1)) {
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const int64_t q = (int64_t)y1 * W + x1;
+        const float *P = R1 + q;
+        r2 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1]; P += plane;
+        r3 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1]; P += plane;
+        r4 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1]; P += plane;
+        r5 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1]; P += plane;
+        r6 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1];
+        r4 = (R0[2 * plane + o] + r4) * 0.5f;
+        r5 = (R0[3 * plane + o] + r5) * 0.5f;
+        r6 = (R0[4 * plane + o] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * plane + o]; r5 = R0[3 * plane + o]; r6 = R0[4 * plane + o] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[plane + o] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10)) {
+        const float scale = (x < 5 ? border[x] : 1.f) * (x >= W - 5 ? border[W - x - 1] : 1.f) *
+                            (y < 5 ? border[y] : 1.f) * (y >= H - 5 ? border[H - y - 1] : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    M[o] = r4 * r4 + r6 * r6;
+    M[plane + o] = (r4 + r5) * r6;
+    M[2 * plane + o] = r5 * r5 + r6 * r6;
+    M[3 * plane + o] = r4 * r2 + r6 * r3;
+    M[4 * plane + o] = r6 * r2 + r5 * r3;
+}
+
+// ---- FarnebackUpdateFlow_Blur: box filter of M (double) + 2x2 solve ------------------------------
+// Tile: 64 x 16 outputs per 256-thread workgroup (each thread: one column, 4 rows); per channel the
+// (64 + 2m) x (16 + 2m) float tile is staged in LDS, reduced to column sums (double) and then row sums.
+#define FBT_W 64
+#define FBT_H 16
+#define FB_MAX_M 8
+__global__ void __launch_bounds__(256)
+k_fb_blur_solve(const float *__restrict__ M, int H, int W, int64_t plane, int m, float *__restrict__ flow)
+{
+    __shared__ float tile[(FBT_H + 2 * FB_MAX_M) * (FBT_W + 2 * FB_MAX_M)];
+    __shared__ double vs[FBT_H * (FBT_W + 2 * FB_MAX_M)];
+    const int tw = FBT_W + 2 * m, th = FBT_H + 2 * m;
+    const int bx = blockIdx.x * FBT_W, by = blockIdx.y * FBT_H;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    double acc[5][4];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float *Mc = M + c * plane;
+        for (int i = tid; i < tw * th; i += 256) {
+            const int ty = i / tw, tx = i - ty * tw;
+            const int gy = tf_clampi(by + ty - m, 0, H - 1), gx = tf_clampi(bx + tx - m, 0, W - 1);
+            tile[i] = Mc[(int64_t)gy * W + gx];
+        }
+        __syncthreads();
+        for (int i = tid; i < tw * FBT_H; i += 256) {           // column sums over 2m+1 rows
+            const int oy = i / tw, tx = i - oy * tw;
+            double s = 0;
+            for (int j = 0; j <= 2 * m; j++) s += (double)tile[(oy + j) * tw + tx];
+            vs[i] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int oy = threadIdx.y * 4 + r;
+            double s = 0;
+            for (int j = 0; j <= 2 * m; j++) s += vs[oy * tw + threadIdx.x + j];
+            acc[c][r] = s;
+        }
+        __syncthreads();
+    }
+    const double scale = 1. / ((2 * m + 1) * (2 * m + 1));
+    const int x = bx + threadIdx.x;
+    if (x >= W) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = by + threadIdx.y * 4 + r;
+        if (y >= H) continue;
+        const double g11 = acc[0][r] * scale, g12 = acc[1][r] * scale, g22 = acc[2][r] * scale;
+        const double h1 = acc[3][r] * scale, h2 = acc[4][r] * scale;
+        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        float2 f;
+        f.x = (float)((g11 * h2 - g12 * h1) * idet);
+        f.y = (float)((g22 * h1 - g12 * h2) * idet);
+        ((float2 *)flow)[(int64_t)y * W + x] = f;
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+extern "C" void tf_farneback_default_params(tf_farneback_params *p) {
+    p->num_levels = 5; p->pyr_scale = 0.5; p->win_size = 13; p->num_iters = 10; p->poly_n = 5; p->poly_sigma = 1.1;
+}
+
+static void fb_gaussian_kernel(int n, double sigma, FbKernel *out) {
+    // cv::getGaussianKernel(n, sigma, CV_32F)
+    static const float small_tab[4][7] = {{1.f}, {0.25f, 0.5f, 0.25f}, {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+        {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    const float *fixed = (n % 2 == 1 && n <= 7 && sigma <= 0) ? small_tab[n >> 1] : nullptr;
+    const double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2X = -0.5 / (sigmaX * sigmaX);
+    double sum = 0;
+    out->ksize = n;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        out->k[i] = (float)(fixed ? (double)fixed[i] : exp(scale2X * x * x));
+        sum += out->k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) out->k[i] = (float)(out->k[i] * sum);
+}
+
+static void fb_prepare_poly(int n, double sigma, FbPoly *pp) {
+    // FarnebackPrepareGaussian: 1-D kernels + the four entries of inv(G) that are used
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    float gb[2 * FB_MAX_POLY_N + 1]; float *g = gb + n;
+    double s = 0;
+    for (int x = -n; x <= n; x++) { g[x] = (float)exp(-x * x / (2 * sigma * sigma)); s += g[x]; }
+    s = 1. / s;
+    pp->n = n;
+    for (int x = -n; x <= n; x++) g[x] = (float)(g[x] * s);
+    for (int x = 0; x <= n; x++) { pp->g[x] = g[x]; pp->xg[x] = (float)(x * g[x]); pp->xxg[x] = (float)(x * x * g[x]); }
+    double G00 = 0, G11 = 0, G33 = 0, G55 = 0;
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G00 += g[y] * g[x]; G11 += g[y] * g[x] * x * x;
+            G33 += g[y] * g[x] * x * x * x * x; G55 += g[y] * g[x] * x * x * y * y;
+        }
+    // G = [[G00,0,0,G11,G11,0],[0,G11,..],[..,G11,..],[G11,0,0,G33,G55,0],[G11,0,0,G55,G33,0],[..G55]]
+    // inverse by blocks: indices {1},{2},{5} are decoupled; {0,3,4} form a 3x3 symmetric block.
+    const double a = G00, b = G11, c = G33, d = G55;
+    // 3x3 block B = [[a,b,b],[b,c,d],[b,d,c]]; cofactors
+    const double det = a * (c * c - d * d) - b * (b * c - b * d) + b * (b * d - b * c);
+    pp->ig11 = 1. / G11;
+    pp->ig03 = -(b * c - d * b) / det;          // inv[0][1] of the block = -(b*c - b*d)/det
+    pp->ig33 = (a * c - b * b) / det;           // inv[1][1] of the block
+    pp->ig55 = 1. / G55;
+}
+
+static int fb_levels(int64_t H, int64_t W, const tf_farneback_params *p) {
+    int k; double scale = 1;
+    for (k = 0; k < p->num_levels; k++) { scale *= p->pyr_scale; if (W * scale < 32 || H * scale < 32) break; }
+    return k;
+}
+
+extern "C" size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_params *p)
+{
+    if (H <= 0 || W <= 0 || !p) return 0;
+    const size_t n = (size_t)H * W, pl = tf_align_up(n * 4, 256);
+    // tmp, blur, I, t0..t2, R0[5], R1[5], M[5], 4 flow buffers of 2 planes, kernel table
+    return 6 * pl + 15 * pl + 4 * 2 * pl + tf_align_up(sizeof(FbKernel), 256) + 4096;
+}
+
+extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H64, int64_t W64,
+                                 const tf_farneback_params *p, float *flow_fwd, float *flow_bwd,
+                                 void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(prev && next && p && ws, "tf_farneback_pair: null pointer");
+    TF_REQUIRE(flow_fwd || flow_bwd, "tf_farneback_pair: both outputs are NULL");
+    TF_REQUIRE(H64 > 0 && W64 > 0 && H64 < (1 << 15) && W64 < (1 << 15), "tf_farneback_pair: bad shape");
+    TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= FB_MAX_POLY_N, "tf_farneback_pair: poly_n out of range");
+    TF_REQUIRE(p->win_size >= 1 && p->win_size / 2 <= FB_MAX_M, "tf_farneback_pair: win_size out of range");
+    TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback_pair: bad params");
+    if (ws_bytes < tf_farneback_workspace_bytes(H64, W64, p)) { tf_set_error("tf_farneback_pair: workspace too small"); return TF_ENOMEM; }
+    const int H = (int)H64, W = (int)W64;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)H * W;
+    TfArena ar(ws, ws_bytes);
+    float *tmp = ar.take<float>(n), *blur = ar.take<float>(n), *I = ar.take<float>(n);
+    float *t0 = ar.take<float>(n), *t1 = ar.take<float>(n), *t2 = ar.take<float>(n);
+    float *R[2] = {ar.take<float>(5 * n), ar.take<float>(5 * n)};
+    float *M = ar.take<float>(5 * n);
+    float *fbuf[2][2] = {{ar.take<float>(2 * n), ar.take<float>(2 * n)}, {ar.take<float>(2 * n), ar.take<float>(2 * n)}};
+    if (!ar.ok()) { tf_set_error("tf_farneback_pair: workspace too small"); return TF_ENOMEM; }
+
+    FbPoly pp; fb_prepare_poly(p->poly_n, p->poly_sigma, &pp);
+    const int levels = fb_levels(H, W, p);
+    const uint8_t *img[2] = {prev, next};
+    float *out[2] = {flow_fwd, flow_bwd};
+    float *prevFlow[2] = {nullptr, nullptr};
+    int pw = 0, ph = 0;
+    dim3 block(64, 4);
+    const dim3 gfull((W + 63) / 64, (H + 3) / 4);
+    for (int k = levels; k >= 0; k--) {
+        double scale = 1; for (int i = 0; i < k; i++) scale *= p->pyr_scale;
+        const double sigma = (1. / scale - 1) * 0.5;
+        int smooth_sz = (int)lrint(sigma * 5) | 1; if (smooth_sz < 3) smooth_sz = 3;
+        TF_REQUIRE(smooth_sz <= FB_MAX_KSIZE, "tf_farneback_pair: blur kernel too large");
+        const int w = (int)lrint(W * scale), h = (int)lrint(H * scale);
+        const int64_t plane = (int64_t)w * h;
+        const dim3 glev((w + 63) / 64, (h + 3) / 4);
+        FbKernel hk; fb_gaussian_kernel(smooth_sz, sigma, &hk);
+        for (int i = 0; i < 2; i++) {
+            hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp);
+            hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur);
+            const float *Ik = blur;
+            if (w != W || h != H) {
+                const double sx = 1. / ((double)w / W), sy = 1. / ((double)h / H);
+                const int isx = (int)(sx + 0.5), isy = (int)(sy + 0.5);
+                if (fabs(sx - isx) < DBL_EPSILON && fabs(sy - isy) < DBL_EPSILON && isx == 2 && isy == 2)
+                    hipLaunchKernelGGL(k_fb_resize_area2, glev, block, 0, s, blur, W, I, h, w);
+                else
+                    hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, blur, H, W, 1, I, h, w, sx, sy, 1.f);
+                Ik = I;
+            }
+            hipLaunchKernelGGL(k_fb_poly_v, glev, block, 0, s, Ik, h, w, pp, t0, t1, t2);
+            hipLaunchKernelGGL(k_fb_poly_h, glev, block, 0, s, t0, t1, t2, h, w, pp, R[i], plane);
+        }
+        TF_CHECK_LAUNCH();
+        for (int d = 0; d < 2; d++) {
+            if (!out[d]) continue;
+            float *flow = (k > 0) ? fbuf[d][k & 1] : out[d];
+            if (!prevFlow[d]) TF_CHECK_HIP(hipMemsetAsync(flow, 0, (size_t)plane * 2 * sizeof(float), s));
+            else {
+                const double sx = 1. / ((double)w / pw), sy = 1. / ((double)h / ph);
+                hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, prevFlow[d], ph, pw, 2, flow, h, w, sx, sy,
+                                   (float)(1. / p->pyr_scale));
+            }
+            const float *R0 = R[d], *R1 = R[1 - d];
+            hipLaunchKernelGGL(k_fb_update_matrices, glev, block, 0, s, R0, R1, flow, h, w, plane, M);
+            const dim3 gt((w + FBT_W - 1) / FBT_W, (h + FBT_H - 1) / FBT_H);
+            for (int it = 0; it < p->num_iters; it++) {
+                hipLaunchKernelGGL(k_fb_blur_solve, gt, block, 0, s, M, h, w, plane, p->win_size / 2, flow);
+                if (it < p->num_iters - 1)
+                    hipLaunchKernelGGL(k_fb_update_matrices, glev, block, 0, s, R0, R1, flow, h, w, plane, M);
+            }
+            TF_CHECK_LAUNCH();
+            prevFlow[d] = flow;
+        }
+        pw = w; ph = h;
+    }
+    return TF_OK;
+}

@@ -1,0 +1,94 @@
+// Device-side cv2.remap semantics (map = absolute float coordinates, BORDER_CONSTANT) as the
+// reference calls it: /root/reference/tobac_flow/convolve.py:65-84 and
+// /root/reference/tobac_flow/utils/flow_utils.py:90-98.
+//  * non-nearest modes quantise the coordinate to 1/32 px (cvRound(x*32); >>5 / &31) and take
+//    the weights of that bin; weights and accumulation are float, taps row-major;
+//  * a patch that straddles the border takes the border value for outside taps (bilinear) or
+//    cval + SUM (S - cval) * w (bicubic): a NaN border value poisons the result;
+//  * nearest uses cvRound (half to even).
+// Built with -ffp-contract=off: every expression below is evaluated as written.
+#pragma once
+#include "tf_common.h"
+
+__device__ __forceinline__ void tf_cubic_coeffs(float x, float *c) {
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+// absolute sampling coordinate exactly as numpy builds it (convolve.py:56-63):
+//   locs = flow + offset (float32)  ;  locs += grid (int64)  ->  float32(float64(locs) + grid)
+__device__ __forceinline__ float tf_loc(float flow, int off, int grid) {
+    float l = flow + (float)off;
+    return (float)((double)l + (double)grid);
+}
+
+template <typename T>
+__device__ __forceinline__ T tf_remap_nearest(const T *__restrict__ img, int h, int w, float mx, float my, T cval) {
+    int sx = tf_sat_short(tf_cvround(mx)), sy = tf_sat_short(tf_cvround(my));
+    return ((unsigned)sx < (unsigned)w && (unsigned)sy < (unsigned)h) ? img[(int64_t)sy * w + sx] : cval;
+}
+
+__device__ __forceinline__ float tf_remap_linear(const float *__restrict__ img, int h, int w, float mx, float my, float cval) {
+    int fx = tf_cvround(mx * 32.f), fy = tf_cvround(my * 32.f);
+    int sx = tf_sat_short(fx >> 5), sy = tf_sat_short(fy >> 5);
+    float ax = (float)(fx & 31) * (1.f / 32.f), ay = (float)(fy & 31) * (1.f / 32.f);
+    float wx0 = 1.f - ax, wx1 = ax, wy0 = 1.f - ay, wy1 = ay;
+    float w0 = wy0 * wx0, w1 = wy0 * wx1, w2 = wy1 * wx0, w3 = wy1 * wx1;
+    int w1lim = w - 1 > 0 ? w - 1 : 0, h1lim = h - 1 > 0 ? h - 1 : 0;
+    if ((unsigned)sx < (unsigned)w1lim && (unsigned)sy < (unsigned)h1lim) {
+        const float *S = img + (int64_t)sy * w + sx;
+        return S[0] * w0 + S[1] * w1 + S[w] * w2 + S[w + 1] * w3;
+    }
+    if (sx >= w || sx + 1 < 0 || sy >= h || sy + 1 < 0) return cval;
+    bool okx0 = sx >= 0 && sx < w, okx1 = sx + 1 >= 0 && sx + 1 < w;
+    bool oky0 = sy >= 0 && sy < h, oky1 = sy + 1 >= 0 && sy + 1 < h;
+    float v0 = (okx0 && oky0) ? img[(int64_t)sy * w + sx] : cval;
+    float v1 = (okx1 && oky0) ? img[(int64_t)sy * w + sx + 1] : cval;
+    float v2 = (okx0 && oky1) ? img[(int64_t)(sy + 1) * w + sx] : cval;
+    float v3 = (okx1 && oky1) ? img[(int64_t)(sy + 1) * w + sx + 1] : cval;
+    return v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+}
+
+__device__ __forceinline__ float tf_remap_cubic(const float *__restrict__ img, int h, int w, float mx, float my, float cval) {
+    int fx = tf_cvround(mx * 32.f), fy = tf_cvround(my * 32.f);
+    int sx = tf_sat_short(fx >> 5), sy = tf_sat_short(fy >> 5);
+    float cx[4], cy[4];
+    tf_cubic_coeffs((float)(fx & 31) * (1.f / 32.f), cx);
+    tf_cubic_coeffs((float)(fy & 31) * (1.f / 32.f), cy);
+    int bx = sx - 1, by = sy - 1;
+    int w1lim = w - 3 > 0 ? w - 3 : 0, h1lim = h - 3 > 0 ? h - 3 : 0;
+    if ((unsigned)bx < (unsigned)w1lim && (unsigned)by < (unsigned)h1lim) {
+        const float *S = img + (int64_t)by * w + bx;
+        float sum = S[0] * (cy[0] * cx[0]) + S[1] * (cy[0] * cx[1]) + S[2] * (cy[0] * cx[2]) + S[3] * (cy[0] * cx[3]);
+#pragma unroll
+        for (int i = 1; i < 4; i++) {
+            const float *R = S + (int64_t)i * w;
+            sum = sum + R[0] * (cy[i] * cx[0]);
+            sum = sum + R[1] * (cy[i] * cx[1]);
+            sum = sum + R[2] * (cy[i] * cx[2]);
+            sum = sum + R[3] * (cy[i] * cx[3]);
+        }
+        return sum;
+    }
+    if (bx >= w || bx + 4 <= 0 || by >= h || by + 4 <= 0) return cval;
+    float sum = cval * 1.f;
+    for (int i = 0; i < 4; i++) {
+        int yi = by + i;
+        if (yi < 0 || yi >= h) continue;
+        for (int j = 0; j < 4; j++) {
+            int xj = bx + j;
+            if (xj >= 0 && xj < w) sum += (img[(int64_t)yi * w + xj] - cval) * (cy[i] * cx[j]);
+        }
+    }
+    return sum;
+}
+
+template <int METHOD>
+__device__ __forceinline__ float tf_remap(const float *__restrict__ img, int h, int w, float mx, float my, float cval) {
+    if (METHOD == TF_INTERP_NEAREST) return tf_remap_nearest<float>(img, h, w, mx, my, cval);
+    if (METHOD == TF_INTERP_LINEAR) return tf_remap_linear(img, h, w, mx, my, cval);
+    return tf_remap_cubic(img, h, w, mx, my, cval);
+}

@@ -1,0 +1,295 @@
+"""Detection recipes (mirrors /root/reference/tobac_flow/detection.py -- same entry points,
+arguments, defaults and results).
+
+The semi-Lagrangian steps (Flow.diff / convolve / sobel / watershed / label warps) run on the
+MI355X through the Flow object; the scipy.ndimage morphology in between is host glue, structured
+like the reference so that labels come out identical.  `detect_growth` is an alias kept for the
+north-star wording; the reference's real entry points are detect_growth_markers / get_growth_rate /
+detect_cores / detect_anvils.  `edge_watershed` (detection.py:257-298) is stale in the reference
+(it passes keywords Flow.watershed does not accept) and is not mirrored.
+"""
+import warnings
+from functools import partial
+
+import numpy as np
+from scipy import ndimage as ndi, stats
+
+from tobac_flow_amd import _lib
+from tobac_flow_amd.analysis import (filter_labels_by_length, filter_labels_by_length_and_multimask_legacy,
+                                     filter_labels_by_mask, find_object_lengths, mask_labels)
+from tobac_flow_amd.convolve import tag_func
+from tobac_flow_amd.decorators import configure_dataarray
+from tobac_flow_amd.utils import (get_time_diff_from_coord, labeled_comprehension, linearise_field,
+                                  make_step_labels, slice_labels)
+from tobac_flow_amd.utils.label_utils import remap_labels
+from tobac_flow_amd.utils.peak_utils import peak_local_max
+
+_DROP = ["standard_name", "units", "valid_range", "_FillValue", "missing_value", "cell_methods", "units_metadata"]
+
+
+@tag_func(_lib.FUNC_NANMEAN)
+def _nanmean0(x):
+    """lambda x: np.nanmean(x, 0) of detection.py:53-55,190-195 (fused on the GPU)."""
+    return np.nanmean(x, 0)
+
+
+def _values(a):
+    """ndarray view of an ndarray / xr.DataArray"""
+    return a.to_numpy() if hasattr(a, "to_numpy") and not isinstance(a, np.ndarray) else np.asarray(a)
+
+
+def _is_dataarray(a):
+    return hasattr(a, "dims") and hasattr(a, "coords")
+
+
+def _plane_struct(conn=1):
+    """(3,3,3) structure acting inside one time step only"""
+    s = ndi.generate_binary_structure(3, conn)
+    s[0] = 0
+    s[2] = 0
+    return s
+
+
+def _time_struct():
+    s = np.zeros([3, 3, 3])
+    s[:, 1, 1] = 1
+    return s
+
+
+def _rate(flow, field, method="linear"):
+    """semi-Lagrangian d/dt per minute"""
+    return flow.diff(field, method=method) / get_time_diff_from_coord(field.t)[:, np.newaxis, np.newaxis]
+
+
+def filtered_tdiff(flow, raw_diff):
+    """3-step semi-Lagrangian moving average of a time derivative (reference: detection.py:33-60)."""
+    return flow.convolve(raw_diff, structure=_time_struct(), func=_nanmean0)
+
+
+def get_curvature_filter(field, sigma=2, threshold=0, direction="negative"):
+    """Where the smoothed field curves down (or up) in both x and y (reference: detection.py:64-94)."""
+    smooth = ndi.gaussian_filter(field, (0, sigma, sigma))
+    x_diff = np.zeros(field.shape)
+    x_diff[:, :, 1:-1] = np.diff(smooth, n=2, axis=2)
+    y_diff = np.zeros(field.shape)
+    y_diff[:, 1:-1] = np.diff(smooth, n=2, axis=1)
+    s = _plane_struct()
+    if direction == "negative":
+        both = np.logical_and(x_diff < -threshold, y_diff < -threshold)
+    elif direction == "positive":
+        both = np.logical_and(x_diff > threshold, y_diff > threshold)
+    else:
+        raise ValueError("Direction must be either positive or negative")
+    return ndi.binary_opening(ndi.binary_fill_holes(both, structure=s), structure=s)
+
+
+def detect_growth_markers(flow, wvd):
+    """Growth markers from the WVD field alone (reference: detection.py:98-125)."""
+    wvd_diff_raw = _rate(flow, wvd)
+    wvd_diff_smoothed = filtered_tdiff(flow, wvd_diff_raw)
+    s2 = ndi.generate_binary_structure(2, 1)[np.newaxis, ...]
+    filtered = ndi.grey_opening(wvd_diff_smoothed, footprint=s2) * get_curvature_filter(wvd)
+    marker_labels = flow.label(ndi.binary_opening(filtered >= 0.25, structure=s2))
+    marker_labels = filter_labels_by_length(marker_labels, 3)
+    marker_labels = filter_labels_by_mask(marker_labels, filtered >= 0.5)
+    marker_labels = filter_labels_by_mask(marker_labels, _values(wvd) >= -5)
+    if _is_dataarray(wvd):
+        import xarray as xr
+        marker_labels = xr.DataArray(marker_labels, wvd.coords, wvd.dims)
+    return wvd_diff_smoothed, marker_labels
+
+
+def nan_gaussian_filter(a, *args, propagate_nan=True, **kwargs):
+    """Gaussian filter that ignores NaNs (normalised convolution) (reference: detection.py:128-146)."""
+    nan = np.isnan(a)
+    filled = a.copy()
+    filled[nan] = 0
+    weight = np.ones_like(a)
+    weight[nan] = 0
+    num = ndi.gaussian_filter(filled, *args, **kwargs)
+    den = ndi.gaussian_filter(weight, *args, **kwargs)
+    den[den == 0] = np.nan
+    out = num / den
+    if propagate_nan:
+        out[nan] = np.nan
+    return out
+
+
+def get_peak_filter(field, sigma=2, min_distance=10, direction="negative"):
+    """Pixels within 5 px of a local extremum of the smoothed field (reference: detection.py:149-168;
+    like the reference, peak_local_max is always called with min_distance=10)."""
+    if direction not in ("negative", "positive"):
+        raise ValueError("Direction must be either positive or negative")
+    smooth = ndi.gaussian_filter(field, (0, sigma, sigma))
+    sign = 1 if direction == "negative" else -1
+    out = np.zeros(field.shape, dtype=np.int32)
+    for i in range(field.shape[0]):
+        locs = peak_local_max(sign * smooth[i], min_distance=10).T
+        out[i][(locs[0], locs[1])] = 1
+        out[i] = ndi.distance_transform_edt(np.logical_not(out[i])) < 5
+    return out
+
+
+def get_growth_rate(flow, field, method: str = "linear"):
+    """Semi-Lagrangian growth / cooling rate, smoothed over the 5-point in-plane cross
+    (reference: detection.py:171-200)."""
+    return flow.convolve(_rate(flow, field, method), structure=_plane_struct(), func=_nanmean0, method=method)
+
+
+detect_growth = get_growth_rate      # alias for BASELINE.json's wording
+
+
+def detect_growth_markers_multichannel(flow, wvd, bt, t_sigma=1, overlap=0.5, subsegment_shrink=0, min_length=4,
+                                       lower_threshold=0.25, upper_threshold=0.5):
+    """Growth markers from WVD and BT together (reference: detection.py:203-254)."""
+    wvd_s = filtered_tdiff(flow, _rate(flow, wvd))
+    bt_s = filtered_tdiff(flow, _rate(flow, bt))
+    markers = np.logical_or((wvd_s * get_curvature_filter(wvd)) >= lower_threshold,
+                            (bt_s * get_curvature_filter(bt, direction="positive")) <= -lower_threshold)
+    markers = flow.label(ndi.binary_opening(markers, structure=ndi.generate_binary_structure(2, 1)[np.newaxis, ...]),
+                         overlap=overlap, subsegment_shrink=subsegment_shrink)
+    if np.count_nonzero(markers) > 0:
+        markers = filter_labels_by_length_and_multimask_legacy(
+            markers, [wvd_s >= upper_threshold, bt_s <= -upper_threshold, _values(wvd) > -5], min_length)
+    else:
+        warnings.warn("No regions detected in labeled array", RuntimeWarning)
+    if _is_dataarray(wvd):
+        import xarray as xr
+        wvd_s = xr.DataArray(wvd_s, wvd.coords, wvd.dims)
+        bt_s = xr.DataArray(bt_s, bt.coords, bt.dims)
+        markers = xr.DataArray(markers, wvd.coords, wvd.dims)
+    return wvd_s, bt_s, markers
+
+
+def get_combined_filters(flow, bt, wvd, swd, use_wvd=True):
+    """Cloud-top filter from curvature + peak filters of BT (and WVD), spread over t+-1 along the
+    flow, weighted by the SWD ramp (reference: detection.py:301-354)."""
+    t_struct = np.zeros([3, 3, 3], dtype=bool)
+    t_struct[:, 1, 1] = True
+    s = _plane_struct()
+
+    def channel(field, direction):
+        seed = np.logical_or(get_curvature_filter(field, direction=direction),
+                             get_peak_filter(field, sigma=0.5, direction=direction)).astype(int)
+        return flow.convolve(seed, structure=t_struct, method="nearest", fill_value=False, dtype=np.int32,
+                             func=partial(np.any, axis=0))
+
+    combined = channel(bt, "positive")
+    if use_wvd:
+        combined = np.logical_or(combined, channel(wvd, "negative"))
+    combined = ndi.binary_opening(ndi.binary_fill_holes(combined, structure=s), structure=s)
+    return combined.astype(float) * (1 - linearise_field(_values(swd), 2.5, 7.5))
+
+
+@configure_dataarray(name="core_label", drop_attrs=_DROP, long_name="Labels of detected core regions", units="",
+                     cell_measures="area: area")
+def detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overlap=0.5, absolute_overlap=4,
+                 subsegment_shrink=0.0, min_length=3, use_wvd=True):
+    """Growing cores from BT, WVD and SWD (reference: detection.py:372-482)."""
+    combined_filter = get_combined_filters(flow, bt, wvd, swd, use_wvd=use_wvd)
+    s = ndi.generate_binary_structure(3, 1)
+    s *= np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
+    bt_markers = (get_growth_rate(flow, -bt, method="cubic") * combined_filter) > bt_threshold
+    if use_wvd:
+        wvd_markers = (get_growth_rate(flow, wvd, method="cubic") * combined_filter) > wvd_threshold
+        combined_markers = ndi.binary_opening(np.logical_or.reduce([wvd_markers, bt_markers]), structure=s)
+        print("WVD growth above threshold: area =", np.sum(wvd_markers))
+    else:
+        combined_markers = ndi.binary_opening(bt_markers, structure=s)
+    print("BT growth above threshold: area =", np.sum(bt_markers))
+    print("Detected markers: area =", np.sum(combined_markers))
+    core_labels = flow.label(combined_markers, overlap=overlap, absolute_overlap=absolute_overlap,
+                             subsegment_shrink=subsegment_shrink)
+    print("Initial core count:", np.max(core_labels))
+    lengths = find_object_lengths(core_labels)
+    print("Core labels meeting length threshold:", np.sum(lengths > min_length))
+    wvd_ok = mask_labels(core_labels, _values(wvd) > -5)
+    print("Core labels meeting WVD threshold:", np.sum(wvd_ok))
+    core_labels = remap_labels(core_labels, np.logical_and(lengths > min_length, wvd_ok))
+
+    # cooling-rate test on the per-step mean BT of every core
+    step_labels = slice_labels(core_labels)
+    step_core = labeled_comprehension(core_labels, step_labels, lambda x: stats.mode(x, keepdims=False)[0], default=0)
+    step_bt = labeled_comprehension(_values(bt), step_labels, np.nanmean, default=np.nan)
+    step_t = labeled_comprehension(np.asarray(bt.t.data)[:, np.newaxis, np.newaxis], step_labels, np.nanmin, default=0)
+
+    def max_cooling(bt_vals, pos):
+        when = step_t[pos]
+        order = np.argsort(when)
+        bt_vals, when = bt_vals[order], when[order]
+        rate = (bt_vals[:-min_length] - bt_vals[min_length:]) / (
+            (when[min_length:] - when[:-min_length]).astype("timedelta64[s]").astype("int") / 60)
+        return np.nanmax(rate) if rate.size > 0 else 0
+
+    cooling = labeled_comprehension(step_bt, step_core, max_cooling, default=0, pass_positions=True)
+    valid = cooling >= 0.5
+    print("Core labels meeting cooling rate threshold:", np.sum(valid))
+    return remap_labels(core_labels, valid)
+
+
+@configure_dataarray(name="anvil_marker_label", drop_attrs=_DROP, long_name="labels for anvil markers", units="",
+                     cell_measures="area: area")
+def get_anvil_markers(flow, field, threshold=-5, overlap=0.5, absolute_overlap=5, subsegment_shrink=0, min_length=3):
+    """Flow-linked labels of the regions above `threshold` (reference: detection.py:500-520)."""
+    s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
+    mask = ndi.binary_opening(_values(field) >= threshold, structure=s)
+    marker_labels = flow.label(mask, overlap=overlap, absolute_overlap=absolute_overlap,
+                               subsegment_shrink=subsegment_shrink)
+    return remap_labels(marker_labels, find_object_lengths(marker_labels) > min_length)
+
+
+@configure_dataarray(name="anvil_label", drop_attrs=_DROP, long_name="Labels of detected anvil regions", units="",
+                     cell_measures="area: area")
+def detect_anvils(flow, field, markers=None, upper_threshold=-5, lower_threshold=-15, erode_distance=1, min_length=3):
+    """Anvil extent by watershedding the combined edge field from eroded markers against an
+    eroded background seed (reference: detection.py:538-587)."""
+    field = linearise_field(_values(field), lower_threshold, upper_threshold)
+    s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
+    if markers is None:
+        markers = field >= 1
+    if hasattr(markers, "values"):
+        markers = markers.values
+    seeds = markers * ndi.binary_erosion(markers != 0, structure=s).astype(int)
+    seeds[get_watershed_mask(field, erode_distance=erode_distance)] = -1
+    edges = get_combined_edge_field(flow, field)
+    anvil_labels = flow.watershed(edges, seeds, mask=None, connectivity=ndi.generate_binary_structure(3, 1))
+    anvil_labels[anvil_labels < 0] = 0
+    anvil_labels *= ndi.binary_opening(anvil_labels != 0, structure=s).astype(int)
+    inside = markers > 0
+    anvil_labels[inside] = markers[inside]
+    lengths = find_object_lengths(anvil_labels)
+    touches_marker = mask_labels(anvil_labels, markers != 0)
+    return remap_labels(anvil_labels, np.logical_and(lengths > min_length, touches_marker))
+
+
+def get_watershed_mask(field, erode_distance: int = 1):
+    """Background seed: field <= 0 (or NaN), eroded by `erode_distance` in (t, y, x), NaNs kept
+    (reference: detection.py:590-617)."""
+    nan = np.isnan(field)
+    mask = ndi.binary_erosion(np.logical_or(field <= 0, nan), structure=np.ones([3, 3, 3]),
+                              iterations=erode_distance, border_value=1)
+    mask[nan] = True
+    return mask
+
+
+def get_combined_edge_field(flow, field, **kwargs):
+    """Uphill semi-Lagrangian Sobel edges (+1 where present) minus the field; NaN -> +inf
+    (reference: detection.py:620-642)."""
+    edges = flow.sobel(field, direction="uphill", method="cubic")
+    edges[edges > 0] += 1
+    edges = edges - field
+    edges[np.isnan(field)] = np.inf
+    return edges
+
+
+@configure_dataarray(name="anvil_label", drop_attrs=_DROP, long_name="Labels of detected anvil regions", units="",
+                     cell_measures="area: area")
+def relabel_anvils(flow, anvil_labels, markers=None, overlap: float = 0.5, absolute_overlap: int = 5,
+                   min_length: int = 3):
+    """Split anvils per time step and re-link them by flow overlap (reference: detection.py:660-687)."""
+    anvil_labels = flow.link_overlap(make_step_labels(anvil_labels), overlap=overlap,
+                                     absolute_overlap=absolute_overlap)
+    keep = find_object_lengths(anvil_labels) > min_length
+    if markers is not None:
+        keep = np.logical_and(keep, mask_labels(anvil_labels, _values(markers) != 0))
+    return remap_labels(anvil_labels, keep)

@@ -1,0 +1,288 @@
+"""Flow object API on the MI355X (mirrors /root/reference/tobac_flow/flow.py).
+
+Same public names, signatures, defaults and exceptions as the reference: `create_flow`,
+`calculate_flow`, `calculate_flow_2`, `calculate_flow_frame`, `smooth_flow_step`, `Flow` and the
+diagnostics.  cv2's Farnebaeck / remap calls are replaced by the HIP library
+(include/tobac_flow_hip.h); numpy inputs give numpy outputs, torch GPU tensors stay on the device.
+
+Not built yet: cv2.VariationalRefinement (`vr_steps > 0`, flow.py:359,513-519).  A
+RuntimeWarning is raised and the refinement step is skipped.
+"""
+import warnings
+from datetime import datetime
+from typing import Callable
+
+import numpy as np
+from scipy import ndimage as ndi
+
+from tobac_flow_amd import _lib
+from tobac_flow_amd.convolve import convolve, tag_func
+from tobac_flow_amd.core import AbstractFlow
+from tobac_flow_amd.label import flow_label, flow_link_overlap
+from tobac_flow_amd.sobel import sobel
+from tobac_flow_amd.utils import mse, select_normalisation_method, select_of_model, to_8bit, warp_flow  # noqa: F401
+from tobac_flow_amd.utils.flow_utils import select_interp_mode
+from tobac_flow_amd.utils.normalisation_utils import linear_norm, to_8bit_pair_dev
+from tobac_flow_amd.watershed import watershed
+
+
+def _is_dataarray(x):
+    return hasattr(x, "dims") and hasattr(x, "to_numpy")
+
+
+def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
+                interp_method: str = "linear", max_value=20) -> "Flow":
+    """Forward and backward optical flow along the leading dimension of `data`, clipped to
+    +-`max_value` pixels, wrapped in a Flow object (reference: flow.py:23-65)."""
+    forward_flow, backward_flow = calculate_flow(data, model=model, vr_steps=vr_steps,
+                                                 smoothing_passes=smoothing_passes, interp_method=interp_method)
+    t = _lib.torch()
+    if isinstance(forward_flow, t.Tensor):
+        T, H, W = forward_flow.shape[:3]
+        # mirroring already applied; this call only clips (the mirror is idempotent after it)
+        forward_flow = forward_flow.clamp(-max_value, max_value)
+        backward_flow = backward_flow.clamp(-max_value, max_value)
+    else:
+        forward_flow = np.minimum(np.maximum(forward_flow, -max_value), max_value)
+        backward_flow = np.minimum(np.maximum(backward_flow, -max_value), max_value)
+    return Flow(forward_flow, backward_flow)
+
+
+@tag_func(_lib.FUNC_DIFF)
+def _diff_func(x):
+    """flow.py:180-184: centred semi-Lagrangian difference, one-sided where a neighbour is missing."""
+    return (np.nansum([x[2] - x[1], x[1] - x[0]], axis=0) * 1
+            / np.maximum(np.sum([np.isfinite(x[2]), np.isfinite(x[0])], 0), 1))
+
+
+class Flow(AbstractFlow):
+    """Semi-Lagrangian operations using optical flow vectors (reference: flow.py:68-355).
+
+    `forward_flow` / `backward_flow`: (T, H, W, 2) arrays (numpy, or torch tensors on the GPU).
+    A float32 device copy is cached on first use; do not mutate the arrays afterwards.
+    """
+
+    def __init__(self, forward_flow, backward_flow) -> None:
+        if tuple(forward_flow.shape) != tuple(backward_flow.shape):
+            raise ValueError("Forward and backward flow vector arrays must have the same shape")
+        if forward_flow.shape[-1] != 2:
+            raise ValueError("Flow vectors must have a size of 2 in the trailing dimension")
+        self.shape = tuple(forward_flow.shape[:-1])
+        self.forward_flow = forward_flow
+        self.backward_flow = backward_flow
+        self._dev = None
+
+    @property
+    def flow(self):
+        return self.forward_flow, self.backward_flow
+
+    def __getitem__(self, items) -> "Flow":
+        return Flow(self.forward_flow[items], self.backward_flow[items])
+
+    def _dev_flows(self):
+        if self._dev is None:
+            t = _lib.torch()
+            self._dev = (_lib.to_dev(self.forward_flow, t.float32), _lib.to_dev(self.backward_flow, t.float32))
+        return self._dev
+
+    def convolve(self, data, structure=ndi.generate_binary_structure(3, 1), method: str = "linear",
+                 fill_value: float = np.nan, dtype: type = np.float32, func: Callable | None = None):
+        assert tuple(data.shape) == self.shape, "Data input must have the same shape as the Flow object"
+        return convolve(data, self.forward_flow, self.backward_flow, structure=structure, method=method,
+                        dtype=dtype, fill_value=fill_value, func=func, _dev_flows=self._dev_flows())
+
+    def diff(self, data, method: str = "linear", dtype: type = np.float32):
+        diff_struct = np.zeros([3, 3, 3])
+        diff_struct[:, 1, 1] = 1
+        return self.convolve(data, structure=diff_struct, func=_diff_func, method=method, dtype=dtype)
+
+    def sobel(self, data, method: str = "linear", dtype: type = None, fill_value: float = np.nan,
+              direction: str | None = None):
+        return sobel(data, self.forward_flow, self.backward_flow, method=method, dtype=dtype,
+                     fill_value=fill_value, direction=direction, _dev_flows=self._dev_flows())
+
+    def watershed(self, field, markers, mask=None, connectivity=1):
+        return watershed(self.forward_flow, self.backward_flow, field, markers, mask=mask,
+                         connectivity=connectivity, _dev_flows=self._dev_flows())
+
+    def label(self, data, structure=ndi.generate_binary_structure(3, 1), dtype: type = np.int32,
+              overlap: float = 0, absolute_overlap: int = 1, subsegment_shrink: float = 0,
+              peak_min_distance: int = 5):
+        return flow_label(self, data, structure=structure, dtype=dtype, overlap=overlap,
+                          absolute_overlap=absolute_overlap, subsegment_shrink=subsegment_shrink,
+                          peak_min_distance=peak_min_distance)
+
+    def link_overlap(self, data, structure=ndi.generate_binary_structure(3, 1), dtype: type = np.int32,
+                     overlap: float = 0, absolute_overlap: int = 1):
+        return flow_link_overlap(self, data, structure=structure, dtype=dtype, overlap=overlap,
+                                 absolute_overlap=absolute_overlap)
+
+
+class _VariationalRefinementStub:
+    """Placeholder for cv2.VariationalRefinement.create() (flow.py:359): not built yet."""
+
+    def calc(self, prev, nxt, flow):
+        warnings.warn("VariationalRefinement has no HIP implementation yet: flow returned unrefined",
+                      RuntimeWarning)
+        return flow
+
+
+vr_model = _VariationalRefinementStub()
+
+
+def _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_steps, interp_method):
+    """calculate_flow_frame on device uint8 tensors; returns device (fwd, bwd)."""
+    L = _lib.lib()
+    t = _lib.torch()
+    interp = select_interp_mode(interp_method) if smoothing_steps > 0 else 1
+    fwd, bwd = of_model.calc_pair_dev(prev8, next8)
+    if vr_steps > 0:
+        fwd = vr_model.calc(prev8, next8, fwd)
+        bwd = vr_model.calc(next8, prev8, bwd)
+    H, W = prev8.shape
+    for _ in range(smoothing_steps):
+        f2, b2 = t.empty_like(fwd), t.empty_like(bwd)
+        _lib.check(L.tf_smooth_flow_step(_lib.ptr(fwd), _lib.ptr(bwd), H, W, interp, _lib.ptr(f2), _lib.ptr(b2),
+                                         _lib.stream_ptr()), "tf_smooth_flow_step")
+        fwd, bwd = f2, b2
+    return fwd, bwd
+
+
+def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_passes, interp_method,
+                         norm_name, norm_method, normalisation_kwargs, on_device):
+    t = _lib.torch()
+    L = _lib.lib()
+    H, W = shape
+    forward = _lib.empty((T, H, W, 2), t.float32)
+    backward = _lib.empty((T, H, W, 2), t.float32)
+    forward.fill_(float("nan"))
+    backward.fill_(float("nan"))
+    for i in range(T - 1):
+        a, b = frame_pairs(i)
+        if norm_name == "linear" and not normalisation_kwargs:
+            prev8, next8 = to_8bit_pair_dev(a, b)
+        else:   # other normalisations are host glue (not on the production path)
+            pair = np.stack([a.cpu().numpy(), b.cpu().numpy()], 0)
+            p8 = to_8bit(norm_method(pair, **normalisation_kwargs), 0, 1)
+            prev8, next8 = _lib.to_dev(p8[0]), _lib.to_dev(p8[1])
+        f, bk = _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_passes, interp_method)
+        forward[i].copy_(f)
+        backward[i + 1].copy_(bk)
+    # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping here
+    _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, float("inf"), _lib.stream_ptr()),
+               "tf_flow_finalize")
+    if on_device:
+        return forward, backward
+    return forward.cpu().numpy(), backward.cpu().numpy()
+
+
+def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
+                   interp_method: str = "linear", normalisation_method: str = "linear", **normalisation_kwargs):
+    """Forward / backward flow for every consecutive frame pair of `data` (reference: flow.py:362-428).
+    forward[i] = flow i -> i+1, backward[i+1] = flow i+1 -> i; the end frames are mirrored."""
+    of_model = select_of_model(model)
+    norm_method = select_normalisation_method(normalisation_method)
+    t = _lib.torch()
+    if _is_dataarray(data):
+        data = data.compute().data if hasattr(data, "compute") else data.to_numpy()
+    on_device = isinstance(data, t.Tensor)
+    d = _lib.to_dev(data, t.float32)
+    if d.dim() != 3:
+        raise ValueError("data must have three dimensions (t, y, x)")
+    T = d.shape[0]
+    return _calculate_flow_impl(lambda i: (d[i], d[i + 1]), T, tuple(d.shape[1:]), of_model, vr_steps,
+                                smoothing_passes, interp_method, normalisation_method, norm_method,
+                                normalisation_kwargs, on_device)
+
+
+def calculate_flow_2(a, b, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
+                     normalisation_method: str = "linear", **normalisation_kwargs):
+    """Flow between the frames of two stacks, a[i] -> b[i] (reference: flow.py:431-496)."""
+    of_model = select_of_model(model)
+    norm_method = select_normalisation_method(normalisation_method)
+    t = _lib.torch()
+    if _is_dataarray(a):
+        a = a.compute().data if hasattr(a, "compute") else a.to_numpy()
+    if _is_dataarray(b):
+        b = b.compute().data if hasattr(b, "compute") else b.to_numpy()
+    on_device = isinstance(a, t.Tensor)
+    da, db = _lib.to_dev(a, t.float32), _lib.to_dev(b, t.float32)
+    T = da.shape[0]
+    return _calculate_flow_impl(lambda i: (da[i], db[i]), T, tuple(da.shape[1:]), of_model, vr_steps,
+                                smoothing_passes, "linear", normalisation_method, norm_method,
+                                normalisation_kwargs, on_device)
+
+
+def calculate_flow_frame(prev_frame, next_frame, of_model, vr_steps: int = 0, smoothing_steps: int = 0,
+                         interp_method: str = "linear"):
+    """Forward and backward flow between two uint8 images (reference: flow.py:499-527)."""
+    t = _lib.torch()
+    on_device = isinstance(prev_frame, t.Tensor)
+    p, n = _lib.to_dev(prev_frame), _lib.to_dev(next_frame)
+    if p.dtype != t.uint8 or n.dtype != t.uint8:
+        raise ValueError("frames must be uint8 (see to_8bit)")
+    f, b = _pair_flows_dev(p, n, of_model, vr_steps, smoothing_steps, interp_method)
+    return (f, b) if on_device else (f.cpu().numpy(), b.cpu().numpy())
+
+
+def smooth_flow_step(forward_flow, backward_flow, method: str = "linear"):
+    """f' = nanmean(f, -warp(b by f)), b' = nanmean(b, -warp(f by b)) (reference: flow.py:530-568)."""
+    t = _lib.torch()
+    L = _lib.lib()
+    interp = select_interp_mode(method)
+    on_device = isinstance(forward_flow, t.Tensor)
+    f, b = _lib.to_dev(forward_flow, t.float32), _lib.to_dev(backward_flow, t.float32)
+    H, W = f.shape[:2]
+    f2, b2 = t.empty_like(f), t.empty_like(b)
+    _lib.check(L.tf_smooth_flow_step(_lib.ptr(f), _lib.ptr(b), H, W, interp, _lib.ptr(f2), _lib.ptr(b2),
+                                     _lib.stream_ptr()), "tf_smooth_flow_step")
+    return (f2, b2) if on_device else (f2.cpu().numpy(), b2.cpu().numpy())
+
+
+# ---- diagnostics (host numpy; reference: flow.py:571-666) -------------------------------------------
+def combine_flow(*args):
+    def blend(pick):
+        mags = [((pick(f)[..., 0] ** 2 + pick(f)[..., 1] ** 2) ** 0.5)[..., np.newaxis] for f in args]
+        return sum(pick(f) * m for f, m in zip(args, mags)) / sum(mags)
+    return Flow(blend(lambda f: f.forward_flow), blend(lambda f: f.backward_flow))
+
+
+def get_forward_warp(da, flow):
+    forward_struct = np.zeros([3, 3, 3], dtype=bool)
+    forward_struct[2, 1, 1] = True
+    return flow.convolve(da.data, forward_struct)[0]
+
+
+def flow_diff_mse_estimate(da, flow):
+    fw = get_forward_warp(da, flow)
+    cold = da.data < 273
+    return mse(fw, da.data), mse(fw[cold], da.data[cold])
+
+
+def get_flow_residual(da, flow, model="Farneback", vr_steps=1, smoothing_passes=1):
+    new_flow, _ = calculate_flow_2(da.data, get_forward_warp(da, flow), model=model, vr_steps=vr_steps,
+                                   smoothing_passes=smoothing_passes)
+    return new_flow
+
+
+def flow_magnitude(flow, direction="forward"):
+    if direction == "forward":
+        v = flow.forward_flow
+    elif direction == "backward":
+        v = flow.backward_flow
+    else:
+        raise ValueError("Direction must be one of 'forward', 'backward'")
+    return (v[..., 0] ** 2 + v[..., 1] ** 2) ** 0.5
+
+
+def flow_residual_mse_estimate(da, flow, model="Farneback", vr_steps=1, smoothing_passes=1):
+    nf = get_flow_residual(da, flow, model=model, vr_steps=vr_steps, smoothing_passes=smoothing_passes)
+    mag = ((nf[..., 0] ** 2 + nf[..., 1] ** 2) ** 0.5)[:, 20:-20, 20:-20]
+    cold = da.data[:, 20:-20, 20:-20] < 273
+    return mse(mag, np.zeros_like(mag)), mse(mag[cold], np.zeros_like(mag[cold]))
+
+
+def time_flow(da, model="Farneback", vr_steps=1, smoothing_passes=1):
+    start = datetime.now()
+    create_flow(da, model=model, vr_steps=vr_steps, smoothing_passes=smoothing_passes)
+    return (datetime.now() - start).total_seconds()

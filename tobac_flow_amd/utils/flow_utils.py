@@ -1,0 +1,92 @@
+"""Optical-flow model factory and single-image warp (mirrors
+/root/reference/tobac_flow/utils/flow_utils.py with cv2 replaced by the HIP library)."""
+import numpy as np
+
+from tobac_flow_amd import _lib
+
+border_modes = ("constant", "nearest", "reflect", "mirror", "wrap", "isolated", "transparent")
+interp_modes = ("nearest", "linear", "cubic", "lanczos")
+_MODELS = ("Farneback", "DeepFlow", "PCA", "SimpleFlow", "SparseToDense", "DIS", "DenseRLOF", "DualTVL1")
+
+
+def select_border_mode(mode: str):
+    if mode not in border_modes:
+        raise ValueError("Invalid border mode")
+    if mode != "constant":
+        raise NotImplementedError(f"border mode '{mode}' has no HIP kernel (only 'constant')")
+    return mode
+
+
+def select_interp_mode(mode: str):
+    if mode not in interp_modes:
+        raise ValueError("Invalid border mode")
+    if mode == "lanczos":
+        raise NotImplementedError("interpolation 'lanczos' has no HIP kernel (nearest / linear / cubic do)")
+    return _lib.INTERP[mode]
+
+
+class FarnebackFlow:
+    """Stand-in for the object returned by cv2.optflow.createOptFlow_Farneback()
+    (flow_utils.py:52-53): `.calc(prev, next, None)` -> (H, W, 2) float32 flow, OpenCV defaults."""
+
+    def __init__(self, num_levels=5, pyr_scale=0.5, win_size=13, num_iters=10, poly_n=5, poly_sigma=1.1):
+        self.params = _lib.FarnebackParams(num_levels, pyr_scale, win_size, num_iters, poly_n, poly_sigma)
+
+    def calc_pair_dev(self, prev, nxt, want_fwd=True, want_bwd=True):
+        """Both directions at once on device uint8 tensors (they share pyramid + expansion)."""
+        import ctypes
+        t = _lib.torch()
+        L = _lib.lib()
+        H, W = prev.shape
+        fwd = _lib.empty((H, W, 2), t.float32) if want_fwd else None
+        bwd = _lib.empty((H, W, 2), t.float32) if want_bwd else None
+        nbytes = L.tf_farneback_workspace_bytes(H, W, ctypes.byref(self.params))
+        ws = _lib.workspace(nbytes, "farneback")
+        rc = L.tf_farneback_pair(_lib.ptr(prev), _lib.ptr(nxt), H, W, ctypes.byref(self.params),
+                                 _lib.ptr(fwd), _lib.ptr(bwd), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "tf_farneback_pair")
+        return fwd, bwd
+
+    def calc(self, prev, nxt, flow=None):
+        t = _lib.torch()
+        on_device = isinstance(prev, t.Tensor)
+        p, n = _lib.to_dev(prev), _lib.to_dev(nxt)
+        if p.dtype != t.uint8 or n.dtype != t.uint8:
+            raise ValueError("Farneback input frames must be uint8")
+        if p.shape != n.shape or p.dim() != 2:
+            raise ValueError("prev and next must be 2-D arrays of the same shape")
+        fwd, _ = self.calc_pair_dev(p, n, True, False)
+        return fwd if on_device else fwd.cpu().numpy()
+
+
+def select_of_model(model: str):
+    """Optical-flow model by name (reference: flow_utils.py:37-77).  Only 'Farneback' -- the model
+    the production scripts use -- exists on the MI355X; the other OpenCV model names are recognised
+    and raise NotImplementedError, unknown names raise ValueError like the reference."""
+    if model == "Farneback":
+        return FarnebackFlow()
+    if model == "DenseRLOF":
+        raise NotImplementedError("DenseRLOF requires multi-channel input which is currently not implemented")
+    if model in _MODELS:
+        raise NotImplementedError(f"optical-flow model '{model}' has no HIP implementation (only 'Farneback')")
+    raise ValueError("'model' parameter must be one of: 'Farneback', 'DeepFlow', 'PCA', 'SimpleFlow', "
+                     "'SparseToDense', 'DIS', 'DenseRLOF', 'DualTVL1'")
+
+
+def warp_flow(img, flow, method: str = "linear", border: str = "constant"):
+    """Warp an image by a set of flow vectors (reference: flow_utils.py:80-99; border value NaN)."""
+    t = _lib.torch()
+    L = _lib.lib()
+    interp = select_interp_mode(method)
+    select_border_mode(border)
+    on_device = isinstance(img, t.Tensor)
+    i, f = _lib.to_dev(img, t.float32), _lib.to_dev(flow, t.float32)
+    H, W = f.shape[:2]
+    if tuple(i.shape) != (H, W) or f.shape[-1] != 2:
+        raise ValueError("img must be (H, W) and flow (H, W, 2)")
+    out = _lib.empty((H, W), t.float32)
+    _lib.check(L.tf_warp_flow(_lib.ptr(i), _lib.ptr(f), H, W, interp, _lib.ptr(out), _lib.stream_ptr()), "tf_warp_flow")
+    return out if on_device else out.cpu().numpy()
+
+
+__all__ = ("select_border_mode", "select_interp_mode", "select_of_model", "warp_flow")

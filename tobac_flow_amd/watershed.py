@@ -1,0 +1,116 @@
+"""Watershed segmentation in a semi-Lagrangian framework, on the MI355X.
+
+Mirrors /root/reference/tobac_flow/watershed.py:17-168 (same signature, coercions and
+ValueErrors).  The reference pads the volume and calls its Cython heap flood
+(tobac_flow/_watershed.pyx:222-344); here the whole flood runs in HIP (tf_watershed,
+include/tobac_flow_hip.h) on the unpadded volume: out-of-volume neighbours are rejected by
+coordinate tests, which is what the zero-padded mask achieves in the reference.
+"""
+import numpy as np
+import scipy.ndimage as ndi
+
+from tobac_flow_amd import _lib
+
+# Neighbour orders of skimage.morphology._util._offsets_to_raveled_neighbors for
+# ndi.generate_binary_structure(3, k) as (dt, dy, dx): skimage sorts by L1 distance with numpy's
+# default NON-stable argsort, so the order is data, not derivable (watershed.py:114-116;
+# recorded from scikit-image 0.18.3 / numpy 1.26 by tests/golden/make_watershed_golden.py).
+_NEIGHBOUR_ORDER = {
+    1: [(-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 1), (0, 1, 0), (1, 0, 0)],
+    2: [(-1, 0, 0), (0, 0, -1), (0, -1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 0), (-1, 0, -1), (0, -1, 1),
+        (0, -1, -1), (-1, 1, 0), (-1, 0, 1), (0, 1, -1), (0, 1, 1), (1, -1, 0), (-1, -1, 0), (1, 0, -1),
+        (1, 0, 1), (1, 1, 0)],
+    3: [(-1, 0, 0), (0, -1, 0), (0, 0, -1), (0, 0, 1), (0, 1, 0), (1, 0, 0), (-1, -1, 0), (0, -1, -1),
+        (0, -1, 1), (0, 1, -1), (-1, 1, 0), (0, 1, 1), (1, -1, 0), (-1, 0, 1), (-1, 0, -1), (1, 0, 1),
+        (1, 0, -1), (1, 1, 0), (-1, 1, -1), (-1, 1, 1), (-1, -1, -1), (-1, -1, 1), (1, -1, -1),
+        (1, -1, 1), (1, 1, -1), (1, 1, 1)],
+}
+
+DEFAULT_CHAIN_DEPTH = 3
+
+
+def neighbour_offsets(connectivity, ndim=3):
+    """(n, 3) int8 neighbour list in the reference's order (skimage `_validate_connectivity` +
+    `_offsets_to_raveled_neighbors`).  Non-standard structuring elements are ordered by a stable
+    sort on L1 distance (documented deviation: skimage's order for those is not reproducible)."""
+    if connectivity is None:
+        connectivity = 1
+    if np.isscalar(connectivity):
+        selem = ndi.generate_binary_structure(ndim, int(connectivity))
+    else:
+        selem = np.array(connectivity, bool)
+        if selem.ndim != ndim:
+            raise ValueError("Connectivity dimension must be same as image")
+        if any(s % 2 == 0 for s in selem.shape):
+            raise ValueError("Connectivity array must have an unambiguous center")
+    if selem.shape != (3, 3, 3):
+        raise ValueError("connectivity must be an integer or a (3, 3, 3) structuring element")
+    for k, order in _NEIGHBOUR_ORDER.items():
+        if np.array_equal(selem, ndi.generate_binary_structure(3, k)):
+            return np.array(order, np.int8)
+    offs = np.stack(np.nonzero(selem), -1) - 1
+    dist = np.abs(offs).sum(1)
+    offs = offs[np.argsort(dist, kind="stable")]
+    return np.ascontiguousarray(offs[np.abs(offs).sum(1) > 0], np.int8)
+
+
+def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None):
+    """Device-resident core: torch tensors in (field f32, markers i32, mask i8 or None), labels out."""
+    t = _lib.torch()
+    L = _lib.lib()
+    T, H, W = field.shape
+    labels = _lib.empty((T, H, W), t.int32)
+    nbytes = L.tf_watershed_workspace_bytes(T, H, W, chain_depth)
+    ws = _lib.workspace(nbytes, "watershed")
+    st = np.zeros(8, np.int64)
+    nbr = np.ascontiguousarray(nbr, np.int8)
+    rc = L.tf_watershed(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
+                        T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), chain_depth, _lib.ptr(labels),
+                        _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr())
+    _lib.check(rc, "tf_watershed")
+    if stats is not None:
+        stats["sweeps"] = st.tolist()
+    return labels
+
+
+def watershed(
+    forward_flow: np.ndarray,
+    backward_flow: np.ndarray,
+    field: np.ndarray,
+    markers: np.ndarray,
+    mask: np.ndarray | None = None,
+    connectivity: int | np.ndarray = 1,
+    _dev_flows=None,
+    chain_depth: int = DEFAULT_CHAIN_DEPTH,
+) -> np.ndarray:
+    """Watershed segmentation of a sequence of images in a semi-Lagrangian framework
+    (reference: watershed.py:17-168).  Returns int32 labels with the shape of `field`."""
+    t = _lib.torch()
+    on_device = isinstance(field, t.Tensor)
+    if hasattr(field, "to_numpy") and not isinstance(field, (np.ndarray, t.Tensor)):
+        field = field.to_numpy()
+    if hasattr(markers, "to_numpy") and not isinstance(markers, (np.ndarray, t.Tensor)):
+        markers = markers.to_numpy()
+    if tuple(markers.shape) != tuple(field.shape):
+        raise ValueError(f"`markers` (shape {tuple(markers.shape)}) must have same "
+                         f"shape as `image` (shape {tuple(field.shape)})")
+    if mask is not None and tuple(mask.shape) != tuple(field.shape):
+        raise ValueError(f"`mask` (shape {tuple(mask.shape)}) must have same shape "
+                         f"as `image` (shape {tuple(field.shape)})")
+    if len(field.shape) != 3:
+        raise ValueError("field must have three dimensions (t, y, x)")
+    nbr = neighbour_offsets(connectivity, 3)
+    f = _lib.to_dev(field, t.float32)                    # watershed.py:64-65
+    m = _lib.to_dev(markers, t.int32)                    # watershed.py:72-73
+    k = None if mask is None else _lib.to_dev(mask).to(t.int8)   # watershed.py:78-79
+    if _dev_flows is not None:
+        fwd, bwd = _dev_flows
+    else:
+        fwd, bwd = _lib.to_dev(forward_flow, t.float32), _lib.to_dev(backward_flow, t.float32)
+    if tuple(fwd.shape) != tuple(field.shape) + (2,):
+        raise ValueError("flow vectors must have shape field.shape + (2,)")
+    out = watershed_dev(fwd, bwd, f, m, k, nbr, chain_depth)
+    return out if on_device else out.cpu().numpy()
+
+
+__all__ = ("watershed", "watershed_dev", "neighbour_offsets")
