@@ -137,8 +137,15 @@ int tf_convolve(const void *data, int data_type, int64_t T, int64_t H, int64_t W
  *   labels   (T, H, W) int32 out
  * No padding is needed: out-of-volume neighbours are rejected by coordinate tests, which is what
  * the reference's zero-padded mask achieves (watershed.py:111-113).
- * stats_host (optional, 8 x int64): sweeps per phase etc.  This call synchronises the stream. */
-size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int chain_depth);
+ * Workspace: the flood keys live in compact arrays over the RELEVANT pixels (floodable pixels +
+ * markers that touch one).  tf_watershed_workspace_bytes(..., max_relevant) sizes the workspace for
+ * at most that many (0 = worst case T*H*W).  If the volume has more, tf_watershed returns
+ * TF_ENOMEM and stats_host[6] holds the exact count to size a retry with.
+ * stats_host (optional, 8 x int64): [0] sweeps phase A, [1] sweeps root phase (fast path),
+ * [2..4] sweeps of the chain phases when the fast path found a label conflict, [5] conflict flag,
+ * [6] relevant pixel count.  This call synchronises the stream. */
+size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int n_nbr, int chain_depth,
+                                    int64_t max_relevant);
 int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
                  const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                  const int8_t *nbr_host, int n_nbr, int chain_depth, int32_t *labels,

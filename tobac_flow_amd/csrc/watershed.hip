@@ -19,21 +19,33 @@
 // Ties between equal-valued MARKERS (age 0 in the reference, heap-internal order there) are
 // broken by push order = raster index.
 //
-// Data layout (all in the caller's workspace, N = T*H*W):
-//   state u8[N] (0 off / 1 floodable / 2 marker), off int16x4[N] rounded (fx, fy, bx, by),
-//   K2, M1, C_1..C_{depth-1}, R, pushed : uint64[N].
-// Every sweep is one launch over the volume; a pixel re-pushes only when its own key changed
-// since its last push (pushed[]), so converged regions cost one 8-byte compare per sweep.
+// Fast path: phase A, then phase R with candidates matched on K2 only.  If afterwards every
+// candidate edge p -> n joins equal labels, the labelling does not depend on any tie-break and is
+// final (induction over strata); otherwise the chain phases run.  Tie-free fields and the
+// detect_anvils plateau structure normally finish on the fast path.
+//
+// Data layout: the volume itself only carries cid int32[N] (compact id of floodable pixels,
+// -2-id for boundary markers, -1 for everything else) and cls u8[N].  All keys live in COMPACT
+// arrays over the R = (#floodable + #boundary markers) relevant pixels, ids in raster order:
+//   pix u64[R] raster index (top bit: marker), val u32[R] ordered field key, nbr int32[R][n_nbr] compact ids of the
+//   floodable out-neighbours (flow displacement already applied), K2, M1, C_1.., Rt, pushed u64[R].
+// A sweep is one launch over the compact arrays; each workgroup makes several relaxation rounds
+// per launch and a pixel re-pushes only when its own key changed since its last push.
 #include "tf_common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <hipcub/hipcub.hpp>
 
 typedef unsigned long long u64;
 #define WS_INF 0xFFFFFFFFFFFFFFFFull
 #define WS_NEVER 0xFFFFFFFFFFFFFFFEull
+#define WS_MARKER_BIT 0x8000000000000000ull
 #define WS_MAX_NBR 26
 #define WS_MAX_DEPTH 8
-#define WS_BATCH 8
+#define WS_BATCH 4
+#ifndef WS_ROUNDS
+#define WS_ROUNDS 6
+#endif
 
 struct WsGeom {
     int64_t T; int H, W; int64_t plane;
@@ -41,15 +53,16 @@ struct WsGeom {
     int8_t dt[WS_MAX_NBR], dy[WS_MAX_NBR], dx[WS_MAX_NBR];
 };
 
-struct WsArrays {
-    const float *field; const uint8_t *state; const short4 *off;
-    u64 *K2, *M1, *C[WS_MAX_DEPTH], *R, *pushed;
+struct WsC {               // compact arrays
+    int64_t R; int n_nbr;
+    const u64 *pix; const unsigned *val; const int *nbr;
+    u64 *K2, *M1, *C[WS_MAX_DEPTH], *Rt, *pushed;
 };
 
-__device__ __forceinline__ u64 ws_ordkey(float v) {
+__device__ __forceinline__ unsigned ws_ordkey(float v) {
     v = v + 0.0f;                                    // -0.0 -> +0.0 (they compare equal in the reference)
     unsigned u = __float_as_uint(v);
-    return (u64)((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ u64 ws_load(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -59,73 +72,125 @@ __device__ __forceinline__ int ws_round_flow(float f) {
     return (f == f) ? __float2int_rn(f) : 0;
 }
 
-__global__ void __launch_bounds__(256)
-k_ws_init(const float *__restrict__ field, const int32_t *__restrict__ markers, const int8_t *__restrict__ mask,
-          const float *__restrict__ fwd, const float *__restrict__ bwd, WsGeom g,
-          uint8_t *__restrict__ state, short4 *__restrict__ off, u64 *__restrict__ K2, u64 *__restrict__ M1)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    const int64_t t = blockIdx.z;
-    if (x >= g.W || y >= g.H) return;
-    const int64_t p = t * g.plane + (int64_t)y * g.W + x;
-    const int32_t m = markers[p];
-    const bool on = mask ? mask[p] != 0 : true;
-    state[p] = m != 0 ? 2 : (on ? 1 : 0);
-    float2 f = ((const float2 *)fwd)[p], b = ((const float2 *)bwd)[p];
-    off[p] = make_short4((short)ws_round_flow(f.x), (short)ws_round_flow(f.y),
-                         (short)ws_round_flow(b.x), (short)ws_round_flow(b.y));
-    K2[p] = m != 0 ? (ws_ordkey(field[p]) << 32) : WS_INF;
-    M1[p] = WS_INF;
-}
-
-__global__ void __launch_bounds__(256) k_ws_fill(u64 *__restrict__ a, int64_t n, u64 v) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = v;
-}
-
-// chain arrays of a marker: C_k = 0 for every k; R = raster index
-__global__ void __launch_bounds__(256)
-k_ws_init_level(const uint8_t *__restrict__ state, u64 *__restrict__ Ck, u64 *__restrict__ pushed, int64_t n, int is_root) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Ck[i] = state[i] == 2 ? (is_root ? (u64)i : 0ull) : WS_INF;
-    pushed[i] = WS_NEVER;
-}
-
 // neighbour of p = (t, y, x) through slot i, or -1 (watershed.pyx:310-313 without the padding)
-__device__ __forceinline__ int64_t ws_neighbour(const WsGeom &g, int64_t t, int y, int x, short4 o, int i) {
+__device__ __forceinline__ int64_t ws_neighbour(const WsGeom &g, int64_t t, int y, int x, int fx, int fy, int bx, int by, int i) {
     const int dt = g.dt[i];
     int yy = y + g.dy[i], xx = x + g.dx[i];
-    if (dt == 1) { xx += o.x; yy += o.y; }
-    else if (dt == -1) { xx += o.z; yy += o.w; }
+    if (dt == 1) { xx += fx; yy += fy; }
+    else if (dt == -1) { xx += bx; yy += by; }
     const int64_t tt = t + dt;
     if (tt < 0 || tt >= g.T || (unsigned)yy >= (unsigned)g.H || (unsigned)xx >= (unsigned)g.W) return -1;
     return tt * g.plane + (int64_t)yy * g.W + xx;
 }
 
-// ---- phase A: K2 and M1 ------------------------------------------------------------------------
+// cls: 0 = not floodable, 1 = floodable (mask set, no marker), 2 = marker
 __global__ void __launch_bounds__(256)
-k_ws_relax_a(WsGeom g, WsArrays a, int *__restrict__ changed)
+k_ws_classify(const int32_t *__restrict__ markers, const int8_t *__restrict__ mask, int64_t n, uint8_t *__restrict__ cls)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t m = markers[i];
+    cls[i] = m != 0 ? 2 : ((mask ? mask[i] != 0 : true) ? 1 : 0);
+}
+
+// flag = 1 for floodable pixels and for markers with at least one floodable out-neighbour
+__global__ void __launch_bounds__(256)
+k_ws_relevant(const uint8_t *__restrict__ cls, const float *__restrict__ fwd, const float *__restrict__ bwd, WsGeom g,
+              uint8_t *__restrict__ flag)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     const int64_t t = blockIdx.z;
     if (x >= g.W || y >= g.H) return;
     const int64_t p = t * g.plane + (int64_t)y * g.W + x;
-    if (a.state[p] == 0) return;
-    const u64 kp = ws_load(&a.K2[p]);
-    if (kp == WS_INF || kp == a.pushed[p]) return;
-    a.pushed[p] = kp;
-    const u64 lp = kp >> 32;
-    const short4 o = a.off[p];
-    bool ch = false;
+    const uint8_t c = cls[p];
+    uint8_t f = c == 1;
+    if (c == 2) {
+        const float2 fw = ((const float2 *)fwd)[p], bw = ((const float2 *)bwd)[p];
+        const int fx = ws_round_flow(fw.x), fy = ws_round_flow(fw.y), bx = ws_round_flow(bw.x), by = ws_round_flow(bw.y);
+        for (int i = 0; i < g.n_nbr && !f; i++) {
+            const int64_t n = ws_neighbour(g, t, y, x, fx, fy, bx, by, i);
+            if (n >= 0 && cls[n] == 1) f = 1;
+        }
+    }
+    flag[p] = f;
+}
+
+// cid from the exclusive scan of flag: id (floodable), -2-id (boundary marker), -1 otherwise
+__global__ void __launch_bounds__(256)
+k_ws_cid(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, const int *__restrict__ scan, int64_t n,
+         int *__restrict__ cid)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = -1;
+    if (flag[i]) c = cls[i] == 1 ? scan[i] : -2 - scan[i];
+    cid[i] = c;
+}
+
+__global__ void __launch_bounds__(256)
+k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, const float *__restrict__ bwd,
+             const int *__restrict__ cid, WsGeom g, u64 *__restrict__ pix, unsigned *__restrict__ val,
+             int *__restrict__ nbr, u64 *__restrict__ K2, u64 *__restrict__ M1, u64 *__restrict__ pushed)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const int64_t p = t * g.plane + (int64_t)y * g.W + x;
+    const int c = cid[p];
+    if (c == -1) return;
+    const bool marker = c < 0;
+    const int64_t id = marker ? -2 - c : c;
+    const float2 fw = ((const float2 *)fwd)[p], bw = ((const float2 *)bwd)[p];
+    const int fx = ws_round_flow(fw.x), fy = ws_round_flow(fw.y), bx = ws_round_flow(bw.x), by = ws_round_flow(bw.y);
+    const unsigned v = ws_ordkey(field[p]);
+    pix[id] = (u64)p | (marker ? WS_MARKER_BIT : 0ull);
+    val[id] = v;
     for (int i = 0; i < g.n_nbr; i++) {
-        const int64_t n = ws_neighbour(g, t, y, x, o, i);
-        if (n < 0 || a.state[n] != 1) continue;
-        const u64 vn = ws_ordkey(a.field[n]);
-        const u64 cand = vn > lp ? ((vn << 32) | 1ull) : (vn == lp ? kp + 1ull : kp);
-        const u64 old = atomicMin(&a.K2[n], cand);
-        ch |= cand < old;
-        atomicMin(&a.M1[n], kp);
+        const int64_t n = ws_neighbour(g, t, y, x, fx, fy, bx, by, i);
+        int cn = -1;
+        if (n >= 0) { cn = cid[n]; if (cn < 0) cn = -1; }
+        nbr[id * g.n_nbr + i] = cn;
+    }
+    K2[id] = marker ? ((u64)v << 32) : WS_INF;
+    M1[id] = WS_INF;
+    pushed[id] = WS_NEVER;
+}
+
+// chain arrays of a marker: C_k = 0 for every k; root = raster index
+__global__ void __launch_bounds__(256)
+k_ws_init_level(const u64 *__restrict__ K2, const u64 *__restrict__ pix, const unsigned *__restrict__ val,
+                u64 *__restrict__ dst, u64 *__restrict__ pushed, int64_t R, int is_root)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const u64 px = pix[i];
+    const bool marker = (px & WS_MARKER_BIT) != 0ull;
+    dst[i] = marker ? (is_root ? (px & ~WS_MARKER_BIT) : 0ull) : WS_INF;
+    pushed[i] = WS_NEVER;
+}
+
+// ---- phase A: K2 and M1 ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_ws_relax_a(WsC c, int *__restrict__ changed)
+{
+    bool ch = false;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < c.R) {
+        for (int round = 0; round < WS_ROUNDS; round++) {
+            const u64 kp = ws_load(&c.K2[p]);
+            if (kp == WS_INF || kp == c.pushed[p]) { if (round) __builtin_amdgcn_s_sleep(2); continue; }
+            c.pushed[p] = kp;
+            const u64 lp = kp >> 32;
+            for (int i = 0; i < c.n_nbr; i++) {
+                const int n = c.nbr[p * c.n_nbr + i];
+                if (n < 0) continue;
+                const u64 vn = c.val[n];
+                const u64 cand = vn > lp ? ((vn << 32) | 1ull) : (vn == lp ? kp + 1ull : kp);
+                const u64 old = atomicMin(&c.K2[n], cand);
+                ch |= cand < old;
+                atomicMin(&c.M1[n], kp);
+            }
+        }
     }
     if (ch) *changed = 1;
 }
@@ -137,74 +202,114 @@ k_ws_relax_a(WsGeom g, WsArrays a, int *__restrict__ changed)
 //   otherwise n continues p's run / descent: chain = [K2 n, tail(p)] -> offered_j = C_j[p]
 // The candidate must agree with n on every level j < k.
 __global__ void __launch_bounds__(256)
-k_ws_relax_chain(WsGeom g, WsArrays a, int k, int depth, int *__restrict__ changed)
+k_ws_relax_chain(WsC c, int k, int depth, int *__restrict__ changed)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    const int64_t t = blockIdx.z;
-    if (x >= g.W || y >= g.H) return;
-    const int64_t p = t * g.plane + (int64_t)y * g.W + x;
-    if (a.state[p] == 0) return;
-    const u64 kp = a.K2[p];                      // final since phase A
-    if (kp == WS_INF) return;
-    u64 *dst = k == depth ? a.R : a.C[k];
-    const u64 own = ws_load(&dst[p]);
-    if (own == a.pushed[p]) return;              // nothing new to offer (first visit: pushed = NEVER)
-    a.pushed[p] = own;
-    const short4 o = a.off[p];
     bool ch = false;
-    for (int i = 0; i < g.n_nbr; i++) {
-        const int64_t n = ws_neighbour(g, t, y, x, o, i);
-        if (n < 0 || a.state[n] != 1) continue;
-        if (a.M1[n] != kp) continue;
-        const u64 kn = a.K2[n];
-        const bool entry = (kn >> 32) == ws_ordkey(a.field[n]) && (kn & 0xFFFFFFFFull) == 1ull;
-        bool match = true;
-        for (int j = 1; j < k && match; j++) {
-            const u64 offered_j = entry ? (j == 1 ? kp : a.C[j - 1][p]) : a.C[j][p];
-            match = offered_j == a.C[j][n];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < c.R) {
+        const u64 kp = c.K2[p];                      // final since phase A
+        u64 *dst = k == depth ? c.Rt : c.C[k];
+        if (kp != WS_INF) {
+            for (int round = 0; round < WS_ROUNDS; round++) {
+                const u64 own = ws_load(&dst[p]);
+                if (own == c.pushed[p]) { if (round) __builtin_amdgcn_s_sleep(2); continue; }
+                c.pushed[p] = own;
+                for (int i = 0; i < c.n_nbr; i++) {
+                    const int n = c.nbr[p * c.n_nbr + i];
+                    if (n < 0) continue;
+                    if (c.M1[n] != kp) continue;
+                    const u64 kn = c.K2[n];
+                    const bool entry = (kn >> 32) == (u64)c.val[n] && (kn & 0xFFFFFFFFull) == 1ull;
+                    bool match = true;
+                    for (int j = 1; j < k && match; j++) {
+                        const u64 offered_j = entry ? (j == 1 ? kp : c.C[j - 1][p]) : c.C[j][p];
+                        match = offered_j == c.C[j][n];
+                    }
+                    if (!match) continue;
+                    u64 offered;
+                    if (k == depth) offered = own;                                    // root: copied along every edge
+                    else offered = entry ? (k == 1 ? kp : c.C[k - 1][p]) : own;
+                    if (offered == WS_INF) continue;
+                    const u64 old = atomicMin(&dst[n], offered);
+                    ch |= offered < old;
+                }
+            }
         }
-        if (!match) continue;
-        u64 offered;
-        if (k == depth) offered = own;                                    // root: copied along every edge
-        else offered = entry ? (k == 1 ? kp : a.C[k - 1][p]) : own;
-        if (offered == WS_INF) continue;
-        const u64 old = atomicMin(&dst[n], offered);
-        ch |= offered < old;
     }
     if (ch) *changed = 1;
 }
 
+// after the K2-only root phase: does any candidate edge join two different labels?
 __global__ void __launch_bounds__(256)
-k_ws_labels(const int32_t *__restrict__ markers, const uint8_t *__restrict__ state, const u64 *__restrict__ R,
+k_ws_conflicts(WsC c, const int32_t *__restrict__ markers, int *__restrict__ conflict)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= c.R) return;
+    const u64 kp = c.K2[p];
+    if (kp == WS_INF) return;
+    const u64 rp = c.Rt[p];
+    if (rp == WS_INF) return;
+    const int32_t lp = markers[rp];
+    bool bad = false;
+    for (int i = 0; i < c.n_nbr; i++) {
+        const int n = c.nbr[p * c.n_nbr + i];
+        if (n < 0 || c.M1[n] != kp) continue;
+        const u64 rn = c.Rt[n];
+        bad |= rn == WS_INF || markers[rn] != lp;
+    }
+    if (bad) *conflict = 1;
+}
+
+__global__ void __launch_bounds__(256)
+k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, const u64 *__restrict__ Rt,
             int32_t *__restrict__ labels, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint8_t s = state[i];
-    int32_t l = 0;
-    if (s == 2) l = markers[i];
-    else if (s == 1) { const u64 r = R[i]; if (r != WS_INF) l = markers[r]; }
+    int32_t l = markers[i];
+    const int c = cid[i];
+    if (l == 0 && c >= 0) { const u64 r = Rt[c]; if (r != WS_INF) l = markers[r]; }
     labels[i] = l;
 }
 
-extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int chain_depth)
-{
-    if (T <= 0 || H <= 0 || W <= 0 || chain_depth < 1 || chain_depth > WS_MAX_DEPTH) return 0;
-    const size_t n = (size_t)T * H * W;
-    // state + off + (K2, M1, C_1..C_{d-1}, R, pushed) + flags, each 256-byte aligned
-    return tf_align_up(n, 256) + tf_align_up(n * 8, 256) + (size_t)(chain_depth + 3) * tf_align_up(n * 8, 256) + 4096;
+struct WsU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
+typedef hipcub::TransformInputIterator<int, WsU8ToInt, const uint8_t *> WsFlagIter;
+
+static size_t ws_scan_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    WsFlagIter it((const uint8_t *)nullptr, WsU8ToInt());
+    hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, (int *)nullptr, (int)(n > 0x7fffffff ? 0x7fffffff : n));
+    return bytes;
 }
 
-static int ws_run_phase(const WsGeom &g, const WsArrays &a, int phase_k, int depth, int *d_flags, int *h_flags,
+static size_t ws_full_bytes(int64_t N) {
+    // cls + flag + scan + cid + scan temp + flags
+    return tf_align_up((size_t)N, 256) * 2 + tf_align_up((size_t)N * 4, 256) * 2 + tf_align_up(ws_scan_temp_bytes(N), 256) + 4096;
+}
+static size_t ws_compact_bytes(int64_t R, int n_nbr, int depth) {
+    // pix + val + nbr + (K2, M1, C_1..C_{d-1}, Rt, pushed)
+    return tf_align_up((size_t)R * 8, 256) + tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 4 * n_nbr, 256)
+         + (size_t)(depth + 3) * tf_align_up((size_t)R * 8, 256) + 4096;
+}
+
+extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int n_nbr, int chain_depth, int64_t max_relevant)
+{
+    if (T <= 0 || H <= 0 || W <= 0 || chain_depth < 1 || chain_depth > WS_MAX_DEPTH || n_nbr < 1 || n_nbr > WS_MAX_NBR) return 0;
+    const int64_t N = T * H * W;
+    if (max_relevant <= 0 || max_relevant > N) max_relevant = N;
+    return ws_full_bytes(N) + ws_compact_bytes(max_relevant, n_nbr, chain_depth);
+}
+
+static int ws_run_phase(const WsC &c, int phase_k, int depth, int *d_flags, int *h_flags,
                         hipStream_t s, int64_t max_sweeps, int64_t *sweeps_out)
 {
-    dim3 block(64, 4, 1), grid((g.W + 63) / 64, (g.H + 3) / 4, (unsigned)g.T);
+    const unsigned nb = (unsigned)((c.R + 255) / 256);
     int64_t sweeps = 0;
     for (;;) {
         TF_CHECK_HIP(hipMemsetAsync(d_flags, 0, WS_BATCH * sizeof(int), s));
         for (int b = 0; b < WS_BATCH; b++) {
-            if (phase_k == 0) hipLaunchKernelGGL(k_ws_relax_a, grid, block, 0, s, g, a, d_flags + b);
-            else hipLaunchKernelGGL(k_ws_relax_chain, grid, block, 0, s, g, a, phase_k, depth, d_flags + b);
+            if (phase_k == 0) hipLaunchKernelGGL(k_ws_relax_a, dim3(nb), dim3(256), 0, s, c, d_flags + b);
+            else hipLaunchKernelGGL(k_ws_relax_chain, dim3(nb), dim3(256), 0, s, c, phase_k, depth, d_flags + b);
         }
         TF_CHECK_LAUNCH();
         TF_CHECK_HIP(hipMemcpyAsync(h_flags, d_flags, WS_BATCH * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -227,45 +332,103 @@ extern "C" int tf_watershed(const float *field, const int32_t *markers, const in
     TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15) && T < 65536, "tf_watershed: bad shape");
     TF_REQUIRE(n_nbr > 0 && n_nbr <= WS_MAX_NBR, "tf_watershed: bad neighbour count");
     TF_REQUIRE(chain_depth >= 1 && chain_depth <= WS_MAX_DEPTH, "tf_watershed: bad chain_depth");
-    if (ws_bytes < tf_watershed_workspace_bytes(T, H, W, chain_depth)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
+    const int64_t N = T * H * W;
+    TF_REQUIRE(N <= 0x7fffffffll * 2, "tf_watershed: volume too large for one call (use time windows)");
+    if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(1, n_nbr, chain_depth)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
     hipStream_t s = (hipStream_t)stream;
     WsGeom g; g.T = T; g.H = (int)H; g.W = (int)W; g.plane = H * W; g.n_nbr = n_nbr;
     for (int i = 0; i < n_nbr; i++) {
         g.dt[i] = nbr_host[i * 3]; g.dy[i] = nbr_host[i * 3 + 1]; g.dx[i] = nbr_host[i * 3 + 2];
         TF_REQUIRE(abs(g.dt[i]) <= 1 && abs(g.dy[i]) <= 1 && abs(g.dx[i]) <= 1, "tf_watershed: neighbour offset out of range");
     }
-    const int64_t N = T * H * W;
+    int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     TfArena ar(ws, ws_bytes);
-    uint8_t *state = ar.take<uint8_t>(N);
-    short4 *off = ar.take<short4>(N);
-    WsArrays a; memset(&a, 0, sizeof(a));
-    a.field = field; a.state = state; a.off = off;
-    a.K2 = ar.take<u64>(N); a.M1 = ar.take<u64>(N);
-    for (int k = 1; k < chain_depth; k++) a.C[k] = ar.take<u64>(N);
-    a.R = ar.take<u64>(N); a.pushed = ar.take<u64>(N);
-    int *d_flags = ar.take<int>(WS_BATCH);
+    uint8_t *cls = ar.take<uint8_t>(N), *flag = ar.take<uint8_t>(N);
+    int *scan = ar.take<int>(N), *cid = ar.take<int>(N);
+    const size_t scan_bytes = ws_scan_temp_bytes(N);
+    char *scan_tmp = ar.take<char>(scan_bytes ? scan_bytes : 1);
+    int *d_flags = ar.take<int>(WS_BATCH + 4);
     if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
-    int h_flags[WS_BATCH];
 
     dim3 block(64, 4, 1), grid((g.W + 63) / 64, (g.H + 3) / 4, (unsigned)T);
     const unsigned nb1 = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(k_ws_init, grid, block, 0, s, field, markers, mask, fwd, bwd, g, state, off, a.K2, a.M1);
-    hipLaunchKernelGGL(k_ws_fill, dim3(nb1), dim3(256), 0, s, a.pushed, N, WS_NEVER);
+    hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
+    hipLaunchKernelGGL(k_ws_relevant, grid, block, 0, s, cls, fwd, bwd, g, flag);
     TF_CHECK_LAUNCH();
-    const int64_t max_sweeps = 64 + 8 * (T + H + W) * 8;
-    int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int rc = ws_run_phase(g, a, 0, chain_depth, d_flags, h_flags, s, max_sweeps * 64, &st[0]);
-    if (rc) return rc;
-    for (int k = 1; k <= chain_depth; k++) {
-        u64 *dst = k == chain_depth ? a.R : a.C[k];
-        hipLaunchKernelGGL(k_ws_init_level, dim3(nb1), dim3(256), 0, s, state, dst, a.pushed, N, k == chain_depth ? 1 : 0);
-        TF_CHECK_LAUNCH();
-        int64_t sw = 0;
-        rc = ws_run_phase(g, a, k, chain_depth, d_flags, h_flags, s, max_sweeps * 64, &sw);
-        if (rc) return rc;
-        st[k < 7 ? k : 7] += sw;
+    // exclusive scan of the flags in chunks of < 2^31 elements (carry added on the host side of the loop)
+    int64_t R = 0;
+    {
+        // N <= 2^32-2: at most two chunks
+        int64_t done = 0;
+        while (done < N) {
+            const int64_t len = (N - done > 0x7fffffffll) ? 0x7fffffffll : (N - done);
+            size_t tb = scan_bytes;
+            WsFlagIter it(flag + done, WsU8ToInt());
+            TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, it, scan + done, (int)len, s));
+            int last_scan = 0; uint8_t last_flag = 0;
+            TF_CHECK_HIP(hipMemcpyAsync(&last_scan, scan + done + len - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipMemcpyAsync(&last_flag, flag + done + len - 1, 1, hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            const int64_t cnt = (int64_t)last_scan + last_flag;
+            if (done > 0 && R > 0) {
+                // second chunk: its ids must continue after the first chunk's
+                TF_REQUIRE(false, "tf_watershed: more than 2^31 voxels per call is not supported yet");
+            }
+            R += cnt; done += len;
+        }
     }
-    hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, state, a.R, labels, N);
+    st[6] = R;
+    if (R >= 0x7fffffffll) { tf_set_error("tf_watershed: too many floodable pixels for 32-bit compact ids"); return TF_EINVAL; }
+    if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(R > 0 ? R : 1, n_nbr, chain_depth)) {
+        if (stats_host) { for (int i = 0; i < 8; i++) stats_host[i] = st[i]; }
+        tf_set_error("tf_watershed: workspace too small for %lld relevant pixels", (long long)R);
+        return TF_ENOMEM;
+    }
+    hipLaunchKernelGGL(k_ws_cid, dim3(nb1), dim3(256), 0, s, cls, flag, scan, N, cid);
+    TF_CHECK_LAUNCH();
+    int h_flags[WS_BATCH + 4];
+    WsC c; memset(&c, 0, sizeof(c));
+    c.R = R; c.n_nbr = n_nbr;
+    if (R > 0) {
+        u64 *pix = ar.take<u64>(R); unsigned *val = ar.take<unsigned>(R); int *nbr = ar.take<int>(R * n_nbr);
+        c.pix = pix; c.val = val; c.nbr = nbr;
+        c.K2 = ar.take<u64>(R); c.M1 = ar.take<u64>(R);
+        for (int k = 1; k < chain_depth; k++) c.C[k] = ar.take<u64>(R);
+        c.Rt = ar.take<u64>(R); c.pushed = ar.take<u64>(R);
+        if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
+        hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1, c.pushed);
+        TF_CHECK_LAUNCH();
+        const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
+        const int64_t max_sweeps = 1024 + 64 * (T + H + W);
+        int rc = ws_run_phase(c, 0, chain_depth, d_flags, h_flags, s, max_sweeps, &st[0]);
+        if (rc) return rc;
+        // fast path: root phase matched on K2 only, then the conflict test
+        hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.K2, c.pix, c.val, c.Rt, c.pushed, R, 1);
+        TF_CHECK_LAUNCH();
+        rc = ws_run_phase(c, 1, 1, d_flags, h_flags, s, max_sweeps, &st[1]);
+        if (rc) return rc;
+        int conflict = 0;
+        if (chain_depth > 1) {
+            TF_CHECK_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), s));
+            hipLaunchKernelGGL(k_ws_conflicts, dim3(nbr_blocks), dim3(256), 0, s, c, markers, d_flags);
+            TF_CHECK_LAUNCH();
+            TF_CHECK_HIP(hipMemcpyAsync(&conflict, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+        }
+        st[5] = conflict;
+        if (conflict) {
+            for (int k = 1; k <= chain_depth; k++) {
+                u64 *dst = k == chain_depth ? c.Rt : c.C[k];
+                hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.K2, c.pix, c.val, dst, c.pushed, R, k == chain_depth ? 1 : 0);
+                TF_CHECK_LAUNCH();
+                int64_t sw = 0;
+                rc = ws_run_phase(c, k, chain_depth, d_flags, h_flags, s, max_sweeps, &sw);
+                if (rc) return rc;
+                st[2 + (k < 3 ? k - 1 : 2)] += sw;
+            }
+        }
+    }
+    hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, labels, N);
     TF_CHECK_LAUNCH();
     TF_CHECK_HIP(hipStreamSynchronize(s));
     if (stats_host) for (int i = 0; i < 8; i++) stats_host[i] = st[i];

@@ -60,13 +60,23 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
     L = _lib.lib()
     T, H, W = field.shape
     labels = _lib.empty((T, H, W), t.int32)
-    nbytes = L.tf_watershed_workspace_bytes(T, H, W, chain_depth)
-    ws = _lib.workspace(nbytes, "watershed")
-    st = np.zeros(8, np.int64)
     nbr = np.ascontiguousarray(nbr, np.int8)
-    rc = L.tf_watershed(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
-                        T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), chain_depth, _lib.ptr(labels),
-                        _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr())
+    # the flood keys are compact over the relevant pixels: size the workspace from a cheap count of
+    # the floodable pixels and retry once with the exact number if boundary markers exceed the slack
+    floodable = (markers == 0) if mask is None else ((markers == 0) & (mask != 0))
+    guess = min(T * H * W, int(floodable.sum().item() * 1.5) + 4096)
+    del floodable
+    st = np.zeros(8, np.int64)
+    for attempt in range(2):
+        nbytes = L.tf_watershed_workspace_bytes(T, H, W, len(nbr), chain_depth, guess)
+        ws = _lib.workspace(nbytes, "watershed")
+        rc = L.tf_watershed(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
+                            T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), chain_depth, _lib.ptr(labels),
+                            _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr())
+        if rc == -2 and attempt == 0 and st[6] > guess:
+            guess = int(st[6])
+            continue
+        break
     _lib.check(rc, "tf_watershed")
     if stats is not None:
         stats["sweeps"] = st.tolist()
