@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- end-to-end Mpix/s of the hot path (dense flow -> semi-Lagrangian Sobel edge field ->
+marker-controlled watershed) on 5424 x 5424 GOES-16 full-disk-sized frames, one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step is one pass of the hot path over one window of `--frames` synthetic frames resident in HBM:
+create_flow(Farneback, smoothing_passes=1, interp_method="cubic")  ->  Flow.sobel(uphill, cubic,
+float64)  ->  combined edge field  ->  Flow.watershed(conn 1) with the detect_anvils marker recipe.
+Frame windows are independent units: every rank processes its own window (weak scaling) and the
+label IDs are stitched at the end of each step with one all-gather (tobac_flow_amd/parallel.py).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(seed):
+    """The oracle (CPU restatement of the reference's cv2/numpy/Cython path, kind = "port") timed on ONE
+    host core on a bounded sample of the same workload: a 5 x 1536 x 1536 stack."""
+    import numpy as np
+    import scipy.ndimage as ndi
+    import ctypes
+    import warnings
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import blob_sequence
+    from oracle import _lib as ol, np_ops, ws_oracle
+    T, H, W = 5, 1536, 1536
+    rng = np.random.default_rng(seed)
+    bt = blob_sequence(rng, T, H, W, n_blobs=36)
+    L = ol.lib()
+    L.oracle_farneback.restype = ctypes.c_int
+
+    def fb(a, b):
+        out = np.zeros((H, W, 2), np.float32)
+        L.oracle_farneback(ol.ptr(np.ascontiguousarray(a), ctypes.c_uint8), ol.ptr(np.ascontiguousarray(b), ctypes.c_uint8),
+                           H, W, ol.ptr(out, ctypes.c_float), 5, ctypes.c_double(0.5), 13, 10, 5, ctypes.c_double(1.1))
+        return out
+    t0 = time.perf_counter()
+    fw = np.full((T, H, W, 2), np.nan, np.float32)
+    bw = np.full((T, H, W, 2), np.nan, np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(T - 1):
+            p8 = np_ops.to_8bit(np_ops.linear_norm(bt[i:i + 2].copy()), 0, 1)
+            f, b = np_ops.smooth_flow_step(fb(p8[0], p8[1]), fb(p8[1], p8[0]), "cubic")
+            fw[i], bw[i + 1] = f, b
+        fw[-1], bw[0] = -bw[-1], -fw[0]
+        fw, bw = np.clip(fw, -20, 20), np.clip(bw, -20, 20)
+        lin = np.clip((bt - 270.0) / (250.0 - 270.0), 0, 1).astype(np.float32)
+        edges = np_ops.sobel(lin, fw, bw, "cubic", None, np.nan, "uphill")
+        edges[edges > 0] += 1
+        edges = edges - lin
+        s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
+        markers = (lin >= 1) * ndi.binary_erosion(lin >= 1, structure=s).astype(np.int32)
+        markers[ndi.binary_erosion(lin <= 0, structure=np.ones([3, 3, 3]), border_value=1)] = -1
+        ws_oracle.watershed(fw, bw, edges, markers.astype(np.int32), None, 1)
+    dt = time.perf_counter() - t0
+    return {"value": round(T * H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": f"{T}x{H}x{W} synthetic stack, same stage sequence, oracle (C/numpy restatement of the "
+                      f"cv2+scipy+Cython path), single thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=12, help="frames per window (per GPU, per step)")
+    ap.add_argument("--height", type=int, default=5424)
+    ap.add_argument("--width", type=int, default=5424)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.parallel import stitch_labels
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    from tools.synth import anvil_inputs, blob_stack
+
+    T, H, W = a.frames, a.height, a.width
+    bt = blob_stack(T, H, W, seed=20240601 + rank)          # resident in HBM before the timed region
+    lin, markers = anvil_inputs(bt)
+    nbr = neighbour_offsets(1)
+    inf = torch.tensor(float("inf"), dtype=torch.float64, device=bt.device)
+
+    def step():
+        flow = tf.create_flow(bt, model="Farneback", smoothing_passes=1, interp_method="cubic")
+        e = flow.sobel(lin, direction="uphill", method="cubic")            # float64, like Flow.sobel(dtype=None)
+        e = torch.where(e > 0, e + 1, e) - lin                             # detection.py:638-641
+        e = torch.where(torch.isnan(lin), inf, e).to(torch.float32)       # watershed.py:64-65
+        fw, bw = flow._dev_flows()
+        labels = watershed_dev(fw, bw, e, markers, None, nbr)
+        return stitch_labels(labels) if world > 1 else labels
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    _lib.profile_enable(True)
+    _lib.profile_collect()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=bt.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
+        roof = None
+        if dom:
+            name, (calls, ms, by) = dom
+            achieved = by / (ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": calls,
+                    "avg_launch_us": round(ms * 1e3 / calls, 2),
+                    "share_of_step": round(ms / (dt * 1e3), 4),
+                    "all_kernels_ms_per_step": {k: round(v[1] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+        out = {"metric": "Mpix/s end-to-end flow+sobel+watershed, 5424^2 frames", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
+               "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"GOES-16 ABI full-disk-sized window: {T}x{H}x{W} float32 frames per GPU per step "
+                                      "(BASELINE config F frame size; 144-frame stack = 12 such windows)",
+                          "stages": "create_flow(Farneback, vr_steps=0, smoothing_passes=1, cubic) + Flow.sobel(uphill, cubic, f64) "
+                                    "+ edge field + Flow.watershed(connectivity 1, detect_anvils markers)",
+                          "sharding": "one time window per GPU, label IDs stitched by all-gather"},
+               "roofline": roof}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(20240601)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

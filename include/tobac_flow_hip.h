@@ -151,6 +151,16 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
                  const int8_t *nbr_host, int n_nbr, int chain_depth, int32_t *labels,
                  void *ws, size_t ws_bytes, int64_t *stats_host, void *stream);
 
+/* ---- measurement aid (bench.py's roofline figure) ---------------------------------------------
+ * tf_profile_enable(1): every kernel launch of the library is bracketed by HIP events on its own
+ * stream and tagged with its ALGORITHMIC byte count.  tf_profile_collect() synchronises
+ * the recorded events and returns, per kernel id < tf_profile_kernel_count(), the number of
+ * launches, their summed duration in ms and their summed algorithmic bytes, then clears them. */
+int tf_profile_enable(int on);
+int tf_profile_kernel_count(void);
+const char *tf_profile_kernel_name(int id);
+int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
+
 #ifdef __cplusplus
 }
 #endif

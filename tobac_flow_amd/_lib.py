@@ -43,6 +43,10 @@ _PROTOS = {
     "tf_watershed_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int64]),
     "tf_watershed": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int,
                                 _P, _P, _c.c_size_t, _P, _P]),
+    "tf_profile_enable": (_c.c_int, [_c.c_int]),
+    "tf_profile_kernel_count": (_c.c_int, []),
+    "tf_profile_kernel_name": (_c.c_char_p, [_c.c_int]),
+    "tf_profile_collect": (_c.c_int, [_P, _P, _P]),
 }
 
 EXPORTS = tuple(_PROTOS)
@@ -156,3 +160,18 @@ def workspace(nbytes, tag="default"):
 
 def release_workspaces():
     _WS.clear()
+
+
+def profile_enable(on=True):
+    lib().tf_profile_enable(1 if on else 0)
+
+
+def profile_collect():
+    """{kernel name: (calls, total ms, total algorithmic bytes)} since the last collect."""
+    L = lib()
+    n = L.tf_profile_kernel_count()
+    calls = np.zeros(n, np.int64)
+    ms = np.zeros(n, np.float64)
+    by = np.zeros(n, np.float64)
+    L.tf_profile_collect(calls.ctypes.data_as(_P), ms.ctypes.data_as(_P), by.ctypes.data_as(_P))
+    return {L.tf_profile_kernel_name(i).decode(): (int(calls[i]), float(ms[i]), float(by[i])) for i in range(n) if calls[i]}

@@ -185,6 +185,9 @@ static int launch_convolve(const void *data, int64_t T, int H, int W, const floa
                            int64_t t0, int64_t t1, hipStream_t s)
 {
     typedef typename StackTraits<TS>::In In;
+    const bool is_sobel = func >= TF_FUNC_SOBEL && func <= TF_FUNC_SOBEL_DOWNHILL;
+    const double out_b = (out_type == TF_F64 ? 8.0 : 4.0) * (func == TF_FUNC_STACK ? (tp.nb + tp.ns + tp.nf) : 1);
+    TfProfScope ps(is_sobel ? TFK_SOBEL : TFK_CONVOLVE, (4.0 + 16.0 + out_b) * (double)H * W * (double)(t1 - t0), s);
     dim3 block(64, 4, 1), grid((W + 63) / 64, (H + 3) / 4, (unsigned)(t1 - t0));
     const In *d = (const In *)data;
     switch (interp) {
@@ -346,6 +349,7 @@ extern "C" int tf_smooth_flow_step(const float *fwd, const float *bwd, int64_t H
     TF_REQUIRE(interp >= 0 && interp <= 2, "tf_smooth_flow_step: bad interp");
     dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
+    TfProfScope ps(TFK_SMOOTH, 48.0 * (double)H * W, s);
     if (interp == 0) hipLaunchKernelGGL(k_smooth<0>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
     else if (interp == 1) hipLaunchKernelGGL(k_smooth<1>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
     else hipLaunchKernelGGL(k_smooth<2>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);

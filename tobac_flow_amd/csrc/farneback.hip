@@ -366,10 +366,14 @@ extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64
         const dim3 glev((w + 63) / 64, (h + 3) / 4);
         FbKernel hk; fb_gaussian_kernel(smooth_sz, sigma, &hk);
         for (int i = 0; i < 2; i++) {
-            hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp);
-            hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur);
+            {
+                TfProfScope ps(TFK_FB_BLUR, 13.0 * n, s);     // u8 r + f32 w, then f32 r + f32 w
+                hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp);
+                hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur);
+            }
             const float *Ik = blur;
             if (w != W || h != H) {
+                TfProfScope ps(TFK_FB_RESIZE, 4.0 * n + 4.0 * plane, s);
                 const double sx = 1. / ((double)w / W), sy = 1. / ((double)h / H);
                 const int isx = (int)(sx + 0.5), isy = (int)(sy + 0.5);
                 if (fabs(sx - isx) < DBL_EPSILON && fabs(sy - isy) < DBL_EPSILON && isx == 2 && isy == 2)
@@ -378,8 +382,11 @@ extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64
                     hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, blur, H, W, 1, I, h, w, sx, sy, 1.f);
                 Ik = I;
             }
-            hipLaunchKernelGGL(k_fb_poly_v, glev, block, 0, s, Ik, h, w, pp, t0, t1, t2);
-            hipLaunchKernelGGL(k_fb_poly_h, glev, block, 0, s, t0, t1, t2, h, w, pp, R[i], plane);
+            {
+                TfProfScope ps(TFK_FB_POLYEXP, 24.0 * plane, s);   // fused-ideal: 4 r + 20 w per level pixel
+                hipLaunchKernelGGL(k_fb_poly_v, glev, block, 0, s, Ik, h, w, pp, t0, t1, t2);
+                hipLaunchKernelGGL(k_fb_poly_h, glev, block, 0, s, t0, t1, t2, h, w, pp, R[i], plane);
+            }
         }
         TF_CHECK_LAUNCH();
         for (int d = 0; d < 2; d++) {
@@ -387,17 +394,26 @@ extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64
             float *flow = (k > 0) ? fbuf[d][k & 1] : out[d];
             if (!prevFlow[d]) TF_CHECK_HIP(hipMemsetAsync(flow, 0, (size_t)plane * 2 * sizeof(float), s));
             else {
+                TfProfScope ps(TFK_FB_RESIZE, 8.0 * pw * ph + 8.0 * plane, s);
                 const double sx = 1. / ((double)w / pw), sy = 1. / ((double)h / ph);
                 hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, prevFlow[d], ph, pw, 2, flow, h, w, sx, sy,
                                    (float)(1. / p->pyr_scale));
             }
             const float *R0 = R[d], *R1 = R[1 - d];
-            hipLaunchKernelGGL(k_fb_update_matrices, glev, block, 0, s, R0, R1, flow, h, w, plane, M);
+            {
+                TfProfScope ps(TFK_FB_MATRICES, 68.0 * plane, s);
+                hipLaunchKernelGGL(k_fb_update_matrices, glev, block, 0, s, R0, R1, flow, h, w, plane, M);
+            }
             const dim3 gt((w + FBT_W - 1) / FBT_W, (h + FBT_H - 1) / FBT_H);
             for (int it = 0; it < p->num_iters; it++) {
-                hipLaunchKernelGGL(k_fb_blur_solve, gt, block, 0, s, M, h, w, plane, p->win_size / 2, flow);
-                if (it < p->num_iters - 1)
+                {
+                    TfProfScope ps(TFK_FB_BLUR_SOLVE, 28.0 * plane, s);
+                    hipLaunchKernelGGL(k_fb_blur_solve, gt, block, 0, s, M, h, w, plane, p->win_size / 2, flow);
+                }
+                if (it < p->num_iters - 1) {
+                    TfProfScope ps(TFK_FB_MATRICES, 68.0 * plane, s);
                     hipLaunchKernelGGL(k_fb_update_matrices, glev, block, 0, s, R0, R1, flow, h, w, plane, M);
+                }
             }
             TF_CHECK_LAUNCH();
             prevFlow[d] = flow;

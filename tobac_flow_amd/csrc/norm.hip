@@ -74,6 +74,7 @@ extern "C" int tf_to8bit_pair(const float *frame0, const float *frame1, int64_t 
     unsigned *mm = (unsigned *)ws;
     const int64_t n = H * W;
     int blocks = (int)((2 * n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    TfProfScope ps(TFK_TO8BIT, 18.0 * n, s);
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, s, mm);
     hipLaunchKernelGGL(k_minmax, dim3(blocks), dim3(256), 0, s, frame0, frame1, n, mm);
     hipLaunchKernelGGL(k_to8bit, dim3(blocks), dim3(256), 0, s, frame0, frame1, n, mm, out0, out1);

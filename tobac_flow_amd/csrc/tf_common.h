@@ -53,3 +53,19 @@ __device__ __forceinline__ int tf_cvround(float v) { return __float2int_rn(v); }
 __device__ __forceinline__ int tf_cvfloor(float v) { return __float2int_rd(v); }
 __device__ __forceinline__ int tf_sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 __device__ __forceinline__ int tf_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- built-in kernel timing (HIP events on the launch stream) ----------------------------------
+// Used by bench.py for the roofline figure: tf_profile_enable(1) makes every annotated launch record
+// a start/stop event pair together with its ALGORITHMIC byte count; tf_profile_get() synchronises and
+// returns calls / total ms / total algorithmic bytes per kernel id.  Disabled: zero overhead.
+enum TfKernelId {
+    TFK_TO8BIT = 0, TFK_FB_BLUR, TFK_FB_RESIZE, TFK_FB_POLYEXP, TFK_FB_MATRICES, TFK_FB_BLUR_SOLVE, TFK_FB_ITER,
+    TFK_SMOOTH, TFK_CONVOLVE, TFK_SOBEL, TFK_WS_SETUP, TFK_WS_RELAX, TFK_WS_LABELS, TFK_COUNT
+};
+extern bool g_tf_prof_on;
+void tf_prof_record(int id, double bytes, hipStream_t s, bool start);
+struct TfProfScope {
+    int id; double bytes; hipStream_t s; bool on;
+    TfProfScope(int id_, double bytes_, hipStream_t s_) : id(id_), bytes(bytes_), s(s_), on(g_tf_prof_on) { if (on) tf_prof_record(id, bytes, s, true); }
+    ~TfProfScope() { if (on) tf_prof_record(id, bytes, s, false); }
+};

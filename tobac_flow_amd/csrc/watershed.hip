@@ -308,6 +308,7 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, int *d_flags, int 
     for (;;) {
         TF_CHECK_HIP(hipMemsetAsync(d_flags, 0, WS_BATCH * sizeof(int), s));
         for (int b = 0; b < WS_BATCH; b++) {
+            TfProfScope ps(TFK_WS_RELAX, 16.0 * (double)c.R, s);     // key + last-pushed key per relevant pixel
             if (phase_k == 0) hipLaunchKernelGGL(k_ws_relax_a, dim3(nb), dim3(256), 0, s, c, d_flags + b);
             else hipLaunchKernelGGL(k_ws_relax_chain, dim3(nb), dim3(256), 0, s, c, phase_k, depth, d_flags + b);
         }

@@ -1,0 +1,89 @@
+"""Multi-GPU scheme: time windows are independent units (one window per GPU, no data-path
+collective); label IDs are stitched at the end with one all-gather.
+
+This is the MI355X form of the reference's own scale-out: independent windows with overlap frames,
+then overlap-based linking of label IDs (/root/reference/tobac_flow/linking.py:49-161 -- overlap
+counts in the shared frames, then connected components).  Here consecutive windows share ONE frame
+(the last frame of rank r is the first frame of rank r+1); the collective is a
+`torch.distributed.all_gather` (RCCL on GPUs, gloo in the CPU tests) of each rank's boundary label
+frame and label count, after which every rank runs the same union-find and rewrites its own labels.
+"""
+import numpy as np
+
+
+def window_bounds(T, world, overlap=1):
+    """Split T frames into `world` contiguous windows sharing `overlap` frames: [(start, stop), ...]."""
+    if world < 1 or T < world + overlap * (world - 1):
+        raise ValueError("not enough frames for the requested number of windows")
+    body = T - overlap
+    edges = [round(i * body / world) for i in range(world + 1)]
+    return [(edges[i], edges[i + 1] + overlap) for i in range(world)]
+
+
+def _find(parent, i):
+    while parent[i] != i:
+        parent[i] = parent[parent[i]]
+        i = parent[i]
+    return i
+
+
+def stitch_lut(counts, pairs_per_boundary):
+    """Global relabelling tables from per-rank label counts and per-boundary (id_left, id_right) pairs.
+
+    counts[r] = number of labels (max id) of rank r; pairs_per_boundary[r] = (k, 2) array of label
+    pairs that coincide in the frame shared by rank r and rank r+1.  Returns one LUT per rank
+    (index = local id, value = global id, contiguous from 1 in order of first appearance over
+    (rank, local id)), identical on every rank."""
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    n = int(offs[-1])
+    parent = np.arange(n + 1)
+    for r, pairs in enumerate(pairs_per_boundary):
+        for a, b in np.asarray(pairs, np.int64).reshape(-1, 2):
+            ra, rb = _find(parent, offs[r] + a), _find(parent, offs[r + 1] + b)
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+    root = np.array([_find(parent, i) for i in range(n + 1)])
+    new = np.zeros(n + 1, np.int64)
+    nxt = 0
+    for i in range(1, n + 1):           # canonical numbering: by smallest member
+        if root[i] == i:
+            nxt += 1
+            new[i] = nxt
+    new = new[root]
+    return [np.concatenate([[0], new[offs[r] + 1: offs[r + 1] + 1]]) for r in range(len(counts))]
+
+
+def stitch_labels(labels, group=None, min_overlap=1):
+    """Make the positive label IDs of per-rank windows globally consistent.
+
+    labels: (T_w, H, W) int32 torch tensor of this rank (negative and zero labels are kept).
+    Rank r's last frame and rank r+1's first frame are the same time step.  Returns the relabelled
+    tensor.  One all_gather of the first frames + one of the label counts."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return labels
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = labels.device
+    count = torch.clamp(labels.max(), min=0).to(torch.int64).reshape(1)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    firsts = [torch.empty_like(labels[0]) for _ in range(world)]
+    dist.all_gather(firsts, labels[0].contiguous(), group=group)
+    counts = [int(c.item()) for c in counts]
+    # every rank evaluates every boundary (identical inputs -> identical union-find everywhere)
+    lasts = [torch.empty_like(labels[0]) for _ in range(world)]
+    dist.all_gather(lasts, labels[-1].contiguous(), group=group)
+    pairs = []
+    for r in range(world - 1):
+        a, b = lasts[r].reshape(-1).to(torch.int64), firsts[r + 1].reshape(-1).to(torch.int64)
+        both = (a > 0) & (b > 0)
+        key, cnt = torch.unique(a[both] * (counts[r + 1] + 1) + b[both], return_counts=True)
+        key = key[cnt >= min_overlap]
+        pairs.append(torch.stack([key // (counts[r + 1] + 1), key % (counts[r + 1] + 1)], 1).cpu().numpy())
+    lut = stitch_lut(counts, pairs)[rank]
+    lut_t = torch.from_numpy(lut.astype(np.int32)).to(dev)
+    pos = labels > 0
+    out = labels.clone()
+    out[pos] = lut_t[labels[pos].to(torch.int64)]
+    return out

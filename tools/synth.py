@@ -15,10 +15,7 @@ def blob_stack(T, H, W, seed=20240601, device="cuda", nan_every=12):
     out = torch.full((T, H, W), 290.0, dtype=torch.float32, device=device)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    # separable sigma = 2 px gaussian for the noise
-    r = 6
-    k1 = torch.exp(-torch.arange(-r, r + 1, device=device, dtype=torch.float32) ** 2 / 8.0)
-    k1 = (k1 / k1.sum())
+    F = torch.nn.functional
     for t in range(T):
         frame = out[t]
         for k in range(K):
@@ -31,10 +28,11 @@ def blob_stack(T, H, W, seed=20240601, device="cuda", nan_every=12):
             yy = torch.arange(ya, yb, device=device, dtype=torch.float32)[:, None] - float(y0)
             xx = torch.arange(xa, xb, device=device, dtype=torch.float32)[None, :] - float(x0)
             frame[ya:yb, xa:xb] -= float(amp[k]) * torch.exp(-(yy * yy + xx * xx) / float(2 * sig[k] ** 2))
+        # band-limited noise: white noise box-filtered three times (~ gaussian, sigma ~ 2 px)
         n = torch.randn((1, 1, H, W), generator=gen, device=device, dtype=torch.float32)
-        n = torch.nn.functional.conv2d(n, k1.view(1, 1, 1, -1), padding=(0, r))
-        n = torch.nn.functional.conv2d(n, k1.view(1, 1, -1, 1), padding=(r, 0))
-        frame += n[0, 0] * 4.0
+        for _ in range(3):
+            n = F.avg_pool2d(n, 5, stride=1, padding=2, count_include_pad=False)
+        frame += n[0, 0] * 16.0
         if nan_every and t % nan_every == nan_every // 2:
             hh, ww = max(H // 10, 1), max(W // 10, 1)
             y1, x1 = int(g.integers(0, H - hh + 1)), int(g.integers(0, W - ww + 1))
