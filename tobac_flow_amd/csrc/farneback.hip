@@ -19,6 +19,7 @@
 #include "tf_common.h"
 #include <math.h>
 #include <float.h>
+#include <stdlib.h>
 
 #define FB_MAX_KSIZE 255
 #define FB_MAX_POLY_N 8
@@ -151,21 +152,17 @@ k_fb_poly_h(const float *__restrict__ t0, const float *__restrict__ t1, const fl
         b5 += (c[xp] + c[xm]) * g0;
     }
     const int64_t o = (int64_t)y * W + x;
-    R[o] = (float)(b3 * pp.ig11);
-    R[plane + o] = (float)(b2 * pp.ig11);
-    R[2 * plane + o] = (float)(b1 * pp.ig03 + b5 * pp.ig33);
-    R[3 * plane + o] = (float)(b1 * pp.ig03 + b4 * pp.ig33);
+    // R layout: float4 {y-lin, x-lin, yy, xx} per pixel, then a separate plane for xy
+    ((float4 *)R)[o] = make_float4((float)(b3 * pp.ig11), (float)(b2 * pp.ig11),
+                                   (float)(b1 * pp.ig03 + b5 * pp.ig33), (float)(b1 * pp.ig03 + b4 * pp.ig33));
     R[4 * plane + o] = (float)(b6 * pp.ig55);
 }
 
 // ---- FarnebackUpdateMatrices ---------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1, const float *__restrict__ flow,
-                     int H, int W, int64_t plane, float *__restrict__ M)
+__device__ __forceinline__ void fb_matrix_at(const float *__restrict__ R0, const float *__restrict__ R1,
+                                             const float *__restrict__ flow, int H, int W, int64_t plane,
+                                             int x, int y, float &m0, float &m1, float &m2, float &m3, float &m4)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || y >= H) return;
-    const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
     const int64_t o = (int64_t)y * W + x;
     const float2 fl = ((const float2 *)flow)[o];
     const float dx = fl.x, dy = fl.y;
@@ -173,36 +170,159 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
     const int x1 = tf_cvfloor(fx), y1 = tf_cvfloor(fy);
     float r2, r3, r4, r5, r6;
     fx -= x1; fy -= y1;
+    const float4 q0 = ((const float4 *)R0)[o];
+    const float q04 = R0[4 * plane + o];
     if ((unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1)) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
         const int64_t q = (int64_t)y1 * W + x1;
-        const float *P = R1 + q;
-        r2 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1]; P += plane;
-        r3 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1]; P += plane;
-        r4 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1]; P += plane;
-        r5 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1]; P += plane;
-        r6 = a00 * P[0] + a01 * P[1] + a10 * P[W] + a11 * P[W + 1];
-        r4 = (R0[2 * plane + o] + r4) * 0.5f;
-        r5 = (R0[3 * plane + o] + r5) * 0.5f;
-        r6 = (R0[4 * plane + o] + r6) * 0.25f;
+        const float4 *P4 = (const float4 *)R1 + q;
+        const float *P1 = R1 + 4 * plane + q;
+        const float4 c00 = P4[0], c01 = P4[1], c10 = P4[W], c11 = P4[W + 1];
+        const float e00 = P1[0], e01 = P1[1], e10 = P1[W], e11 = P1[W + 1];
+        r2 = a00 * c00.x + a01 * c01.x + a10 * c10.x + a11 * c11.x;
+        r3 = a00 * c00.y + a01 * c01.y + a10 * c10.y + a11 * c11.y;
+        r4 = a00 * c00.z + a01 * c01.z + a10 * c10.z + a11 * c11.z;
+        r5 = a00 * c00.w + a01 * c01.w + a10 * c10.w + a11 * c11.w;
+        r6 = a00 * e00 + a01 * e01 + a10 * e10 + a11 * e11;
+        r4 = (q0.z + r4) * 0.5f;
+        r5 = (q0.w + r5) * 0.5f;
+        r6 = (q04 + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = R0[2 * plane + o]; r5 = R0[3 * plane + o]; r6 = R0[4 * plane + o] * 0.5f;
+        r4 = q0.z; r5 = q0.w; r6 = q04 * 0.5f;
     }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[plane + o] - r3) * 0.5f;
+    r2 = (q0.x - r2) * 0.5f;
+    r3 = (q0.y - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     if ((unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10)) {
+        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
         const float scale = (x < 5 ? border[x] : 1.f) * (x >= W - 5 ? border[W - x - 1] : 1.f) *
                             (y < 5 ? border[y] : 1.f) * (y >= H - 5 ? border[H - y - 1] : 1.f);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
-    M[o] = r4 * r4 + r6 * r6;
-    M[plane + o] = (r4 + r5) * r6;
-    M[2 * plane + o] = r5 * r5 + r6 * r6;
-    M[3 * plane + o] = r4 * r2 + r6 * r3;
-    M[4 * plane + o] = r6 * r2 + r5 * r3;
+    m0 = r4 * r4 + r6 * r6;
+    m1 = (r4 + r5) * r6;
+    m2 = r5 * r5 + r6 * r6;
+    m3 = r4 * r2 + r6 * r3;
+    m4 = r6 * r2 + r5 * r3;
+}
+
+__global__ void __launch_bounds__(256)
+k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1, const float *__restrict__ flow,
+                     int H, int W, int64_t plane, float *__restrict__ M)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    float m0, m1, m2, m3, m4;
+    fb_matrix_at(R0, R1, flow, H, W, plane, x, y, m0, m1, m2, m3, m4);
+    const int64_t o = (int64_t)y * W + x;
+    M[o] = m0; M[plane + o] = m1; M[2 * plane + o] = m2; M[3 * plane + o] = m3; M[4 * plane + o] = m4;
+}
+
+// ---- fused iteration: UpdateMatrices -> 13x13 box sums (double) -> 2x2 solve -----------------------
+// One launch = one Farnebaeck iteration of BOTH directions (blockIdx.z).  A 256-thread workgroup owns
+// a strip of FBI_OW = 244 output columns (+ 6 halo columns each side) and FBI_HS rows.  Thread j walks
+// DOWN its column: at every row it evaluates M = UpdateMatrices(R0, R1, flow_old) in registers, keeps
+// the last 13 rows of M in a register ring and the running 13-row column sums in double; the five
+// column sums go to an LDS row (double buffered, one barrier per row), from which the 244 interior
+// threads add 13 neighbours, solve the 2x2 system and write flow_new.  The 5-plane matrix M never
+// exists in HBM: per level pixel the kernel moves R0 (20 B) + R1 (20 B) + flow in (8 B) + flow out (8 B).
+#define FBI_M 6
+#define FBI_WIN (2 * FBI_M + 1)
+#define FBI_OW (256 - 2 * FBI_M)
+#define FBI_HS 64
+struct FbIterArgs { const float *R0[2], *R1[2], *fin[2]; float *fout[2]; };
+#define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
+
+struct FbIterCtx {
+    const float *R0, *R1, *fin; float *fout;
+    int H, W; int64_t plane; int j, xo, xc, y0, s_end; bool writer;
+};
+
+// one group of G consecutive window rows with STATIC ring slots K0 .. K0+G-1:
+//   1. evaluate M for the G rows (all loads of the group in flight together),
+//   2. slide the 13-row column sums, park the sums of completed windows in LDS,
+//   3. one barrier, then 13-neighbour row sums + 2x2 solve + store for up to G output rows.
+template <int K0, int G, int ABL>
+__device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int base, float (&ring)[FBI_WIN][5], double (&S)[5],
+                                              double (*vrow)[5][256])
+{
+    float nm[G][5];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int s = base + K0 + g;
+        if (s <= c.s_end) {
+            if (ABL == 1) { nm[g][0] = (float)s; nm[g][1] = (float)c.xc; nm[g][2] = 1.f; nm[g][3] = 2.f; nm[g][4] = (float)(s + c.xc); }
+            else fb_matrix_at(c.R0, c.R1, c.fin, c.H, c.W, c.plane, c.xc, tf_clampi(s, 0, c.H - 1),
+                              nm[g][0], nm[g][1], nm[g][2], nm[g][3], nm[g][4]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int s = base + K0 + g;
+        if (s <= c.s_end) {
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) { S[ch] += (double)nm[g][ch] - (double)ring[K0 + g][ch]; ring[K0 + g][ch] = nm[g][ch]; }
+            if (s - FBI_M >= c.y0) {
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) vrow[g][ch][c.j] = S[ch];
+            }
+        }
+    }
+    __syncthreads();
+    if (c.writer) {
+        const double scale = 1. / (FBI_WIN * FBI_WIN);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int s = base + K0 + g, yo = s - FBI_M;
+            if (s <= c.s_end && yo >= c.y0) {
+                double g11 = 0, g12 = 0, g22 = 0, h1 = 0, h2 = 0;
+#pragma unroll
+                for (int i = (ABL == 2 ? 0 : -FBI_M); i <= (ABL == 2 ? 0 : FBI_M); i++) {
+                    g11 += vrow[g][0][c.j + i]; g12 += vrow[g][1][c.j + i]; g22 += vrow[g][2][c.j + i];
+                    h1 += vrow[g][3][c.j + i]; h2 += vrow[g][4][c.j + i];
+                }
+                g11 *= scale; g12 *= scale; g22 *= scale; h1 *= scale; h2 *= scale;
+                const double det = g11 * g22 - g12 * g12 + 1e-3;
+                double idet = __builtin_amdgcn_rcp(det);
+                idet = idet * (2.0 - det * idet);
+                idet = idet * (2.0 - det * idet);
+                float2 f;
+                f.x = (float)((g11 * h2 - g12 * h1) * idet);
+                f.y = (float)((g22 * h1 - g12 * h2) * idet);
+                ((float2 *)c.fout)[(int64_t)yo * c.W + c.xo] = f;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int ABL>
+__global__ void __launch_bounds__(256)
+k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
+{
+    __shared__ double vrow[FBI_G][5][256];
+    const int d = blockIdx.z;
+    FbIterCtx c;
+    c.R0 = a.R0[d]; c.R1 = a.R1[d]; c.fin = a.fin[d]; c.fout = a.fout[d];
+    c.H = H; c.W = W; c.plane = plane;
+    c.j = threadIdx.x;
+    c.xo = blockIdx.x * FBI_OW + c.j - FBI_M;                         // column this thread evaluates M for
+    c.xc = tf_clampi(c.xo, 0, W - 1);                                 // replicate border
+    c.y0 = blockIdx.y * hs;
+    const int y1 = min(c.y0 + hs, H);                             // output rows [y0, y1)
+    c.writer = c.j >= FBI_M && c.j < 256 - FBI_M && c.xo < W;
+    c.s_end = y1 - 1 + FBI_M;                                         // last window row (inclusive)
+    float ring[FBI_WIN][5];
+#pragma unroll
+    for (int k = 0; k < FBI_WIN; k++) { ring[k][0] = ring[k][1] = ring[k][2] = ring[k][3] = ring[k][4] = 0.f; }
+    double S[5] = {0, 0, 0, 0, 0};
+    for (int base = c.y0 - FBI_M; base <= c.s_end; base += FBI_WIN) {
+        fb_iter_group<0, 4, ABL>(c, base, ring, S, vrow);
+        fb_iter_group<4, 4, ABL>(c, base, ring, S, vrow);
+        fb_iter_group<8, 5, ABL>(c, base, ring, S, vrow);
+    }
 }
 
 // ---- FarnebackUpdateFlow_Blur: box filter of M (double) + 2x2 solve ------------------------------
@@ -389,6 +509,57 @@ extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64
             }
         }
         TF_CHECK_LAUNCH();
+        const bool fused = p->win_size == FBI_WIN;
+        if (fused) {
+            // ping-pong buffers per direction: slot 0 = caller's output (full-res sized), slot 1 = scratch.
+            // cur[d] holds the level's initial flow; every iteration reads cur and writes the other slot.
+            FbIterArgs ia;
+            int nd = 0, dirs[2];
+            for (int d = 0; d < 2; d++) if (out[d]) dirs[nd++] = d;
+            float *cur[2] = {nullptr, nullptr};
+            for (int q = 0; q < nd; q++) {
+                const int d = dirs[q];
+                // choose the start slot so that after all remaining iterations of all remaining levels the
+                // result of level 0 lands in out[d]: each level flips the slot (1 + num_iters) times
+                float *slot[2] = {out[d], fbuf[d][0]};
+                int start;
+                if (!prevFlow[d]) {
+                    const int flips_per_level = p->num_iters + 1;              // upsample (1) + iterations
+                    const int total = (k + 1) * flips_per_level - 1;           // no upsample at the coarsest level
+                    start = (total % 2 == 0) ? 0 : 1;                          // slot index of the initial flow
+                    cur[d] = slot[start];
+                    TF_CHECK_HIP(hipMemsetAsync(cur[d], 0, (size_t)plane * 2 * sizeof(float), s));
+                } else {
+                    float *dst = prevFlow[d] == slot[0] ? slot[1] : slot[0];
+                    TfProfScope ps(TFK_FB_RESIZE, 8.0 * pw * ph + 8.0 * plane, s);
+                    const double sx = 1. / ((double)w / pw), sy = 1. / ((double)h / ph);
+                    hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, prevFlow[d], ph, pw, 2, dst, h, w, sx, sy,
+                                       (float)(1. / p->pyr_scale));
+                    cur[d] = dst;
+                }
+            }
+            // strip height: tall strips amortise the 12-row halo, short ones keep all CUs busy on coarse levels
+            int hs = FBI_HS;
+            while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd < 1536) hs >>= 1;
+            const dim3 gi((w + FBI_OW - 1) / FBI_OW, (h + hs - 1) / hs, nd);
+            for (int it = 0; it < p->num_iters; it++) {
+                for (int q = 0; q < nd; q++) {
+                    const int d = dirs[q];
+                    float *other = cur[d] == out[d] ? fbuf[d][0] : out[d];
+                    ia.R0[q] = R[d]; ia.R1[q] = R[1 - d]; ia.fin[q] = cur[d]; ia.fout[q] = other;
+                }
+                {
+                    TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd, s);
+                    static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
+                    if (abl == 1) hipLaunchKernelGGL(k_fb_iter<1>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else if (abl == 2) hipLaunchKernelGGL(k_fb_iter<2>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else hipLaunchKernelGGL(k_fb_iter<0>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                }
+                for (int q = 0; q < nd; q++) { const int d = dirs[q]; cur[d] = (float *)ia.fout[q]; }
+            }
+            TF_CHECK_LAUNCH();
+            for (int q = 0; q < nd; q++) prevFlow[dirs[q]] = cur[dirs[q]];
+        } else
         for (int d = 0; d < 2; d++) {
             if (!out[d]) continue;
             float *flow = (k > 0) ? fbuf[d][k & 1] : out[d];
