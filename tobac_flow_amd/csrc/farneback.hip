@@ -109,6 +109,94 @@ k_fb_resize_area2(const float *__restrict__ src, int sw, float *__restrict__ dst
     dst[(int64_t)dy * dw + dx] = sum * 0.25f;
 }
 
+// ---- GaussianBlur + INTER_LINEAR resize, evaluated only where the resize samples it -----------------
+// For pyramid level k >= 1 OpenCV blurs the FULL-RES image and then reads just two blurred pixels
+// per axis for every level pixel.  These two kernels compute exactly those values, with the same
+// arithmetic order as the full blur followed by resize (row filter first, then symmetric column
+// filter, then the bilinear combination):
+//   pass 1  rowf[y][dx] = float2(row filter at column sx(dx), row filter at column sx(dx)+1), all H rows
+//   pass 2  level(dy, dx) from the column filter at rows sy(dy), sy(dy)+1 of rowf
+// Work drops from H*W*ksize*2 to about H*w*ksize*2 + h*w*ksize*4 multiply-adds per image.
+struct FbResizeGeom { int sh, sw, dh, dw; double scale_x, scale_y; };
+
+__device__ __forceinline__ void fb_resize_coord(int d, double scale, int slen, int &s0, float &f) {
+    // cv::resize INTER_LINEAR x-coordinate rule (the y rule differs only in the clamping, done by the caller)
+    f = (float)((d + 0.5) * scale - 0.5);
+    s0 = tf_cvfloor(f); f -= s0;
+}
+
+template <typename TIn>
+__global__ void __launch_bounds__(256)
+k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKernel kk, float2 *__restrict__ rowf)
+{
+    const int dx = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= g.dw || y >= g.sh) return;
+    int sx; float fx;
+    fb_resize_coord(dx, g.scale_x, g.sw, sx, fx);
+    if (sx < 0) sx = 0;
+    if (sx >= g.sw - 1) sx = g.sw - 1;
+    const int sx1 = sx + 1 < g.sw ? sx + 1 : sx;
+    const int ksize = kk.ksize, r = ksize >> 1, W = g.sw;
+    const float *k = kk.k;
+    const TIn *S = src + (int64_t)y * W;
+    float2 out;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int x = c ? sx1 : sx;
+        float s;
+        if (ksize == 3) {
+            s = (float)S[x] * k[1] + ((float)S[fb_reflect101(x - 1, W)] + (float)S[fb_reflect101(x + 1, W)]) * k[0];
+        } else if (ksize == 5) {
+            s = (float)S[x] * k[2] + ((float)S[fb_reflect101(x - 1, W)] + (float)S[fb_reflect101(x + 1, W)]) * k[1]
+              + ((float)S[fb_reflect101(x - 2, W)] + (float)S[fb_reflect101(x + 2, W)]) * k[0];
+        } else {
+            s = k[0] * (float)S[fb_reflect101(x - r, W)];
+            if (x - r >= 0 && x + r < W) { for (int i = 1; i < ksize; i++) s += k[i] * (float)S[x - r + i]; }
+            else { for (int i = 1; i < ksize; i++) s += k[i] * (float)S[fb_reflect101(x - r + i, W)]; }
+        }
+        if (c) out.y = s; else out.x = s;
+    }
+    rowf[(int64_t)y * g.dw + dx] = out;
+}
+
+__global__ void __launch_bounds__(256)
+k_fb_blur_cols_resize(const float2 *__restrict__ rowf, FbResizeGeom g, const FbKernel kk, float *__restrict__ dst)
+{
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= g.dw || dy >= g.dh) return;
+    int sx, sy; float fx, fy;
+    fb_resize_coord(dx, g.scale_x, g.sw, sx, fx);
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= g.sw - 1) { fx = 0; sx = g.sw - 1; }
+    fb_resize_coord(dy, g.scale_y, g.sh, sy, fy);
+    const int H = g.sh, w = g.dw, r = kk.ksize >> 1;
+    const float *k = kk.k;
+    const int rows[2] = {tf_clampi(sy, 0, H - 1), tf_clampi(sy + 1, 0, H - 1)};
+    float b[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int y = rows[q];
+        const float2 c0 = rowf[(int64_t)y * w + dx];
+        float s0 = k[r] * c0.x, s1 = k[r] * c0.y;
+        if (y - r >= 0 && y + r < H) {
+            for (int i = 1; i <= r; i++) {
+                const float2 p = rowf[(int64_t)(y + i) * w + dx], m = rowf[(int64_t)(y - i) * w + dx];
+                s0 += k[r + i] * (p.x + m.x); s1 += k[r + i] * (p.y + m.y);
+            }
+        } else {
+            for (int i = 1; i <= r; i++) {
+                const float2 p = rowf[(int64_t)fb_reflect101(y + i, H) * w + dx], m = rowf[(int64_t)fb_reflect101(y - i, H) * w + dx];
+                s0 += k[r + i] * (p.x + m.x); s1 += k[r + i] * (p.y + m.y);
+            }
+        }
+        b[q][0] = s0; b[q][1] = s1;
+    }
+    const float ax0 = 1.f - fx, ax1 = fx, ay0 = 1.f - fy, ay1 = fy;
+    const float r0 = b[0][0] * ax0 + b[0][1] * ax1;
+    const float r1 = b[1][0] * ax0 + b[1][1] * ax1;
+    dst[(int64_t)dy * g.dw + dx] = r0 * ay0 + r1 * ay1;
+}
+
 // ---- polynomial expansion ------------------------------------------------------------------------
 struct FbPoly { int n; float g[FB_MAX_POLY_N + 1], xg[FB_MAX_POLY_N + 1], xxg[FB_MAX_POLY_N + 1]; double ig11, ig03, ig33, ig55; };
 
@@ -443,7 +531,7 @@ extern "C" size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_fa
     if (H <= 0 || W <= 0 || !p) return 0;
     const size_t n = (size_t)H * W, pl = tf_align_up(n * 4, 256);
     // tmp, blur, I, t0..t2, R0[5], R1[5], M[5], 4 flow buffers of 2 planes, kernel table
-    return 6 * pl + 15 * pl + 4 * 2 * pl + tf_align_up(sizeof(FbKernel), 256) + 4096;
+    return 6 * pl + 15 * pl + 4 * 2 * pl + tf_align_up((2 * (size_t)H + 64) * 4, 256) + 8192;
 }
 
 extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H64, int64_t W64,
@@ -461,7 +549,7 @@ extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)H * W;
     TfArena ar(ws, ws_bytes);
-    float *tmp = ar.take<float>(n), *blur = ar.take<float>(n), *I = ar.take<float>(n);
+    float *tmp = ar.take<float>(n + 2 * (size_t)H + 64), *blur = ar.take<float>(n), *I = ar.take<float>(n);
     float *t0 = ar.take<float>(n), *t1 = ar.take<float>(n), *t2 = ar.take<float>(n);
     float *R[2] = {ar.take<float>(5 * n), ar.take<float>(5 * n)};
     float *M = ar.take<float>(5 * n);
@@ -486,20 +574,28 @@ extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64
         const dim3 glev((w + 63) / 64, (h + 3) / 4);
         FbKernel hk; fb_gaussian_kernel(smooth_sz, sigma, &hk);
         for (int i = 0; i < 2; i++) {
-            {
-                TfProfScope ps(TFK_FB_BLUR, 13.0 * n, s);     // u8 r + f32 w, then f32 r + f32 w
-                hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp);
-                hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur);
-            }
             const float *Ik = blur;
-            if (w != W || h != H) {
-                TfProfScope ps(TFK_FB_RESIZE, 4.0 * n + 4.0 * plane, s);
-                const double sx = 1. / ((double)w / W), sy = 1. / ((double)h / H);
-                const int isx = (int)(sx + 0.5), isy = (int)(sy + 0.5);
-                if (fabs(sx - isx) < DBL_EPSILON && fabs(sy - isy) < DBL_EPSILON && isx == 2 && isy == 2)
+            const double rsx = 1. / ((double)w / W), rsy = 1. / ((double)h / H);
+            const int irx = (int)(rsx + 0.5), iry = (int)(rsy + 0.5);
+            const bool same = (w == W && h == H);
+            const bool area2 = !same && fabs(rsx - irx) < DBL_EPSILON && fabs(rsy - iry) < DBL_EPSILON && irx == 2 && iry == 2;
+            if (same || area2) {
+                {
+                    TfProfScope ps(TFK_FB_BLUR, 13.0 * n, s);     // u8 r + f32 w, then f32 r + f32 w
+                    hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp);
+                    hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur);
+                }
+                if (area2) {
+                    TfProfScope ps(TFK_FB_RESIZE, 4.0 * n + 4.0 * plane, s);
                     hipLaunchKernelGGL(k_fb_resize_area2, glev, block, 0, s, blur, W, I, h, w);
-                else
-                    hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, blur, H, W, 1, I, h, w, sx, sy, 1.f);
+                    Ik = I;
+                }
+            } else {
+                // blur + resize fused on the sampled columns / rows (tmp holds rowf: H * w float2 <= n floats)
+                TfProfScope ps(TFK_FB_BLUR, 1.0 * n + 8.0 * (double)H * w * 2 + 4.0 * plane, s);
+                FbResizeGeom rg; rg.sh = H; rg.sw = W; rg.dh = h; rg.dw = w; rg.scale_x = rsx; rg.scale_y = rsy;
+                hipLaunchKernelGGL(k_fb_blur_rows_sampled<uint8_t>, dim3((w + 63) / 64, (H + 3) / 4), block, 0, s, img[i], rg, hk, (float2 *)tmp);
+                hipLaunchKernelGGL(k_fb_blur_cols_resize, glev, block, 0, s, (const float2 *)tmp, rg, hk, I);
                 Ik = I;
             }
             {

@@ -28,9 +28,9 @@
 // -2-id for boundary markers, -1 for everything else) and cls u8[N].  All keys live in COMPACT
 // arrays over the R = (#floodable + #boundary markers) relevant pixels, ids in raster order:
 //   pix u64[R] raster index (top bit: marker), val u32[R] ordered field key, nbr int32[R][n_nbr] compact ids of the
-//   floodable out-neighbours (flow displacement already applied), K2, M1, C_1.., Rt, pushed u64[R].
-// A sweep is one launch over the compact arrays; each workgroup makes several relaxation rounds
-// per launch and a pixel re-pushes only when its own key changed since its last push.
+//   floodable out-neighbours (flow displacement already applied), K2, M1, C_1.., Rt u64[R].
+// Sweeps are frontier driven: two ping-pong queues of compact ids hold the pixels whose key just
+// changed; a sweep costs work proportional to the frontier, not to the volume.
 #include "tf_common.h"
 #include <string.h>
 #include <stdlib.h>
@@ -38,14 +38,10 @@
 
 typedef unsigned long long u64;
 #define WS_INF 0xFFFFFFFFFFFFFFFFull
-#define WS_NEVER 0xFFFFFFFFFFFFFFFEull
 #define WS_MARKER_BIT 0x8000000000000000ull
 #define WS_MAX_NBR 26
 #define WS_MAX_DEPTH 8
-#define WS_BATCH 4
-#ifndef WS_ROUNDS
-#define WS_ROUNDS 6
-#endif
+#define WS_BATCH 16
 
 struct WsGeom {
     int64_t T; int H, W; int64_t plane;
@@ -56,7 +52,7 @@ struct WsGeom {
 struct WsC {               // compact arrays
     int64_t R; int n_nbr;
     const u64 *pix; const unsigned *val; const int *nbr;
-    u64 *K2, *M1, *C[WS_MAX_DEPTH], *Rt, *pushed;
+    u64 *K2, *M1, *C[WS_MAX_DEPTH], *Rt;
 };
 
 __device__ __forceinline__ unsigned ws_ordkey(float v) {
@@ -130,7 +126,7 @@ k_ws_cid(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, cons
 __global__ void __launch_bounds__(256)
 k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, const float *__restrict__ bwd,
              const int *__restrict__ cid, WsGeom g, u64 *__restrict__ pix, unsigned *__restrict__ val,
-             int *__restrict__ nbr, u64 *__restrict__ K2, u64 *__restrict__ M1, u64 *__restrict__ pushed)
+             int *__restrict__ nbr, u64 *__restrict__ K2, u64 *__restrict__ M1)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     const int64_t t = blockIdx.z;
@@ -153,46 +149,88 @@ k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, con
     }
     K2[id] = marker ? ((u64)v << 32) : WS_INF;
     M1[id] = WS_INF;
-    pushed[id] = WS_NEVER;
 }
 
 // chain arrays of a marker: C_k = 0 for every k; root = raster index
 __global__ void __launch_bounds__(256)
-k_ws_init_level(const u64 *__restrict__ K2, const u64 *__restrict__ pix, const unsigned *__restrict__ val,
-                u64 *__restrict__ dst, u64 *__restrict__ pushed, int64_t R, int is_root)
+k_ws_init_level(const u64 *__restrict__ pix, u64 *__restrict__ dst, int64_t R, int is_root)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const u64 px = pix[i];
     const bool marker = (px & WS_MARKER_BIT) != 0ull;
     dst[i] = marker ? (is_root ? (px & ~WS_MARKER_BIT) : 0ull) : WS_INF;
-    pushed[i] = WS_NEVER;
+}
+
+// ---- frontier queues ---------------------------------------------------------------------------
+// A sweep processes the queue of pixels whose key changed (qin) and appends every pixel whose key it
+// lowers to qout.  inq[n] = 1 while n sits in a queue and has not been processed since: the flag is
+// cleared BEFORE the pixel's key is read, so a later decrease always re-queues it (no lost update); a
+// pixel can appear at most twice per queue, hence the 2R capacity.  Appends are aggregated per wave
+// (one atomicAdd per 64 lanes).
+#define WS_LDS_CAP (256 * WS_MAX_NBR)
+struct WsStage { int cnt; int base; int buf[WS_LDS_CAP]; };
+
+// stage an append in LDS (one LDS atomic per appended id)
+__device__ __forceinline__ void ws_stage(WsStage &st, bool enq, int n) {
+    if (enq) { const int pos = atomicAdd(&st.cnt, 1); st.buf[pos] = n; }
+}
+// flush the workgroup's staged ids with ONE global atomicAdd; must be reached by every thread
+__device__ __forceinline__ void ws_flush(WsStage &st, int *__restrict__ qout, int *__restrict__ cnt_out, int qcap) {
+    __syncthreads();
+    const int n = st.cnt;
+    if (n > 0) {
+        if (threadIdx.x == 0) st.base = atomicAdd(cnt_out, n);
+        __syncthreads();
+        const int base = st.base;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const int pos = base + i; if (pos < qcap) qout[pos] = st.buf[i]; }
+        __syncthreads();
+        if (threadIdx.x == 0) st.cnt = 0;
+    }
+    __syncthreads();
 }
 
 // ---- phase A: K2 and M1 ------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_ws_relax_a(WsC c, int *__restrict__ changed)
+k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in, int *__restrict__ qout,
+             int *__restrict__ cnt_out, int *__restrict__ inq, int qcap)
 {
-    bool ch = false;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < c.R) {
-        for (int round = 0; round < WS_ROUNDS; round++) {
-            const u64 kp = ws_load(&c.K2[p]);
-            if (kp == WS_INF || kp == c.pushed[p]) { if (round) __builtin_amdgcn_s_sleep(2); continue; }
-            c.pushed[p] = kp;
-            const u64 lp = kp >> 32;
-            for (int i = 0; i < c.n_nbr; i++) {
-                const int n = c.nbr[p * c.n_nbr + i];
-                if (n < 0) continue;
-                const u64 vn = c.val[n];
-                const u64 cand = vn > lp ? ((vn << 32) | 1ull) : (vn == lp ? kp + 1ull : kp);
-                const u64 old = atomicMin(&c.K2[n], cand);
-                ch |= cand < old;
-                atomicMin(&c.M1[n], kp);
-            }
+    __shared__ WsStage st;
+    if (threadIdx.x == 0) st.cnt = 0;
+    __syncthreads();
+    // qin == nullptr: first sweep of the phase = scan of all relevant pixels (no seed queue needed)
+    const int64_t n_in = qin ? (int64_t)min(*cnt_in, qcap) : c.R;
+    const int64_t n_pad = (n_in + 255) & ~255ll;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n_pad; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool act = i < n_in;
+        int p = 0; u64 kp = WS_INF;
+        if (act) {
+            p = qin ? qin[i] : (int)i;
+            // relaxed L2 atomics only: the load below is issued after the exchange has returned
+            const int was = atomicExch(&inq[p], 0);
+            kp = was == 0x7fffffff ? WS_INF : ws_load(&c.K2[p]);
         }
+        const u64 lp = kp >> 32;
+        for (int s = 0; s < c.n_nbr; s++) {
+            bool enq = false; int n = -1;
+            if (act) {
+                n = c.nbr[(int64_t)p * c.n_nbr + s];
+                if (n >= 0) {
+                    const u64 vn = c.val[n];
+                    const u64 cand = vn > lp ? ((vn << 32) | 1ull) : (vn == lp ? kp + 1ull : kp);
+                    // keys only decrease, so a (possibly stale, i.e. larger) plain read is a safe pre-filter
+                    if (kp < c.M1[n]) atomicMin(&c.M1[n], kp);
+                    if (cand < c.K2[n]) {
+                        const u64 old = atomicMin(&c.K2[n], cand);
+                        if (cand < old) enq = atomicExch(&inq[n], 1) == 0;
+                    }
+                }
+            }
+            ws_stage(st, enq, n);
+        }
+        ws_flush(st, qout, cnt_out, qcap);
     }
-    if (ch) *changed = 1;
 }
 
 // ---- phase k >= 1 (chain level k) and phase R (k == depth) ----------------------------------------
@@ -202,22 +240,30 @@ k_ws_relax_a(WsC c, int *__restrict__ changed)
 //   otherwise n continues p's run / descent: chain = [K2 n, tail(p)] -> offered_j = C_j[p]
 // The candidate must agree with n on every level j < k.
 __global__ void __launch_bounds__(256)
-k_ws_relax_chain(WsC c, int k, int depth, int *__restrict__ changed)
+k_ws_sweep_chain(WsC c, int k, int depth, const int *__restrict__ qin, const int *__restrict__ cnt_in,
+                 int *__restrict__ qout, int *__restrict__ cnt_out, int *__restrict__ inq, int qcap)
 {
-    bool ch = false;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < c.R) {
-        const u64 kp = c.K2[p];                      // final since phase A
-        u64 *dst = k == depth ? c.Rt : c.C[k];
-        if (kp != WS_INF) {
-            for (int round = 0; round < WS_ROUNDS; round++) {
-                const u64 own = ws_load(&dst[p]);
-                if (own == c.pushed[p]) { if (round) __builtin_amdgcn_s_sleep(2); continue; }
-                c.pushed[p] = own;
-                for (int i = 0; i < c.n_nbr; i++) {
-                    const int n = c.nbr[p * c.n_nbr + i];
-                    if (n < 0) continue;
-                    if (c.M1[n] != kp) continue;
+    __shared__ WsStage st;
+    if (threadIdx.x == 0) st.cnt = 0;
+    __syncthreads();
+    const int64_t n_in = qin ? (int64_t)min(*cnt_in, qcap) : c.R;
+    const int64_t n_pad = (n_in + 255) & ~255ll;
+    u64 *dst = k == depth ? c.Rt : c.C[k];
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n_pad; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool act = i < n_in;
+        int p = 0; u64 kp = WS_INF, own = WS_INF;
+        if (act) {
+            p = qin ? qin[i] : (int)i;
+            const int was = atomicExch(&inq[p], 0);
+            kp = c.K2[p];                        // final since phase A
+            own = was == 0x7fffffff ? WS_INF : ws_load(&dst[p]);
+        }
+        for (int s = 0; s < c.n_nbr; s++) {
+            bool enq = false; int n = -1;
+            if (act && kp != WS_INF) {
+                n = c.nbr[(int64_t)p * c.n_nbr + s];
+                if (n >= 0 && c.M1[n] == kp) {
                     const u64 kn = c.K2[n];
                     const bool entry = (kn >> 32) == (u64)c.val[n] && (kn & 0xFFFFFFFFull) == 1ull;
                     bool match = true;
@@ -225,18 +271,21 @@ k_ws_relax_chain(WsC c, int k, int depth, int *__restrict__ changed)
                         const u64 offered_j = entry ? (j == 1 ? kp : c.C[j - 1][p]) : c.C[j][p];
                         match = offered_j == c.C[j][n];
                     }
-                    if (!match) continue;
-                    u64 offered;
-                    if (k == depth) offered = own;                                    // root: copied along every edge
-                    else offered = entry ? (k == 1 ? kp : c.C[k - 1][p]) : own;
-                    if (offered == WS_INF) continue;
-                    const u64 old = atomicMin(&dst[n], offered);
-                    ch |= offered < old;
+                    if (match) {
+                        u64 offered;
+                        if (k == depth) offered = own;                                    // root: copied along every edge
+                        else offered = entry ? (k == 1 ? kp : c.C[k - 1][p]) : own;
+                        if (offered != WS_INF && offered < dst[n]) {
+                            const u64 old = atomicMin(&dst[n], offered);
+                            if (offered < old) enq = atomicExch(&inq[n], 1) == 0;
+                        }
+                    }
                 }
             }
+            ws_stage(st, enq, n);
         }
+        ws_flush(st, qout, cnt_out, qcap);
     }
-    if (ch) *changed = 1;
 }
 
 // after the K2-only root phase: does any candidate edge join two different labels?
@@ -287,9 +336,10 @@ static size_t ws_full_bytes(int64_t N) {
     return tf_align_up((size_t)N, 256) * 2 + tf_align_up((size_t)N * 4, 256) * 2 + tf_align_up(ws_scan_temp_bytes(N), 256) + 4096;
 }
 static size_t ws_compact_bytes(int64_t R, int n_nbr, int depth) {
-    // pix + val + nbr + (K2, M1, C_1..C_{d-1}, Rt, pushed)
+    // pix + val + nbr + keys + queues
     return tf_align_up((size_t)R * 8, 256) + tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 4 * n_nbr, 256)
-         + (size_t)(depth + 3) * tf_align_up((size_t)R * 8, 256) + 4096;
+         + (size_t)(depth + 2) * tf_align_up((size_t)R * 8, 256)          // K2, M1, C_1..C_{d-1}, Rt
+         + 2 * tf_align_up((size_t)R * 8 + 256, 256) + tf_align_up((size_t)R * 4, 256) + 4096;   // two queues (2R ints), inq
 }
 
 extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int n_nbr, int chain_depth, int64_t max_relevant)
@@ -300,25 +350,48 @@ extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, 
     return ws_full_bytes(N) + ws_compact_bytes(max_relevant, n_nbr, chain_depth);
 }
 
-static int ws_run_phase(const WsC &c, int phase_k, int depth, int *d_flags, int *h_flags,
-                        hipStream_t s, int64_t max_sweeps, int64_t *sweeps_out)
+struct WsQueues { int *q[2]; int *cnt; int *inq; int qcap; int *h_cnt; int64_t *processed; };
+
+// Run one relaxation phase to its fixpoint.  phase_k = 0: K2/M1; otherwise chain level k (k == depth: root).
+static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q, hipStream_t s, int64_t max_sweeps,
+                        int64_t *sweeps_out)
 {
-    const unsigned nb = (unsigned)((c.R + 255) / 256);
+    const unsigned nbR = (unsigned)((c.R + 255) / 256);
+    const unsigned nb = nbR < 2048u ? nbR : 2048u;
+    TF_CHECK_HIP(hipMemsetAsync(Q.cnt, 0, (WS_BATCH + 1) * sizeof(int), s));
+    TF_CHECK_HIP(hipMemsetAsync(Q.inq, 0, (size_t)c.R * sizeof(int), s));
     int64_t sweeps = 0;
+    int parity = 0;
+    bool first = true;
     for (;;) {
-        TF_CHECK_HIP(hipMemsetAsync(d_flags, 0, WS_BATCH * sizeof(int), s));
         for (int b = 0; b < WS_BATCH; b++) {
-            TfProfScope ps(TFK_WS_RELAX, 16.0 * (double)c.R, s);     // key + last-pushed key per relevant pixel
-            if (phase_k == 0) hipLaunchKernelGGL(k_ws_relax_a, dim3(nb), dim3(256), 0, s, c, d_flags + b);
-            else hipLaunchKernelGGL(k_ws_relax_chain, dim3(nb), dim3(256), 0, s, c, phase_k, depth, d_flags + b);
+            TfProfScope ps(TFK_WS_RELAX, 0.0, s);
+            const int *qin = first ? nullptr : Q.q[parity];
+            const unsigned blocks = first ? nbR : nb;
+            if (phase_k == 0)
+                hipLaunchKernelGGL(k_ws_sweep_a, dim3(blocks), dim3(256), 0, s, c, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, Q.inq, Q.qcap);
+            else
+                hipLaunchKernelGGL(k_ws_sweep_chain, dim3(blocks), dim3(256), 0, s, c, phase_k, depth, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, Q.inq, Q.qcap);
+            parity ^= 1;
+            first = false;
         }
         TF_CHECK_LAUNCH();
-        TF_CHECK_HIP(hipMemcpyAsync(h_flags, d_flags, WS_BATCH * sizeof(int), hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipMemcpyAsync(Q.h_cnt, Q.cnt, (WS_BATCH + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
         TF_CHECK_HIP(hipStreamSynchronize(s));
         bool done = false;
-        for (int b = 0; b < WS_BATCH; b++) { sweeps++; if (!h_flags[b]) { done = true; break; } }
+        // slot b holds the size of the queue consumed by sweep b (slot 0 of the first batch is unused:
+        // that sweep scans everything)
+        for (int b = (sweeps == 0 ? 1 : 0); b <= WS_BATCH; b++) {
+            if (Q.h_cnt[b] > Q.qcap) { tf_set_error("tf_watershed: frontier queue overflow"); return TF_EHIP; }
+            if (Q.h_cnt[b] == 0) { done = true; break; }
+            if (b < WS_BATCH) *Q.processed += Q.h_cnt[b];
+        }
+        sweeps += WS_BATCH;
         if (done) break;
         if (sweeps > max_sweeps) { tf_set_error("tf_watershed: phase %d did not converge in %lld sweeps", phase_k, (long long)sweeps); return TF_ENOCONV; }
+        // carry the last count into slot 0, clear the rest
+        TF_CHECK_HIP(hipMemcpyAsync(Q.cnt, Q.cnt + WS_BATCH, sizeof(int), hipMemcpyDeviceToDevice, s));
+        TF_CHECK_HIP(hipMemsetAsync(Q.cnt + 1, 0, WS_BATCH * sizeof(int), s));
     }
     *sweeps_out = sweeps;
     return TF_OK;
@@ -348,7 +421,7 @@ extern "C" int tf_watershed(const float *field, const int32_t *markers, const in
     int *scan = ar.take<int>(N), *cid = ar.take<int>(N);
     const size_t scan_bytes = ws_scan_temp_bytes(N);
     char *scan_tmp = ar.take<char>(scan_bytes ? scan_bytes : 1);
-    int *d_flags = ar.take<int>(WS_BATCH + 4);
+    int *d_flags = ar.take<int>(WS_BATCH + 8);
     if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
 
     dim3 block(64, 4, 1), grid((g.W + 63) / 64, (g.H + 3) / 4, (unsigned)T);
@@ -387,7 +460,7 @@ extern "C" int tf_watershed(const float *field, const int32_t *markers, const in
     }
     hipLaunchKernelGGL(k_ws_cid, dim3(nb1), dim3(256), 0, s, cls, flag, scan, N, cid);
     TF_CHECK_LAUNCH();
-    int h_flags[WS_BATCH + 4];
+    int h_cnt[WS_BATCH + 8];
     WsC c; memset(&c, 0, sizeof(c));
     c.R = R; c.n_nbr = n_nbr;
     if (R > 0) {
@@ -395,18 +468,22 @@ extern "C" int tf_watershed(const float *field, const int32_t *markers, const in
         c.pix = pix; c.val = val; c.nbr = nbr;
         c.K2 = ar.take<u64>(R); c.M1 = ar.take<u64>(R);
         for (int k = 1; k < chain_depth; k++) c.C[k] = ar.take<u64>(R);
-        c.Rt = ar.take<u64>(R); c.pushed = ar.take<u64>(R);
+        c.Rt = ar.take<u64>(R);
+        WsQueues Q;
+        Q.qcap = (int)(2 * R < 0x7fffff00ll ? 2 * R : 0x7fffff00ll);
+        Q.q[0] = ar.take<int>(2 * R + 64); Q.q[1] = ar.take<int>(2 * R + 64); Q.inq = ar.take<int>(R);
+        Q.cnt = d_flags; Q.h_cnt = h_cnt; Q.processed = &st[7];
         if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
-        hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1, c.pushed);
+        hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1);
         TF_CHECK_LAUNCH();
         const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
-        const int64_t max_sweeps = 1024 + 64 * (T + H + W);
-        int rc = ws_run_phase(c, 0, chain_depth, d_flags, h_flags, s, max_sweeps, &st[0]);
+        const int64_t max_sweeps = 4096 + 512 * (T + H + W);
+        int rc = ws_run_phase(c, 0, chain_depth, Q, s, max_sweeps, &st[0]);
         if (rc) return rc;
         // fast path: root phase matched on K2 only, then the conflict test
-        hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.K2, c.pix, c.val, c.Rt, c.pushed, R, 1);
+        hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1);
         TF_CHECK_LAUNCH();
-        rc = ws_run_phase(c, 1, 1, d_flags, h_flags, s, max_sweeps, &st[1]);
+        rc = ws_run_phase(c, 1, 1, Q, s, max_sweeps, &st[1]);
         if (rc) return rc;
         int conflict = 0;
         if (chain_depth > 1) {
@@ -420,10 +497,10 @@ extern "C" int tf_watershed(const float *field, const int32_t *markers, const in
         if (conflict) {
             for (int k = 1; k <= chain_depth; k++) {
                 u64 *dst = k == chain_depth ? c.Rt : c.C[k];
-                hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.K2, c.pix, c.val, dst, c.pushed, R, k == chain_depth ? 1 : 0);
+                hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, dst, R, k == chain_depth ? 1 : 0);
                 TF_CHECK_LAUNCH();
                 int64_t sw = 0;
-                rc = ws_run_phase(c, k, chain_depth, d_flags, h_flags, s, max_sweeps, &sw);
+                rc = ws_run_phase(c, k, chain_depth, Q, s, max_sweeps, &sw);
                 if (rc) return rc;
                 st[2 + (k < 3 ? k - 1 : 2)] += sw;
             }
