@@ -1,0 +1,174 @@
+"""CPU-only tests: the C ABI library loads and exports every symbol include/*.h declares, the host
+layer mirrors the reference's interface (names, defaults, exception types) and the numpy glue gives
+the reference's known answers (ports of /root/reference/tests/test_flow.py:8-49,364-412,
+tests/test_analysis.py, tests/test_label_utils.py, tests/test_detection.py:7-33)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from tobac_flow_amd import _lib
+    header = open(os.path.join(ROOT, "include", "tobac_flow_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 18
+    L = ctypes.CDLL(_lib.lib_path())
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) <= declared
+    assert _lib.lib().tf_version() >= 100
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd._lib import TobacFlowHipError
+    z = np.zeros((3, 5, 2), np.float32)
+    with pytest.raises(TobacFlowHipError):
+        tf.smooth_flow_step(z, z)
+    with pytest.raises(TobacFlowHipError):
+        tf.Flow(z[None], z[None]).sobel(np.zeros((1, 3, 5), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tobac_flow_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_select_of_model_errors():
+    import tobac_flow_amd.flow as tf
+    assert hasattr(tf.select_of_model("Farneback"), "calc")
+    with pytest.raises(NotImplementedError):
+        tf.select_of_model("DenseRLOF")
+    with pytest.raises(NotImplementedError):
+        tf.select_of_model("DIS")
+    with pytest.raises(ValueError):
+        tf.select_of_model("not_an_of_model")
+
+
+def test_flow_object_contract():
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.core import AbstractFlow
+    z = np.zeros([3, 5, 2])
+    f = tf.Flow(z, z)
+    assert isinstance(f, AbstractFlow) and f.shape == (3, 5)
+    with pytest.raises(ValueError):
+        tf.Flow(z, np.zeros([2, 4, 2]))
+    with pytest.raises(ValueError):
+        tf.Flow(np.zeros([3, 5, 1]), np.zeros([3, 5, 1]))
+    fw, bw = f.flow
+    assert fw is f.forward_flow and bw is f.backward_flow
+    assert f[:2, :4].shape == (2, 4)
+    with pytest.raises(AssertionError):
+        f.convolve(np.zeros((4, 4)))
+    for name in ("create_flow", "calculate_flow", "calculate_flow_2", "calculate_flow_frame", "smooth_flow_step",
+                 "to_8bit", "warp_flow", "select_of_model", "vr_model", "combine_flow", "flow_magnitude"):
+        assert hasattr(tf, name), name
+
+
+def test_to_8bit_reference_known_answers():
+    import tobac_flow_amd.flow as tf
+    assert np.all(tf.to_8bit(np.zeros(5)) == 0)
+    assert np.all(tf.to_8bit(np.ones(5)) == 0)
+    assert np.all(tf.to_8bit(np.ones(5), vmin=0, vmax=1) == 255)
+    arr = np.arange(256)
+    assert np.all(tf.to_8bit(arr) == arr)
+    assert np.all(tf.to_8bit(arr + 10, vmin=10, vmax=10 + 255) == arr)
+    pair = np.array([[np.nan, 1.0, 0.0], [0.5, np.nan, np.nan]])
+    assert np.array_equal(tf.to_8bit(pair, 0, 1), np.array([[127, 255, 0], [127, 255, 0]], np.uint8))
+
+
+def test_convolve_argument_validation():
+    from tobac_flow_amd.convolve import convolve
+    z = np.zeros((2, 4, 4, 2), np.float32)
+    d = np.zeros((2, 4, 4), np.float32)
+    with pytest.raises(AssertionError):
+        convolve(d, z, z, structure=np.ones((3, 3)))
+    with pytest.raises(ValueError):
+        convolve(d, z, z, method="spline")
+
+
+def test_analysis_known_answers():
+    from tobac_flow_amd import analysis
+    assert analysis.find_object_lengths(np.zeros([3]).astype(int)).size == 0
+    one = np.array([0, 1, 0]).astype(int)
+    assert analysis.find_object_lengths(one)[0] == 1
+    l3 = np.array([[1, 1, 1]]).astype(int)
+    assert analysis.find_object_lengths(l3)[0] == 1 and analysis.find_object_lengths(l3, axis=1)[0] == 3
+    assert np.all(analysis.find_object_lengths(np.arange(10).astype(int)) == np.ones([9]))
+    empty = np.zeros([3]).astype(int)
+    assert analysis.mask_labels(empty, empty).size == 0
+    assert analysis.mask_labels(one, empty)[0] == False  # noqa: E712
+    assert analysis.mask_labels(one, one)[0] == True     # noqa: E712
+
+
+def test_label_utils_known_answers():
+    from tobac_flow_amd.utils.label_utils import apply_func_to_labels, make_step_labels, slice_labels
+    lab = np.zeros([5, 10, 15], dtype=np.int32)
+    lab[:, 3:6, 4:8] = 1
+    assert np.all(np.unique(slice_labels(lab)) == np.arange(6))
+    lab[:, 5:8, 10:13] = 2
+    s = slice_labels(lab)
+    assert np.all(np.unique(s) == np.arange(11))
+    for i in range(5):
+        assert np.all(np.unique(s[i]) == np.array([0, 2 * i + 1, 2 * i + 2]))
+    t = np.array([[[0, 0, 0, 1], [0, 2, 1, 0], [0, 2, 0, 3]], [[0, 0, 0, 0], [0, 2, 2, 0], [0, 2, 0, 4]]])
+    want = np.array([[[0, 0, 0, 1], [0, 3, 2, 0], [0, 3, 0, 4]], [[0, 0, 0, 0], [0, 5, 5, 0], [0, 5, 0, 6]]])
+    assert np.all(make_step_labels(t) == want)
+    tl = np.zeros([4, 6])
+    tl[1:3, 1:3] = 1
+    tl[2:3, 3:6] = 3
+    tl = tl.astype(int)
+    d1 = np.arange(24).reshape([4, 6])
+    r = apply_func_to_labels(tl, d1, func=np.mean)
+    assert np.allclose(r[0], d1[tl == 1].mean()) and np.allclose(r[2], d1[tl == 3].mean())
+    r = apply_func_to_labels(tl, d1, np.array([1, 2, 3, 3, 2, 1]), func=lambda a, w: (np.average(a, weights=w), np.std(a)),
+                             default=np.nan)
+    assert r.shape == (2, 3) and np.isnan(r[0, 1])
+
+
+def test_get_watershed_mask_known_answers():
+    from tobac_flow_amd.detection import get_watershed_mask
+    f = np.zeros([1, 5, 5], dtype=np.float32)
+    f[:, 3:] = 1
+    r = get_watershed_mask(f)
+    assert np.all(r[:, :2]) and not np.any(r[:, 2:])
+    r = get_watershed_mask(f, erode_distance=2)
+    assert np.all(r[:, :1]) and not np.any(r[:, 1:])
+    assert not np.any(get_watershed_mask(f, erode_distance=3))
+    f[:, 2] = np.nan
+    r = get_watershed_mask(f, erode_distance=1)
+    assert np.all(r[:, :3]) and not np.any(r[:, 3:])
+
+
+def test_peak_local_max_documented_examples():
+    from tobac_flow_amd.utils.peak_utils import peak_local_max
+    img = np.zeros((7, 7))
+    img[3, 4] = 1
+    img[3, 2] = 1.5
+    assert np.array_equal(peak_local_max(img, min_distance=1), [[3, 2], [3, 4]])
+    assert np.array_equal(peak_local_max(img, min_distance=2), [[3, 2]])
+
+
+def test_window_bounds_and_stitch_lut():
+    from tobac_flow_amd.parallel import stitch_lut, window_bounds
+    assert window_bounds(10, 1) == [(0, 10)]
+    b = window_bounds(144, 8)
+    assert b[0][0] == 0 and b[-1][1] == 144 and all(b[i][1] - 1 == b[i + 1][0] for i in range(7))
+    with pytest.raises(ValueError):
+        window_bounds(3, 4)
+    # rank 0 has labels 1..3, rank 1 has 1..2, rank 2 has 1..2; 0:2 == 1:1, 1:2 == 2:1
+    luts = stitch_lut([3, 2, 2], [np.array([[2, 1]]), np.array([[2, 1]])])
+    assert [l.tolist() for l in luts] == [[0, 1, 2, 3], [0, 2, 4], [0, 4, 5]]
