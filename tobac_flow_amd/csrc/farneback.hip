@@ -319,7 +319,7 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 #define FBI_M 6
 #define FBI_WIN (2 * FBI_M + 1)
 #define FBI_OW (256 - 2 * FBI_M)
-#define FBI_HS 64
+#define FBI_HS 128
 struct FbIterArgs { const float *R0[2], *R1[2], *fin[2]; float *fout[2]; };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
 
@@ -351,16 +351,25 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int base, floa
         const int s = base + K0 + g;
         if (s <= c.s_end) {
 #pragma unroll
-            for (int ch = 0; ch < 5; ch++) { S[ch] += (double)nm[g][ch] - (double)ring[K0 + g][ch]; ring[K0 + g][ch] = nm[g][ch]; }
+            for (int ch = 0; ch < 5; ch++) { S[ch] += (double)(nm[g][ch] - ring[K0 + g][ch]); ring[K0 + g][ch] = nm[g][ch]; }
             if (s - FBI_M >= c.y0) {
+                if (ABL == 3) {
+                    if (c.writer) {
+                        const double det = S[0] * S[2] - S[1] * S[1] + 28.561;
+                        double idet = __builtin_amdgcn_rcp(det);
+                        float2 f; f.x = (float)((S[0] * S[4] - S[1] * S[3]) * idet); f.y = (float)((S[2] * S[3] - S[1] * S[4]) * idet);
+                        ((float2 *)c.fout)[(int64_t)(s - FBI_M) * c.W + c.xo] = f;
+                    }
+                } else {
 #pragma unroll
                 for (int ch = 0; ch < 5; ch++) vrow[g][ch][c.j] = S[ch];
+                }
             }
         }
     }
+    if (ABL == 3) return;
     __syncthreads();
     if (c.writer) {
-        const double scale = 1. / (FBI_WIN * FBI_WIN);
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int s = base + K0 + g, yo = s - FBI_M;
@@ -371,10 +380,10 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int base, floa
                     g11 += vrow[g][0][c.j + i]; g12 += vrow[g][1][c.j + i]; g22 += vrow[g][2][c.j + i];
                     h1 += vrow[g][3][c.j + i]; h2 += vrow[g][4][c.j + i];
                 }
-                g11 *= scale; g12 *= scale; g22 *= scale; h1 *= scale; h2 *= scale;
-                const double det = g11 * g22 - g12 * g12 + 1e-3;
+                // flow = (G h)/(det G + 1e-3) with G, h the window MEANS: evaluated on the window SUMS with the
+                // regulariser scaled by 169^2 instead (saves five multiplies); hardware reciprocal + one Newton step
+                const double det = g11 * g22 - g12 * g12 + 1e-3 * (double)(FBI_WIN * FBI_WIN) * (double)(FBI_WIN * FBI_WIN);
                 double idet = __builtin_amdgcn_rcp(det);
-                idet = idet * (2.0 - det * idet);
                 idet = idet * (2.0 - det * idet);
                 float2 f;
                 f.x = (float)((g11 * h2 - g12 * h1) * idet);
@@ -649,6 +658,7 @@ extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
                     if (abl == 1) hipLaunchKernelGGL(k_fb_iter<1>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
                     else if (abl == 2) hipLaunchKernelGGL(k_fb_iter<2>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else if (abl == 3) hipLaunchKernelGGL(k_fb_iter<3>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
                     else hipLaunchKernelGGL(k_fb_iter<0>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
                 }
                 for (int q = 0; q < nd; q++) { const int d = dirs[q]; cur[d] = (float *)ia.fout[q]; }
