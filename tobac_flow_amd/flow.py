@@ -8,6 +8,7 @@ diagnostics.  cv2's Farnebaeck / remap calls are replaced by the HIP library
 Not built yet: cv2.VariationalRefinement (`vr_steps > 0`, flow.py:359,513-519).  A
 RuntimeWarning is raised and the refinement step is skipped.
 """
+import os
 import warnings
 from datetime import datetime
 from typing import Callable
@@ -130,12 +131,12 @@ class _VariationalRefinementStub:
 vr_model = _VariationalRefinementStub()
 
 
-def _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_steps, interp_method):
+def _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_steps, interp_method, tag="farneback"):
     """calculate_flow_frame on device uint8 tensors; returns device (fwd, bwd)."""
     L = _lib.lib()
     t = _lib.torch()
     interp = select_interp_mode(interp_method) if smoothing_steps > 0 else 1
-    fwd, bwd = of_model.calc_pair_dev(prev8, next8)
+    fwd, bwd = of_model.calc_pair_dev(prev8, next8, tag=tag)
     if vr_steps > 0:
         fwd = vr_model.calc(prev8, next8, fwd)
         bwd = vr_model.calc(next8, prev8, bwd)
@@ -157,17 +158,35 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     backward = _lib.empty((T, H, W, 2), t.float32)
     forward.fill_(float("nan"))
     backward.fill_(float("nan"))
+    # Frame pairs are independent: issue them round-robin on a few HIP streams so that the small kernels of
+    # the coarse pyramid levels of one pair overlap with the full-resolution kernels of another.
+    n_streams = max(1, min(int(os.environ.get("TF_FLOW_STREAMS", "4")), T - 1))
+    main = t.cuda.current_stream()
+    streams = [main] if n_streams == 1 else [t.cuda.Stream() for _ in range(n_streams)]
+    ready = t.cuda.Event()
+    ready.record(main)
+    keep = []
     for i in range(T - 1):
-        a, b = frame_pairs(i)
-        if norm_name == "linear" and not normalisation_kwargs:
-            prev8, next8 = to_8bit_pair_dev(a, b)
-        else:   # other normalisations are host glue (not on the production path)
-            pair = np.stack([a.cpu().numpy(), b.cpu().numpy()], 0)
-            p8 = to_8bit(norm_method(pair, **normalisation_kwargs), 0, 1)
-            prev8, next8 = _lib.to_dev(p8[0]), _lib.to_dev(p8[1])
-        f, bk = _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_passes, interp_method)
-        forward[i].copy_(f)
-        backward[i + 1].copy_(bk)
+        st = streams[i % n_streams]
+        if st is not main:
+            st.wait_event(ready)
+        with t.cuda.stream(st):
+            a, b = frame_pairs(i)
+            if norm_name == "linear" and not normalisation_kwargs:
+                prev8, next8 = to_8bit_pair_dev(a, b, tag=f"to8bit{i % n_streams}")
+            else:   # other normalisations are host glue (not on the production path)
+                pair = np.stack([a.cpu().numpy(), b.cpu().numpy()], 0)
+                p8 = to_8bit(norm_method(pair, **normalisation_kwargs), 0, 1)
+                prev8, next8 = _lib.to_dev(p8[0]), _lib.to_dev(p8[1])
+            f, bk = _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_passes, interp_method,
+                                    tag=f"farneback{i % n_streams}")
+            forward[i].copy_(f)
+            backward[i + 1].copy_(bk)
+            keep.append((prev8, next8, f, bk))       # keep alive until the streams are joined
+    for st in streams:
+        if st is not main:
+            main.wait_stream(st)
+    del keep
     # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping here
     _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, float("inf"), _lib.stream_ptr()),
                "tf_flow_finalize")

@@ -32,7 +32,7 @@ class FarnebackFlow:
     def __init__(self, num_levels=5, pyr_scale=0.5, win_size=13, num_iters=10, poly_n=5, poly_sigma=1.1):
         self.params = _lib.FarnebackParams(num_levels, pyr_scale, win_size, num_iters, poly_n, poly_sigma)
 
-    def calc_pair_dev(self, prev, nxt, want_fwd=True, want_bwd=True):
+    def calc_pair_dev(self, prev, nxt, want_fwd=True, want_bwd=True, tag="farneback"):
         """Both directions at once on device uint8 tensors (they share pyramid + expansion)."""
         import ctypes
         t = _lib.torch()
@@ -41,7 +41,7 @@ class FarnebackFlow:
         fwd = _lib.empty((H, W, 2), t.float32) if want_fwd else None
         bwd = _lib.empty((H, W, 2), t.float32) if want_bwd else None
         nbytes = L.tf_farneback_workspace_bytes(H, W, ctypes.byref(self.params))
-        ws = _lib.workspace(nbytes, "farneback")
+        ws = _lib.workspace(nbytes, tag)
         rc = L.tf_farneback_pair(_lib.ptr(prev), _lib.ptr(nxt), H, W, ctypes.byref(self.params),
                                  _lib.ptr(fwd), _lib.ptr(bwd), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "tf_farneback_pair")
