@@ -14,6 +14,7 @@
 // (two flow vectors) + 4 or 8 (output) bytes.
 #include "remap_dev.h"
 #include <type_traits>
+#include <stdlib.h>
 
 struct ConvTaps {
     int nb, ns, nf;        // taps taken from t-1 (backward flow), t, t+1 (forward flow)
@@ -157,6 +158,149 @@ k_convolve(const typename StackTraits<TS>::In *__restrict__ data, const float *_
     }
 }
 
+// ---- dedicated 27-tap semi-Lagrangian Sobel --------------------------------------------------------
+// Same arithmetic as k_convolve + TF_FUNC_SOBEL*, specialised for the full 3x3x3 structure:
+//  * the 9 taps of a warped plane normally share one sub-pixel phase and sit on consecutive integer
+//    positions, so their 4x4 (cubic) / 2x2 (linear) footprints are slices of ONE 6x6 / 4x4 patch:
+//    the patch and the 16 / 4 interpolation weights are fetched / built once instead of 9 times,
+//    each tap is still the reference's row-major 16-term (4-term) sum -> bit-identical results;
+//    planes whose taps do not line up (float rounding of the coordinates) or that touch the image
+//    border take the generic per-tap path;
+//  * Sobel weights are compile-time constants: zero-weight products are skipped (adding 0 is exact),
+//    unit weights need no multiply.
+template <int METHOD>
+__device__ __forceinline__ void sobel_plane_taps(const float *__restrict__ img, int H, int W, int x, int y,
+                                                 float flx, float fly, float cval, float (&tap)[9])
+{
+    if (METHOD == TF_INTERP_NEAREST) {
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            tap[k] = tf_remap_nearest<float>(img, H, W, tf_loc(flx, k % 3 - 1, x), tf_loc(fly, k / 3 - 1, y), cval);
+        return;
+    }
+    int fx[3], fy[3];
+#pragma unroll
+    for (int o = 0; o < 3; o++) { fx[o] = tf_cvround(tf_loc(flx, o - 1, x) * 32.f); fy[o] = tf_cvround(tf_loc(fly, o - 1, y) * 32.f); }
+    const bool aligned = fx[0] + 32 == fx[1] && fx[1] + 32 == fx[2] && fy[0] + 32 == fy[1] && fy[1] + 32 == fy[2];
+    constexpr int R = METHOD == TF_INTERP_CUBIC ? 4 : 2;       // footprint size
+    constexpr int P = R + 2;                                   // patch size
+    const int bx = (fx[0] >> 5) - (R == 4 ? 1 : 0), by = (fy[0] >> 5) - (R == 4 ? 1 : 0);
+    // every tap must take the reference's "patch fully inside" branch:
+    //   cubic: 0 <= sx - 1 <= W - 4 for sx = sx0 .. sx0 + 2   <=>  bx >= 0 and bx + 6 <= W   (bx = sx0 - 1)
+    //   linear: 0 <= sx <= W - 2                               <=>  bx >= 0 and bx + 4 <= W   (bx = sx0)
+    if (aligned && bx >= 0 && by >= 0 && bx + P <= W && by + P <= H) {
+        float wt[R * R];
+        if (R == 4) {
+            float cx[4], cy[4];
+            tf_cubic_coeffs((float)(fx[0] & 31) * (1.f / 32.f), cx);
+            tf_cubic_coeffs((float)(fy[0] & 31) * (1.f / 32.f), cy);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) wt[i * 4 + j] = cy[i] * cx[j];
+        } else {
+            const float ax = (float)(fx[0] & 31) * (1.f / 32.f), ay = (float)(fy[0] & 31) * (1.f / 32.f);
+            wt[0] = (1.f - ay) * (1.f - ax); wt[1] = (1.f - ay) * ax; wt[2] = ay * (1.f - ax); wt[3] = ay * ax;
+        }
+        float pt[P][P];
+#pragma unroll
+        for (int r = 0; r < P; r++)
+#pragma unroll
+            for (int c = 0; c < P; c++) pt[r][c] = img[(int64_t)(by + r) * W + bx + c];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int oy = k / 3, ox = k % 3;
+            float sum = pt[oy][ox] * wt[0];
+#pragma unroll
+            for (int q = 1; q < R * R; q++) sum = sum + pt[oy + q / R][ox + q % R] * wt[q];
+            tap[k] = sum;
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        tap[k] = tf_remap<METHOD>(img, H, W, tf_loc(flx, k % 3 - 1, x), tf_loc(fly, k / 3 - 1, y), cval);
+}
+
+template <typename TS, int DIR>
+__device__ __forceinline__ void sobel_accumulate(TS v, TS c, int wx, int wy, int wt, double &gx, double &gy, double &gt)
+{
+    TS d = v - c;
+    if (DIR == TF_FUNC_SOBEL_UPHILL) d = (d != d) ? (TS)0 : (d > (TS)0 ? d : (TS)0);
+    else if (DIR == TF_FUNC_SOBEL_DOWNHILL) d = (d != d) ? (TS)0 : (d < (TS)0 ? d : (TS)0);
+    const double dd = (double)d;
+    if (DIR == TF_FUNC_SOBEL && dd != dd) return;            // nansum skips NaN products
+    // (inf * 0 is NaN in the reference and is skipped there too; inf * w stays in the sum)
+    if (wx) gx += dd * (double)wx;
+    if (wy) gy += dd * (double)wy;
+    if (wt) gt += dd * (double)wt;
+}
+
+template <int METHOD, typename TS, int DIR>
+__global__ void __launch_bounds__(256)
+k_sobel27(const float *__restrict__ data, const float *__restrict__ fwd, const float *__restrict__ bwd,
+          int64_t T, int H, int W, double fill, void *__restrict__ out, int out_type, int64_t t0)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = t0 + blockIdx.z;
+    if (x >= W || y >= H) return;
+    const int64_t plane = (int64_t)H * W, pix = t * plane + (int64_t)y * W + x;
+    const float fillf = (float)fill;
+    const float centre = data[pix];
+    const TS c = (TS)centre;
+    double gx = 0, gy = 0, gt = 0;
+    const int a3[3] = {1, 2, 1}, d3[3] = {-1, 0, 1};
+    float tap[9];
+    // plane 0: previous frame through the backward flow (stack slots 0..8)
+    if (t > 0) { const float2 f = ((const float2 *)bwd)[pix]; sobel_plane_taps<METHOD>(data + (t - 1) * plane, H, W, x, y, f.x, f.y, fillf, tap); }
+    else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) tap[k] = fillf;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int r = k / 3, cc = k % 3;
+        sobel_accumulate<TS, DIR>((TS)tap[k], c, a3[0] * a3[r] * d3[cc], a3[cc] * a3[0] * d3[r], a3[r] * a3[cc] * d3[0], gx, gy, gt);
+    }
+    // plane 1: same step, integer offsets, out of image -> fill
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int r = k / 3, cc = k % 3;
+        const int xx = x + cc - 1, yy = y + r - 1;
+        const float v = (xx < 0 || yy < 0 || xx >= W || yy >= H) ? fillf : data[t * plane + (int64_t)yy * W + xx];
+        sobel_accumulate<TS, DIR>((TS)v, c, a3[1] * a3[r] * d3[cc], a3[cc] * a3[1] * d3[r], a3[r] * a3[cc] * d3[1], gx, gy, gt);
+    }
+    // plane 2: next frame through the forward flow
+    if (t + 1 < T) { const float2 f = ((const float2 *)fwd)[pix]; sobel_plane_taps<METHOD>(data + (t + 1) * plane, H, W, x, y, f.x, f.y, fillf, tap); }
+    else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) tap[k] = fillf;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int r = k / 3, cc = k % 3;
+        sobel_accumulate<TS, DIR>((TS)tap[k], c, a3[2] * a3[r] * d3[cc], a3[cc] * a3[2] * d3[r], a3[r] * a3[cc] * d3[2], gx, gy, gt);
+    }
+    double m = gx * gx;
+    m += gy * gy;
+    m += gt * gt;
+    double r = sqrt(m);
+    if (centre != centre) r = fill;
+    store_out<double>(out, out_type, pix, r);
+}
+
+template <int METHOD, typename TS>
+static void launch_sobel27(int func, dim3 grid, dim3 block, hipStream_t s, const float *d, const float *fwd, const float *bwd,
+                           int64_t T, int H, int W, double fill, void *out, int out_type, int64_t t0)
+{
+    if (func == TF_FUNC_SOBEL_UPHILL)
+        hipLaunchKernelGGL((k_sobel27<METHOD, TS, TF_FUNC_SOBEL_UPHILL>), grid, block, 0, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
+    else if (func == TF_FUNC_SOBEL_DOWNHILL)
+        hipLaunchKernelGGL((k_sobel27<METHOD, TS, TF_FUNC_SOBEL_DOWNHILL>), grid, block, 0, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
+    else
+        hipLaunchKernelGGL((k_sobel27<METHOD, TS, TF_FUNC_SOBEL>), grid, block, 0, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
+}
+
 static int build_taps(const uint8_t *structure, ConvTaps &tp) {
     // stack order = plane 0 taps (C order) | plane 1 | plane 2; offsets as (x, y) = (col-1, row-1)
     // (convolve.py:212,224,234: np.where(structure[k])[..., ::-1] - centre)
@@ -190,6 +334,15 @@ static int launch_convolve(const void *data, int64_t T, int H, int W, const floa
     TfProfScope ps(is_sobel ? TFK_SOBEL : TFK_CONVOLVE, (4.0 + 16.0 + out_b) * (double)H * W * (double)(t1 - t0), s);
     dim3 block(64, 4, 1), grid((W + 63) / 64, (H + 3) / 4, (unsigned)(t1 - t0));
     const In *d = (const In *)data;
+    if constexpr (!std::is_same<TS, int32_t>::value) {
+        if (is_sobel && !getenv("TF_SOBEL_GENERIC")) {
+            if (interp == TF_INTERP_NEAREST) launch_sobel27<TF_INTERP_NEAREST, TS>(func, grid, block, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
+            else if (interp == TF_INTERP_LINEAR) launch_sobel27<TF_INTERP_LINEAR, TS>(func, grid, block, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
+            else launch_sobel27<TF_INTERP_CUBIC, TS>(func, grid, block, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
+            TF_CHECK_LAUNCH();
+            return TF_OK;
+        }
+    }
     switch (interp) {
     case TF_INTERP_NEAREST:
         hipLaunchKernelGGL((k_convolve<TF_INTERP_NEAREST, TS>), grid, block, 0, s, d, fwd, bwd, T, H, W, tp, fill, func, out, out_type, t0); break;

@@ -41,7 +41,7 @@ typedef unsigned long long u64;
 #define WS_MARKER_BIT 0x8000000000000000ull
 #define WS_MAX_NBR 26
 #define WS_MAX_DEPTH 8
-#define WS_BATCH 16
+#define WS_BATCH 32
 
 struct WsGeom {
     int64_t T; int H, W; int64_t plane;
@@ -363,11 +363,12 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
     int64_t sweeps = 0;
     int parity = 0;
     bool first = true;
+    unsigned grid_hint = nb;          // sized from the frontier seen at the end of the previous batch
     for (;;) {
         for (int b = 0; b < WS_BATCH; b++) {
             TfProfScope ps(TFK_WS_RELAX, 0.0, s);
             const int *qin = first ? nullptr : Q.q[parity];
-            const unsigned blocks = first ? nbR : nb;
+            const unsigned blocks = first ? nbR : grid_hint;
             if (phase_k == 0)
                 hipLaunchKernelGGL(k_ws_sweep_a, dim3(blocks), dim3(256), 0, s, c, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, Q.inq, Q.qcap);
             else
@@ -387,6 +388,13 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
             if (b < WS_BATCH) *Q.processed += Q.h_cnt[b];
         }
         sweeps += WS_BATCH;
+        {   // frontiers shrink slowly: 4x the last frontier (in 256-pixel chunks) is a generous grid for the next batch
+            const int64_t last = Q.h_cnt[WS_BATCH];
+            int64_t gb = (last * 4 + 255) / 256;
+            if (gb < 64) gb = 64;
+            if (gb > (int64_t)nb) gb = nb;
+            grid_hint = (unsigned)gb;
+        }
         if (done) break;
         if (sweeps > max_sweeps) { tf_set_error("tf_watershed: phase %d did not converge in %lld sweeps", phase_k, (long long)sweeps); return TF_ENOCONV; }
         // carry the last count into slot 0, clear the rest
