@@ -92,7 +92,8 @@ def warp_flow_single(img, flow, method="linear"):
     return remap(img, locs, method, np.nan)
 
 
-def warp_flow_multi(img, flow, method="linear", fill_value=np.nan, offsets=np.array([[0, 0]]), grid_locs=None):
+def warp_flow_multi(img, flow, method="linear", fill_value=np.nan, offsets=np.array([[0, 0]]), grid_locs=None,
+                    origin=(0, 0)):
     h, w = flow.shape[:2]
     locs = flow[np.newaxis, ...] + np.atleast_2d(offsets)[:, np.newaxis, np.newaxis, :].astype(np.float32)
     if grid_locs is None:
@@ -100,6 +101,12 @@ def warp_flow_multi(img, flow, method="linear", fill_value=np.nan, offsets=np.ar
         locs[..., 1] += np.arange(h)[..., np.newaxis]
     else:
         locs += grid_locs
+    if origin != (0, 0):
+        # test aid: `img` is a crop whose pixel (0, 0) sits at `origin` (x, y) of the full frame and
+        # grid_locs holds FULL-FRAME coordinates, so the float32 rounding of the coordinates is that of
+        # the full frame; subtracting the integer origin afterwards is exact
+        locs[..., 0] -= np.float32(origin[0])
+        locs[..., 1] -= np.float32(origin[1])
     res = remap(img, locs.reshape([-1, locs.shape[-2], locs.shape[-1]]), method, fill_value)
     return res.reshape(locs.shape[:-1])
 
@@ -114,7 +121,8 @@ def convolve_same_step(img, offsets, fill_value, grid_locs):
     return res, oob
 
 
-def convolve_step(prev_step, same_step, next_step, fwd, bwd, structure, method, dtype, fill_value, grid_locs):
+def convolve_step(prev_step, same_step, next_step, fwd, bwd, structure, method, dtype, fill_value, grid_locs,
+                  origin=(0, 0)):
     if len(structure.shape) != 3:
         raise ValueError("structure must have three dimensions")
     if structure.shape[0] != 3:
@@ -125,20 +133,20 @@ def convolve_step(prev_step, same_step, next_step, fwd, bwd, structure, method, 
     nb, ns, nf = (np.count_nonzero(structure[k]) for k in range(3))
     if nb:
         offs = np.stack(np.where(structure[0]), -1)[..., ::-1] - centre
-        res[:nb] = warp_flow_multi(prev_step, bwd, method, fill_value, offs, grid_locs)
+        res[:nb] = warp_flow_multi(prev_step, bwd, method, fill_value, offs, grid_locs, origin)
     if ns:
         offs = np.stack(np.where(structure[1]), -1)[..., ::-1] - centre
-        vals, oob = convolve_same_step(same_step, offs, fill_value, grid_locs)
+        vals, oob = convolve_same_step(same_step, offs, fill_value, grid_locs - np.array(origin))
         res[nb:nb + ns] = vals
         res[nb:nb + ns][oob] = fill_value
     if nf:
         offs = np.stack(np.where(structure[2]), -1)[..., ::-1] - centre
-        res[nb + ns:] = warp_flow_multi(next_step, fwd, method, fill_value, offs, grid_locs)
+        res[nb + ns:] = warp_flow_multi(next_step, fwd, method, fill_value, offs, grid_locs, origin)
     return res
 
 
 def convolve(data, fwd, bwd, structure=ndi.generate_binary_structure(3, 1), method="linear",
-             dtype=np.float32, fill_value=np.nan, func=None):
+             dtype=np.float32, fill_value=np.nan, func=None, origin=(0, 0)):
     assert structure.shape == (3, 3, 3), "Structure input must be a 3x3x3 array"
     n_struct = np.count_nonzero(structure)
     if func is not None:
@@ -146,13 +154,13 @@ def convolve(data, fwd, bwd, structure=ndi.generate_binary_structure(3, 1), meth
     else:
         res = np.full((n_struct,) + data.shape, fill_value, dtype=dtype)
     h, w = data.shape[1:]
-    grid_locs = np.stack(np.meshgrid(np.arange(w), np.arange(h)), -1)
+    grid_locs = np.stack(np.meshgrid(np.arange(w) + origin[0], np.arange(h) + origin[1]), -1)
     T = data.shape[0]
     for i in range(T):
         prev_frame = np.full(data[i].shape, fill_value, dtype=dtype) if i == 0 else data[i - 1]
         next_frame = np.full(data[i].shape, fill_value, dtype=dtype) if i == T - 1 else data[i + 1]
         stack = convolve_step(prev_frame, data[i], next_frame, fwd[i], bwd[i], structure, method, dtype,
-                              fill_value, grid_locs)
+                              fill_value, grid_locs, origin)
         if func is not None:
             res[i] = func(stack)
         else:
@@ -193,9 +201,9 @@ def sobel_func(direction):
     return lambda x: _mag(x - x[13])
 
 
-def sobel(data, fwd, bwd, method="linear", dtype=np.float32, fill_value=np.nan, direction=None):
+def sobel(data, fwd, bwd, method="linear", dtype=np.float32, fill_value=np.nan, direction=None, origin=(0, 0)):
     return convolve(data, fwd, bwd, ndi.generate_binary_structure(3, 3), method, dtype, fill_value,
-                    sobel_func(direction))
+                    sobel_func(direction), origin)
 
 
 def diff(data, fwd, bwd, method="linear", dtype=np.float32):

@@ -1,0 +1,157 @@
+"""GPU tests at BASELINE.json's frame sizes (config C 1500 x 2500, config F 5424 x 5424).
+
+Where the oracle finishes in seconds the comparison is direct (bit-exact); at 5424^2 the checks are
+size-independent properties of the operators: exact power-of-two linearity of the Sobel magnitude,
+crop-consistency of local operators against the oracle, translation recovery and antisymmetry of
+the flow, idempotence / label-set closure of the watershed."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+F = (5424, 5424)
+C = (1500, 2500)
+
+
+@pytest.fixture(scope="module")
+def full():
+    """3 full-disk-sized frames + flows + detect_anvils-style inputs, all resident on the GPU"""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tools.synth import anvil_inputs, blob_stack
+    bt = blob_stack(3, *F, seed=7)
+    flow = tf.create_flow(bt, smoothing_passes=1, interp_method="cubic")
+    lin, markers = anvil_inputs(bt)
+    torch.cuda.synchronize()
+    return dict(bt=bt, flow=flow, lin=lin, markers=markers, tf=tf)
+
+
+def test_to8bit_full_frame_matches_numpy_oracle(full):
+    from oracle import np_ops
+    from tobac_flow_amd.utils.normalisation_utils import to_8bit_pair_dev
+    import warnings
+    a, b = to_8bit_pair_dev(full["bt"][0], full["bt"][1])
+    pair = full["bt"][:2].cpu().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = np_ops.to_8bit(np_ops.linear_norm(pair), 0, 1)
+    assert np.array_equal(a.cpu().numpy(), want[0]) and np.array_equal(b.cpu().numpy(), want[1])
+
+
+def test_flow_full_frame_finite_clipped_and_mirrored(full):
+    import torch
+    fl = full["flow"]
+    fw, bw = fl.forward_flow, fl.backward_flow
+    assert fw.shape == (3,) + F + (2,)
+    assert bool(torch.isfinite(fw).all()) and bool(torch.isfinite(bw).all())
+    assert float(fw.abs().max()) <= 20 and float(bw.abs().max()) <= 20
+    assert bool((fw[-1] == -bw[-1]).all()) and bool((bw[0] == -fw[0]).all())     # flow.py:425-426
+
+
+def test_farneback_full_frame_recovers_translation():
+    import torch
+    import tobac_flow_amd.flow as tf
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = torch.randn((1, 1) + F, generator=g, device="cuda")
+    for _ in range(4):
+        n = torch.nn.functional.avg_pool2d(n, 7, stride=1, padding=3, count_include_pad=False)
+    img = ((n - n.min()) / (n.max() - n.min()) * 255).to(torch.uint8)[0, 0]
+    nxt = torch.roll(img, (2, -3), (0, 1))
+    f, b = tf.calculate_flow_frame(img, nxt, tf.select_of_model("Farneback"))
+    core = (slice(200, -200), slice(200, -200))
+    mf, mb = f[core].reshape(-1, 2).median(0).values, b[core].reshape(-1, 2).median(0).values
+    assert abs(float(mf[0]) + 3) < 0.1 and abs(float(mf[1]) - 2) < 0.1, mf
+    assert abs(float(mb[0]) - 3) < 0.1 and abs(float(mb[1]) + 2) < 0.1, mb
+    assert float((f[core] + b[core]).abs().median()) < 0.1          # antisymmetry away from the wrap seam
+
+
+def test_sobel_full_frame_power_of_two_linearity(full):
+    """sobel(4 x) == 4 sobel(x) bit for bit (scaling by a power of two commutes with every rounding)"""
+    import torch
+    fl, lin = full["flow"], full["lin"]
+    a = fl.sobel(lin, direction="uphill", method="cubic")
+    b = fl.sobel(lin * 4, direction="uphill", method="cubic")
+    assert a.dtype == torch.float64
+    assert bool(((a * 4 == b) | (torch.isnan(a) & torch.isnan(b))).all())
+    assert float(torch.nan_to_num(a).max()) > 0
+
+
+@pytest.mark.parametrize("method", ["linear", "cubic"])
+def test_sobel_full_frame_crop_matches_oracle(full, method):
+    """local operator: an interior crop computed by the oracle on a haloed sub-volume equals the GPU result"""
+    from oracle import np_ops
+    fl, lin = full["flow"], full["lin"]
+    got = fl.sobel(lin, direction="uphill", method=method)
+    for (y0, x0) in ((1000, 2000), (4000, 300), (5424 - 200, 5424 - 260)):
+        halo, n = 30, 160
+        ys, xs = slice(max(y0 - halo, 0), min(y0 + n + halo, F[0])), slice(max(x0 - halo, 0), min(x0 + n + halo, F[1]))
+        sub = lin[:, ys, xs].cpu().numpy()
+        fw = fl.forward_flow[:, ys, xs].cpu().numpy()
+        bw = fl.backward_flow[:, ys, xs].cpu().numpy()
+        want = np_ops.sobel(sub, fw, bw, method, None, np.nan, "uphill", origin=(xs.start, ys.start))
+        oy, ox = y0 - ys.start, x0 - xs.start
+        g = got[:, y0:y0 + n, x0:x0 + n].cpu().numpy()
+        w = want[:, oy:oy + n, ox:ox + n]
+        # pixels whose taps could reach the crop border are excluded (only matters for the corner crop)
+        inner = (slice(None), slice(0, min(n, F[0] - y0 - 25)), slice(0, min(n, F[1] - x0 - 25)))
+        assert np.array_equal(np.isnan(g[inner]), np.isnan(w[inner]))
+        assert np.array_equal(np.nan_to_num(g[inner]), np.nan_to_num(w[inner]))
+
+
+def test_watershed_full_frame_properties(full):
+    import torch
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    fl, lin, markers = full["flow"], full["lin"], full["markers"]
+    e = fl.sobel(lin, direction="uphill", method="cubic")
+    e = (torch.where(e > 0, e + 1, e) - lin).to(torch.float32)
+    fw, bw = fl._dev_flows()
+    nbr = neighbour_offsets(1)
+    st = {}
+    lab = watershed_dev(fw, bw, e, markers, None, nbr, 3, st)
+    assert lab.dtype == torch.int32 and lab.shape == markers.shape
+    assert bool((lab[markers != 0] == markers[markers != 0]).all())            # seeds keep their label
+    assert set(torch.unique(lab).tolist()) <= set(torch.unique(markers).tolist()) | {0}
+    assert int((lab == 0).sum()) == 0                                          # mask=None: everything reachable floods
+    again = watershed_dev(fw, bw, e, lab, None, nbr, 3)                        # idempotence
+    assert bool((again == lab).all())
+    # determinism: the chaotic relaxation has a unique fixpoint
+    lab2 = watershed_dev(fw, bw, e, markers, None, nbr, 3)
+    assert bool((lab2 == lab).all())
+
+
+def test_watershed_config_c_frame_bit_exact_vs_oracle():
+    """config C frame size (1500 x 2500), 3 frames: direct comparison with the sequential oracle"""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from oracle import ws_oracle
+    from tools.synth import anvil_inputs, blob_stack
+    bt = blob_stack(3, *C, seed=11)
+    fl = tf.create_flow(bt, smoothing_passes=1, interp_method="cubic")
+    lin, markers = anvil_inputs(bt)
+    e = fl.sobel(lin, direction="uphill", method="cubic")
+    e = (torch.where(e > 0, e + 1, e) - lin).to(torch.float32)
+    got = fl.watershed(e, markers, connectivity=1).cpu().numpy()
+    want = ws_oracle.watershed(fl.forward_flow.cpu().numpy(), fl.backward_flow.cpu().numpy(), e.cpu().numpy(),
+                               markers.cpu().numpy(), None, 1)
+    ideal = ws_oracle.watershed(fl.forward_flow.cpu().numpy(), fl.backward_flow.cpu().numpy(), e.cpu().numpy(),
+                                markers.cpu().numpy(), None, 1, tie_mode=1)
+    assert np.array_equal(got, ideal)
+    assert int((got != want).sum()) == 0, f"{int((got != want).sum())} px differ from the reference-order flood"
+
+
+def test_smooth_flow_config_c_matches_oracle():
+    from oracle import np_ops
+    import tobac_flow_amd.flow as tf
+    rng = np.random.default_rng(2)
+    import scipy.ndimage as ndi
+    f = (ndi.gaussian_filter(rng.normal(size=C + (2,)), (6, 6, 0)) * 40).astype(np.float32)
+    b = (-f + ndi.gaussian_filter(rng.normal(size=C + (2,)), (4, 4, 0)) * 5).astype(np.float32)
+    gf, gb = tf.smooth_flow_step(f, b, "cubic")
+    wf, wb = np_ops.smooth_flow_step(f, b, "cubic")
+    assert np.array_equal(np.isnan(gf), np.isnan(wf)) and np.array_equal(np.nan_to_num(gf), np.nan_to_num(wf))
+    assert np.array_equal(np.nan_to_num(gb), np.nan_to_num(wb))
