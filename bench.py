@@ -79,7 +79,6 @@ def main():
     ap.add_argument("--height", type=int, default=5424)
     ap.add_argument("--width", type=int, default=5424)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap-pass", action="store_true")
     a = ap.parse_args()
 
     import numpy as np
@@ -136,22 +135,6 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=bt.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    # informational second pass (NOT the headline value): frame pairs issued on 4 HIP streams so that coarse
-    # pyramid levels overlap full-resolution kernels; per-kernel timings are meaningless there, so the
-    # roofline figures above come from the single-stream timed region only
-    overlap = None
-    if world == 1 and not a.no_overlap_pass:
-        os.environ["TF_FLOW_STREAMS"] = "4"
-        step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        barrier()
-        dt4 = time.perf_counter() - t1
-        os.environ["TF_FLOW_STREAMS"] = "1"
-        overlap = {"streams": 4, "value": round(a.steps * T * H * W / dt4 / 1e6, 2), "unit": "Mpix/s",
-                   "ms_per_step": round(dt4 / a.steps * 1e3, 2)}
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
         roof = None
@@ -173,7 +156,6 @@ def main():
                                     "+ edge field + Flow.watershed(connectivity 1, detect_anvils markers)",
                           "sharding": "one time window per GPU, label IDs stitched by all-gather"},
                "roofline": roof}
-        out["overlap"] = overlap
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(20240601)
         print(json.dumps(out))

@@ -88,6 +88,16 @@ size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_par
 int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H, int64_t W,
                       const tf_farneback_params *p, float *flow_fwd, float *flow_bwd,
                       void *ws, size_t ws_bytes, void *stream);
+/* The same for B independent frame pairs in one set of launches (the loop of tobac_flow/flow.py:411-423):
+ * pair b reads prev + b*img_stride / next + b*img_stride (bytes = pixels, uint8) and writes
+ * flow_fwd + b*flow_stride / flow_bwd + b*flow_stride (strides in floats), so the results can land
+ * directly in forward_flow[i0 + b] and backward_flow[i0 + 1 + b].  Batching keeps the coarse pyramid
+ * levels -- a few hundred workgroups per pair -- busy on all 256 CUs. */
+size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const tf_farneback_params *p);
+int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B, int64_t img_stride,
+                       int64_t H, int64_t W, const tf_farneback_params *p,
+                       float *flow_fwd, float *flow_bwd, int64_t flow_stride,
+                       void *ws, size_t ws_bytes, void *stream);
 
 /* ---- a6: forward/backward consistency smoothing ----------------------------------------------
  * replaces tobac_flow/flow.py:530-568 smooth_flow_step (4 x cv2.remap via

@@ -35,8 +35,9 @@ struct FbKernel { int ksize; float k[FB_MAX_KSIZE]; };
 
 template <typename TIn>
 __global__ void __launch_bounds__(256)
-k_fb_blur_rows(const TIn *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst)
+k_fb_blur_rows(const TIn *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst, int64_t bs_src, int64_t bs_dst)
 {
+    src += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
     const int ksize = kk.ksize, r = ksize >> 1;
@@ -57,8 +58,9 @@ k_fb_blur_rows(const TIn *__restrict__ src, int H, int W, const FbKernel kk, flo
 }
 
 __global__ void __launch_bounds__(256)
-k_fb_blur_cols(const float *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst)
+k_fb_blur_cols(const float *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst, int64_t bs_src, int64_t bs_dst)
 {
+    src += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
     const int r = kk.ksize >> 1;
@@ -76,8 +78,9 @@ k_fb_blur_cols(const float *__restrict__ src, int H, int W, const FbKernel kk, f
 // ---- cv::resize INTER_LINEAR (cn interleaved channels), optional post-scale ---------------------
 __global__ void __launch_bounds__(256)
 k_fb_resize_linear(const float *__restrict__ src, int sh, int sw, int cn, float *__restrict__ dst, int dh, int dw,
-                   double scale_x, double scale_y, float post)
+                   double scale_x, double scale_y, float post, int64_t bs_src, int64_t bs_dst)
 {
+    src += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
     const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
     if (dx >= dw || dy >= dh) return;
     float fx = (float)((dx + 0.5) * scale_x - 0.5);
@@ -99,8 +102,9 @@ k_fb_resize_linear(const float *__restrict__ src, int sh, int sw, int cn, float 
 
 // exact 2x decimation: OpenCV switches INTER_LINEAR to the INTER_AREA fast path
 __global__ void __launch_bounds__(256)
-k_fb_resize_area2(const float *__restrict__ src, int sw, float *__restrict__ dst, int dh, int dw)
+k_fb_resize_area2(const float *__restrict__ src, int sw, float *__restrict__ dst, int dh, int dw, int64_t bs_src, int64_t bs_dst)
 {
+    src += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
     const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
     if (dx >= dw || dy >= dh) return;
     const float *S = src + (int64_t)(2 * dy) * sw + 2 * dx;
@@ -127,8 +131,9 @@ __device__ __forceinline__ void fb_resize_coord(int d, double scale, int slen, i
 
 template <typename TIn>
 __global__ void __launch_bounds__(256)
-k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKernel kk, float2 *__restrict__ rowf)
+k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKernel kk, float2 *__restrict__ rowf, int64_t bs_src, int64_t bs_dst)
 {
+    src += (int64_t)blockIdx.z * bs_src; rowf += (int64_t)blockIdx.z * bs_dst;
     const int dx = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (dx >= g.dw || y >= g.sh) return;
     int sx; float fx;
@@ -160,8 +165,9 @@ k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKern
 }
 
 __global__ void __launch_bounds__(256)
-k_fb_blur_cols_resize(const float2 *__restrict__ rowf, FbResizeGeom g, const FbKernel kk, float *__restrict__ dst)
+k_fb_blur_cols_resize(const float2 *__restrict__ rowf, FbResizeGeom g, const FbKernel kk, float *__restrict__ dst, int64_t bs_src, int64_t bs_dst)
 {
+    rowf += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
     const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
     if (dx >= g.dw || dy >= g.dh) return;
     int sx, sy; float fx, fy;
@@ -202,8 +208,10 @@ struct FbPoly { int n; float g[FB_MAX_POLY_N + 1], xg[FB_MAX_POLY_N + 1], xxg[FB
 
 // vertical pass: t0 = sum g (I_up + I_dn), t1 = sum xg (I_dn - I_up), t2 = sum xxg (I_up + I_dn); rows replicate
 __global__ void __launch_bounds__(256)
-k_fb_poly_v(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restrict__ t0, float *__restrict__ t1, float *__restrict__ t2)
+k_fb_poly_v(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restrict__ t0, float *__restrict__ t1, float *__restrict__ t2,
+            int64_t bs_I, int64_t bs_t)
 {
+    I += (int64_t)blockIdx.z * bs_I; t0 += (int64_t)blockIdx.z * bs_t; t1 += (int64_t)blockIdx.z * bs_t; t2 += (int64_t)blockIdx.z * bs_t;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
     float r0 = I[(int64_t)y * W + x] * pp.g[0], r1 = 0.f, r2 = 0.f;
@@ -222,8 +230,9 @@ k_fb_poly_v(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restr
 // horizontal pass (double accumulators, columns replicate) -> planar R[5]
 __global__ void __launch_bounds__(256)
 k_fb_poly_h(const float *__restrict__ t0, const float *__restrict__ t1, const float *__restrict__ t2, int H, int W, FbPoly pp,
-            float *__restrict__ R, int64_t plane)
+            float *__restrict__ R, int64_t plane, int64_t bs_t, int64_t bs_R)
 {
+    t0 += (int64_t)blockIdx.z * bs_t; t1 += (int64_t)blockIdx.z * bs_t; t2 += (int64_t)blockIdx.z * bs_t; R += (int64_t)blockIdx.z * bs_R;
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
     const float *a = t0 + (int64_t)y * W, *b = t1 + (int64_t)y * W, *c = t2 + (int64_t)y * W;
@@ -320,7 +329,8 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 #define FBI_WIN (2 * FBI_M + 1)
 #define FBI_OW (256 - 2 * FBI_M)
 #define FBI_HS 128
-struct FbIterArgs { const float *R0[2], *R1[2], *fin[2]; float *fout[2]; };
+// R[img] / fin[q] / fout[q] are the pointers of batch item 0; item b adds b * the matching stride
+struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd; int64_t bs_R, bs_fin[2], bs_fout[2]; };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
 
 struct FbIterCtx {
@@ -400,9 +410,11 @@ __global__ void __launch_bounds__(256)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
 {
     __shared__ double vrow[FBI_G][5][256];
-    const int d = blockIdx.z;
+    const int b = blockIdx.z / a.nd, q = blockIdx.z % a.nd;
+    const int d = a.dir[q];                                            // 0: prev -> next, 1: next -> prev
     FbIterCtx c;
-    c.R0 = a.R0[d]; c.R1 = a.R1[d]; c.fin = a.fin[d]; c.fout = a.fout[d];
+    c.R0 = a.R[d] + b * a.bs_R; c.R1 = a.R[1 - d] + b * a.bs_R;
+    c.fin = a.fin[q] + b * a.bs_fin[q]; c.fout = a.fout[q] + b * a.bs_fout[q];
     c.H = H; c.W = W; c.plane = plane;
     c.j = threadIdx.x;
     c.xo = blockIdx.x * FBI_OW + c.j - FBI_M;                         // column this thread evaluates M for
@@ -479,6 +491,11 @@ k_fb_blur_solve(const float *__restrict__ M, int H, int W, int64_t plane, int m,
     }
 }
 
+__global__ void __launch_bounds__(256) k_fb_zero(float *__restrict__ p, int64_t count, int64_t bs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[(int64_t)blockIdx.z * bs + i] = 0.f;
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 extern "C" void tf_farneback_default_params(tf_farneback_params *p) {
     p->num_levels = 5; p->pyr_scale = 0.5; p->win_size = 13; p->num_iters = 10; p->poly_n = 5; p->poly_sigma = 1.1;
@@ -535,167 +552,191 @@ static int fb_levels(int64_t H, int64_t W, const tf_farneback_params *p) {
     return k;
 }
 
-extern "C" size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_params *p)
-{
-    if (H <= 0 || W <= 0 || !p) return 0;
-    const size_t n = (size_t)H * W, pl = tf_align_up(n * 4, 256);
-    // tmp, blur, I, t0..t2, R0[5], R1[5], M[5], 4 flow buffers of 2 planes, kernel table
-    return 6 * pl + 15 * pl + 4 * 2 * pl + tf_align_up((2 * (size_t)H + 64) * 4, 256) + 8192;
+static size_t fb_pair_floats(int64_t H, int64_t W) {
+    // per pair: tmp (n + 2H + 64), blur, I, t0..t2, R[2] (5n each), M (5n, unfused fallback only), 2 flow scratch (2n each)
+    const size_t n = (size_t)H * W;
+    return tf_align_up(n + 2 * (size_t)H + 64, 64) + 5 * tf_align_up(n, 64) + 15 * tf_align_up(n, 64) + 2 * tf_align_up(2 * n, 64);
 }
 
-extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H64, int64_t W64,
-                                 const tf_farneback_params *p, float *flow_fwd, float *flow_bwd,
-                                 void *ws, size_t ws_bytes, void *stream)
+extern "C" size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const tf_farneback_params *p)
 {
-    TF_REQUIRE(prev && next && p && ws, "tf_farneback_pair: null pointer");
-    TF_REQUIRE(flow_fwd || flow_bwd, "tf_farneback_pair: both outputs are NULL");
-    TF_REQUIRE(H64 > 0 && W64 > 0 && H64 < (1 << 15) && W64 < (1 << 15), "tf_farneback_pair: bad shape");
-    TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= FB_MAX_POLY_N, "tf_farneback_pair: poly_n out of range");
-    TF_REQUIRE(p->win_size >= 1 && p->win_size / 2 <= FB_MAX_M, "tf_farneback_pair: win_size out of range");
-    TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback_pair: bad params");
-    if (ws_bytes < tf_farneback_workspace_bytes(H64, W64, p)) { tf_set_error("tf_farneback_pair: workspace too small"); return TF_ENOMEM; }
-    const int H = (int)H64, W = (int)W64;
+    if (B <= 0 || H <= 0 || W <= 0 || !p) return 0;
+    return (size_t)B * fb_pair_floats(H, W) * sizeof(float) + 8192;
+}
+
+extern "C" size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_params *p)
+{
+    return tf_farneback_workspace_bytes_batch(1, H, W, p);
+}
+
+extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B64, int64_t img_stride,
+                                  int64_t H64, int64_t W64, const tf_farneback_params *p,
+                                  float *flow_fwd, float *flow_bwd, int64_t flow_stride,
+                                  void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(prev && next && p && ws, "tf_farneback: null pointer");
+    TF_REQUIRE(flow_fwd || flow_bwd, "tf_farneback: both outputs are NULL");
+    TF_REQUIRE(B64 >= 1 && B64 <= 1024, "tf_farneback: bad batch size");
+    TF_REQUIRE(H64 > 0 && W64 > 0 && H64 < (1 << 15) && W64 < (1 << 15), "tf_farneback: bad shape");
+    TF_REQUIRE(img_stride >= H64 * W64 && flow_stride >= H64 * W64 * 2, "tf_farneback: strides smaller than one frame");
+    TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= FB_MAX_POLY_N, "tf_farneback: poly_n out of range");
+    TF_REQUIRE(p->win_size >= 1 && p->win_size / 2 <= FB_MAX_M, "tf_farneback: win_size out of range");
+    TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback: bad params");
+    if (ws_bytes < tf_farneback_workspace_bytes_batch(B64, H64, W64, p)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+    const int H = (int)H64, W = (int)W64, B = (int)B64;
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)H * W;
+    // every scratch array holds B items back to back; bs_* = items' stride in floats
     TfArena ar(ws, ws_bytes);
-    float *tmp = ar.take<float>(n + 2 * (size_t)H + 64), *blur = ar.take<float>(n), *I = ar.take<float>(n);
-    float *t0 = ar.take<float>(n), *t1 = ar.take<float>(n), *t2 = ar.take<float>(n);
-    float *R[2] = {ar.take<float>(5 * n), ar.take<float>(5 * n)};
-    float *M = ar.take<float>(5 * n);
-    float *fbuf[2][2] = {{ar.take<float>(2 * n), ar.take<float>(2 * n)}, {ar.take<float>(2 * n), ar.take<float>(2 * n)}};
-    if (!ar.ok()) { tf_set_error("tf_farneback_pair: workspace too small"); return TF_ENOMEM; }
+    const int64_t bs_tmp = (int64_t)tf_align_up(n + 2 * (size_t)H + 64, 64), bs_n = (int64_t)tf_align_up(n, 64);
+    const int64_t bs_R = 5 * bs_n, bs_f = (int64_t)tf_align_up(2 * n, 64);
+    float *tmp = ar.take<float>(bs_tmp * B), *blur = ar.take<float>(bs_n * B), *I = ar.take<float>(bs_n * B);
+    float *t0 = ar.take<float>(bs_n * B), *t1 = ar.take<float>(bs_n * B), *t2 = ar.take<float>(bs_n * B);
+    float *R[2] = {ar.take<float>(bs_R * B), ar.take<float>(bs_R * B)};
+    float *M = ar.take<float>(bs_R * B);
+    float *fbuf[2] = {ar.take<float>(bs_f * B), ar.take<float>(bs_f * B)};
+    if (!ar.ok()) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
 
     FbPoly pp; fb_prepare_poly(p->poly_n, p->poly_sigma, &pp);
     const int levels = fb_levels(H, W, p);
     const uint8_t *img[2] = {prev, next};
     float *out[2] = {flow_fwd, flow_bwd};
-    float *prevFlow[2] = {nullptr, nullptr};
+    int nd = 0, dirs[2];
+    for (int d = 0; d < 2; d++) if (out[d]) dirs[nd++] = d;
+    // per direction two ping-pong slots: slot 0 = the caller's output (stride flow_stride), slot 1 = scratch
+    float *slot[2][2]; int64_t slot_bs[2][2];
+    for (int d = 0; d < 2; d++) { slot[d][0] = out[d]; slot_bs[d][0] = flow_stride; slot[d][1] = fbuf[d]; slot_bs[d][1] = bs_f; }
+    int cur[2] = {-1, -1};                       // slot index that holds the current flow of direction d
     int pw = 0, ph = 0;
-    dim3 block(64, 4);
-    const dim3 gfull((W + 63) / 64, (H + 3) / 4);
+    const dim3 block(64, 4);
+    const dim3 gfull((W + 63) / 64, (H + 3) / 4, B);
+    const bool fused = p->win_size == FBI_WIN;
     for (int k = levels; k >= 0; k--) {
         double scale = 1; for (int i = 0; i < k; i++) scale *= p->pyr_scale;
         const double sigma = (1. / scale - 1) * 0.5;
         int smooth_sz = (int)lrint(sigma * 5) | 1; if (smooth_sz < 3) smooth_sz = 3;
-        TF_REQUIRE(smooth_sz <= FB_MAX_KSIZE, "tf_farneback_pair: blur kernel too large");
+        TF_REQUIRE(smooth_sz <= FB_MAX_KSIZE, "tf_farneback: blur kernel too large");
         const int w = (int)lrint(W * scale), h = (int)lrint(H * scale);
         const int64_t plane = (int64_t)w * h;
-        const dim3 glev((w + 63) / 64, (h + 3) / 4);
+        const dim3 glev((w + 63) / 64, (h + 3) / 4, B);
         FbKernel hk; fb_gaussian_kernel(smooth_sz, sigma, &hk);
         for (int i = 0; i < 2; i++) {
-            const float *Ik = blur;
+            const float *Ik = blur; int64_t bs_Ik = bs_n;
             const double rsx = 1. / ((double)w / W), rsy = 1. / ((double)h / H);
             const int irx = (int)(rsx + 0.5), iry = (int)(rsy + 0.5);
             const bool same = (w == W && h == H);
             const bool area2 = !same && fabs(rsx - irx) < DBL_EPSILON && fabs(rsy - iry) < DBL_EPSILON && irx == 2 && iry == 2;
             if (same || area2) {
                 {
-                    TfProfScope ps(TFK_FB_BLUR, 13.0 * n, s);     // u8 r + f32 w, then f32 r + f32 w
-                    hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp);
-                    hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur);
+                    TfProfScope ps(TFK_FB_BLUR, 13.0 * n * B, s);     // u8 r + f32 w, then f32 r + f32 w
+                    hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp, img_stride, bs_tmp);
+                    hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur, bs_tmp, bs_n);
                 }
                 if (area2) {
-                    TfProfScope ps(TFK_FB_RESIZE, 4.0 * n + 4.0 * plane, s);
-                    hipLaunchKernelGGL(k_fb_resize_area2, glev, block, 0, s, blur, W, I, h, w);
+                    TfProfScope ps(TFK_FB_RESIZE, (4.0 * n + 4.0 * plane) * B, s);
+                    hipLaunchKernelGGL(k_fb_resize_area2, glev, block, 0, s, blur, W, I, h, w, bs_n, bs_n);
                     Ik = I;
                 }
             } else {
-                // blur + resize fused on the sampled columns / rows (tmp holds rowf: H * w float2 <= n floats)
-                TfProfScope ps(TFK_FB_BLUR, 1.0 * n + 8.0 * (double)H * w * 2 + 4.0 * plane, s);
+                // blur + resize fused on the sampled columns / rows (tmp holds rowf: H * w float2 <= n + 2H floats)
+                TfProfScope ps(TFK_FB_BLUR, (1.0 * n + 8.0 * (double)H * w * 2 + 4.0 * plane) * B, s);
                 FbResizeGeom rg; rg.sh = H; rg.sw = W; rg.dh = h; rg.dw = w; rg.scale_x = rsx; rg.scale_y = rsy;
-                hipLaunchKernelGGL(k_fb_blur_rows_sampled<uint8_t>, dim3((w + 63) / 64, (H + 3) / 4), block, 0, s, img[i], rg, hk, (float2 *)tmp);
-                hipLaunchKernelGGL(k_fb_blur_cols_resize, glev, block, 0, s, (const float2 *)tmp, rg, hk, I);
+                hipLaunchKernelGGL(k_fb_blur_rows_sampled<uint8_t>, dim3((w + 63) / 64, (H + 3) / 4, B), block, 0, s, img[i], rg, hk,
+                                   (float2 *)tmp, img_stride, bs_tmp / 2);
+                hipLaunchKernelGGL(k_fb_blur_cols_resize, glev, block, 0, s, (const float2 *)tmp, rg, hk, I, bs_tmp / 2, bs_n);
                 Ik = I;
             }
             {
-                TfProfScope ps(TFK_FB_POLYEXP, 24.0 * plane, s);   // fused-ideal: 4 r + 20 w per level pixel
-                hipLaunchKernelGGL(k_fb_poly_v, glev, block, 0, s, Ik, h, w, pp, t0, t1, t2);
-                hipLaunchKernelGGL(k_fb_poly_h, glev, block, 0, s, t0, t1, t2, h, w, pp, R[i], plane);
+                TfProfScope ps(TFK_FB_POLYEXP, 24.0 * plane * B, s);   // fused-ideal: 4 r + 20 w per level pixel
+                hipLaunchKernelGGL(k_fb_poly_v, glev, block, 0, s, Ik, h, w, pp, t0, t1, t2, bs_Ik, bs_n);
+                hipLaunchKernelGGL(k_fb_poly_h, glev, block, 0, s, t0, t1, t2, h, w, pp, R[i], plane, bs_n, bs_R);
             }
         }
         TF_CHECK_LAUNCH();
-        const bool fused = p->win_size == FBI_WIN;
-        if (fused) {
-            // ping-pong buffers per direction: slot 0 = caller's output (full-res sized), slot 1 = scratch.
-            // cur[d] holds the level's initial flow; every iteration reads cur and writes the other slot.
-            FbIterArgs ia;
-            int nd = 0, dirs[2];
-            for (int d = 0; d < 2; d++) if (out[d]) dirs[nd++] = d;
-            float *cur[2] = {nullptr, nullptr};
-            for (int q = 0; q < nd; q++) {
-                const int d = dirs[q];
-                // choose the start slot so that after all remaining iterations of all remaining levels the
-                // result of level 0 lands in out[d]: each level flips the slot (1 + num_iters) times
-                float *slot[2] = {out[d], fbuf[d][0]};
-                int start;
-                if (!prevFlow[d]) {
-                    const int flips_per_level = p->num_iters + 1;              // upsample (1) + iterations
-                    const int total = (k + 1) * flips_per_level - 1;           // no upsample at the coarsest level
-                    start = (total % 2 == 0) ? 0 : 1;                          // slot index of the initial flow
-                    cur[d] = slot[start];
-                    TF_CHECK_HIP(hipMemsetAsync(cur[d], 0, (size_t)plane * 2 * sizeof(float), s));
-                } else {
-                    float *dst = prevFlow[d] == slot[0] ? slot[1] : slot[0];
-                    TfProfScope ps(TFK_FB_RESIZE, 8.0 * pw * ph + 8.0 * plane, s);
-                    const double sx = 1. / ((double)w / pw), sy = 1. / ((double)h / ph);
-                    hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, prevFlow[d], ph, pw, 2, dst, h, w, sx, sy,
-                                       (float)(1. / p->pyr_scale));
-                    cur[d] = dst;
-                }
+        // level's initial flow
+        for (int q = 0; q < nd; q++) {
+            const int d = dirs[q];
+            if (cur[d] < 0) {
+                // choose the start slot so that the result of level 0 lands in slot 0 (the caller's buffer):
+                // every level flips the slot num_iters times (+1 for the upsample on all but the coarsest level);
+                // the unfused fallback iterates in place (no flips from iterations)
+                const int flips_per_level = (fused ? p->num_iters : 0) + 1;
+                const int total = (k + 1) * flips_per_level - 1;
+                cur[d] = (total % 2 == 0) ? 0 : 1;
+                hipLaunchKernelGGL(k_fb_zero, dim3((unsigned)((plane * 2 + 255) / 256), 1, B), dim3(256), 0, s,
+                                   slot[d][cur[d]], plane * 2, slot_bs[d][cur[d]]);
+            } else {
+                const int src = cur[d], dst = 1 - cur[d];
+                TfProfScope ps(TFK_FB_RESIZE, (8.0 * pw * ph + 8.0 * plane) * B, s);
+                const double sx = 1. / ((double)w / pw), sy = 1. / ((double)h / ph);
+                hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, slot[d][src], ph, pw, 2, slot[d][dst], h, w, sx, sy,
+                                   (float)(1. / p->pyr_scale), slot_bs[d][src], slot_bs[d][dst]);
+                cur[d] = dst;
             }
+        }
+        TF_CHECK_LAUNCH();
+        if (fused) {
             // strip height: tall strips amortise the 12-row halo, short ones keep all CUs busy on coarse levels
             int hs = FBI_HS;
-            while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd < 1536) hs >>= 1;
-            const dim3 gi((w + FBI_OW - 1) / FBI_OW, (h + hs - 1) / hs, nd);
+            while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd * B < 1536) hs >>= 1;
+            const dim3 gi((w + FBI_OW - 1) / FBI_OW, (h + hs - 1) / hs, nd * B);
+            FbIterArgs ia;
+            ia.R[0] = R[0]; ia.R[1] = R[1]; ia.bs_R = bs_R; ia.nd = nd;
             for (int it = 0; it < p->num_iters; it++) {
                 for (int q = 0; q < nd; q++) {
                     const int d = dirs[q];
-                    float *other = cur[d] == out[d] ? fbuf[d][0] : out[d];
-                    ia.R0[q] = R[d]; ia.R1[q] = R[1 - d]; ia.fin[q] = cur[d]; ia.fout[q] = other;
+                    ia.dir[q] = d;
+                    ia.fin[q] = slot[d][cur[d]]; ia.bs_fin[q] = slot_bs[d][cur[d]];
+                    ia.fout[q] = slot[d][1 - cur[d]]; ia.bs_fout[q] = slot_bs[d][1 - cur[d]];
                 }
                 {
-                    TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd, s);
+                    TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd * B, s);
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
                     if (abl == 1) hipLaunchKernelGGL(k_fb_iter<1>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
                     else if (abl == 2) hipLaunchKernelGGL(k_fb_iter<2>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
                     else if (abl == 3) hipLaunchKernelGGL(k_fb_iter<3>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
                     else hipLaunchKernelGGL(k_fb_iter<0>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
                 }
-                for (int q = 0; q < nd; q++) { const int d = dirs[q]; cur[d] = (float *)ia.fout[q]; }
+                for (int q = 0; q < nd; q++) cur[dirs[q]] = 1 - cur[dirs[q]];
             }
             TF_CHECK_LAUNCH();
-            for (int q = 0; q < nd; q++) prevFlow[dirs[q]] = cur[dirs[q]];
-        } else
-        for (int d = 0; d < 2; d++) {
-            if (!out[d]) continue;
-            float *flow = (k > 0) ? fbuf[d][k & 1] : out[d];
-            if (!prevFlow[d]) TF_CHECK_HIP(hipMemsetAsync(flow, 0, (size_t)plane * 2 * sizeof(float), s));
-            else {
-                TfProfScope ps(TFK_FB_RESIZE, 8.0 * pw * ph + 8.0 * plane, s);
-                const double sx = 1. / ((double)w / pw), sy = 1. / ((double)h / ph);
-                hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, prevFlow[d], ph, pw, 2, flow, h, w, sx, sy,
-                                   (float)(1. / p->pyr_scale));
-            }
-            const float *R0 = R[d], *R1 = R[1 - d];
-            {
-                TfProfScope ps(TFK_FB_MATRICES, 68.0 * plane, s);
-                hipLaunchKernelGGL(k_fb_update_matrices, glev, block, 0, s, R0, R1, flow, h, w, plane, M);
-            }
+        } else {
+            // generic window size: separate UpdateMatrices / box-filter+solve kernels, one pair at a time, in place
+            const dim3 glev1((w + 63) / 64, (h + 3) / 4, 1);
             const dim3 gt((w + FBT_W - 1) / FBT_W, (h + FBT_H - 1) / FBT_H);
-            for (int it = 0; it < p->num_iters; it++) {
-                {
-                    TfProfScope ps(TFK_FB_BLUR_SOLVE, 28.0 * plane, s);
-                    hipLaunchKernelGGL(k_fb_blur_solve, gt, block, 0, s, M, h, w, plane, p->win_size / 2, flow);
+            for (int b = 0; b < B; b++)
+                for (int q = 0; q < nd; q++) {
+                    const int d = dirs[q];
+                    float *flow = slot[d][cur[d]] + (int64_t)b * slot_bs[d][cur[d]];
+                    const float *R0 = R[d] + (int64_t)b * bs_R, *R1 = R[1 - d] + (int64_t)b * bs_R;
+                    float *Mb = M + (int64_t)b * bs_R;
+                    {
+                        TfProfScope ps(TFK_FB_MATRICES, 68.0 * plane, s);
+                        hipLaunchKernelGGL(k_fb_update_matrices, glev1, block, 0, s, R0, R1, flow, h, w, plane, Mb);
+                    }
+                    for (int it = 0; it < p->num_iters; it++) {
+                        {
+                            TfProfScope ps(TFK_FB_BLUR_SOLVE, 28.0 * plane, s);
+                            hipLaunchKernelGGL(k_fb_blur_solve, gt, block, 0, s, Mb, h, w, plane, p->win_size / 2, flow);
+                        }
+                        if (it < p->num_iters - 1) {
+                            TfProfScope ps(TFK_FB_MATRICES, 68.0 * plane, s);
+                            hipLaunchKernelGGL(k_fb_update_matrices, glev1, block, 0, s, R0, R1, flow, h, w, plane, Mb);
+                        }
+                    }
                 }
-                if (it < p->num_iters - 1) {
-                    TfProfScope ps(TFK_FB_MATRICES, 68.0 * plane, s);
-                    hipLaunchKernelGGL(k_fb_update_matrices, glev, block, 0, s, R0, R1, flow, h, w, plane, M);
-                }
-            }
             TF_CHECK_LAUNCH();
-            prevFlow[d] = flow;
         }
         pw = w; ph = h;
     }
+    for (int q = 0; q < nd; q++)
+        if (cur[dirs[q]] != 0) { tf_set_error("tf_farneback: internal slot parity error"); return TF_EINVAL; }
     return TF_OK;
+}
+
+extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H, int64_t W,
+                                 const tf_farneback_params *p, float *flow_fwd, float *flow_bwd,
+                                 void *ws, size_t ws_bytes, void *stream)
+{
+    return tf_farneback_batch(prev, next, 1, H * W, H, W, p, flow_fwd, flow_bwd, H * W * 2, ws, ws_bytes, stream);
 }

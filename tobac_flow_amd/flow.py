@@ -158,37 +158,41 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     backward = _lib.empty((T, H, W, 2), t.float32)
     forward.fill_(float("nan"))
     backward.fill_(float("nan"))
-    # Frame pairs are independent: with TF_FLOW_STREAMS > 1 they are issued round-robin on several HIP streams
-    # so that the small kernels of the coarse pyramid levels of one pair overlap with the full-resolution
-    # kernels of another (about +10 % throughput at 5424^2; per-kernel timings then overlap, so the default
-    # -- and bench.py's timed region -- is one stream).
-    n_streams = max(1, min(int(os.environ.get("TF_FLOW_STREAMS", "1")), T - 1))
-    main = t.cuda.current_stream()
-    streams = [main] if n_streams == 1 else [t.cuda.Stream() for _ in range(n_streams)]
-    ready = t.cuda.Event()
-    ready.record(main)
-    keep = []
-    for i in range(T - 1):
-        st = streams[i % n_streams]
-        if st is not main:
-            st.wait_event(ready)
-        with t.cuda.stream(st):
-            a, b = frame_pairs(i)
-            if norm_name == "linear" and not normalisation_kwargs:
-                prev8, next8 = to_8bit_pair_dev(a, b, tag=f"to8bit{i % n_streams}")
+    # Frame pairs are independent units: they are processed in batches of TF_FLOW_BATCH pairs per set of
+    # kernel launches (tf_farneback_batch), which keeps the coarse pyramid levels busy on all CUs.
+    linear = norm_name == "linear" and not normalisation_kwargs
+    if vr_steps > 0:
+        vr_model.calc(None, None, None)        # warns once: VariationalRefinement is not built yet
+    interp = select_interp_mode(interp_method) if smoothing_passes > 0 else 1
+    chunk = max(1, int(os.environ.get("TF_FLOW_BATCH", "8")))
+    for i0 in range(0, T - 1, chunk):
+        B = min(chunk, T - 1 - i0)
+        prev8 = _lib.empty((B, H, W), t.uint8)
+        next8 = _lib.empty((B, H, W), t.uint8)
+        for b in range(B):
+            fa, fb = frame_pairs(i0 + b)
+            if linear:
+                to_8bit_pair_dev(fa, fb, out=(prev8[b], next8[b]))
             else:   # other normalisations are host glue (not on the production path)
-                pair = np.stack([a.cpu().numpy(), b.cpu().numpy()], 0)
+                pair = np.stack([fa.cpu().numpy(), fb.cpu().numpy()], 0)
                 p8 = to_8bit(norm_method(pair, **normalisation_kwargs), 0, 1)
-                prev8, next8 = _lib.to_dev(p8[0]), _lib.to_dev(p8[1])
-            f, bk = _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_passes, interp_method,
-                                    tag=f"farneback{i % n_streams}")
-            forward[i].copy_(f)
-            backward[i + 1].copy_(bk)
-            keep.append((prev8, next8, f, bk))       # keep alive until the streams are joined
-    for st in streams:
-        if st is not main:
-            main.wait_stream(st)
-    del keep
+                prev8[b].copy_(_lib.to_dev(p8[0]))
+                next8[b].copy_(_lib.to_dev(p8[1]))
+        if smoothing_passes == 0:
+            of_model.calc_batch_dev(prev8, next8, forward[i0:i0 + B], backward[i0 + 1:i0 + 1 + B])
+        else:
+            f = _lib.empty((B, H, W, 2), t.float32)
+            bk = _lib.empty((B, H, W, 2), t.float32)
+            of_model.calc_batch_dev(prev8, next8, f, bk)
+            for b in range(B):
+                fi, bi = f[b], bk[b]
+                for k in range(smoothing_passes):
+                    last = k == smoothing_passes - 1
+                    fo = forward[i0 + b] if last else t.empty_like(fi)
+                    bo = backward[i0 + 1 + b] if last else t.empty_like(bi)
+                    _lib.check(L.tf_smooth_flow_step(_lib.ptr(fi), _lib.ptr(bi), H, W, interp, _lib.ptr(fo), _lib.ptr(bo),
+                                                     _lib.stream_ptr()), "tf_smooth_flow_step")
+                    fi, bi = fo, bo
     # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping here
     _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, float("inf"), _lib.stream_ptr()),
                "tf_flow_finalize")

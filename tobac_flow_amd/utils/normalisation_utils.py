@@ -33,12 +33,12 @@ def to_8bit(array, vmin=None, vmax=None, fill_value=127):
         return scaled.astype("uint8")
 
 
-def to_8bit_pair_dev(frame0, frame1, tag="to8bit"):
+def to_8bit_pair_dev(frame0, frame1, tag="to8bit", out=None):
     """GPU: to_8bit(linear_norm(stack([frame0, frame1])), 0, 1) -> two uint8 torch tensors."""
     t = _lib.torch()
     L = _lib.lib()
     H, W = frame0.shape
-    o0, o1 = _lib.empty((H, W), t.uint8), _lib.empty((H, W), t.uint8)
+    o0, o1 = out if out is not None else (_lib.empty((H, W), t.uint8), _lib.empty((H, W), t.uint8))
     ws = _lib.workspace(max(L.tf_to8bit_workspace_bytes(H, W), 256), tag)
     rc = L.tf_to8bit_pair(_lib.ptr(frame0), _lib.ptr(frame1), H, W, _lib.ptr(o0), _lib.ptr(o1),
                           _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
