@@ -95,6 +95,7 @@ def main():
 
     import tobac_flow_amd.flow as tf
     from tobac_flow_amd import _lib
+    from tobac_flow_amd.detection import get_combined_edge_field
     from tobac_flow_amd.parallel import stitch_labels
     from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
     from tools.synth import anvil_inputs, blob_stack
@@ -103,13 +104,11 @@ def main():
     bt = blob_stack(T, H, W, seed=20240601 + rank)          # resident in HBM before the timed region
     lin, markers = anvil_inputs(bt)
     nbr = neighbour_offsets(1)
-    inf = torch.tensor(float("inf"), dtype=torch.float64, device=bt.device)
 
     def step():
         flow = tf.create_flow(bt, model="Farneback", smoothing_passes=1, interp_method="cubic")
-        e = flow.sobel(lin, direction="uphill", method="cubic")            # float64, like Flow.sobel(dtype=None)
-        e = torch.where(e > 0, e + 1, e) - lin                             # detection.py:638-641
-        e = torch.where(torch.isnan(lin), inf, e).to(torch.float32)       # watershed.py:64-65
+        # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
+        e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
         labels = watershed_dev(fw, bw, e, markers, None, nbr)
         return stitch_labels(labels) if world > 1 else labels

@@ -133,6 +133,12 @@ int tf_convolve(const void *data, int data_type, int64_t T, int64_t H, int64_t W
                 int interp, double fill, int func, void *out, int out_type,
                 int64_t t0, int64_t t1, void *stream);
 
+/* ---- a17 piece: combined edge field --------------------------------------------------------------
+ * the elementwise tail of tobac_flow/detection.py:620-642 get_combined_edge_field:
+ * edges[edges > 0] += 1; edges -= field; edges[isnan(field)] = inf, in float64 like the reference;
+ * out_type TF_F64 (the function's own result) or TF_F32 (the cast tobac_flow/watershed.py:64-65 applies). */
+int tf_edge_field(const double *sobel, const float *field, int64_t n, void *out, int out_type, void *stream);
+
 /* ---- a14/a15: semi-Lagrangian marker-controlled watershed -------------------------------------
  * replaces tobac_flow/watershed.py:17-168 (wrapper) and tobac_flow/_watershed.pyx:222-344
  * (watershed_raveled, the reference's only native kernel; compactness = 0, wsl = False).

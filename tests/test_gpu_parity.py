@@ -296,3 +296,20 @@ def test_watershed_errors(tf):
         tf.watershed(z, z, f, np.zeros((2, 5, 5), np.int32), mask=np.ones((1, 5, 5), bool))
     out = tf.watershed(z, z, f, np.zeros((2, 5, 5), np.int32))       # no markers: nothing flooded
     assert out.dtype == np.int32 and not out.any()
+
+
+def test_combined_edge_field_device_path_equals_numpy_path(tf):
+    """detection.get_combined_edge_field: fused device kernel == the reference's numpy tail"""
+    import torch
+    from tobac_flow_amd.detection import get_combined_edge_field
+    rng = np.random.default_rng(31)
+    shape = (3, 40, 52)
+    field = np.clip(rand_field(rng, shape, nan_frac=0.01) * 3, 0, 1).astype(np.float32)
+    fwd, bwd = rand_flow(rng, shape, 1.5), rand_flow(rng, shape, 1.5)
+    fl = tf.Flow(fwd, bwd)
+    want = get_combined_edge_field(fl, field)
+    assert want.dtype == np.float64
+    dev = get_combined_edge_field(fl, torch.from_numpy(field).cuda())
+    assert dev.dtype == torch.float64 and np.array_equal(dev.cpu().numpy(), want)
+    dev32 = get_combined_edge_field(fl, torch.from_numpy(field).cuda(), dtype=np.float32)
+    assert np.array_equal(dev32.cpu().numpy(), want.astype(np.float32))

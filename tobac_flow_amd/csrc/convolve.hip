@@ -399,14 +399,18 @@ k_warp(const float *__restrict__ img, const float *__restrict__ flow, int H, int
     out[pix] = tf_remap<METHOD>(img, H, W, tf_loc(f.x, 0, x), tf_loc(f.y, 0, y), NAN);
 }
 
-// strided component sampler: flow images are interleaved (H, W, 2); the reference warps the two
-// components as separate (H, W) images (flow.py:545-546) -- identical arithmetic, stride 2 here.
+// two-component sampler: flow images are interleaved (H, W, 2); the reference warps the two components
+// as separate (H, W) images with the SAME map (flow.py:545-546), so both are sampled here with one set of
+// coordinates / weights and float2 loads -- per component the arithmetic is exactly tf_remap's.
+__device__ __forceinline__ float2 f2_mul(float2 a, float w) { return make_float2(a.x * w, a.y * w); }
+__device__ __forceinline__ float2 f2_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 f2_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
 template <int METHOD>
-__device__ __forceinline__ float sample_component(const float *__restrict__ f2, int comp, int H, int W, float mx, float my)
+__device__ __forceinline__ float2 sample_flow2(const float *__restrict__ f2, int H, int W, float mx, float my)
 {
-    // re-implementation of tf_remap on a stride-2 image
-    const float cval = NAN;
-    auto at = [&](int yy, int xx) { return f2[((int64_t)yy * W + xx) * 2 + comp]; };
+    const float2 cval = make_float2(NAN, NAN);
+    auto at = [&](int yy, int xx) { return ((const float2 *)f2)[(int64_t)yy * W + xx]; };
     if (METHOD == TF_INTERP_NEAREST) {
         int sx = tf_sat_short(tf_cvround(mx)), sy = tf_sat_short(tf_cvround(my));
         return ((unsigned)sx < (unsigned)W && (unsigned)sy < (unsigned)H) ? at(sy, sx) : cval;
@@ -418,12 +422,12 @@ __device__ __forceinline__ float sample_component(const float *__restrict__ f2, 
         float w0 = (1.f - ay) * (1.f - ax), w1 = (1.f - ay) * ax, w2 = ay * (1.f - ax), w3 = ay * ax;
         int w1lim = W - 1 > 0 ? W - 1 : 0, h1lim = H - 1 > 0 ? H - 1 : 0;
         if ((unsigned)sx < (unsigned)w1lim && (unsigned)sy < (unsigned)h1lim)
-            return at(sy, sx) * w0 + at(sy, sx + 1) * w1 + at(sy + 1, sx) * w2 + at(sy + 1, sx + 1) * w3;
+            return f2_add(f2_add(f2_add(f2_mul(at(sy, sx), w0), f2_mul(at(sy, sx + 1), w1)), f2_mul(at(sy + 1, sx), w2)), f2_mul(at(sy + 1, sx + 1), w3));
         if (sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0) return cval;
         bool okx0 = sx >= 0 && sx < W, okx1 = sx + 1 >= 0 && sx + 1 < W, oky0 = sy >= 0 && sy < H, oky1 = sy + 1 >= 0 && sy + 1 < H;
-        float v0 = (okx0 && oky0) ? at(sy, sx) : cval, v1 = (okx1 && oky0) ? at(sy, sx + 1) : cval;
-        float v2 = (okx0 && oky1) ? at(sy + 1, sx) : cval, v3 = (okx1 && oky1) ? at(sy + 1, sx + 1) : cval;
-        return v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+        float2 v0 = (okx0 && oky0) ? at(sy, sx) : cval, v1 = (okx1 && oky0) ? at(sy, sx + 1) : cval;
+        float2 v2 = (okx0 && oky1) ? at(sy + 1, sx) : cval, v3 = (okx1 && oky1) ? at(sy + 1, sx + 1) : cval;
+        return f2_add(f2_add(f2_add(f2_mul(v0, w0), f2_mul(v1, w1)), f2_mul(v2, w2)), f2_mul(v3, w3));
     }
     float cx[4], cy[4];
     tf_cubic_coeffs((float)(fx & 31) * (1.f / 32.f), cx);
@@ -431,21 +435,19 @@ __device__ __forceinline__ float sample_component(const float *__restrict__ f2, 
     int bx = sx - 1, by = sy - 1;
     int w1lim = W - 3 > 0 ? W - 3 : 0, h1lim = H - 3 > 0 ? H - 3 : 0;
     if ((unsigned)bx < (unsigned)w1lim && (unsigned)by < (unsigned)h1lim) {
-        float sum = at(by, bx) * (cy[0] * cx[0]) + at(by, bx + 1) * (cy[0] * cx[1]) + at(by, bx + 2) * (cy[0] * cx[2]) + at(by, bx + 3) * (cy[0] * cx[3]);
+        float2 sum = f2_mul(at(by, bx), cy[0] * cx[0]);
 #pragma unroll
-        for (int i = 1; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) sum = sum + at(by + i, bx + j) * (cy[i] * cx[j]);
+        for (int q = 1; q < 16; q++) sum = f2_add(sum, f2_mul(at(by + q / 4, bx + q % 4), cy[q / 4] * cx[q % 4]));
         return sum;
     }
     if (bx >= W || bx + 4 <= 0 || by >= H || by + 4 <= 0) return cval;
-    float sum = cval * 1.f;
+    float2 sum = f2_mul(cval, 1.f);
     for (int i = 0; i < 4; i++) {
         int yi = by + i;
         if (yi < 0 || yi >= H) continue;
         for (int j = 0; j < 4; j++) {
             int xj = bx + j;
-            if (xj >= 0 && xj < W) sum += (at(yi, xj) - cval) * (cy[i] * cx[j]);
+            if (xj >= 0 && xj < W) sum = f2_add(sum, f2_mul(f2_sub(at(yi, xj), cval), cy[i] * cx[j]));
         }
     }
     return sum;
@@ -470,11 +472,13 @@ k_smooth(const float *__restrict__ fwd, const float *__restrict__ bwd, int H, in
     const float fmx = tf_loc(f.x, 0, x), fmy = tf_loc(f.y, 0, y);
     const float bmx = tf_loc(b.x, 0, x), bmy = tf_loc(b.y, 0, y);
     float2 r;
-    r.x = nanmean2(f.x, -sample_component<METHOD>(bwd, 0, H, W, fmx, fmy));
-    r.y = nanmean2(f.y, -sample_component<METHOD>(bwd, 1, H, W, fmx, fmy));
+    const float2 wb = sample_flow2<METHOD>(bwd, H, W, fmx, fmy);
+    r.x = nanmean2(f.x, -wb.x);
+    r.y = nanmean2(f.y, -wb.y);
     ((float2 *)fo)[pix] = r;
-    r.x = nanmean2(b.x, -sample_component<METHOD>(fwd, 0, H, W, bmx, bmy));
-    r.y = nanmean2(b.y, -sample_component<METHOD>(fwd, 1, H, W, bmx, bmy));
+    const float2 wf = sample_flow2<METHOD>(fwd, H, W, bmx, bmy);
+    r.x = nanmean2(b.x, -wf.x);
+    r.y = nanmean2(b.y, -wf.y);
     ((float2 *)bo)[pix] = r;
 }
 
@@ -532,6 +536,32 @@ extern "C" int tf_flow_finalize(float *fwd, float *bwd, int64_t T, int64_t H, in
     const int64_t plane2 = H * W * 2;
     dim3 block(256), grid((unsigned)((plane2 + 255) / 256), (unsigned)T);
     hipLaunchKernelGGL(k_flow_finalize, grid, block, 0, (hipStream_t)stream, fwd, bwd, T, plane2, max_value);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+// ---- combined edge field (detection.py:638-642), fused elementwise -----------------------------------
+//   edges[edges > 0] += 1; edges = edges - field; edges[isnan(field)] = inf   (float64 arithmetic as in the
+//   reference), optionally rounded once to float32 -- the cast watershed.py:64-65 applies anyway.
+__global__ void __launch_bounds__(256)
+k_edge_field(const double *__restrict__ sob, const float *__restrict__ field, int64_t n, void *__restrict__ out, int out_type)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double e = sob[i];
+    const float f = field[i];
+    if (e > 0) e += 1.0;
+    e = e - (double)f;
+    if (f != f) e = INFINITY;
+    if (out_type == TF_F64) ((double *)out)[i] = e; else ((float *)out)[i] = (float)e;
+}
+
+extern "C" int tf_edge_field(const double *sobel, const float *field, int64_t n, void *out, int out_type, void *stream)
+{
+    TF_REQUIRE(sobel && field && out && n > 0, "tf_edge_field: bad arguments");
+    TF_REQUIRE(out_type == TF_F32 || out_type == TF_F64, "tf_edge_field: out_type must be f32 or f64");
+    TfProfScope ps(TFK_CONVOLVE, (8.0 + 4.0 + (out_type == TF_F64 ? 8.0 : 4.0)) * (double)n, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_edge_field, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sobel, field, n, out, out_type);
     TF_CHECK_LAUNCH();
     return TF_OK;
 }

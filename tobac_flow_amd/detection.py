@@ -275,6 +275,18 @@ def get_watershed_mask(field, erode_distance: int = 1):
 def get_combined_edge_field(flow, field, **kwargs):
     """Uphill semi-Lagrangian Sobel edges (+1 where present) minus the field; NaN -> +inf
     (reference: detection.py:620-642)."""
+    t = _lib.torch()
+    if isinstance(field, t.Tensor):
+        # device-resident pipeline: one fused elementwise kernel; `dtype=np.float32` gives the field already
+        # rounded the way watershed.py:64-65 would round it
+        out_dtype = kwargs.get("dtype", np.float64)
+        f32 = field.to(t.float32).contiguous()
+        edges = flow.sobel(f32, direction="uphill", method="cubic")
+        out = _lib.empty(tuple(edges.shape), t.float32 if np.dtype(out_dtype) == np.float32 else t.float64)
+        _lib.check(_lib.lib().tf_edge_field(_lib.ptr(edges), _lib.ptr(f32), edges.numel(), _lib.ptr(out),
+                                            _lib.TF_F32 if out.dtype == t.float32 else _lib.TF_F64, _lib.stream_ptr()),
+                   "tf_edge_field")
+        return out
     edges = flow.sobel(field, direction="uphill", method="cubic")
     edges[edges > 0] += 1
     edges = edges - field

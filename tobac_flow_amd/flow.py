@@ -35,17 +35,11 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
                 interp_method: str = "linear", max_value=20) -> "Flow":
     """Forward and backward optical flow along the leading dimension of `data`, clipped to
     +-`max_value` pixels, wrapped in a Flow object (reference: flow.py:23-65)."""
+    # the clip of flow.py:60-61 is applied by the same kernel that mirrors the end frames (tf_flow_finalize);
+    # clipping commutes with the sign-flipped mirror
     forward_flow, backward_flow = calculate_flow(data, model=model, vr_steps=vr_steps,
-                                                 smoothing_passes=smoothing_passes, interp_method=interp_method)
-    t = _lib.torch()
-    if isinstance(forward_flow, t.Tensor):
-        T, H, W = forward_flow.shape[:3]
-        # mirroring already applied; this call only clips (the mirror is idempotent after it)
-        forward_flow = forward_flow.clamp(-max_value, max_value)
-        backward_flow = backward_flow.clamp(-max_value, max_value)
-    else:
-        forward_flow = np.minimum(np.maximum(forward_flow, -max_value), max_value)
-        backward_flow = np.minimum(np.maximum(backward_flow, -max_value), max_value)
+                                                 smoothing_passes=smoothing_passes, interp_method=interp_method,
+                                                 _max_value=float(max_value))
     return Flow(forward_flow, backward_flow)
 
 
@@ -150,7 +144,7 @@ def _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_steps, interp_me
 
 
 def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_passes, interp_method,
-                         norm_name, norm_method, normalisation_kwargs, on_device):
+                         norm_name, norm_method, normalisation_kwargs, on_device, max_value=float("inf")):
     t = _lib.torch()
     L = _lib.lib()
     H, W = shape
@@ -193,8 +187,8 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                     _lib.check(L.tf_smooth_flow_step(_lib.ptr(fi), _lib.ptr(bi), H, W, interp, _lib.ptr(fo), _lib.ptr(bo),
                                                      _lib.stream_ptr()), "tf_smooth_flow_step")
                     fi, bi = fo, bo
-    # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping here
-    _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, float("inf"), _lib.stream_ptr()),
+    # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping
+    _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
                "tf_flow_finalize")
     if on_device:
         return forward, backward
@@ -205,6 +199,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
                    interp_method: str = "linear", normalisation_method: str = "linear", **normalisation_kwargs):
     """Forward / backward flow for every consecutive frame pair of `data` (reference: flow.py:362-428).
     forward[i] = flow i -> i+1, backward[i+1] = flow i+1 -> i; the end frames are mirrored."""
+    max_value = normalisation_kwargs.pop("_max_value", float("inf"))
     of_model = select_of_model(model)
     norm_method = select_normalisation_method(normalisation_method)
     t = _lib.torch()
@@ -217,7 +212,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     T = d.shape[0]
     return _calculate_flow_impl(lambda i: (d[i], d[i + 1]), T, tuple(d.shape[1:]), of_model, vr_steps,
                                 smoothing_passes, interp_method, normalisation_method, norm_method,
-                                normalisation_kwargs, on_device)
+                                normalisation_kwargs, on_device, max_value)
 
 
 def calculate_flow_2(a, b, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
