@@ -206,53 +206,69 @@ k_fb_blur_cols_resize(const float2 *__restrict__ rowf, FbResizeGeom g, const FbK
 // ---- polynomial expansion ------------------------------------------------------------------------
 struct FbPoly { int n; float g[FB_MAX_POLY_N + 1], xg[FB_MAX_POLY_N + 1], xxg[FB_MAX_POLY_N + 1]; double ig11, ig03, ig33, ig55; };
 
-// vertical pass: t0 = sum g (I_up + I_dn), t1 = sum xg (I_dn - I_up), t2 = sum xxg (I_up + I_dn); rows replicate
+// Fused vertical + horizontal pass on an LDS tile: 64 x 16 outputs per 256-thread workgroup, the
+// (64 + 2n) x (16 + 2n) image tile is staged once (replicate borders), the three vertical moments
+// t0 = sum g (I_up + I_dn), t1 = sum xg (I_dn - I_up), t2 = sum xxg (I_up + I_dn) are kept in LDS for all
+// 64 + 2n columns, the horizontal pass accumulates in double exactly like OpenCV and writes R
+// (float4 {y, x, yy, xx} + float {xy}).  HBM traffic = 4 B read + 20 B written per level pixel.
+#define FBP_W 64
+#define FBP_H 16
+#define FBP_MAXN FB_MAX_POLY_N
 __global__ void __launch_bounds__(256)
-k_fb_poly_v(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restrict__ t0, float *__restrict__ t1, float *__restrict__ t2,
-            int64_t bs_I, int64_t bs_t)
+k_fb_polyexp(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restrict__ R, int64_t plane,
+             int64_t bs_I, int64_t bs_R)
 {
-    I += (int64_t)blockIdx.z * bs_I; t0 += (int64_t)blockIdx.z * bs_t; t1 += (int64_t)blockIdx.z * bs_t; t2 += (int64_t)blockIdx.z * bs_t;
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || y >= H) return;
-    float r0 = I[(int64_t)y * W + x] * pp.g[0], r1 = 0.f, r2 = 0.f;
-    for (int k = 1; k <= pp.n; k++) {
-        const float s0 = I[(int64_t)(y - k > 0 ? y - k : 0) * W + x];
-        const float s1 = I[(int64_t)(y + k < H - 1 ? y + k : H - 1) * W + x];
-        const float p = s0 + s1;
-        r0 = r0 + pp.g[k] * p;
-        r1 = r1 + pp.xg[k] * (s1 - s0);
-        r2 = r2 + pp.xxg[k] * p;
+    __shared__ float tI[(FBP_H + 2 * FBP_MAXN) * (FBP_W + 2 * FBP_MAXN)];
+    __shared__ float tT[3][FBP_H * (FBP_W + 2 * FBP_MAXN)];
+    I += (int64_t)blockIdx.z * bs_I; R += (int64_t)blockIdx.z * bs_R;
+    const int n = pp.n, tw = FBP_W + 2 * n, th = FBP_H + 2 * n;
+    const int bx = blockIdx.x * FBP_W, by = blockIdx.y * FBP_H;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int i = tid; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        tI[i] = I[(int64_t)tf_clampi(by + ty - n, 0, H - 1) * W + tf_clampi(bx + tx - n, 0, W - 1)];
     }
-    const int64_t o = (int64_t)y * W + x;
-    t0[o] = r0; t1[o] = r1; t2[o] = r2;
-}
-
-// horizontal pass (double accumulators, columns replicate) -> planar R[5]
-__global__ void __launch_bounds__(256)
-k_fb_poly_h(const float *__restrict__ t0, const float *__restrict__ t1, const float *__restrict__ t2, int H, int W, FbPoly pp,
-            float *__restrict__ R, int64_t plane, int64_t bs_t, int64_t bs_R)
-{
-    t0 += (int64_t)blockIdx.z * bs_t; t1 += (int64_t)blockIdx.z * bs_t; t2 += (int64_t)blockIdx.z * bs_t; R += (int64_t)blockIdx.z * bs_R;
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || y >= H) return;
-    const float *a = t0 + (int64_t)y * W, *b = t1 + (int64_t)y * W, *c = t2 + (int64_t)y * W;
-    float g0 = pp.g[0];
-    double b1 = a[x] * g0, b2 = 0, b3 = b[x] * g0, b4 = 0, b5 = c[x] * g0, b6 = 0;
-    for (int k = 1; k <= pp.n; k++) {
-        const int xp = x + k < W - 1 ? x + k : W - 1, xm = x - k > 0 ? x - k : 0;
-        const double tg = a[xp] + a[xm];
-        g0 = pp.g[k];
-        b1 += tg * g0; b4 += tg * pp.xxg[k];
-        b2 += (a[xp] - a[xm]) * pp.xg[k];
-        b3 += (b[xp] + b[xm]) * g0;
-        b6 += (b[xp] - b[xm]) * pp.xg[k];
-        b5 += (c[xp] + c[xm]) * g0;
+    __syncthreads();
+    for (int i = tid; i < tw * FBP_H; i += 256) {
+        const int oy = i / tw, tx = i - oy * tw;
+        const int y = by + oy;                                   // image row of this output row
+        const float *col = tI + (oy + n) * tw + tx;
+        float r0 = col[0] * pp.g[0], r1 = 0.f, r2 = 0.f;
+        for (int k = 1; k <= n; k++) {
+            // rows are clamped in IMAGE space (replicate): the tile already holds clamp(y +- k)
+            const float s0 = col[-k * tw], s1 = col[k * tw];
+            const float p = s0 + s1;
+            r0 = r0 + pp.g[k] * p;
+            r1 = r1 + pp.xg[k] * (s1 - s0);
+            r2 = r2 + pp.xxg[k] * p;
+        }
+        (void)y;
+        tT[0][i] = r0; tT[1][i] = r1; tT[2][i] = r2;
     }
-    const int64_t o = (int64_t)y * W + x;
-    // R layout: float4 {y-lin, x-lin, yy, xx} per pixel, then a separate plane for xy
-    ((float4 *)R)[o] = make_float4((float)(b3 * pp.ig11), (float)(b2 * pp.ig11),
-                                   (float)(b1 * pp.ig03 + b5 * pp.ig33), (float)(b1 * pp.ig03 + b4 * pp.ig33));
-    R[4 * plane + o] = (float)(b6 * pp.ig55);
+    __syncthreads();
+    const int x = bx + threadIdx.x;
+    if (x >= W) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int oy = threadIdx.y * 4 + r, y = by + oy;
+        if (y >= H) continue;
+        const float *a = tT[0] + oy * tw + threadIdx.x + n, *b = tT[1] + oy * tw + threadIdx.x + n, *c = tT[2] + oy * tw + threadIdx.x + n;
+        float g0 = pp.g[0];
+        double b1 = a[0] * g0, b2 = 0, b3 = b[0] * g0, b4 = 0, b5 = c[0] * g0, b6 = 0;
+        for (int k = 1; k <= n; k++) {
+            const double tg = a[k] + a[-k];
+            g0 = pp.g[k];
+            b1 += tg * g0; b4 += tg * pp.xxg[k];
+            b2 += (a[k] - a[-k]) * pp.xg[k];
+            b3 += (b[k] + b[-k]) * g0;
+            b6 += (b[k] - b[-k]) * pp.xg[k];
+            b5 += (c[k] + c[-k]) * g0;
+        }
+        const int64_t o = (int64_t)y * W + x;
+        ((float4 *)R)[o] = make_float4((float)(b3 * pp.ig11), (float)(b2 * pp.ig11),
+                                       (float)(b1 * pp.ig03 + b5 * pp.ig33), (float)(b1 * pp.ig03 + b4 * pp.ig33));
+        R[4 * plane + o] = (float)(b6 * pp.ig55);
+    }
 }
 
 // ---- FarnebackUpdateMatrices ---------------------------------------------------------------------
@@ -553,9 +569,9 @@ static int fb_levels(int64_t H, int64_t W, const tf_farneback_params *p) {
 }
 
 static size_t fb_pair_floats(int64_t H, int64_t W) {
-    // per pair: tmp (n + 2H + 64), blur, I, t0..t2, R[2] (5n each), M (5n, unfused fallback only), 2 flow scratch (2n each)
+    // per pair: tmp (n + 2H + 64), blur, I, R[2] (5n each), M (5n, unfused fallback only), 2 flow scratch (2n each)
     const size_t n = (size_t)H * W;
-    return tf_align_up(n + 2 * (size_t)H + 64, 64) + 5 * tf_align_up(n, 64) + 15 * tf_align_up(n, 64) + 2 * tf_align_up(2 * n, 64);
+    return tf_align_up(n + 2 * (size_t)H + 64, 64) + 2 * tf_align_up(n, 64) + 15 * tf_align_up(n, 64) + 2 * tf_align_up(2 * n, 64);
 }
 
 extern "C" size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const tf_farneback_params *p)
@@ -591,7 +607,6 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
     const int64_t bs_tmp = (int64_t)tf_align_up(n + 2 * (size_t)H + 64, 64), bs_n = (int64_t)tf_align_up(n, 64);
     const int64_t bs_R = 5 * bs_n, bs_f = (int64_t)tf_align_up(2 * n, 64);
     float *tmp = ar.take<float>(bs_tmp * B), *blur = ar.take<float>(bs_n * B), *I = ar.take<float>(bs_n * B);
-    float *t0 = ar.take<float>(bs_n * B), *t1 = ar.take<float>(bs_n * B), *t2 = ar.take<float>(bs_n * B);
     float *R[2] = {ar.take<float>(bs_R * B), ar.take<float>(bs_R * B)};
     float *M = ar.take<float>(bs_R * B);
     float *fbuf[2] = {ar.take<float>(bs_f * B), ar.take<float>(bs_f * B)};
@@ -648,8 +663,8 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
             }
             {
                 TfProfScope ps(TFK_FB_POLYEXP, 24.0 * plane * B, s);   // fused-ideal: 4 r + 20 w per level pixel
-                hipLaunchKernelGGL(k_fb_poly_v, glev, block, 0, s, Ik, h, w, pp, t0, t1, t2, bs_Ik, bs_n);
-                hipLaunchKernelGGL(k_fb_poly_h, glev, block, 0, s, t0, t1, t2, h, w, pp, R[i], plane, bs_n, bs_R);
+                hipLaunchKernelGGL(k_fb_polyexp, dim3((w + FBP_W - 1) / FBP_W, (h + FBP_H - 1) / FBP_H, B), block, 0, s,
+                                   Ik, h, w, pp, R[i], plane, bs_Ik, bs_R);
             }
         }
         TF_CHECK_LAUNCH();
