@@ -145,6 +145,22 @@ k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKern
     const float *k = kk.k;
     const TIn *S = src + (int64_t)y * W;
     float2 out;
+    if (ksize > 5 && sx1 == sx + 1 && sx - r >= 0 && sx1 + r < W) {
+        // interior: the two windows overlap in ksize - 1 pixels -> one pass over ksize + 1 pixels feeding two
+        // independent accumulation chains (each chain keeps the reference's left-to-right order)
+        const TIn *P = S + sx - r;
+        float prev = (float)P[0];
+        float s0 = k[0] * prev, s1;
+        float cur = (float)P[1];
+        s1 = k[0] * cur;
+        for (int i = 1; i < ksize; i++) {
+            const float nxt = (float)P[i + 1];
+            s0 += k[i] * cur;
+            s1 += k[i] * nxt;
+            cur = nxt;
+        }
+        out.x = s0; out.y = s1;
+    } else {
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int x = c ? sx1 : sx;
@@ -160,6 +176,7 @@ k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKern
             else { for (int i = 1; i < ksize; i++) s += k[i] * (float)S[fb_reflect101(x - r + i, W)]; }
         }
         if (c) out.y = s; else out.x = s;
+    }
     }
     rowf[(int64_t)y * g.dw + dx] = out;
 }
