@@ -313,3 +313,33 @@ def test_combined_edge_field_device_path_equals_numpy_path(tf):
     assert dev.dtype == torch.float64 and np.array_equal(dev.cpu().numpy(), want)
     dev32 = get_combined_edge_field(fl, torch.from_numpy(field).cuda(), dtype=np.float32)
     assert np.array_equal(dev32.cpu().numpy(), want.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------- flow-aware labelling
+@pytest.mark.parametrize("overlap,absolute_overlap", [(0.0, 0), (0.5, 4), (0.9, 1), (0.2, 12)])
+def test_flow_label_matches_oracle(tf, overlap, absolute_overlap):
+    from oracle import np_label
+    rng = np.random.default_rng(int(overlap * 10) + absolute_overlap)
+    shape = (6, 48, 60)
+    mask = ndi.gaussian_filter(rng.normal(size=shape), (0.5, 1.5, 1.5)) > 0.12
+    fwd, bwd = rand_flow(rng, shape, 2.0), rand_flow(rng, shape, 2.0)
+    fl = tf.Flow(fwd, bwd)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = fl.label(mask, overlap=overlap, absolute_overlap=absolute_overlap)
+    want = np_label.flow_label(fwd, bwd, mask, overlap=overlap, absolute_overlap=absolute_overlap)
+    assert got.dtype == np.int32 and np.array_equal(got, want), f"{int((got != want).sum())} px differ"
+
+
+def test_flow_link_overlap_matches_oracle(tf):
+    from oracle import np_label
+    from tobac_flow_amd.utils.label_utils import make_step_labels
+    rng = np.random.default_rng(77)
+    shape = (5, 40, 44)
+    lab3 = ndi.label(ndi.gaussian_filter(rng.normal(size=shape), (1, 2, 2)) > 0.05)[0].astype(np.int32)
+    step = make_step_labels(lab3).astype(np.int32)
+    fwd, bwd = rand_flow(rng, shape, 1.5), rand_flow(rng, shape, 1.5)
+    got = tf.Flow(fwd, bwd).link_overlap(step, overlap=0.5, absolute_overlap=5)
+    want = np_label.flow_link_overlap(fwd, bwd, step, overlap=0.5, absolute_overlap=5)
+    assert np.array_equal(got, want)
