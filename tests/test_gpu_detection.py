@@ -1,0 +1,126 @@
+"""Detection recipes end to end on the GPU path against the same recipes assembled from oracle pieces
+(the scipy.ndimage glue is identical by construction; what is checked is the plumbing through Flow.diff /
+convolve / sobel / watershed / label, i.e. SURVEY.md section 8 row a17)."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+from helpers import blob_sequence, rand_flow
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeDataArray(np.ndarray):
+    """ndarray with the two xarray attributes the recipes touch: `.t` (time coordinate) and `.to_numpy()`"""
+
+    def __new__(cls, data, minutes=10):
+        obj = np.asarray(data).view(cls)
+        obj.t = np.datetime64("2020-06-01T00:00") + np.arange(obj.shape[0]) * np.timedelta64(minutes, "m")
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.t = getattr(obj, "t", None)
+
+    def to_numpy(self):
+        return np.asarray(self)
+
+
+@pytest.fixture(scope="module")
+def scene():
+    import tobac_flow_amd.flow as tf
+    rng = np.random.default_rng(42)
+    bt = blob_sequence(rng, 6, 96, 120, n_blobs=5, vmax=2.0, noise=0.5)
+    flow = tf.create_flow(bt, smoothing_passes=1, interp_method="cubic")
+    return dict(tf=tf, bt=bt, flow=flow, fwd=flow.forward_flow, bwd=flow.backward_flow)
+
+
+def test_detect_anvils_matches_oracle_recipe(scene):
+    from oracle import np_ops, ws_oracle
+    from tobac_flow_amd.detection import detect_anvils
+    from tobac_flow_amd.analysis import find_object_lengths, mask_labels
+    from tobac_flow_amd.utils import linearise_field, remap_labels
+    bt, fwd, bwd = scene["bt"], scene["fwd"], scene["bwd"]
+    wvd = (250.0 - bt) / 2.0 - 10.0           # WVD-like: positive in the cold cores
+    got = detect_anvils(scene["flow"], wvd, upper_threshold=-5, lower_threshold=-15, min_length=1)
+    # the same recipe from oracle pieces (reference detection.py:538-587)
+    field = linearise_field(wvd, -15, -5)
+    s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
+    markers = field >= 1
+    seeds = markers * ndi.binary_erosion(markers != 0, structure=s).astype(int)
+    nan = np.isnan(field)
+    bg = ndi.binary_erosion(np.logical_or(field <= 0, nan), structure=np.ones([3, 3, 3]), iterations=1, border_value=1)
+    bg[nan] = True
+    seeds[bg] = -1
+    edges = np_ops.sobel(field, fwd, bwd, "cubic", None, np.nan, "uphill")
+    edges[edges > 0] += 1
+    edges = edges - field
+    edges[np.isnan(field)] = np.inf
+    lab = ws_oracle.watershed(fwd, bwd, edges, seeds, None, ndi.generate_binary_structure(3, 1))
+    lab[lab < 0] = 0
+    lab *= ndi.binary_opening(lab != 0, structure=s).astype(int)
+    lab[markers > 0] = markers[markers > 0]
+    want = remap_labels(lab, np.logical_and(find_object_lengths(lab) > 1, mask_labels(lab, markers != 0)))
+    assert got.shape == bt.shape and np.array_equal(got, want)
+    assert got.max() >= 1
+
+
+def test_growth_rate_and_markers_match_oracle(scene):
+    from oracle import np_ops
+    from tobac_flow_amd.detection import filtered_tdiff, get_growth_rate
+    bt, fwd, bwd, flow = scene["bt"], scene["fwd"], scene["bwd"], scene["flow"]
+    da = FakeDataArray(-bt, minutes=10)
+    for method in ("linear", "cubic"):
+        got = get_growth_rate(flow, da, method=method)
+        dt = np.full(bt.shape[0], 10.0)
+        rate = np_ops.diff(np.asarray(da), fwd, bwd, method) / dt[:, None, None]
+        s_struct = ndi.generate_binary_structure(3, 1)
+        s_struct[0] = 0
+        s_struct[2] = 0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = np_ops.convolve(rate, fwd, bwd, s_struct, method, func=lambda x: np.nanmean(x, 0))
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(want))
+    raw = flow.diff(bt)
+    t_struct = np.zeros([3, 3, 3])
+    t_struct[:, 1, 1] = 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = np_ops.convolve(raw, fwd, bwd, t_struct, "linear", func=lambda x: np.nanmean(x, 0))
+    got = filtered_tdiff(flow, raw)
+    assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want))
+
+
+def test_get_anvil_markers_and_relabel(scene):
+    from oracle import np_label
+    from tobac_flow_amd.analysis import find_object_lengths
+    from tobac_flow_amd.detection import get_anvil_markers, relabel_anvils
+    from tobac_flow_amd.utils import remap_labels
+    from tobac_flow_amd.utils.label_utils import make_step_labels
+    bt, fwd, bwd, flow = scene["bt"], scene["fwd"], scene["bwd"], scene["flow"]
+    wvd = (250.0 - bt) / 2.0 - 10.0
+    got = get_anvil_markers(flow, wvd, threshold=-5, overlap=0.5, absolute_overlap=5, min_length=1)
+    s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
+    mask = ndi.binary_opening(wvd >= -5, structure=s)
+    lab = np_label.flow_label(fwd, bwd, mask, overlap=0.5, absolute_overlap=5)
+    want = remap_labels(lab, find_object_lengths(lab) > 1)
+    assert np.array_equal(got, want) and got.max() >= 1
+    re = relabel_anvils(flow, got, overlap=0.5, absolute_overlap=5, min_length=1)
+    lk = np_label.flow_link_overlap(fwd, bwd, make_step_labels(got), overlap=0.5, absolute_overlap=5)
+    want = remap_labels(lk, find_object_lengths(lk) > 1)
+    assert np.array_equal(re, want)
+
+
+def test_get_combined_filters_runs_and_matches_any_reduction(scene):
+    """detect_cores' cloud-top filter: the int32 / nearest / np.any convolve path"""
+    from functools import partial
+    from oracle import np_ops
+    bt, fwd, bwd, flow = scene["bt"], scene["fwd"], scene["bwd"], scene["flow"]
+    seed = (bt < 265).astype(int)
+    t_struct = np.zeros([3, 3, 3], dtype=bool)
+    t_struct[:, 1, 1] = True
+    got = flow.convolve(seed, structure=t_struct, method="nearest", fill_value=False, dtype=np.int32,
+                        func=partial(np.any, axis=0))
+    want = np_ops.convolve(seed.astype(np.int32), fwd, bwd, t_struct, "nearest", np.int32, False, func=partial(np.any, axis=0))
+    assert np.array_equal(got, want)
