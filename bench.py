@@ -144,7 +144,9 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": calls,
                     "avg_launch_us": round(ms * 1e3 / calls, 2),
                     "share_of_step": round(ms / (dt * 1e3), 4),
-                    "all_kernels_ms_per_step": {k: round(v[1] / a.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+                    "all_kernels": {k: {"ms_per_step": round(v[1] / a.steps, 3),
+                                        "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[2] > 0 else None}
+                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
         out = {"metric": "Mpix/s end-to-end flow+sobel+watershed, 5424^2 frames", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
                "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",

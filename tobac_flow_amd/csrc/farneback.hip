@@ -363,7 +363,7 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 #define FBI_OW (256 - 2 * FBI_M)
 #define FBI_HS 128
 // R[img] / fin[q] / fout[q] are the pointers of batch item 0; item b adds b * the matching stride
-struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd; int64_t bs_R, bs_fin[2], bs_fout[2]; };
+struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2]; };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
 
 struct FbIterCtx {
@@ -443,14 +443,24 @@ __global__ void __launch_bounds__(256)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
 {
     __shared__ double vrow[FBI_G][5][256];
-    const int b = blockIdx.z / a.nd, q = blockIdx.z % a.nd;
+    // Work-item order.  Both directions of one strip read the same two R images (each is the other's gather
+    // target), so they are placed on the SAME XCD (block ids that differ by 8 share an XCD under the observed
+    // round-robin dispatch; this is for L2 reuse only, never for correctness): within a group of 8*nd
+    // consecutive block ids, id % 8 picks the strip and id / 8 the direction.
+    const int nstrips = a.nx;                                          // column strips per row-strip
+    const int gid = blockIdx.x;
+    const int grp = gid / (8 * a.nd), rem = gid % (8 * a.nd);
+    const int q = rem / 8;
+    const int sx = grp * 8 + rem % 8;
+    if (sx >= nstrips) return;
+    const int b = blockIdx.z;
     const int d = a.dir[q];                                            // 0: prev -> next, 1: next -> prev
     FbIterCtx c;
     c.R0 = a.R[d] + b * a.bs_R; c.R1 = a.R[1 - d] + b * a.bs_R;
     c.fin = a.fin[q] + b * a.bs_fin[q]; c.fout = a.fout[q] + b * a.bs_fout[q];
     c.H = H; c.W = W; c.plane = plane;
     c.j = threadIdx.x;
-    c.xo = blockIdx.x * FBI_OW + c.j - FBI_M;                         // column this thread evaluates M for
+    c.xo = sx * FBI_OW + c.j - FBI_M;                         // column this thread evaluates M for
     c.xc = tf_clampi(c.xo, 0, W - 1);                                 // replicate border
     c.y0 = blockIdx.y * hs;
     const int y1 = min(c.y0 + hs, H);                             // output rows [y0, y1)
@@ -711,9 +721,10 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
             // strip height: tall strips amortise the 12-row halo, short ones keep all CUs busy on coarse levels
             int hs = FBI_HS;
             while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd * B < 1536) hs >>= 1;
-            const dim3 gi((w + FBI_OW - 1) / FBI_OW, (h + hs - 1) / hs, nd * B);
+            const int nx = (w + FBI_OW - 1) / FBI_OW;
+            const dim3 gi(((nx + 7) / 8) * 8 * nd, (h + hs - 1) / hs, B);
             FbIterArgs ia;
-            ia.R[0] = R[0]; ia.R[1] = R[1]; ia.bs_R = bs_R; ia.nd = nd;
+            ia.R[0] = R[0]; ia.R[1] = R[1]; ia.bs_R = bs_R; ia.nd = nd; ia.nx = nx;
             for (int it = 0; it < p->num_iters; it++) {
                 for (int q = 0; q < nd; q++) {
                     const int d = dirs[q];
