@@ -57,30 +57,55 @@ def stitch_labels(labels, group=None, min_overlap=1):
     """Make the positive label IDs of per-rank windows globally consistent.
 
     labels: (T_w, H, W) int32 torch tensor of this rank (negative and zero labels are kept).
-    Rank r's last frame and rank r+1's first frame are the same time step.  Returns the relabelled
-    tensor.  One all_gather of the first frames + one of the label counts."""
+    Rank r's last frame and rank r+1's first frame are the same time step.  Communication:
+      1. all_gather of the per-rank label counts (one int64 each),
+      2. neighbour exchange: rank r+1 sends its first label frame to rank r (one point-to-point
+         message per boundary over a single xGMI link),
+      3. all_gather of the (id_left, id_right) pair lists found on each boundary, padded to the longest
+         list -- a few KB..MB; every rank then runs the same union-find and rewrites its own labels."""
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return labels
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = labels.device
+    if dist.get_backend(group) == "gloo" and labels.is_cuda:
+        # gloo has no GPU collectives for these ops: stage the exchanged frames through the host
+        return stitch_labels(labels.cpu(), group, min_overlap).to(dev)
     count = torch.clamp(labels.max(), min=0).to(torch.int64).reshape(1)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, count, group=group)
-    firsts = [torch.empty_like(labels[0]) for _ in range(world)]
-    dist.all_gather(firsts, labels[0].contiguous(), group=group)
     counts = [int(c.item()) for c in counts]
-    # every rank evaluates every boundary (identical inputs -> identical union-find everywhere)
-    lasts = [torch.empty_like(labels[0]) for _ in range(world)]
-    dist.all_gather(lasts, labels[-1].contiguous(), group=group)
-    pairs = []
-    for r in range(world - 1):
-        a, b = lasts[r].reshape(-1).to(torch.int64), firsts[r + 1].reshape(-1).to(torch.int64)
+    # neighbour exchange of the shared frame
+    first = labels[0].contiguous()
+    right_first = torch.empty_like(first)
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, first, rank - 1, group))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.irecv, right_first, rank + 1, group))
+    for req in dist.batch_isend_irecv(ops) if ops else []:
+        req.wait()
+    # pairs on my right boundary
+    if rank < world - 1:
+        a, b = labels[-1].reshape(-1).to(torch.int64), right_first.reshape(-1).to(torch.int64)
         both = (a > 0) & (b > 0)
-        key, cnt = torch.unique(a[both] * (counts[r + 1] + 1) + b[both], return_counts=True)
+        base = counts[rank + 1] + 1
+        key, cnt = torch.unique(a[both] * base + b[both], return_counts=True)
         key = key[cnt >= min_overlap]
-        pairs.append(torch.stack([key // (counts[r + 1] + 1), key % (counts[r + 1] + 1)], 1).cpu().numpy())
+        mine = torch.stack([key // base, key % base], 1)
+    else:
+        mine = torch.zeros((0, 2), dtype=torch.int64, device=dev)
+    n_mine = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)
+    n_all = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(n_all, n_mine, group=group)
+    n_all = [int(v.item()) for v in n_all]
+    width = max(max(n_all), 1)
+    padded = torch.zeros((width, 2), dtype=torch.int64, device=dev)
+    padded[:mine.shape[0]] = mine
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded, group=group)
+    pairs = [gathered[r][:n_all[r]].cpu().numpy() for r in range(world - 1)]
     lut = stitch_lut(counts, pairs)[rank]
     lut_t = torch.from_numpy(lut.astype(np.int32)).to(dev)
     pos = labels > 0
