@@ -56,7 +56,7 @@ def test_parallel_model_equals_idealised_oracle(golden_ws):
     """The chain-key formulation implemented by the HIP kernels (tools/ws_parallel_model.py is its
     numpy model) reproduces the sequential flood exactly."""
     import sys, os
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    sys.path.insert(0, os.path.dirname(__file__))
     import ws_parallel_model as M
     for name, depth in (("A_cont_c1", 1), ("D_anvil_like_c1", 3), ("C_quant4_c1", 3), ("G_big_flow_c1", 1)):
         c = golden_ws[name]

@@ -1,4 +1,4 @@
-"""CPU model (numpy) of the parallel watershed formulation used by the HIP kernels.
+"""TEST INFRASTRUCTURE: CPU model (numpy) of the parallel watershed formulation used by the HIP kernels.
 
 Not the oracle and not the product: a readable model of the chain-key fixpoint
 ("Watershed") used to validate the theory against the oracle on small cases.
