@@ -1,0 +1,160 @@
+"""Edge cases through the C ABI: degenerate shapes, empty / saturated inputs, extreme flows, NaN / inf."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+from helpers import rand_field, rand_flow, seeds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import tobac_flow_amd.flow as flow
+    return flow
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype
+    if a.dtype.kind == "f":
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        a, b = np.nan_to_num(a, posinf=1e300, neginf=-1e300), np.nan_to_num(b, posinf=1e300, neginf=-1e300)
+    assert np.array_equal(a, b), f"{int((a != b).sum())} elements differ"
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 7, 1), (1, 1, 9), (2, 3, 4), (1, 5, 5), (3, 2, 70)])
+@pytest.mark.parametrize("method", ["nearest", "linear", "cubic"])
+def test_sobel_and_convolve_degenerate_shapes(tf, shape, method):
+    from oracle import np_ops
+    rng = np.random.default_rng(sum(shape))
+    data = rng.normal(size=shape).astype(np.float32)
+    fwd = rng.uniform(-2.5, 2.5, shape + (2,)).astype(np.float32)
+    bwd = rng.uniform(-2.5, 2.5, shape + (2,)).astype(np.float32)
+    fl = tf.Flow(fwd, bwd)
+    _same(fl.sobel(data, method=method, direction="uphill"), np_ops.sobel(data, fwd, bwd, method, None, np.nan, "uphill"))
+    _same(fl.convolve(data, method=method), np_ops.convolve(data, fwd, bwd, method=method))
+    _same(fl.diff(data, method=method), np_ops.diff(data, fwd, bwd, method))
+
+
+def test_convolve_fill_value_number_and_border_taps(tf):
+    """numeric fill value exercises the straddling-border formulas (cval + sum (S - cval) w)"""
+    from oracle import np_ops
+    rng = np.random.default_rng(9)
+    shape = (3, 12, 14)
+    data = rng.normal(size=shape).astype(np.float32)
+    fwd = rng.uniform(-6, 6, shape + (2,)).astype(np.float32)
+    bwd = rng.uniform(-6, 6, shape + (2,)).astype(np.float32)
+    st = ndi.generate_binary_structure(3, 3)
+    for method in ("nearest", "linear", "cubic"):
+        got = tf.Flow(fwd, bwd).convolve(data, structure=st, method=method, fill_value=-3.5)
+        want = np_ops.convolve(data, fwd, bwd, st, method, np.float32, -3.5)
+        _same(got, want)
+
+
+def test_to8bit_special_values(tf):
+    from oracle import np_ops
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.utils.normalisation_utils import to_8bit_pair_dev
+    base = np.linspace(200, 300, 6 * 8, dtype=np.float32).reshape(2, 6, 4)
+    cases = [base.copy() for _ in range(5)]
+    cases[1][:] = 7.0                                  # vmin == vmax -> factor 0
+    cases[2][0, 0, 0] = np.inf                         # infinite range -> everything non-finite or 0
+    cases[3][1, 2, :] = -np.inf
+    cases[4][0] = np.nan                               # one frame entirely NaN: patched from the other
+    for pair in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = np_ops.to_8bit(np_ops.linear_norm(pair.copy()), 0, 1)
+        a, b = to_8bit_pair_dev(_lib.to_dev(pair[0]), _lib.to_dev(pair[1]))
+        assert np.array_equal(a.cpu().numpy(), want[0]) and np.array_equal(b.cpu().numpy(), want[1])
+
+
+def test_farneback_reference_test_blob(tf):
+    """the 15 x 10 blob of the reference's tests/test_flow.py:203-204 (single pyramid level: < 32 px)"""
+    from test_gpu_parity import _oracle_farneback
+    xx, yy = np.meshgrid(np.arange(15), np.arange(10))
+    blob = tf.to_8bit((7 ** 2 - (xx - 7) ** 2) * (4.5 ** 2 - (yy - 4.5) ** 2))
+    nxt = np.roll(blob, 1, 1)
+    f, b = tf.calculate_flow_frame(blob, nxt, tf.select_of_model("Farneback"))
+    assert f.shape == (10, 15, 2)
+    assert np.max(np.abs(f - _oracle_farneback(blob, nxt))) <= 1e-4
+    assert np.max(np.abs(b - _oracle_farneback(nxt, blob))) <= 1e-4
+    z, _ = tf.calculate_flow_frame(blob, blob, tf.select_of_model("Farneback"))
+    assert np.max(np.abs(z - _oracle_farneback(blob, blob))) <= 1e-4 and np.allclose(z, 0, atol=0.05)
+
+
+@pytest.mark.parametrize("shape", [(33, 47), (64, 31), (100, 333)])
+def test_farneback_odd_sizes_match_oracle(tf, shape):
+    from test_gpu_parity import _oracle_farneback
+    rng = np.random.default_rng(shape[1])
+    a = (ndi.gaussian_filter(rng.normal(size=shape), 3) * 400 + 128).clip(0, 255).astype(np.uint8)
+    b = np.roll(a, (1, 2), (0, 1))
+    f, bk = tf.calculate_flow_frame(a, b, tf.select_of_model("Farneback"))
+    assert np.max(np.abs(f - _oracle_farneback(a, b))) <= 1e-4
+    assert np.max(np.abs(bk - _oracle_farneback(b, a))) <= 1e-4
+
+
+def test_create_flow_short_series(tf):
+    rng = np.random.default_rng(1)
+    two = rng.normal(size=(2, 40, 48)).astype(np.float32)
+    fl = tf.create_flow(two)
+    assert fl.shape == (2, 40, 48) and np.isfinite(fl.forward_flow).all()
+    assert np.array_equal(fl.forward_flow[1], -fl.backward_flow[1]) and np.array_equal(fl.backward_flow[0], -fl.forward_flow[0])
+    one = tf.create_flow(two[:1])                      # no frame pair: the reference leaves NaN
+    assert one.shape == (1, 40, 48) and np.isnan(one.forward_flow).all() and np.isnan(one.backward_flow).all()
+
+
+def test_watershed_degenerate_volumes(tf):
+    from oracle import ws_oracle
+    z1 = np.zeros((1, 1, 1, 2), np.float32)
+    assert tf.watershed(z1, z1, np.zeros((1, 1, 1), np.float32), np.array([[[3]]], np.int32)).tolist() == [[[3]]]
+    assert tf.watershed(z1, z1, np.zeros((1, 1, 1), np.float32), np.zeros((1, 1, 1), np.int32)).tolist() == [[[0]]]
+    rng = np.random.default_rng(4)
+    shape = (1, 17, 23)                                # T = 1: no temporal neighbours at all
+    f = rand_field(rng, shape)
+    m = seeds(rng, shape, 4)
+    fl = rand_flow(rng, shape, 3.0)
+    for conn in (1, 2, 3):
+        assert np.array_equal(tf.watershed(fl, fl, f, m, connectivity=conn), ws_oracle.watershed(fl, fl, f, m, None, conn))
+    allm = np.arange(1, 1 + np.prod(shape), dtype=np.int32).reshape(shape)       # every pixel is a seed
+    assert np.array_equal(tf.watershed(fl, fl, f, allm), allm)
+    nomask = np.zeros(shape, bool)                                              # nothing floodable, seeds kept
+    assert np.array_equal(tf.watershed(fl, fl, f, m, mask=nomask), m)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_watershed_extreme_flows_and_seeds_outside_mask(tf, seed):
+    """flows at the create_flow clip bound (+-20 px), half-integer flows (round half to even), NaN flows
+    are rounded to 0 here (the reference would crash on them), markers that lie outside the mask still seed"""
+    from oracle import ws_oracle
+    rng = np.random.default_rng(200 + seed)
+    shape = (4, 45, 50)
+    field = rand_field(rng, shape)
+    markers = seeds(rng, shape, 8)
+    mask = ndi.gaussian_filter(rng.normal(size=shape), (0, 2, 2)) > -0.1
+    fwd = rng.choice(np.array([-20, -7.5, -2.5, -0.5, 0, 0.5, 1.5, 3.5, 20], np.float32), size=shape + (2,))
+    bwd = rng.choice(np.array([-20, -7.5, -2.5, -0.5, 0, 0.5, 1.5, 3.5, 20], np.float32), size=shape + (2,))
+    conn = [1, 3][seed % 2]
+    got = tf.watershed(fwd, bwd, field, markers, mask=mask, connectivity=conn)
+    want = ws_oracle.watershed(fwd, bwd, field, markers, mask, conn)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} px differ"
+    assert np.array_equal(got[markers != 0], markers[markers != 0])
+
+
+def test_watershed_custom_structure_and_inf_field(tf):
+    from oracle import ws_oracle
+    rng = np.random.default_rng(8)
+    shape = (3, 30, 34)
+    field = rand_field(rng, shape)
+    field[rng.random(shape) < 0.05] = np.inf
+    markers = seeds(rng, shape, 6)
+    st = np.zeros((3, 3, 3), bool)
+    st[1] = True                       # in-plane 8-neighbourhood only
+    st[0, 1, 1] = st[2, 1, 1] = True   # + the two temporal neighbours
+    fwd, bwd = rand_flow(rng, shape, 2.0), rand_flow(rng, shape, 2.0)
+    got = tf.watershed(fwd, bwd, field, markers, connectivity=st)
+    want = ws_oracle.watershed(fwd, bwd, field, markers, None, st)
+    assert np.array_equal(got, want)

@@ -54,8 +54,11 @@ __device__ __forceinline__ TS gather_tap(const typename StackTraits<TS>::In *__r
     }
     const bool prev = i < tp.nb;
     const int64_t tt = prev ? t - 1 : t + 1;
-    if (tt < 0 || tt >= T) return (TS)fillv;             // all-fill neighbour frame (convolve.py:307-314)
     const float mx = tf_loc(prev ? fbx : ffx, ox, x), my = tf_loc(prev ? fby : ffy, oy, y);
+    if (tt < 0 || tt >= T) {                             // all-fill neighbour frame (convolve.py:307-314)
+        if constexpr (std::is_same<In, int32_t>::value) return (TS)fillv;
+        else return (TS)tf_remap_const<METHOD>(H, W, mx, my, (float)fillv);
+    }
     const In *img = data + tt * plane;
     if constexpr (std::is_same<In, int32_t>::value) {
         return (TS)tf_remap_nearest<int32_t>(img, H, W, mx, my, fillv);
@@ -252,10 +255,13 @@ k_sobel27(const float *__restrict__ data, const float *__restrict__ fwd, const f
     const int a3[3] = {1, 2, 1}, d3[3] = {-1, 0, 1};
     float tap[9];
     // plane 0: previous frame through the backward flow (stack slots 0..8)
-    if (t > 0) { const float2 f = ((const float2 *)bwd)[pix]; sobel_plane_taps<METHOD>(data + (t - 1) * plane, H, W, x, y, f.x, f.y, fillf, tap); }
-    else {
+    {
+        const float2 f = ((const float2 *)bwd)[pix];
+        if (t > 0) sobel_plane_taps<METHOD>(data + (t - 1) * plane, H, W, x, y, f.x, f.y, fillf, tap);
+        else {
 #pragma unroll
-        for (int k = 0; k < 9; k++) tap[k] = fillf;
+            for (int k = 0; k < 9; k++) tap[k] = tf_remap_const<METHOD>(H, W, tf_loc(f.x, k % 3 - 1, x), tf_loc(f.y, k / 3 - 1, y), fillf);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -271,10 +277,13 @@ k_sobel27(const float *__restrict__ data, const float *__restrict__ fwd, const f
         sobel_accumulate<TS, DIR>((TS)v, c, a3[1] * a3[r] * d3[cc], a3[cc] * a3[1] * d3[r], a3[r] * a3[cc] * d3[1], gx, gy, gt);
     }
     // plane 2: next frame through the forward flow
-    if (t + 1 < T) { const float2 f = ((const float2 *)fwd)[pix]; sobel_plane_taps<METHOD>(data + (t + 1) * plane, H, W, x, y, f.x, f.y, fillf, tap); }
-    else {
+    {
+        const float2 f = ((const float2 *)fwd)[pix];
+        if (t + 1 < T) sobel_plane_taps<METHOD>(data + (t + 1) * plane, H, W, x, y, f.x, f.y, fillf, tap);
+        else {
 #pragma unroll
-        for (int k = 0; k < 9; k++) tap[k] = fillf;
+            for (int k = 0; k < 9; k++) tap[k] = tf_remap_const<METHOD>(H, W, tf_loc(f.x, k % 3 - 1, x), tf_loc(f.y, k / 3 - 1, y), fillf);
+        }
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) {

@@ -92,3 +92,35 @@ __device__ __forceinline__ float tf_remap(const float *__restrict__ img, int h, 
     if (METHOD == TF_INTERP_LINEAR) return tf_remap_linear(img, h, w, mx, my, cval);
     return tf_remap_cubic(img, h, w, mx, my, cval);
 }
+
+// The reference substitutes a missing neighbour frame (t-1 before the first frame, t+1 after the last) by an image
+// that is CONSTANT = fill_value and still runs cv2.remap on it (convolve.py:307-314).  For NaN that is NaN; for a
+// numeric fill the interpolation of a constant image is fill * (sum of weights), which is not exactly fill in
+// float.  This evaluates tf_remap on such a constant image without touching memory (same branches, same order).
+template <int METHOD>
+__device__ __forceinline__ float tf_remap_const(int h, int w, float mx, float my, float fill) {
+    if (METHOD == TF_INTERP_NEAREST || fill != fill) return fill;
+    int fx = tf_cvround(mx * 32.f), fy = tf_cvround(my * 32.f);
+    int sx = tf_sat_short(fx >> 5), sy = tf_sat_short(fy >> 5);
+    if (METHOD == TF_INTERP_LINEAR) {
+        if (sx >= w || sx + 1 < 0 || sy >= h || sy + 1 < 0) {
+            int w1lim = w - 1 > 0 ? w - 1 : 0, h1lim = h - 1 > 0 ? h - 1 : 0;
+            if (!((unsigned)sx < (unsigned)w1lim && (unsigned)sy < (unsigned)h1lim)) return fill;
+        }
+        float ax = (float)(fx & 31) * (1.f / 32.f), ay = (float)(fy & 31) * (1.f / 32.f);
+        float w0 = (1.f - ay) * (1.f - ax), w1 = (1.f - ay) * ax, w2 = ay * (1.f - ax), w3 = ay * ax;
+        return fill * w0 + fill * w1 + fill * w2 + fill * w3;      // inside and border taps all read `fill`
+    }
+    int bx = sx - 1, by = sy - 1;
+    int w1lim = w - 3 > 0 ? w - 3 : 0, h1lim = h - 3 > 0 ? h - 3 : 0;
+    if ((unsigned)bx < (unsigned)w1lim && (unsigned)by < (unsigned)h1lim) {
+        float cx[4], cy[4];
+        tf_cubic_coeffs((float)(fx & 31) * (1.f / 32.f), cx);
+        tf_cubic_coeffs((float)(fy & 31) * (1.f / 32.f), cy);
+        float sum = fill * (cy[0] * cx[0]);
+#pragma unroll
+        for (int q = 1; q < 16; q++) sum = sum + fill * (cy[q / 4] * cx[q % 4]);
+        return sum;
+    }
+    return fill;           // fully outside -> cval; straddling -> cval + sum (fill - cval) * w = fill
+}
