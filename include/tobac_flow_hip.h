@@ -167,6 +167,23 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
                  const int8_t *nbr_host, int n_nbr, int chain_depth, int32_t *labels,
                  void *ws, size_t ws_bytes, int64_t *stats_host, void *stream);
 
+/* ---- section 8f-2: scipy.ndimage glue of the detection recipes (bit-exact with SciPy) ---------------------
+ * tf_binary_morph: scipy.ndimage.binary_erosion (op 0) / binary_dilation (op 1) of a (T, H, W) uint8 volume with a
+ *   3x3x3 structuring element (27 host bytes, C order), `iterations` >= 1, `border_value` 0/1
+ *   (tobac_flow/detection.py:80-93, 509, 551-553, 571-573, 608-616; binary_opening = erosion then dilation).
+ *   tmp: scratch of the same size, required when iterations > 1.
+ * tf_linearise: tobac_flow/utils/normalisation_utils.py:36-56 linearise_field in float32.
+ * tf_label_extent: per label 1..n_labels the first / last leading index (tobac_flow/analysis.py:15-35
+ *   find_object_lengths = tmax - tmin + 1) and whether it touches `mask` (analysis.py:38-63 mask_labels);
+ *   arrays of n_labels + 1 entries, entry 0 unused; absent labels: tmin = 0x7f7f7f7f, tmax = -1.
+ * tf_apply_lut: out = lut[labels] (tobac_flow/utils/label_utils.py:265-309 remap_labels' gather). */
+int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
+                    int op, int iterations, int border_value, uint8_t *out, uint8_t *tmp, void *stream);
+int tf_linearise(const float *field, int64_t n, double lower, double upper, float *out, void *stream);
+int tf_label_extent(const int32_t *labels, const uint8_t *mask, int64_t T, int64_t H, int64_t W, int n_labels,
+                    int *tmin, int *tmax, uint8_t *hit, void *stream);
+int tf_apply_lut(const int32_t *labels, int64_t n, const int32_t *lut, int n_lut, int32_t *out, void *stream);
+
 /* ---- measurement aid (bench.py's roofline figure) ---------------------------------------------
  * tf_profile_enable(1): every kernel launch of the library is bracketed by HIP events on its own
  * stream and tagged with its ALGORITHMIC byte count.  tf_profile_collect() synchronises

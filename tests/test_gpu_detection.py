@@ -124,3 +124,57 @@ def test_get_combined_filters_runs_and_matches_any_reduction(scene):
                         func=partial(np.any, axis=0))
     want = np_ops.convolve(seed.astype(np.int32), fwd, bwd, t_struct, "nearest", np.int32, False, func=partial(np.any, axis=0))
     assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- section 8f-2: ndimage glue on the GPU
+@pytest.mark.parametrize("iterations,border", [(1, 0), (1, 1), (3, 0), (2, 1)])
+def test_binary_morphology_matches_scipy(iterations, border):
+    import torch
+    from tobac_flow_amd import ndimage_dev as nd
+    rng = np.random.default_rng(iterations * 10 + border)
+    x = ndi.gaussian_filter(rng.normal(size=(5, 37, 45)), (0.5, 1.5, 1.5)) > 0.0
+    cross = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
+    skew = np.zeros((3, 3, 3), bool)
+    skew[0, 0, 1] = skew[1, 1, 1] = skew[1, 1, 2] = skew[2, 2, 0] = True            # asymmetric: checks the reflection rule
+    for st in (cross, np.ones((3, 3, 3), bool), ndi.generate_binary_structure(3, 1), skew):
+        xd = torch.from_numpy(x).cuda()
+        got = nd.binary_erosion(xd, st, iterations, border).cpu().numpy()
+        assert np.array_equal(got, ndi.binary_erosion(x, structure=st, iterations=iterations, border_value=border))
+        got = nd.binary_dilation(xd, st, iterations, border).cpu().numpy()
+        assert np.array_equal(got, ndi.binary_dilation(x, structure=st, iterations=iterations, border_value=border))
+        got = nd.binary_opening(xd, st, iterations).cpu().numpy()
+        assert np.array_equal(got, ndi.binary_opening(x, structure=st, iterations=iterations))
+
+
+def test_device_glue_matches_numpy_glue(scene):
+    import torch
+    from tobac_flow_amd import ndimage_dev as nd
+    from tobac_flow_amd.analysis import find_object_lengths, mask_labels
+    from tobac_flow_amd.detection import get_watershed_mask
+    from tobac_flow_amd.utils import linearise_field, remap_labels
+    bt = scene["bt"]
+    wvd = ((250.0 - bt) / 2.0 - 10.0).astype(np.float32)
+    wvd[1, 10:14, 20:30] = np.nan
+    for lo, hi in ((-15, -5), (-5, -15)):
+        want = linearise_field(wvd, lo, hi)
+        got = nd.linearise_field(torch.from_numpy(wvd).cuda(), lo, hi).cpu().numpy()
+        assert want.dtype == np.float32 and np.array_equal(np.nan_to_num(got, nan=-7), np.nan_to_num(want, nan=-7))
+    lin = linearise_field(wvd, -15, -5)
+    for e in (1, 2):
+        assert np.array_equal(get_watershed_mask(torch.from_numpy(lin).cuda(), e).cpu().numpy(), get_watershed_mask(lin, e))
+    lab = ndi.label(lin > 0.3)[0].astype(np.int32)
+    msk = lin >= 1
+    lengths, hit = nd.label_extent(torch.from_numpy(lab).cuda(), torch.from_numpy(msk).cuda())
+    assert np.array_equal(lengths, find_object_lengths(lab)) and np.array_equal(hit, mask_labels(lab, msk))
+    keep = np.logical_and(lengths > 1, hit)
+    assert np.array_equal(nd.remap_labels(torch.from_numpy(lab).cuda(), keep).cpu().numpy(), remap_labels(lab, keep))
+
+
+def test_detect_anvils_device_path_equals_numpy_path(scene):
+    import torch
+    from tobac_flow_amd.detection import detect_anvils
+    bt = scene["bt"]
+    wvd = ((250.0 - bt) / 2.0 - 10.0).astype(np.float32)
+    want = detect_anvils(scene["flow"], wvd, upper_threshold=-5, lower_threshold=-15, min_length=1)
+    got = detect_anvils(scene["flow"], torch.from_numpy(wvd).cuda(), upper_threshold=-5, lower_threshold=-15, min_length=1)
+    assert isinstance(got, torch.Tensor) and np.array_equal(got.cpu().numpy(), want)

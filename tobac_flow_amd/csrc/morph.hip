@@ -1,0 +1,134 @@
+// scipy.ndimage glue of the detection recipes on the GPU, bit-exact with SciPy:
+//   tf_binary_morph   ndi.binary_erosion / binary_dilation with a 3x3x3 structuring element, `iterations`
+//                     and `border_value` (detection.py:80-93, 105-119, 509, 551-553, 571-573, 608-616)
+//   tf_linearise      utils/normalisation_utils.py:36-56 linearise_field
+//   tf_label_extent   analysis.py:15-35 find_object_lengths + :38-63 mask_labels (per-label t-extent / hit flag)
+//   tf_apply_lut      utils/label_utils.py:265-309 remap_labels' final gather
+// All are one-pass HBM-bound stencils / reductions on uint8 / int32 volumes.
+#include "tf_common.h"
+
+struct MorphTaps { int n; int8_t dt[27], dy[27], dx[27]; };
+
+// op 0: erosion  out = AND_d in[p + d]   (out of volume -> border)
+// op 1: dilation out = OR_d  in[p - d]   (SciPy reflects the structure; out of volume -> border)
+__global__ void __launch_bounds__(256)
+k_binary_morph(const uint8_t *__restrict__ in, int64_t T, int H, int W, MorphTaps tp, int op, int border,
+               uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const int64_t plane = (int64_t)H * W;
+    bool r = op == 0;
+    for (int i = 0; i < tp.n; i++) {
+        const int s = op == 0 ? 1 : -1;
+        const int64_t tt = t + s * tp.dt[i];
+        const int yy = y + s * tp.dy[i], xx = x + s * tp.dx[i];
+        bool v;
+        if (tt < 0 || tt >= T || yy < 0 || yy >= H || xx < 0 || xx >= W) v = border != 0;
+        else v = in[tt * plane + (int64_t)yy * W + xx] != 0;
+        if (op == 0) { if (!v) { r = false; break; } }
+        else if (v) { r = true; break; }
+    }
+    out[t * plane + (int64_t)y * W + x] = r ? 1 : 0;
+}
+
+extern "C" int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
+                               int op, int iterations, int border_value, uint8_t *out, uint8_t *tmp, void *stream)
+{
+    TF_REQUIRE(in && out && structure_host, "tf_binary_morph: null pointer");
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && T < 65536 && H < (1 << 15) && W < (1 << 15), "tf_binary_morph: bad shape");
+    TF_REQUIRE(op == 0 || op == 1, "tf_binary_morph: op must be 0 (erosion) or 1 (dilation)");
+    TF_REQUIRE(iterations >= 1, "tf_binary_morph: iterations must be >= 1");
+    TF_REQUIRE(iterations == 1 || tmp, "tf_binary_morph: iterations > 1 needs a tmp buffer");
+    TF_REQUIRE(out != in && tmp != in && (tmp != out || iterations == 1), "tf_binary_morph: buffers alias");
+    MorphTaps tp; tp.n = 0;
+    for (int p = 0; p < 3; p++) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+        if (structure_host[p * 9 + r * 3 + c]) { tp.dt[tp.n] = (int8_t)(p - 1); tp.dy[tp.n] = (int8_t)(r - 1); tp.dx[tp.n] = (int8_t)(c - 1); tp.n++; }
+    TF_REQUIRE(tp.n > 0, "tf_binary_morph: empty structure");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 block(64, 4), grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
+    const uint8_t *src = in;
+    for (int it = 0; it < iterations; it++) {
+        // ping-pong so that the last iteration writes `out`
+        uint8_t *dst = ((iterations - 1 - it) % 2 == 0) ? out : tmp;
+        TfProfScope ps(TFK_CONVOLVE, 2.0 * (double)T * H * W, s);
+        hipLaunchKernelGGL(k_binary_morph, grid, block, 0, s, src, T, (int)H, (int)W, tp, op, border_value, dst);
+        src = dst;
+    }
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+// linearise_field: clip((f - lo) / (hi - lo), 0, 1), reversed thresholds flip the ramp (float32 like numpy on float32)
+__global__ void __launch_bounds__(256)
+k_linearise(const float *__restrict__ f, int64_t n, float lo, float hi, int flip, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = (f[i] - lo) / (hi - lo);
+    v = (v != v) ? v : fminf(v, 1.f);          // np.minimum / np.maximum propagate NaN
+    v = (v != v) ? v : fmaxf(v, 0.f);
+    out[i] = flip ? 1.f - v : v;
+}
+
+extern "C" int tf_linearise(const float *field, int64_t n, double lower, double upper, float *out, void *stream)
+{
+    TF_REQUIRE(field && out && n > 0, "tf_linearise: bad arguments");
+    TF_REQUIRE(lower != upper, "tf_linearise: lower and upper thresholds must have different values");
+    int flip = 0;
+    if (lower > upper) { const double t = lower; lower = upper; upper = t; flip = 1; }
+    hipLaunchKernelGGL(k_linearise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, field, n,
+                       (float)lower, (float)upper, flip, out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+// per-label first / last time step and "overlaps the mask" flag: tmin/tmax int32[n_labels + 1], hit u8[n_labels + 1]
+__global__ void __launch_bounds__(256)
+k_label_extent(const int32_t *__restrict__ labels, const uint8_t *__restrict__ mask, int64_t plane, int n_labels,
+               int *__restrict__ tmin, int *__restrict__ tmax, uint8_t *__restrict__ hit)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
+    if (i >= plane) return;
+    const int64_t p = (int64_t)t * plane + i;
+    const int32_t l = labels[p];
+    if (l <= 0 || l > n_labels) return;
+    if (tmin[l] > t) atomicMin(&tmin[l], t);
+    if (tmax[l] < t) atomicMax(&tmax[l], t);
+    if (mask && mask[p] && !hit[l]) hit[l] = 1;
+}
+
+extern "C" int tf_label_extent(const int32_t *labels, const uint8_t *mask, int64_t T, int64_t H, int64_t W, int n_labels,
+                               int *tmin, int *tmax, uint8_t *hit, void *stream)
+{
+    TF_REQUIRE(labels && tmin && tmax && hit && n_labels >= 0, "tf_label_extent: bad arguments");
+    TF_REQUIRE(T > 0 && T < 65536 && H > 0 && W > 0, "tf_label_extent: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    TF_CHECK_HIP(hipMemsetAsync(tmin, 0x7f, (size_t)(n_labels + 1) * sizeof(int), s));
+    TF_CHECK_HIP(hipMemsetAsync(tmax, 0xff, (size_t)(n_labels + 1) * sizeof(int), s));       // -1
+    TF_CHECK_HIP(hipMemsetAsync(hit, 0, (size_t)(n_labels + 1), s));
+    const int64_t plane = H * W;
+    hipLaunchKernelGGL(k_label_extent, dim3((unsigned)((plane + 255) / 256), (unsigned)T), dim3(256), 0, s,
+                       labels, mask, plane, n_labels, tmin, tmax, hit);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+__global__ void __launch_bounds__(256)
+k_apply_lut(const int32_t *__restrict__ labels, int64_t n, const int32_t *__restrict__ lut, int n_lut, int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = labels[i];
+    out[i] = (l >= 0 && l < n_lut) ? lut[l] : 0;
+}
+
+extern "C" int tf_apply_lut(const int32_t *labels, int64_t n, const int32_t *lut, int n_lut, int32_t *out, void *stream)
+{
+    TF_REQUIRE(labels && lut && out && n > 0 && n_lut > 0, "tf_apply_lut: bad arguments");
+    hipLaunchKernelGGL(k_apply_lut, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, labels, n, lut, n_lut, out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}

@@ -242,7 +242,10 @@ def get_anvil_markers(flow, field, threshold=-5, overlap=0.5, absolute_overlap=5
                      cell_measures="area: area")
 def detect_anvils(flow, field, markers=None, upper_threshold=-5, lower_threshold=-15, erode_distance=1, min_length=3):
     """Anvil extent by watershedding the combined edge field from eroded markers against an
-    eroded background seed (reference: detection.py:538-587)."""
+    eroded background seed (reference: detection.py:538-587).  A torch GPU tensor as `field` keeps the
+    whole recipe on the device (tobac_flow_amd/ndimage_dev.py) and returns a tensor."""
+    if isinstance(field, _lib.torch().Tensor):
+        return _detect_anvils_dev(flow, field, markers, upper_threshold, lower_threshold, erode_distance, min_length)
     field = linearise_field(_values(field), lower_threshold, upper_threshold)
     s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
     if markers is None:
@@ -262,9 +265,39 @@ def detect_anvils(flow, field, markers=None, upper_threshold=-5, lower_threshold
     return remap_labels(anvil_labels, np.logical_and(lengths > min_length, touches_marker))
 
 
+def _detect_anvils_dev(flow, field, markers, upper_threshold, lower_threshold, erode_distance, min_length):
+    """detect_anvils with every step on the GPU; same operations in the same order as the numpy path"""
+    from tobac_flow_amd import ndimage_dev as nd
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    t = _lib.torch()
+    field = nd.linearise_field(field, lower_threshold, upper_threshold)
+    s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
+    if markers is None:
+        markers = field >= 1
+    markers = _lib.to_dev(markers)
+    markers_i = markers.to(t.int32)
+    seeds = markers_i * nd.binary_erosion(markers_i != 0, s).to(t.int32)
+    seeds[get_watershed_mask(field, erode_distance=erode_distance)] = -1
+    edges = get_combined_edge_field(flow, field, dtype=np.float32)
+    fw, bw = flow._dev_flows()
+    labels = watershed_dev(fw, bw, edges, seeds, None, neighbour_offsets(ndi.generate_binary_structure(3, 1)))
+    labels = t.where(labels < 0, t.zeros_like(labels), labels)
+    labels = labels * nd.binary_opening(labels != 0, s).to(t.int32)
+    inside = markers_i > 0
+    labels = t.where(inside, markers_i, labels)
+    lengths, touches = nd.label_extent(labels, markers_i != 0)
+    return nd.remap_labels(labels, np.logical_and(lengths > min_length, touches))
+
+
 def get_watershed_mask(field, erode_distance: int = 1):
     """Background seed: field <= 0 (or NaN), eroded by `erode_distance` in (t, y, x), NaNs kept
     (reference: detection.py:590-617)."""
+    t = _lib.torch()
+    if isinstance(field, t.Tensor):
+        from tobac_flow_amd import ndimage_dev as nd
+        nan = t.isnan(field)
+        mask = nd.binary_erosion((field <= 0) | nan, np.ones([3, 3, 3]), iterations=erode_distance, border_value=1)
+        return mask | nan
     nan = np.isnan(field)
     mask = ndi.binary_erosion(np.logical_or(field <= 0, nan), structure=np.ones([3, 3, 3]),
                               iterations=erode_distance, border_value=1)

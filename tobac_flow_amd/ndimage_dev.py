@@ -1,0 +1,85 @@
+"""Device-resident versions of the scipy.ndimage / numpy glue the detection recipes use (SURVEY.md
+section 8f-2).  Every function takes and returns torch tensors on the GPU and is bit-exact with the SciPy /
+numpy call it replaces (tests/test_gpu_detection.py); the numpy paths of detection.py keep using SciPy."""
+import numpy as np
+
+from tobac_flow_amd import _lib
+
+
+def _structure27(structure):
+    s = np.asarray(structure) != 0
+    if s.shape != (3, 3, 3):
+        raise ValueError("structure must be a (3, 3, 3) array")
+    return np.ascontiguousarray(s, np.uint8)
+
+
+def _binary(t_in, structure, op, iterations, border_value):
+    t = _lib.torch()
+    L = _lib.lib()
+    x = (t_in != 0).to(t.uint8).contiguous()
+    T, H, W = x.shape
+    out = t.empty_like(x)
+    tmp = t.empty_like(x) if iterations > 1 else None
+    st = _structure27(structure)
+    _lib.check(L.tf_binary_morph(_lib.ptr(x), T, H, W, st.ctypes.data_as(_lib._P), op, int(iterations), int(bool(border_value)),
+                                 _lib.ptr(out), _lib.ptr(tmp), _lib.stream_ptr()), "tf_binary_morph")
+    return out.to(t.bool)
+
+
+def binary_erosion(x, structure, iterations=1, border_value=0):
+    """scipy.ndimage.binary_erosion(x, structure=structure, iterations=iterations, border_value=border_value)"""
+    return _binary(x, structure, 0, iterations, border_value)
+
+
+def binary_dilation(x, structure, iterations=1, border_value=0):
+    return _binary(x, structure, 1, iterations, border_value)
+
+
+def binary_opening(x, structure, iterations=1):
+    """scipy.ndimage.binary_opening: erosion then dilation, border_value 0"""
+    return binary_dilation(binary_erosion(x, structure, iterations), structure, iterations)
+
+
+def linearise_field(field, lower_threshold, upper_threshold):
+    """utils.normalisation_utils.linearise_field on a float32 device tensor"""
+    t = _lib.torch()
+    if lower_threshold == upper_threshold:
+        raise ValueError("lower and upper thresholds must have different values")
+    f = field.to(t.float32).contiguous()
+    out = t.empty_like(f)
+    _lib.check(_lib.lib().tf_linearise(_lib.ptr(f), f.numel(), float(lower_threshold), float(upper_threshold),
+                                       _lib.ptr(out), _lib.stream_ptr()), "tf_linearise")
+    return out
+
+
+def label_extent(labels, mask=None):
+    """(lengths, hit): for labels 1..max the extent along the leading axis (analysis.find_object_lengths) and whether
+    the label overlaps `mask` (analysis.mask_labels); numpy arrays of length max label."""
+    t = _lib.torch()
+    lab = labels.to(t.int32).contiguous()
+    T, H, W = lab.shape
+    n = int(lab.max().item()) if lab.numel() else 0
+    n = max(n, 0)
+    tmin = t.empty(n + 1, dtype=t.int32, device=lab.device)
+    tmax = t.empty(n + 1, dtype=t.int32, device=lab.device)
+    hit = t.empty(n + 1, dtype=t.uint8, device=lab.device)
+    m = None if mask is None else (mask != 0).to(t.uint8).contiguous()
+    _lib.check(_lib.lib().tf_label_extent(_lib.ptr(lab), _lib.ptr(m), T, H, W, n, _lib.ptr(tmin), _lib.ptr(tmax),
+                                          _lib.ptr(hit), _lib.stream_ptr()), "tf_label_extent")
+    tmin, tmax = tmin[1:].cpu().numpy().astype(np.int64), tmax[1:].cpu().numpy().astype(np.int64)
+    lengths = np.where(tmax >= 0, tmax - tmin + 1, 0)
+    return lengths, hit[1:].cpu().numpy().astype(bool)
+
+
+def remap_labels(labels, locations):
+    """utils.label_utils.remap_labels(labels, locations) for a boolean `locations` of length max label"""
+    t = _lib.torch()
+    lab = labels.to(t.int32).contiguous()
+    locations = np.asarray(locations, bool)
+    lut = np.zeros(locations.size + 1, np.int32)
+    lut[1:][locations] = np.arange(1, int(locations.sum()) + 1)
+    lut_t = t.from_numpy(lut).to(lab.device)
+    out = t.empty_like(lab)
+    _lib.check(_lib.lib().tf_apply_lut(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut.size, _lib.ptr(out), _lib.stream_ptr()),
+               "tf_apply_lut")
+    return out
