@@ -183,6 +183,13 @@ int tf_linearise(const float *field, int64_t n, double lower, double upper, floa
 int tf_label_extent(const int32_t *labels, const uint8_t *mask, int64_t T, int64_t H, int64_t W, int n_labels,
                     int *tmin, int *tmax, uint8_t *hit, void *stream);
 int tf_apply_lut(const int32_t *labels, int64_t n, const int32_t *lut, int n_lut, int32_t *out, void *stream);
+/* tf_label: scipy.ndimage.label(input, structure) for a (T, H, W) uint8 volume and a centro-symmetric 3x3x3
+ *   structuring element -- used as tobac_flow/utils/label_utils.py:143-180 flat_label (time planes of the structure
+ *   zeroed) and for 3-D labelling.  Component numbers follow SciPy (raster order of each component's first pixel).
+ *   n_labels_host receives the component count; the call synchronises the stream. */
+size_t tf_label_workspace_bytes(int64_t T, int64_t H, int64_t W);
+int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
+             int32_t *labels, int *n_labels_host, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- measurement aid (bench.py's roofline figure) ---------------------------------------------
  * tf_profile_enable(1): every kernel launch of the library is bracketed by HIP events on its own

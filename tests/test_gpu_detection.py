@@ -178,3 +178,43 @@ def test_detect_anvils_device_path_equals_numpy_path(scene):
     want = detect_anvils(scene["flow"], wvd, upper_threshold=-5, lower_threshold=-15, min_length=1)
     got = detect_anvils(scene["flow"], torch.from_numpy(wvd).cuda(), upper_threshold=-5, lower_threshold=-15, min_length=1)
     assert isinstance(got, torch.Tensor) and np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("conn", [1, 2, 3])
+def test_label_matches_scipy(conn):
+    import torch
+    from tobac_flow_amd import ndimage_dev as nd
+    rng = np.random.default_rng(conn)
+    for shape, thr in (((4, 33, 47), 0.0), ((1, 64, 64), 0.3), ((6, 20, 130), -0.2), ((2, 1, 1), -9.0)):
+        x = ndi.gaussian_filter(rng.normal(size=shape), (0.4, 1.2, 1.2)) > thr
+        st = ndi.generate_binary_structure(3, conn)
+        want, n = ndi.label(x, structure=st)
+        got, ng = nd.label(torch.from_numpy(x).cuda(), st)
+        assert ng == n and np.array_equal(got.cpu().numpy(), want)
+        flat = st.copy()
+        flat[0] = 0
+        flat[-1] = 0
+        want = ndi.label(x, structure=flat, output=np.int32)[0]
+        assert np.array_equal(nd.flat_label(torch.from_numpy(x).cuda(), st).cpu().numpy(), want)
+    snake = np.zeros((1, 40, 41), bool)           # long serpentine component: deep union-find chains
+    snake[0, ::2, :] = True
+    snake[0, 1::4, -1] = True
+    snake[0, 3::4, 0] = True
+    want, n = ndi.label(snake)
+    got, ng = nd.label(torch.from_numpy(snake).cuda())
+    assert ng == n == 1 and np.array_equal(got.cpu().numpy(), want)
+
+
+def test_anvil_pipeline_device_resident_equals_numpy(scene):
+    """get_anvil_markers -> detect_anvils(markers=...) entirely on the device == the numpy recipes"""
+    import torch
+    from tobac_flow_amd.detection import detect_anvils, get_anvil_markers
+    bt, flow = scene["bt"], scene["flow"]
+    wvd = ((250.0 - bt) / 2.0 - 10.0).astype(np.float32)
+    m_np = get_anvil_markers(flow, wvd, threshold=-5, overlap=0.5, absolute_overlap=5, min_length=1)
+    a_np = detect_anvils(flow, wvd, markers=m_np, upper_threshold=-5, lower_threshold=-15, min_length=1)
+    wd = torch.from_numpy(wvd).cuda()
+    m_dev = get_anvil_markers(flow, wd, threshold=-5, overlap=0.5, absolute_overlap=5, min_length=1)
+    a_dev = detect_anvils(flow, wd, markers=m_dev, upper_threshold=-5, lower_threshold=-15, min_length=1)
+    assert isinstance(m_dev, torch.Tensor) and np.array_equal(m_dev.cpu().numpy(), m_np)
+    assert np.array_equal(a_dev.cpu().numpy(), a_np) and a_np.max() >= 1

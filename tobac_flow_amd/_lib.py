@@ -51,6 +51,8 @@ _PROTOS = {
     "tf_linearise": (_c.c_int, [_P, _c.c_int64, _c.c_double, _c.c_double, _P, _P]),
     "tf_label_extent": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _P, _P, _P, _P]),
     "tf_apply_lut": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int, _P, _P]),
+    "tf_label_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64]),
+    "tf_label": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _c.c_size_t, _P]),
     "tf_profile_enable": (_c.c_int, [_c.c_int]),
     "tf_profile_kernel_count": (_c.c_int, []),
     "tf_profile_kernel_name": (_c.c_char_p, [_c.c_int]),

@@ -132,3 +132,124 @@ extern "C" int tf_apply_lut(const int32_t *labels, int64_t n, const int32_t *lut
     TF_CHECK_LAUNCH();
     return TF_OK;
 }
+
+// ---- connected-component labelling: scipy.ndimage.label(input, structure) ---------------------------------
+// Union-find on the GPU.  Roots are the smallest raster index of each component, so numbering components by
+// ascending root (an exclusive scan over the root flags) reproduces SciPy's numbering, which labels
+// components in the order their first pixel is met in a raster scan.  `structure` must be centro-symmetric
+// (SciPy requires that too); only the "forward" half of its offsets is needed for the unions.
+#include <hipcub/hipcub.hpp>
+
+__device__ __forceinline__ int ccl_find(int *__restrict__ parent, int p) {
+    int q = parent[p];
+    while (q != p) { p = q; q = parent[p]; }
+    return p;
+}
+
+__device__ __forceinline__ void ccl_union(int *__restrict__ parent, int a, int b) {
+    for (;;) {
+        a = ccl_find(parent, a); b = ccl_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }        // a > b: attach the larger root to the smaller
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;                                             // somebody else re-rooted a meanwhile: retry from there
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_init(const uint8_t *__restrict__ in, int64_t n, int *__restrict__ parent) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = in[i] ? (int)i : -1;
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_union(const uint8_t *__restrict__ in, int64_t T, int H, int W, MorphTaps tp, int *__restrict__ parent)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const int64_t plane = (int64_t)H * W, p = t * plane + (int64_t)y * W + x;
+    if (!in[p]) return;
+    for (int i = 0; i < tp.n; i++) {
+        const int64_t tt = t + tp.dt[i];
+        const int yy = y + tp.dy[i], xx = x + tp.dx[i];
+        if (tt < 0 || tt >= T || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const int64_t q = tt * plane + (int64_t)yy * W + xx;
+        if (in[q]) ccl_union(parent, (int)p, (int)q);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_flatten(int64_t n, int *__restrict__ parent, uint8_t *__restrict__ isroot) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = parent[i];
+    if (p < 0) { isroot[i] = 0; return; }
+    const int r = ccl_find(parent, (int)i);
+    parent[i] = r;
+    isroot[i] = r == (int)i;
+}
+
+__global__ void __launch_bounds__(256)
+k_ccl_number(int64_t n, const int *__restrict__ parent, const int *__restrict__ rank, int32_t *__restrict__ labels) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = parent[i];
+    labels[i] = r < 0 ? 0 : rank[r] + 1;
+}
+
+struct CclU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
+typedef hipcub::TransformInputIterator<int, CclU8ToInt, const uint8_t *> CclFlagIter;
+
+extern "C" size_t tf_label_workspace_bytes(int64_t T, int64_t H, int64_t W)
+{
+    if (T <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t n = T * H * W;
+    size_t scan = 0;
+    CclFlagIter it((const uint8_t *)nullptr, CclU8ToInt());
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, it, (int *)nullptr, (int)(n > 0x7fffffff ? 0x7fffffff : n));
+    return tf_align_up((size_t)n * 4, 256) * 2 + tf_align_up((size_t)n, 256) + tf_align_up(scan, 256) + 4096;
+}
+
+// labels: int32 (T, H, W) out; n_labels_host: number of components.  Synchronises the stream.
+extern "C" int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
+                        int32_t *labels, int *n_labels_host, void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(in && labels && structure_host && ws, "tf_label: null pointer");
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && T < 65536 && H < (1 << 15) && W < (1 << 15), "tf_label: bad shape");
+    const int64_t n = T * H * W;
+    TF_REQUIRE(n < 0x7fffffffll, "tf_label: volume too large for 32-bit parents (use time windows)");
+    if (ws_bytes < tf_label_workspace_bytes(T, H, W)) { tf_set_error("tf_label: workspace too small"); return TF_ENOMEM; }
+    MorphTaps tp; tp.n = 0;
+    for (int p = 0; p < 3; p++) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+        const int i = p * 9 + r * 3 + c;
+        TF_REQUIRE((structure_host[i] != 0) == (structure_host[26 - i] != 0), "tf_label: structuring element must be symmetric");
+        if (structure_host[i] && i > 13) { tp.dt[tp.n] = (int8_t)(p - 1); tp.dy[tp.n] = (int8_t)(r - 1); tp.dx[tp.n] = (int8_t)(c - 1); tp.n++; }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    TfArena ar(ws, ws_bytes);
+    int *parent = ar.take<int>(n), *rank = ar.take<int>(n);
+    uint8_t *isroot = ar.take<uint8_t>(n);
+    size_t scan_bytes = 0;
+    CclFlagIter it0((const uint8_t *)nullptr, CclU8ToInt());
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, it0, (int *)nullptr, (int)n);
+    char *scan_tmp = ar.take<char>(scan_bytes ? scan_bytes : 1);
+    if (!ar.ok()) { tf_set_error("tf_label: workspace too small"); return TF_ENOMEM; }
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    dim3 block(64, 4), grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
+    hipLaunchKernelGGL(k_ccl_init, dim3(nb), dim3(256), 0, s, in, n, parent);
+    if (tp.n) hipLaunchKernelGGL(k_ccl_union, grid, block, 0, s, in, T, (int)H, (int)W, tp, parent);
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(nb), dim3(256), 0, s, n, parent, isroot);
+    TF_CHECK_LAUNCH();
+    CclFlagIter it(isroot, CclU8ToInt());
+    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, it, rank, (int)n, s));
+    hipLaunchKernelGGL(k_ccl_number, dim3(nb), dim3(256), 0, s, n, parent, rank, labels);
+    TF_CHECK_LAUNCH();
+    int last_rank = 0; uint8_t last_root = 0;
+    TF_CHECK_HIP(hipMemcpyAsync(&last_rank, rank + n - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipMemcpyAsync(&last_root, isroot + n - 1, 1, hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    if (n_labels_host) *n_labels_host = last_rank + last_root;
+    return TF_OK;
+}

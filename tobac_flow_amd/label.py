@@ -38,7 +38,7 @@ def _overlap_edges(flat, warped, sizes, overlap, absolute_overlap):
     return ea[ok].cpu().numpy(), eb[ok].cpu().numpy()
 
 
-def _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, present_mask):
+def _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, present_mask, on_device=False):
     t = _lib.torch()
     label_struct = structure * np.array([1, 0, 1])[:, np.newaxis, np.newaxis]
     flat_dev = _lib.to_dev(flat_labels, t.int32)
@@ -76,6 +76,10 @@ def _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, presen
     group_of[sizes_np == 0] = 0          # labels without pixels are never written (label.py:166-170)
     lut = t.from_numpy(group_of.astype(np.int64)).to(flat_dev.device)
     new_dev = lut[flat_dev.to(t.int64)]
+    if on_device:
+        if not bool(((new_dev != 0) == present_mask).all()):
+            warnings.warn("Not all regions present in labeled array", RuntimeWarning)
+        return new_dev.to(t.int32)
     new_labels = new_dev.cpu().numpy().astype(dtype)
     if not np.all((new_labels != 0) == present_mask):
         warnings.warn("Not all regions present in labeled array", RuntimeWarning)
@@ -85,12 +89,18 @@ def _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, presen
 def flow_label(flow, mask, structure=ndi.generate_binary_structure(3, 1), dtype=np.int32, overlap: float = 0.0,
                absolute_overlap: int = 0, subsegment_shrink: float = 0.0, peak_min_distance: int = 10):
     """Label 3-D connected objects in a semi-Lagrangian frame (reference: label.py:84-175)."""
-    mask = np.asarray(mask)
     if subsegment_shrink != 0:
         raise NotImplementedError("subsegment_shrink != 0 (label.py:13-80, scikit-image watershed) is outside the "
                                   "MI355X hot path; production uses subsegment_shrink=0")
-    flat_labels = flat_label(mask != 0, structure=structure).astype(dtype)
-    return _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, mask != 0)
+    t = _lib.torch()
+    from tobac_flow_amd import ndimage_dev as nd
+    on_device = isinstance(mask, t.Tensor)
+    m = _lib.to_dev(mask) != 0
+    # per-frame connected components on the GPU (tf_label: SciPy's numbering, tests/test_gpu_detection.py)
+    flat_labels = nd.flat_label(m, structure)
+    if on_device:
+        return _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, m, on_device=True)
+    return _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, np.asarray(mask) != 0)
 
 
 def find_neighbour_labels(label, label_stack, bins, args, processed_labels, forward_labels, back_labels,

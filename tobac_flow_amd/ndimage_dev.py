@@ -83,3 +83,30 @@ def remap_labels(labels, locations):
     _lib.check(_lib.lib().tf_apply_lut(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut.size, _lib.ptr(out), _lib.stream_ptr()),
                "tf_apply_lut")
     return out
+
+
+def label(x, structure=None):
+    """scipy.ndimage.label(x, structure) -> (int32 labels tensor, n_labels).  `structure`: (3, 3, 3), symmetric;
+    default = ndi.generate_binary_structure(3, 1)."""
+    import ctypes
+    import scipy.ndimage as ndi
+    t = _lib.torch()
+    L = _lib.lib()
+    xb = (x != 0).to(t.uint8).contiguous()
+    T, H, W = xb.shape
+    st = _structure27(ndi.generate_binary_structure(3, 1) if structure is None else structure)
+    out = t.empty((T, H, W), dtype=t.int32, device=xb.device)
+    ws = _lib.workspace(L.tf_label_workspace_bytes(T, H, W), "label")
+    n = ctypes.c_int(0)
+    _lib.check(L.tf_label(_lib.ptr(xb), T, H, W, st.ctypes.data_as(_lib._P), _lib.ptr(out), ctypes.byref(n),
+                          _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "tf_label")
+    return out, n.value
+
+
+def flat_label(mask, structure=None):
+    """utils.label_utils.flat_label: components that never connect across the leading (time) axis"""
+    import scipy.ndimage as ndi
+    s = np.array(ndi.generate_binary_structure(3, 1) if structure is None else structure, bool).copy()
+    s[0] = 0
+    s[-1] = 0
+    return label(mask, s)[0]
