@@ -351,13 +351,17 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 }
 
 // ---- fused iteration: UpdateMatrices -> 13x13 box sums (double) -> 2x2 solve -----------------------
-// One launch = one Farnebaeck iteration of BOTH directions (blockIdx.z).  A 256-thread workgroup owns
-// a strip of FBI_OW = 244 output columns (+ 6 halo columns each side) and FBI_HS rows.  Thread j walks
-// DOWN its column: at every row it evaluates M = UpdateMatrices(R0, R1, flow_old) in registers, keeps
-// the last 13 rows of M in a register ring and the running 13-row column sums in double; the five
-// column sums go to an LDS row (double buffered, one barrier per row), from which the 244 interior
-// threads add 13 neighbours, solve the 2x2 system and write flow_new.  The 5-plane matrix M never
-// exists in HBM: per level pixel the kernel moves R0 (20 B) + R1 (20 B) + flow in (8 B) + flow out (8 B).
+// One launch = one Farnebaeck iteration of BOTH directions for a batch of frame pairs.  A 256-thread
+// workgroup owns a strip of FBI_OW = 244 output columns (+ 6 halo columns each side) and `hs` rows.
+// Thread j walks DOWN its column: at every row it evaluates M = UpdateMatrices(R0, R1, flow_old) in
+// registers, keeps the last 13 rows of M in a register ring and the running 13-row column sums in
+// double; the five column sums go to an LDS row, from which the 244 interior threads add 13 neighbours,
+// solve the 2x2 system and write flow_new.  The 5-plane matrix M never exists in HBM: per level pixel
+// the kernel moves R0 (20 B) + R1 (20 B) + flow in (8 B) + flow out (8 B).
+// The per-row evaluation is BRANCH-FREE (out-of-image gathers read a valid dummy address and are
+// discarded by selects) so that the loads of two rows are in flight together, and the flow of the next
+// row group is fetched before the LDS phase of the current one: the kernel is bound by memory latency
+// at 3 waves / SIMD, not by bytes.
 #define FBI_M 6
 #define FBI_WIN (2 * FBI_M + 1)
 #define FBI_OW (256 - 2 * FBI_M)
@@ -368,81 +372,218 @@ struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int 
 
 struct FbIterCtx {
     const float *R0, *R1, *fin; float *fout;
-    int H, W; int64_t plane; int j, xo, xc, y0, s_end; bool writer;
+    int H, W; int64_t plane; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale;
 };
 
-// one group of G consecutive window rows with STATIC ring slots K0 .. K0+G-1:
-//   1. evaluate M for the G rows (all loads of the group in flight together),
-//   2. slide the 13-row column sums, park the sums of completed windows in LDS,
-//   3. one barrier, then 13-neighbour row sums + 2x2 solve + store for up to G output rows.
-template <int K0, int G, int ABL>
-__device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int base, float (&ring)[FBI_WIN][5], double (&S)[5],
-                                              double (*vrow)[5][256])
+struct FbTaps { float4 q0, c00, c01, c10, c11; float2 e0, e1; float q04, dx, dy; };
+
+__device__ __forceinline__ float2 fb_iter_flow_at(const FbIterCtx &c, int s)
 {
-    float nm[G][5];
+    return ((const float2 *)c.fin)[(int64_t)tf_clampi(s, 0, c.H - 1) * c.W + c.xc];
+}
+
+// issue every load of one M evaluation (same arithmetic as fb_matrix_at, branch-free)
+__device__ __forceinline__ void fb_taps_load(const FbIterCtx &c, int s, float2 fl, FbTaps &t)
+{
+    const int y = tf_clampi(s, 0, c.H - 1);
+    const int64_t o = (int64_t)y * c.W + c.xc;
+    t.dx = fl.x; t.dy = fl.y;
+    const float fx = c.xc + t.dx, fy = y + t.dy;
+    const int x1 = tf_cvfloor(fx), y1 = tf_cvfloor(fy);
+    const bool inb = (unsigned)x1 < (unsigned)(c.W - 1) && (unsigned)y1 < (unsigned)(c.H - 1);
+    const int64_t q = inb ? (int64_t)y1 * c.W + x1 : 0;
+    const int sx = inb ? 1 : 0, sy = inb ? c.W : 0;                   // dummy taps all read element 0
+    const float4 *P4 = (const float4 *)c.R1 + q;
+    const float *P1 = c.R1 + 4 * c.plane + q;
+    t.q0 = ((const float4 *)c.R0)[o];
+    t.q04 = c.R0[4 * c.plane + o];
+    t.c00 = P4[0]; t.c01 = P4[sx]; t.c10 = P4[sy]; t.c11 = P4[sy + sx];
+    t.e0.x = P1[0]; t.e0.y = P1[sx]; t.e1.x = P1[sy]; t.e1.y = P1[sy + sx];
+}
+
+__device__ __forceinline__ void fb_taps_eval(const FbIterCtx &c, int s, const FbTaps &t, float (&m)[5])
+{
+    // the (cheap) coordinate arithmetic is redone here instead of being carried in registers while loads fly
+    const int y = tf_clampi(s, 0, c.H - 1);
+    const float dx = t.dx, dy = t.dy;
+    float fx = c.xc + dx, fy = y + dy;
+    const int x1 = tf_cvfloor(fx), y1 = tf_cvfloor(fy);
+    fx -= x1; fy -= y1;
+    const bool inb = (unsigned)x1 < (unsigned)(c.W - 1) && (unsigned)y1 < (unsigned)(c.H - 1);
+    const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+    float r2 = a00 * t.c00.x + a01 * t.c01.x + a10 * t.c10.x + a11 * t.c11.x;
+    float r3 = a00 * t.c00.y + a01 * t.c01.y + a10 * t.c10.y + a11 * t.c11.y;
+    float r4 = a00 * t.c00.z + a01 * t.c01.z + a10 * t.c10.z + a11 * t.c11.z;
+    float r5 = a00 * t.c00.w + a01 * t.c01.w + a10 * t.c10.w + a11 * t.c11.w;
+    float r6 = a00 * t.e0.x + a01 * t.e0.y + a10 * t.e1.x + a11 * t.e1.y;
+    r4 = (t.q0.z + r4) * 0.5f;
+    r5 = (t.q0.w + r5) * 0.5f;
+    r6 = (t.q04 + r6) * 0.25f;
+    r2 = inb ? r2 : 0.f; r3 = inb ? r3 : 0.f;
+    r4 = inb ? r4 : t.q0.z; r5 = inb ? r5 : t.q0.w; r6 = inb ? r6 : t.q04 * 0.5f;
+    r2 = (t.q0.x - r2) * 0.5f;
+    r3 = (t.q0.y - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    // border attenuation: (x factor, fixed per thread) * y factors (uniform), == 1 in the interior
+    const float b0 = y == 0 ? 0.14f : (y == 1 ? 0.14f : 0.4472f), yb = c.H - 1 - y;
+    const float b1 = yb == 0 ? 0.14f : (yb == 1 ? 0.14f : 0.4472f);
+    const float scale = c.xscale * (y < 5 ? b0 : 1.f) * (yb < 5 ? b1 : 1.f);
+    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    m[0] = r4 * r4 + r6 * r6;
+    m[1] = (r4 + r5) * r6;
+    m[2] = r5 * r5 + r6 * r6;
+    m[3] = r4 * r2 + r6 * r3;
+    m[4] = r6 * r2 + r5 * r3;
+}
+
+// LDS row of column sums: column i lives at i + i/4 (one pad per four) so that both access patterns are
+// conflict-free: the vertical phase writes consecutive i, the horizontal phase reads i = 4 q + k (stride 5).
+#define FBI_VS 320
+#define FBI_Q (FBI_OW / 4)          // 61 quads of 4 outputs per strip row
+
+// horizontal phase for one (row g, quad q): 16 column sums per channel -> four 13-wide window sums ->
+// four 2x2 solves.  The four windows share the ten middle terms.
+__device__ __forceinline__ void fb_iter_quad(const FbIterCtx &c, int yo, int g, int q, const double *vrow)
+{
+    const int x0 = c.x_strip + 4 * q;
+    if (yo < c.y0 || yo >= c.y1 || x0 >= c.W) return;
+    const double *base = vrow + (g * 5) * FBI_VS + 5 * q;
+    double sum[5][4];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        const int s = base + K0 + g;
-        if (s <= c.s_end) {
-            if (ABL == 1) { nm[g][0] = (float)s; nm[g][1] = (float)c.xc; nm[g][2] = 1.f; nm[g][3] = 2.f; nm[g][4] = (float)(s + c.xc); }
-            else fb_matrix_at(c.R0, c.R1, c.fin, c.H, c.W, c.plane, c.xc, tf_clampi(s, 0, c.H - 1),
-                              nm[g][0], nm[g][1], nm[g][2], nm[g][3], nm[g][4]);
-        }
+    for (int ch = 0; ch < 5; ch++) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = base[ch * FBI_VS + k + (k >> 2)];
+        // balanced tree over the ten shared terms (short dependency chains: two waves per SIMD do not hide a serial sum)
+        const double T = (((v[3] + v[4]) + (v[5] + v[6])) + ((v[7] + v[8]) + (v[9] + v[10]))) + (v[11] + v[12]);
+        const double lo = v[1] + v[2], hi = v[13] + v[14];
+        sum[ch][0] = v[0] + lo + T;
+        sum[ch][1] = lo + T + v[13];
+        sum[ch][2] = v[2] + T + hi;
+        sum[ch][3] = T + hi + v[15];
     }
+    float2 *out = (float2 *)c.fout + (int64_t)yo * c.W + x0;
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        const int s = base + K0 + g;
-        if (s <= c.s_end) {
+    for (int u = 0; u < 4; u++) {
+        const double g11 = sum[0][u], g12 = sum[1][u], g22 = sum[2][u], h1 = sum[3][u], h2 = sum[4][u];
+        // flow = (G h)/(det G + 1e-3) with G, h the window MEANS: evaluated on the window SUMS with the
+        // regulariser scaled by 169^2 instead (saves five multiplies); hardware reciprocal + one Newton step
+        const double det = g11 * g22 - g12 * g12 + 1e-3 * (double)(FBI_WIN * FBI_WIN) * (double)(FBI_WIN * FBI_WIN);
+        double idet = __builtin_amdgcn_rcp(det);
+        idet = idet * (2.0 - det * idet);
+        float2 f;
+        f.x = (float)((g11 * h2 - g12 * h1) * idet);
+        f.y = (float)((g22 * h1 - g12 * h2) * idet);
+        if (x0 + u < c.W) out[u] = f;
+    }
+}
+
+// non-pipelined variant: NB rows at a time, flows of the next group fetched before the barrier
+template <int K0, int G, int GN, int NB, int ABL>
+__device__ __forceinline__ void fb_iter_group_np(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
+                                                 float2 (&fl)[FBI_G], double *vrow)
+{
 #pragma unroll
-            for (int ch = 0; ch < 5; ch++) { S[ch] += (double)(nm[g][ch] - ring[K0 + g][ch]); ring[K0 + g][ch] = nm[g][ch]; }
-            if (s - FBI_M >= c.y0) {
-                if (ABL == 3) {
-                    if (c.writer) {
-                        const double det = S[0] * S[2] - S[1] * S[1] + 28.561;
-                        double idet = __builtin_amdgcn_rcp(det);
-                        float2 f; f.x = (float)((S[0] * S[4] - S[1] * S[3]) * idet); f.y = (float)((S[2] * S[3] - S[1] * S[4]) * idet);
-                        ((float2 *)c.fout)[(int64_t)(s - FBI_M) * c.W + c.xo] = f;
-                    }
-                } else {
+    for (int g0 = 0; g0 < G; g0 += NB) {
+        FbTaps t[NB];
+        float m[NB][5];
 #pragma unroll
-                for (int ch = 0; ch < 5; ch++) vrow[g][ch][c.j] = S[ch];
+        for (int r = 0; r < NB; r++)
+            if (g0 + r < G && ABL != 1) fb_taps_load(c, s0 + g0 + r, fl[g0 + r], t[r]);
+#pragma unroll
+        for (int r = 0; r < NB; r++)
+            if (g0 + r < G) {
+                const int g = g0 + r, s = s0 + g;
+                if (ABL == 1) { m[r][0] = (float)s; m[r][1] = (float)c.xc; m[r][2] = 1.f; m[r][3] = 2.f; m[r][4] = (float)(s + c.xc); }
+                else if (ABL == 3) {
+                    const FbTaps &q = t[r];
+                    m[r][0] = q.q0.x + q.c00.x + q.c01.x + q.c10.x + q.c11.x; m[r][1] = q.q0.y + q.c00.y + q.c01.y + q.c10.y + q.c11.y;
+                    m[r][2] = q.q0.z + q.c00.z + q.c01.z + q.c10.z + q.c11.z; m[r][3] = q.q0.w + q.c00.w + q.c01.w + q.c10.w + q.c11.w;
+                    m[r][4] = q.q04 + q.e0.x + q.e0.y + q.e1.x + q.e1.y;
+                }
+                else fb_taps_eval(c, s, t[r], m[r]);
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    S[ch] += (double)(m[r][ch] - ring[K0 + g][ch]); ring[K0 + g][ch] = m[r][ch];
+                    vrow[(g * 5 + ch) * FBI_VS + c.dj] = S[ch];
                 }
             }
-        }
     }
-    if (ABL == 3) return;
+    if (ABL != 1) {
+#pragma unroll
+        for (int g = 0; g < GN; g++) fl[g] = fb_iter_flow_at(c, s0 + G + g);
+    }
     __syncthreads();
-    if (c.writer) {
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int s = base + K0 + g, yo = s - FBI_M;
-            if (s <= c.s_end && yo >= c.y0) {
-                double g11 = 0, g12 = 0, g22 = 0, h1 = 0, h2 = 0;
-#pragma unroll
-                for (int i = (ABL == 2 ? 0 : -FBI_M); i <= (ABL == 2 ? 0 : FBI_M); i++) {
-                    g11 += vrow[g][0][c.j + i]; g12 += vrow[g][1][c.j + i]; g22 += vrow[g][2][c.j + i];
-                    h1 += vrow[g][3][c.j + i]; h2 += vrow[g][4][c.j + i];
-                }
-                // flow = (G h)/(det G + 1e-3) with G, h the window MEANS: evaluated on the window SUMS with the
-                // regulariser scaled by 169^2 instead (saves five multiplies); hardware reciprocal + one Newton step
-                const double det = g11 * g22 - g12 * g12 + 1e-3 * (double)(FBI_WIN * FBI_WIN) * (double)(FBI_WIN * FBI_WIN);
-                double idet = __builtin_amdgcn_rcp(det);
-                idet = idet * (2.0 - det * idet);
-                float2 f;
-                f.x = (float)((g11 * h2 - g12 * h1) * idet);
-                f.y = (float)((g22 * h1 - g12 * h2) * idet);
-                ((float2 *)c.fout)[(int64_t)yo * c.W + c.xo] = f;
-            }
-        }
+    if (ABL == 2 || ABL == 3) {
+        // no horizontal phase: every thread stores its own column sums
+        const int yo = s0 + G - 1 - FBI_M, xo = c.x_strip + c.j - FBI_M;
+        if (yo >= c.y0 && yo < c.y1 && c.j >= FBI_M && c.j < 256 - FBI_M && xo < c.W)
+            ((float2 *)c.fout)[(int64_t)yo * c.W + xo] = make_float2((float)(S[0] + S[1] + S[2]), (float)(S[3] + S[4]));
+    } else {
+        if (c.j < G * FBI_Q) fb_iter_quad(c, s0 + c.tg - FBI_M, c.tg, c.tq, vrow);
+        if (G * FBI_Q > 256 && c.j < G * FBI_Q - 256) fb_iter_quad(c, s0 + 4 - FBI_M, 4, c.j + 256 - 4 * FBI_Q, vrow);
     }
     __syncthreads();
 }
 
-template <int ABL>
+// one group of G consecutive window rows s0 .. s0+G-1 with STATIC ring slots K0 .. K0+G-1, software
+// pipelined in batches of NB rows: the loads of batch i+1 are issued before batch i is evaluated, and the
+// first batch of the NEXT group is issued before this group's last batch is evaluated, so it is in flight
+// across the barriers and the horizontal phase.
+//   on entry : T[P] holds the taps of rows [0, NB) of this group, fl the flows of its rows;
+//   on exit  : T[P ^ (nbatch & 1)] holds the first batch of the next group, fl the next group's flows.
+template <int K0, int G, int GN, int NB, int P, int ABL>
+__device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
+                                              float2 (&fl)[FBI_G], FbTaps (&T)[2][NB], double *vrow)
+{
+    constexpr int nbatch = (G + NB - 1) / NB;
+    float2 fln[FBI_G];
+#pragma unroll
+    for (int bi = 0; bi < nbatch; bi++) {
+        const int cur = (P + bi) & 1, nxt = cur ^ 1;
+        if (ABL != 1) {
+            if (bi + 1 < nbatch) {
+#pragma unroll
+                for (int r = 0; r < NB; r++)
+                    if ((bi + 1) * NB + r < G) fb_taps_load(c, s0 + (bi + 1) * NB + r, fl[(bi + 1) * NB + r], T[nxt][r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < NB; r++) fb_taps_load(c, s0 + G + r, fln[r], T[nxt][r]);
+            }
+            if (bi == 0) {
+#pragma unroll
+                for (int g = 0; g < GN; g++) fln[g] = fb_iter_flow_at(c, s0 + G + g);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NB; r++)
+            if (bi * NB + r < G) {
+                const int g = bi * NB + r, s = s0 + g;
+                float m[5];
+                if (ABL != 1) fb_taps_eval(c, s, T[cur][r], m);
+                else { m[0] = (float)s; m[1] = (float)c.xc; m[2] = 1.f; m[3] = 2.f; m[4] = (float)(s + c.xc); }
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    S[ch] += (double)(m[ch] - ring[K0 + g][ch]); ring[K0 + g][ch] = m[ch];
+                    vrow[(g * 5 + ch) * FBI_VS + c.dj] = S[ch];
+                }
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < FBI_G; g++) fl[g] = fln[g];
+    __syncthreads();
+    if (c.j < G * FBI_Q) fb_iter_quad(c, s0 + c.tg - FBI_M, c.tg, c.tq, vrow);
+    if (G * FBI_Q > 256 && c.j < G * FBI_Q - 256) fb_iter_quad(c, s0 + 4 - FBI_M, 4, c.j + 256 - 4 * FBI_Q, vrow);
+    __syncthreads();
+}
+
+template <int NB, int PIPE, int ABL>
 __global__ void __launch_bounds__(256)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
 {
-    __shared__ double vrow[FBI_G][5][256];
+    static_assert(NB == 2 || !PIPE, "group sizes 4 + 4 + 5 are pipelined in batches of two rows");
+    __shared__ double vrow[FBI_G * 5 * FBI_VS];
     // Work-item order.  Both directions of one strip read the same two R images (each is the other's gather
     // target), so they are placed on the SAME XCD (block ids that differ by 8 share an XCD under the observed
     // round-robin dispatch; this is for L2 reuse only, never for correctness): within a group of 8*nd
@@ -460,20 +601,48 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
     c.fin = a.fin[q] + b * a.bs_fin[q]; c.fout = a.fout[q] + b * a.bs_fout[q];
     c.H = H; c.W = W; c.plane = plane;
     c.j = threadIdx.x;
-    c.xo = sx * FBI_OW + c.j - FBI_M;                         // column this thread evaluates M for
-    c.xc = tf_clampi(c.xo, 0, W - 1);                                 // replicate border
+    c.dj = c.j + (c.j >> 2);
+    c.tg = c.j / FBI_Q; c.tq = c.j - c.tg * FBI_Q;
+    c.x_strip = sx * FBI_OW;
+    c.xc = tf_clampi(c.x_strip + c.j - FBI_M, 0, W - 1);              // column this thread evaluates M for (replicate border)
     c.y0 = blockIdx.y * hs;
-    const int y1 = min(c.y0 + hs, H);                             // output rows [y0, y1)
-    c.writer = c.j >= FBI_M && c.j < 256 - FBI_M && c.xo < W;
-    c.s_end = y1 - 1 + FBI_M;                                         // last window row (inclusive)
+    c.y1 = min(c.y0 + hs, H);                                         // output rows [y0, y1)
+    {
+        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        const int xb = W - 1 - c.xc;
+        float lo = 1.f, hi = 1.f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { lo = c.xc == k ? border[k] : lo; hi = xb == k ? border[k] : hi; }
+        c.xscale = lo * hi;
+    }
     float ring[FBI_WIN][5];
 #pragma unroll
     for (int k = 0; k < FBI_WIN; k++) { ring[k][0] = ring[k][1] = ring[k][2] = ring[k][3] = ring[k][4] = 0.f; }
     double S[5] = {0, 0, 0, 0, 0};
-    for (int base = c.y0 - FBI_M; base <= c.s_end; base += FBI_WIN) {
-        fb_iter_group<0, 4, ABL>(c, base, ring, S, vrow);
-        fb_iter_group<4, 4, ABL>(c, base, ring, S, vrow);
-        fb_iter_group<8, 5, ABL>(c, base, ring, S, vrow);
+    float2 fl[FBI_G];
+    const int s_first = c.y0 - FBI_M, s_last = c.y1 - 1 + FBI_M;       // window rows needed (inclusive)
+#pragma unroll
+    for (int g = 0; g < FBI_G; g++) fl[g] = (ABL != 1) ? fb_iter_flow_at(c, s_first + g) : make_float2(0.f, 0.f);
+    if (!PIPE) {
+        for (int base = s_first; base <= s_last; base += FBI_WIN) {
+            fb_iter_group_np<0, 4, 4, NB, ABL>(c, base, ring, S, fl, vrow);
+            fb_iter_group_np<4, 4, 5, NB, ABL>(c, base + 4, ring, S, fl, vrow);
+            fb_iter_group_np<8, 5, 4, NB, ABL>(c, base + 8, ring, S, fl, vrow);
+        }
+        return;
+    }
+    FbTaps T[2][NB];
+    if (ABL != 1) {
+#pragma unroll
+        for (int r = 0; r < NB; r++) fb_taps_load(c, s_first + r, fl[r], T[0][r]);
+    }
+    // rows past s_last are evaluated (clamped, harmless) but never produce output
+    for (int base = s_first; base <= s_last; base += FBI_WIN) {
+        fb_iter_group<0, 4, 4, NB, 0, ABL>(c, base, ring, S, fl, T, vrow);          // 2 batches: parity kept
+        fb_iter_group<4, 4, 5, NB, 0, ABL>(c, base + 4, ring, S, fl, T, vrow);
+        fb_iter_group<8, 5, 4, NB, 0, ABL>(c, base + 8, ring, S, fl, T, vrow);      // 3 batches: next batch in T[1]
+#pragma unroll
+        for (int r = 0; r < NB; r++) T[0][r] = T[1][r];
     }
 }
 
@@ -719,7 +888,8 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
         TF_CHECK_LAUNCH();
         if (fused) {
             // strip height: tall strips amortise the 12-row halo, short ones keep all CUs busy on coarse levels
-            int hs = FBI_HS;
+            static const int hs_max = getenv("TF_FBI_HS") ? atoi(getenv("TF_FBI_HS")) : FBI_HS;
+            int hs = hs_max;
             while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd * B < 1536) hs >>= 1;
             const int nx = (w + FBI_OW - 1) / FBI_OW;
             const dim3 gi(((nx + 7) / 8) * 8 * nd, (h + hs - 1) / hs, B);
@@ -735,10 +905,14 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 {
                     TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd * B, s);
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
-                    if (abl == 1) hipLaunchKernelGGL(k_fb_iter<1>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else if (abl == 2) hipLaunchKernelGGL(k_fb_iter<2>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else if (abl == 3) hipLaunchKernelGGL(k_fb_iter<3>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else hipLaunchKernelGGL(k_fb_iter<0>, gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    static const int nb = getenv("TF_FBI_NB") ? atoi(getenv("TF_FBI_NB")) : 4;
+                    static const int pipe = getenv("TF_FBI_PIPE") ? atoi(getenv("TF_FBI_PIPE")) : 0;
+                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<4, 0, 1>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<4, 0, 2>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else if (abl == 3) hipLaunchKernelGGL((k_fb_iter<4, 0, 3>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else if (pipe) hipLaunchKernelGGL((k_fb_iter<2, 1, 0>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else if (nb == 2) hipLaunchKernelGGL((k_fb_iter<2, 0, 0>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else hipLaunchKernelGGL((k_fb_iter<4, 0, 0>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
                 }
                 for (int q = 0; q < nd; q++) cur[dirs[q]] = 1 - cur[dirs[q]];
             }
