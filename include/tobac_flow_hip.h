@@ -166,6 +166,17 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
                  const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                  const int8_t *nbr_host, int n_nbr, int chain_depth, int32_t *labels,
                  void *ws, size_t ws_bytes, int64_t *stats_host, void *stream);
+/* tf_watershed_ex = tf_watershed + `flags`.
+ * TF_WS_SKIP_FAST_PATH: after phase A go straight to the chain phases instead of first trying the
+ *   K2-only root phase + conflict test.  The labels are IDENTICAL either way (the fast path is only
+ *   taken when no tie-break can matter); the flag is a scheduling hint for inputs known to contain
+ *   label conflicts (exact plateaus, as in detect_anvils), where the speculative root phase is wasted
+ *   work.  With the flag stats_host[1] = 0 and stats_host[5] = -1 (conflict test not evaluated). */
+#define TF_WS_SKIP_FAST_PATH 1
+int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
+                    const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                    const int8_t *nbr_host, int n_nbr, int chain_depth, int flags, int32_t *labels,
+                    void *ws, size_t ws_bytes, int64_t *stats_host, void *stream);
 
 /* ---- section 8f-2: scipy.ndimage glue of the detection recipes (bit-exact with SciPy) ---------------------
  * tf_binary_morph: scipy.ndimage.binary_erosion (op 0) / binary_dilation (op 1) of a (T, H, W) uint8 volume with a

@@ -287,6 +287,75 @@ def test_watershed_random_vs_oracle(tf, seed):
     assert np.array_equal(got, want), f"{int((got != want).sum())} px differ"
 
 
+def _ws_both_paths(c_fwd, c_bwd, field, markers, mask, conn, depth):
+    """Run the HIP flood with the speculative root phase (probe) and without it (TF_WS_SKIP_FAST_PATH)."""
+    import torch
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    fw, bw = _lib.to_dev(c_fwd, torch.float32), _lib.to_dev(c_bwd, torch.float32)
+    f, m = _lib.to_dev(field, torch.float32), _lib.to_dev(markers, torch.int32)
+    k = None if mask is None else _lib.to_dev(mask).to(torch.int8)
+    nbr = neighbour_offsets(conn, 3)
+    out = []
+    for skip in (False, True):
+        st = {}
+        lab = watershed_dev(fw, bw, f, m, k, nbr, depth, st, expect_conflict=skip).cpu().numpy()
+        out.append((lab, st["sweeps"]))
+    return out
+
+
+GOLDEN_DEPTH = {"C_quant32_c1": 6}
+
+
+@pytest.mark.parametrize("name", EXACT_VS_REFERENCE + ["C_quant4_c1", "C_quant32_c1", "E_const_plateau_c1"])
+def test_watershed_skip_fast_path_gives_identical_labels_golden(tf, golden_ws, name):
+    """The scheduling hint must never change a label: chain phases alone == root-phase fast path
+    (when it is accepted) == fast path + chain phases (when it is rejected)."""
+    c = golden_ws[name]
+    (probe, st_p), (skip, st_s) = _ws_both_paths(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"),
+                                                 int(c["conn"]), GOLDEN_DEPTH.get(name, 3))
+    assert st_p[5] in (0, 1) and st_p[1] > 0              # probed: root phase ran, conflict flag evaluated
+    assert st_s[5] == -1 and st_s[1] == 0 and st_s[2] > 0  # skipped: no root phase, chain phases ran
+    assert np.array_equal(probe, skip), f"{int((probe != skip).sum())} px depend on the scheduling hint"
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_watershed_skip_fast_path_gives_identical_labels_random(tf, seed):
+    rng = np.random.default_rng(100 + seed)
+    shape = (int(rng.integers(1, 7)), int(rng.integers(20, 60)), int(rng.integers(20, 70)))
+    field = rand_field(rng, shape)
+    if seed % 2 == 1:
+        field = np.round(field * 8) / 8                    # exact plateaus: conflicts, deep chains
+    markers = seeds(rng, shape, int(rng.integers(1, 15)))
+    mask = None if seed % 2 == 0 else ndi.gaussian_filter(rng.normal(size=shape), (0, 2, 2)) > -0.03
+    fwd, bwd = rand_flow(rng, shape, 2.5), rand_flow(rng, shape, 2.5)
+    (probe, st_p), (skip, st_s) = _ws_both_paths(fwd, bwd, field, markers, mask, [1, 2, 3][seed % 3], 3)
+    assert st_s[5] == -1 and st_s[1] == 0
+    assert np.array_equal(probe, skip), f"{int((probe != skip).sum())} px depend on the scheduling hint"
+
+
+def test_watershed_conflict_memo_schedules_but_never_changes_labels(tf, golden_ws):
+    """Default path (expect_conflict=None): a shape whose probe conflicted skips the root phase on the
+    following calls and probes again after _REPROBE calls."""
+    import torch
+    from tobac_flow_amd import _lib, watershed as wsmod
+    c = golden_ws["E_const_plateau_c1"]
+    fw, bw = _lib.to_dev(c["fwd"], torch.float32), _lib.to_dev(c["bwd"], torch.float32)
+    f, m = _lib.to_dev(c["field"], torch.float32), _lib.to_dev(c["markers"], torch.int32)
+    nbr = wsmod.neighbour_offsets(int(c["conn"]), 3)
+    wsmod._conflict_memo.clear()
+    flags, first = [], None
+    for _ in range(wsmod._REPROBE + 3):
+        st = {}
+        lab = wsmod.watershed_dev(fw, bw, f, m, None, nbr, 3, st).cpu().numpy()
+        first = lab if first is None else first
+        assert np.array_equal(lab, first)
+        flags.append(st["sweeps"][5])
+    assert flags[0] == 1                                   # probe: the plateau field conflicts
+    assert flags[1:1 + wsmod._REPROBE] == [-1] * wsmod._REPROBE
+    assert flags[1 + wsmod._REPROBE] == 1                  # probed again
+
+
 def test_watershed_errors(tf):
     z = np.zeros((2, 5, 5, 2), np.float32)
     f = np.zeros((2, 5, 5), np.float32)

@@ -382,6 +382,12 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
         bool done = false;
         // slot b holds the size of the queue consumed by sweep b (slot 0 of the first batch is unused:
         // that sweep scans everything)
+        static const bool trace = getenv("TF_WS_TRACE") != nullptr;      // development aid: frontier size per sweep
+        if (trace) {
+            fprintf(stderr, "ws_trace phase %d sweeps %lld:", phase_k, (long long)sweeps);
+            for (int b = 0; b <= WS_BATCH; b++) fprintf(stderr, " %d", Q.h_cnt[b]);
+            fprintf(stderr, "\n");
+        }
         for (int b = (sweeps == 0 ? 1 : 0); b <= WS_BATCH; b++) {
             if (Q.h_cnt[b] > Q.qcap) { tf_set_error("tf_watershed: frontier queue overflow"); return TF_EHIP; }
             if (Q.h_cnt[b] == 0) { done = true; break; }
@@ -405,11 +411,12 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
     return TF_OK;
 }
 
-extern "C" int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
-                            const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
-                            const int8_t *nbr_host, int n_nbr, int chain_depth, int32_t *labels,
-                            void *ws, size_t ws_bytes, int64_t *stats_host, void *stream)
+extern "C" int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
+                               const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                               const int8_t *nbr_host, int n_nbr, int chain_depth, int flags, int32_t *labels,
+                               void *ws, size_t ws_bytes, int64_t *stats_host, void *stream)
 {
+    TF_REQUIRE((flags & ~TF_WS_SKIP_FAST_PATH) == 0, "tf_watershed: unknown flag");
     TF_REQUIRE(field && markers && fwd && bwd && nbr_host && labels && ws, "tf_watershed: null pointer");
     TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15) && T < 65536, "tf_watershed: bad shape");
     TF_REQUIRE(n_nbr > 0 && n_nbr <= WS_MAX_NBR, "tf_watershed: bad neighbour count");
@@ -488,13 +495,17 @@ extern "C" int tf_watershed(const float *field, const int32_t *markers, const in
         const int64_t max_sweeps = 4096 + 512 * (T + H + W);
         int rc = ws_run_phase(c, 0, chain_depth, Q, s, max_sweeps, &st[0]);
         if (rc) return rc;
-        // fast path: root phase matched on K2 only, then the conflict test
-        hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1);
-        TF_CHECK_LAUNCH();
-        rc = ws_run_phase(c, 1, 1, Q, s, max_sweeps, &st[1]);
-        if (rc) return rc;
-        int conflict = 0;
-        if (chain_depth > 1) {
+        // fast path: root phase matched on K2 only, then the conflict test (skipped on the caller's hint:
+        // the chain phases below give the same labels whenever the fast path would have been accepted)
+        const bool speculate = !((flags & TF_WS_SKIP_FAST_PATH) && chain_depth > 1);
+        int conflict = speculate ? 0 : -1;
+        if (speculate) {
+            hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1);
+            TF_CHECK_LAUNCH();
+            rc = ws_run_phase(c, 1, 1, Q, s, max_sweeps, &st[1]);
+            if (rc) return rc;
+        }
+        if (speculate && chain_depth > 1) {
             TF_CHECK_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), s));
             hipLaunchKernelGGL(k_ws_conflicts, dim3(nbr_blocks), dim3(256), 0, s, c, markers, d_flags);
             TF_CHECK_LAUNCH();
@@ -519,4 +530,13 @@ extern "C" int tf_watershed(const float *field, const int32_t *markers, const in
     TF_CHECK_HIP(hipStreamSynchronize(s));
     if (stats_host) for (int i = 0; i < 8; i++) stats_host[i] = st[i];
     return TF_OK;
+}
+
+extern "C" int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
+                            const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                            const int8_t *nbr_host, int n_nbr, int chain_depth, int32_t *labels,
+                            void *ws, size_t ws_bytes, int64_t *stats_host, void *stream)
+{
+    return tf_watershed_ex(field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, chain_depth, 0, labels,
+                           ws, ws_bytes, stats_host, stream);
 }

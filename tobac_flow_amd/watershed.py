@@ -54,8 +54,19 @@ def neighbour_offsets(connectivity, ndim=3):
     return np.ascontiguousarray(offs[np.abs(offs).sum(1) > 0], np.int8)
 
 
-def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None):
-    """Device-resident core: torch tensors in (field f32, markers i32, mask i8 or None), labels out."""
+# Scheduling memo (never affects the labels): tf_watershed first tries a cheap root phase and falls back to
+# the chain phases when it finds a label conflict.  Fields with exact plateaus (detect_anvils) conflict
+# every time, so for a volume shape whose last probe conflicted the speculative phase is skipped
+# (TF_WS_SKIP_FAST_PATH); every _REPROBE-th call probes again so that a change of data is noticed.
+_conflict_memo = {}
+_REPROBE = 8
+TF_WS_SKIP_FAST_PATH = 1
+
+
+def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
+                  expect_conflict=None):
+    """Device-resident core: torch tensors in (field f32, markers i32, mask i8 or None), labels out.
+    expect_conflict: True / False force the scheduling hint, None (default) uses the per-shape memo."""
     t = _lib.torch()
     L = _lib.lib()
     T, H, W = field.shape
@@ -67,17 +78,25 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
     guess = min(T * H * W, int(floodable.sum().item() * 1.5) + 4096)
     del floodable
     st = np.zeros(8, np.int64)
+    key = (T, H, W, len(nbr), chain_depth)
+    memo = _conflict_memo.setdefault(key, [False, 0])          # [last probe conflicted, calls since that probe]
+    skip = expect_conflict if expect_conflict is not None else (memo[0] and memo[1] < _REPROBE)
+    flags = TF_WS_SKIP_FAST_PATH if (skip and chain_depth > 1) else 0
     for attempt in range(2):
         nbytes = L.tf_watershed_workspace_bytes(T, H, W, len(nbr), chain_depth, guess)
         ws = _lib.workspace(nbytes, "watershed")
-        rc = L.tf_watershed(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
-                            T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), chain_depth, _lib.ptr(labels),
-                            _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr())
+        rc = L.tf_watershed_ex(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
+                               T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), chain_depth, flags, _lib.ptr(labels),
+                               _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr())
         if rc == -2 and attempt == 0 and st[6] > guess:
             guess = int(st[6])
             continue
         break
     _lib.check(rc, "tf_watershed")
+    if st[5] >= 0:
+        memo[0], memo[1] = bool(st[5]), 0                      # this call probed
+    else:
+        memo[1] += 1
     if stats is not None:
         stats["sweeps"] = st.tolist()
     return labels
