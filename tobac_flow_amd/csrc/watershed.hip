@@ -327,7 +327,8 @@ typedef hipcub::TransformInputIterator<int, WsU8ToInt, const uint8_t *> WsFlagIt
 static size_t ws_scan_temp_bytes(int64_t n) {
     size_t bytes = 0;
     WsFlagIter it((const uint8_t *)nullptr, WsU8ToInt());
-    hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, (int *)nullptr, (int)(n > 0x7fffffff ? 0x7fffffff : n));
+    // size query only (null temp storage): fills `bytes`
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, (int *)nullptr, (int)(n > 0x7fffffff ? 0x7fffffff : n));
     return bytes;
 }
 
