@@ -111,13 +111,16 @@ def main():
     bt = blob_stack(T, H, W, seed=20240601 + rank)          # resident in HBM before the timed region
     lin, markers = anvil_inputs(bt)
     nbr = neighbour_offsets(1)
+    ws_stats = []                                            # tf_watershed stats of every step (warmup included)
 
     def step():
         flow = tf.create_flow(bt, model="Farneback", smoothing_passes=1, interp_method="cubic")
         # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
         e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
-        labels = watershed_dev(fw, bw, e, markers, None, nbr)
+        st = {}
+        labels = watershed_dev(fw, bw, e, markers, None, nbr, stats=st)
+        ws_stats.append(st["sweeps"])
         return stitch_labels(labels) if world > 1 else labels
 
     def barrier():
@@ -164,6 +167,12 @@ def main():
                                     "+ edge field + Flow.watershed(connectivity 1, detect_anvils markers)",
                           "sharding": "one time window per GPU, label IDs stitched by all-gather"},
                "roofline": roof}
+        # which watershed schedule the timed steps ran: stats[5] = 1 / 0 probe (speculative root phase + conflict test,
+        # conflict found / not found), -1 = root phase skipped on the conflict memo of watershed.py (identical labels)
+        timed = ws_stats[a.warmup:]
+        out["watershed"] = {"sweeps_per_phase_last_step": timed[-1][:5], "relevant_pixels": timed[-1][6],
+                            "timed_steps_probing": sum(1 for t_ in timed if t_[5] >= 0),
+                            "timed_steps_skipping_root_phase": sum(1 for t_ in timed if t_[5] < 0)}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(20240601)
         print(json.dumps(out))
