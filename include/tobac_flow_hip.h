@@ -188,6 +188,18 @@ int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *ma
  *   find_object_lengths = tmax - tmin + 1) and whether it touches `mask` (analysis.py:38-63 mask_labels);
  *   arrays of n_labels + 1 entries, entry 0 unused; absent labels: tmin = 0x7f7f7f7f, tmax = -1.
  * tf_apply_lut: out = lut[labels] (tobac_flow/utils/label_utils.py:265-309 remap_labels' gather). */
+/* tf_correlate1d_sym: one pass of scipy.ndimage.correlate1d along `axis` (0 = t, 1 = y, 2 = x) with a SYMMETRIC kernel
+ *   of 2*radius+1 host doubles, mode 'reflect' -- the pass scipy.ndimage.gaussian_filter is made of
+ *   (tobac_flow/detection.py:65, 137-138, 150: ndi.gaussian_filter(field, (0, sigma, sigma)) = the y pass then the x pass,
+ *   each rounding to the array's dtype).  type TF_F32 / TF_F64 (in and out alike); in != out; radius <= 64.
+ *   Bit-exact with SciPy: double accumulation, centre first, then the pairs from the OUTERMOST inwards.
+ * tf_grey_morph: scipy.ndimage.grey_erosion (op 0) / grey_dilation (op 1) with a flat, point-symmetric footprint inside a
+ *   3x3x3 box (27 host bytes, C order), mode 'reflect' (tobac_flow/detection.py:106-108 ndi.grey_opening = erosion then
+ *   dilation).  SciPy's visiting order and strict comparisons are kept, so NaNs land where SciPy puts them. */
+int tf_correlate1d_sym(const void *in, int type, int64_t T, int64_t H, int64_t W, int axis,
+                       const double *weights_host, int radius, void *out, void *stream);
+int tf_grey_morph(const void *in, int type, int64_t T, int64_t H, int64_t W, const uint8_t *footprint_host,
+                  int op, void *out, void *stream);
 int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
                     int op, int iterations, int border_value, uint8_t *out, uint8_t *tmp, void *stream);
 int tf_linearise(const float *field, int64_t n, double lower, double upper, float *out, void *stream);

@@ -218,3 +218,72 @@ def test_anvil_pipeline_device_resident_equals_numpy(scene):
     a_dev = detect_anvils(flow, wd, markers=m_dev, upper_threshold=-5, lower_threshold=-15, min_length=1)
     assert isinstance(m_dev, torch.Tensor) and np.array_equal(m_dev.cpu().numpy(), m_np)
     assert np.array_equal(a_dev.cpu().numpy(), a_np) and a_np.max() >= 1
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(3, 40, 50), (2, 5, 7), (1, 17, 3), (2, 1, 9), (4, 33, 65)])
+def test_gaussian_filter_matches_scipy_bit_for_bit(dtype, shape):
+    """ndi.gaussian_filter as the recipes call it (detection.py:65, 137-138, 150) and with a time sigma
+    (detect_growth_markers_multichannel); axes shorter than the kernel radius exercise the repeated reflection."""
+    import torch
+    from tobac_flow_amd import ndimage_dev as nd
+    rng = np.random.default_rng(sum(shape))
+    x = (rng.normal(size=shape) * 10).astype(dtype)
+    xd = torch.from_numpy(x).cuda()
+    for sigma in [(0, 2, 2), (1, 2, 2), (0, 0.7, 3.1), 1.5, (0, 0, 0), (2.5, 0, 0)]:
+        want = ndi.gaussian_filter(x, sigma)
+        got = nd.gaussian_filter(xd, sigma)
+        assert got.dtype == xd.dtype and got.data_ptr() != xd.data_ptr()
+        got = got.cpu().numpy()
+        assert np.array_equal(got, want), f"sigma {sigma}: {int((got != want).sum())} values differ, max {np.abs(got - want).max()}"
+    w, r = nd.gaussian_kernel1d(2.0)
+    from scipy.ndimage._filters import _gaussian_kernel1d
+    assert r == 8 and np.array_equal(w, _gaussian_kernel1d(2.0, 0, 8))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(2, 9, 11), (1, 1, 6), (3, 4, 1), (3, 31, 47)])
+def test_grey_morphology_matches_scipy_including_nan_placement(dtype, shape):
+    import torch
+    from tobac_flow_amd import ndimage_dev as nd
+    rng = np.random.default_rng(7 + sum(shape))
+    x = rng.normal(size=shape).astype(dtype)
+    x[rng.random(shape) < 0.08] = np.nan
+    xd = torch.from_numpy(x).cuda()
+    cross2d = ndi.generate_binary_structure(2, 1)[np.newaxis, ...]                  # detection.py:105
+    diag = np.zeros((3, 3, 3), bool)
+    diag[0, 0, 0] = diag[1, 1, 1] = diag[2, 2, 2] = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for fp in (cross2d, ndi.generate_binary_structure(3, 1), ndi.generate_binary_structure(3, 2), diag):
+            for name in ("grey_erosion", "grey_dilation", "grey_opening"):
+                want = getattr(ndi, name)(x, footprint=fp)
+                got = getattr(nd, name)(xd, fp).cpu().numpy()
+                assert np.array_equal(got, want, equal_nan=True), f"{name} {fp.shape}: {int((~np.isclose(got, want, equal_nan=True)).sum())} differ"
+    with pytest.raises(NotImplementedError):
+        nd.grey_erosion(xd, np.ones((3, 3, 3), bool))
+    with pytest.raises(ValueError):
+        skew = np.zeros((3, 3, 3), bool)
+        skew[1, 1, 1] = skew[1, 1, 2] = True
+        nd.grey_erosion(xd, skew)
+
+
+@pytest.mark.parametrize("shape", [(4, 41, 53), (1, 30, 30), (3, 8, 9)])
+def test_binary_fill_holes_matches_scipy(shape):
+    import torch
+    from tobac_flow_amd import ndimage_dev as nd
+    rng = np.random.default_rng(11 + sum(shape))
+    field = ndi.gaussian_filter(rng.normal(size=shape), (0.7, 2, 2))
+    rings = np.logical_and(field > 0.02, field < 0.09)                              # thin closed curves: many holes
+    blobs = field > 0.05
+    per_frame = ndi.generate_binary_structure(3, 1)
+    per_frame[0] = 0
+    per_frame[2] = 0                                                                # detection.py:72-74
+    for x in (rings, blobs, np.zeros(shape, bool), np.ones(shape, bool)):
+        xd = torch.from_numpy(x).cuda()
+        for st in (per_frame, ndi.generate_binary_structure(3, 1), ndi.generate_binary_structure(3, 3)):
+            want = ndi.binary_fill_holes(x, structure=st)
+            got = nd.binary_fill_holes(xd, st).cpu().numpy()
+            assert got.dtype == bool and np.array_equal(got, want), f"{int((got != want).sum())} px differ"
+    if shape[1] >= 30:                                                              # (the 8 x 9 case is too small to enclose anything)
+        assert ndi.binary_fill_holes(rings, structure=per_frame).sum() > rings.sum()    # the case really has holes

@@ -253,3 +253,115 @@ extern "C" int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, cons
     if (n_labels_host) *n_labels_host = last_rank + last_root;
     return TF_OK;
 }
+
+// ---- scipy.ndimage.correlate1d with a SYMMETRIC kernel, mode 'reflect' (the pass gaussian_filter is made of) ---------
+// ndi.gaussian_filter(field, (0, sigma, sigma)) at tobac_flow/detection.py:65, 137-138, 150 = one such pass per axis with
+// sigma > 0, in axis order, each pass rounding to the array's dtype.  SciPy's arithmetic, reproduced bit for bit
+// (checked against SciPy 1.15 for float32 / float64, rows shorter than the radius included):
+//   every sample converted to double;  tmp = x[c] * w[r];  for j = r .. 1 (OUTERMOST pair first):
+//   tmp += (x[c - j] + x[c + j]) * w[r + j];  indices reflected half-sample symmetrically (d c b a | a b c d | d c b a).
+// One thread per output; along y / t neighbouring threads stay coalesced in x, along x the taps are L1 hits.
+#define TF_C1D_MAX_RADIUS 64
+struct Corr1dW { double w[TF_C1D_MAX_RADIUS + 1]; int r; };          // w[j] = weight at distance j from the centre
+
+__device__ __forceinline__ int64_t tf_reflect_index(int64_t i, int64_t n)
+{
+    if (n == 1) return 0;
+    const int64_t p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(256)
+k_correlate1d_sym(const TS *__restrict__ in, int64_t T, int H, int W, int axis, Corr1dW kw, TS *__restrict__ out)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const int64_t plane = (int64_t)H * W;
+    const int64_t o = t * plane + (int64_t)y * W + x;
+    const int64_t n = axis == 0 ? T : (axis == 1 ? H : W);
+    const int64_t c = axis == 0 ? t : (axis == 1 ? y : x);
+    const int64_t stride = axis == 0 ? plane : (axis == 1 ? W : 1);
+    const TS *line = in + (o - c * stride);                             // element 0 of this thread's line
+    double tmp = (double)line[c * stride] * kw.w[0];
+    for (int j = kw.r; j >= 1; j--) {
+        const double a = (double)line[tf_reflect_index(c - j, n) * stride];
+        const double b = (double)line[tf_reflect_index(c + j, n) * stride];
+        tmp += (a + b) * kw.w[j];
+    }
+    out[o] = (TS)tmp;
+}
+
+extern "C" int tf_correlate1d_sym(const void *in, int type, int64_t T, int64_t H, int64_t W, int axis,
+                                  const double *weights_host, int radius, void *out, void *stream)
+{
+    TF_REQUIRE(in && out && weights_host, "tf_correlate1d_sym: null pointer");
+    TF_REQUIRE(in != out, "tf_correlate1d_sym: in-place operation is not supported");
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 30) && W < (1 << 30) && T < 65536, "tf_correlate1d_sym: bad shape");
+    TF_REQUIRE(axis >= 0 && axis <= 2, "tf_correlate1d_sym: axis must be 0, 1 or 2");
+    TF_REQUIRE(radius >= 0 && radius <= TF_C1D_MAX_RADIUS, "tf_correlate1d_sym: radius out of range");
+    TF_REQUIRE(type == TF_F32 || type == TF_F64, "tf_correlate1d_sym: type must be TF_F32 or TF_F64");
+    Corr1dW kw; kw.r = radius;
+    for (int j = 0; j <= radius; j++) {
+        // weights_host has 2r+1 entries; symmetric by contract
+        TF_REQUIRE(weights_host[radius - j] == weights_host[radius + j], "tf_correlate1d_sym: kernel is not symmetric");
+        kw.w[j] = weights_host[radius + j];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(64, 4, 1), grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
+    if (type == TF_F32) hipLaunchKernelGGL(k_correlate1d_sym<float>, grid, block, 0, s, (const float *)in, T, (int)H, (int)W, axis, kw, (float *)out);
+    else hipLaunchKernelGGL(k_correlate1d_sym<double>, grid, block, 0, s, (const double *)in, T, (int)H, (int)W, axis, kw, (double *)out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+// ---- scipy.ndimage.grey_erosion / grey_dilation with a flat footprint, mode 'reflect' ---------------------------------
+// ndi.grey_opening(x, footprint=cross) at tobac_flow/detection.py:106-108 = erosion then dilation.  SciPy's
+// min_or_max_filter visits the footprint's true cells in C order, starts from the FIRST cell's value and replaces it
+// only on a strict comparison (v < tmp / v > tmp): a NaN in the first cell sticks, a NaN elsewhere is ignored.  That
+// order is kept here (bit-exact incl. NaN placement, checked against SciPy 1.15).  Restricted to point-symmetric
+// footprints of a 3x3x3 box: for those SciPy's mirrored dilation footprint visits the same cells in the same order.
+template <typename TS>
+__global__ void __launch_bounds__(256)
+k_grey_morph(const TS *__restrict__ in, int64_t T, int H, int W, MorphTaps tp, int op, TS *__restrict__ out)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const int64_t plane = (int64_t)H * W;
+    TS tmp = 0;
+    for (int i = 0; i < tp.n; i++) {
+        const int64_t tt = tf_reflect_index(t + tp.dt[i], T);
+        const int64_t yy = tf_reflect_index(y + tp.dy[i], H), xx = tf_reflect_index(x + tp.dx[i], W);
+        const TS v = in[tt * plane + yy * W + xx];
+        if (i == 0) tmp = v;
+        else if (op == 0) { if (v < tmp) tmp = v; }
+        else { if (v > tmp) tmp = v; }
+    }
+    out[t * plane + (int64_t)y * W + x] = tmp;
+}
+
+extern "C" int tf_grey_morph(const void *in, int type, int64_t T, int64_t H, int64_t W, const uint8_t *footprint_host,
+                             int op, void *out, void *stream)
+{
+    TF_REQUIRE(in && out && footprint_host, "tf_grey_morph: null pointer");
+    TF_REQUIRE(in != out, "tf_grey_morph: in-place operation is not supported");
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 30) && W < (1 << 30) && T < 65536, "tf_grey_morph: bad shape");
+    TF_REQUIRE(op == 0 || op == 1, "tf_grey_morph: op must be 0 (erosion) or 1 (dilation)");
+    TF_REQUIRE(type == TF_F32 || type == TF_F64, "tf_grey_morph: type must be TF_F32 or TF_F64");
+    MorphTaps tp; tp.n = 0;
+    for (int i = 0; i < 27; i++) {
+        TF_REQUIRE((footprint_host[i] != 0) == (footprint_host[26 - i] != 0), "tf_grey_morph: footprint must be point-symmetric");
+        if (footprint_host[i]) { tp.dt[tp.n] = (int8_t)(i / 9 - 1); tp.dy[tp.n] = (int8_t)((i / 3) % 3 - 1); tp.dx[tp.n] = (int8_t)(i % 3 - 1); tp.n++; }
+    }
+    TF_REQUIRE(tp.n > 0, "tf_grey_morph: empty footprint");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(64, 4, 1), grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
+    if (type == TF_F32) hipLaunchKernelGGL(k_grey_morph<float>, grid, block, 0, s, (const float *)in, T, (int)H, (int)W, tp, op, (float *)out);
+    else hipLaunchKernelGGL(k_grey_morph<double>, grid, block, 0, s, (const double *)in, T, (int)H, (int)W, tp, op, (double *)out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}

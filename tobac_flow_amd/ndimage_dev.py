@@ -110,3 +110,111 @@ def flat_label(mask, structure=None):
     s[0] = 0
     s[-1] = 0
     return label(mask, s)[0]
+
+
+def _float_type(x):
+    t = _lib.torch()
+    if x.dtype == t.float32:
+        return _lib.TF_F32
+    if x.dtype == t.float64:
+        return _lib.TF_F64
+    raise TypeError(f"float32 or float64 tensor required, got {x.dtype}")
+
+
+def gaussian_kernel1d(sigma, truncate=4.0):
+    """(weights, radius) of scipy.ndimage.gaussian_filter1d(order=0): radius = int(truncate * sigma + 0.5),
+    exp(-0.5 / sigma^2 * x^2) normalised to sum 1, float64"""
+    sd = float(sigma)
+    radius = int(truncate * sd + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    return np.ascontiguousarray(phi / phi.sum(), np.float64), radius
+
+
+def gaussian_filter(x, sigma, truncate=4.0):
+    """scipy.ndimage.gaussian_filter(x, sigma, mode='reflect', truncate=truncate) for a (T, H, W) float32 / float64
+    device tensor: one symmetric correlate1d pass per axis with sigma > 1e-15, in axis order, each pass rounding to
+    x's dtype (SciPy filters the later axes in place on the output of the earlier ones)."""
+    t = _lib.torch()
+    L = _lib.lib()
+    ty = _float_type(x)
+    sig = [float(v) for v in (sigma if np.ndim(sigma) else [sigma] * 3)]
+    if x.dim() != 3 or len(sig) != 3:
+        raise ValueError("gaussian_filter: a (T, H, W) tensor and a scalar or 3 sigmas are required")
+    if any(v < 0 for v in sig):
+        raise ValueError("gaussian_filter: sigma must be non-negative")
+    cur = x.contiguous()
+    T, H, W = cur.shape
+    bufs = [None, None]
+    k = 0
+    for axis, sd in enumerate(sig):
+        if sd <= 1e-15:
+            continue
+        w, r = gaussian_kernel1d(sd, truncate)
+        if bufs[k] is None:
+            bufs[k] = t.empty_like(cur)
+        out = bufs[k]
+        _lib.check(L.tf_correlate1d_sym(_lib.ptr(cur), ty, T, H, W, axis, w.ctypes.data_as(_lib._P), r, _lib.ptr(out),
+                                        _lib.stream_ptr()), "tf_correlate1d_sym")
+        cur, k = out, k ^ 1
+    return cur.clone() if cur is x else cur
+
+
+def _grey(x, footprint, op):
+    t = _lib.torch()
+    ty = _float_type(x)
+    fp = np.asarray(footprint) != 0
+    while fp.ndim < 3:
+        fp = fp[np.newaxis]
+    if fp.ndim != 3 or any(n not in (1, 3) for n in fp.shape):
+        raise ValueError("footprint axes must have length 1 or 3")
+    full = np.zeros((3, 3, 3), np.uint8)                     # centre the footprint in a 3x3x3 box
+    full[tuple(slice(1, 2) if n == 1 else slice(0, 3) for n in fp.shape)] = fp
+    if not np.array_equal(full, full[::-1, ::-1, ::-1]):
+        raise ValueError("footprint must be point-symmetric (SciPy mirrors it for dilations)")
+    if fp.all() and fp.size > 1:
+        raise NotImplementedError("an all-true footprint takes SciPy's separable min/max path, whose NaN handling "
+                                  "differs from the footprint path implemented here")
+    xc = x.contiguous()
+    T, H, W = xc.shape
+    out = t.empty_like(xc)
+    _lib.check(_lib.lib().tf_grey_morph(_lib.ptr(xc), ty, T, H, W, np.ascontiguousarray(full).ctypes.data_as(_lib._P), op,
+                                        _lib.ptr(out), _lib.stream_ptr()), "tf_grey_morph")
+    return out
+
+
+def grey_erosion(x, footprint):
+    """scipy.ndimage.grey_erosion(x, footprint=footprint) (flat footprint, mode 'reflect')"""
+    return _grey(x, footprint, 0)
+
+
+def grey_dilation(x, footprint):
+    """scipy.ndimage.grey_dilation(x, footprint=footprint) (flat footprint, mode 'reflect')"""
+    return _grey(x, footprint, 1)
+
+
+def grey_opening(x, footprint):
+    """scipy.ndimage.grey_opening(x, footprint=footprint): erosion then dilation"""
+    return grey_dilation(grey_erosion(x, footprint), footprint)
+
+
+def binary_fill_holes(x, structure):
+    """scipy.ndimage.binary_fill_holes(x, structure): SciPy floods the background from outside the array
+    (binary_dilation of the empty set, border_value 1, mask = ~x, to convergence) and returns what the flood does
+    not reach.  Here: the background components (tf_label, same structure) that contain a pixel whose structure
+    neighbourhood leaves the volume are 'outside'; every other background pixel is a hole."""
+    t = _lib.torch()
+    xb = x != 0
+    bg = ~xb
+    edge = binary_dilation(t.zeros_like(xb), structure, 1, border_value=1)      # one SciPy dilation step from outside
+    lab, n = label(bg, structure)
+    if n == 0:
+        return xb.clone()
+    _, outside = label_extent(lab, mask=edge & bg)
+    lut = np.zeros(n + 1, np.int32)
+    lut[1:][outside[:n]] = 1
+    lut_t = t.from_numpy(lut).to(lab.device)
+    reached = t.empty_like(lab)
+    _lib.check(_lib.lib().tf_apply_lut(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut.size, _lib.ptr(reached),
+                                       _lib.stream_ptr()), "tf_apply_lut")
+    return ~(reached != 0)
