@@ -287,3 +287,83 @@ def test_binary_fill_holes_matches_scipy(shape):
             assert got.dtype == bool and np.array_equal(got, want), f"{int((got != want).sum())} px differ"
     if shape[1] >= 30:                                                              # (the 8 x 9 case is too small to enclose anything)
         assert ndi.binary_fill_holes(rings, structure=per_frame).sum() > rings.sum()    # the case really has holes
+
+
+def _same(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
+
+
+@pytest.mark.parametrize("direction", ["negative", "positive"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_curvature_filter_device_path_equals_scipy_path(scene, direction, dtype):
+    import torch
+    from tobac_flow_amd.detection import get_curvature_filter
+    field = (-scene["bt"]).astype(dtype)
+    for sigma, threshold in [(2, 0), (1.2, 0.01)]:
+        want = get_curvature_filter(field, sigma=sigma, threshold=threshold, direction=direction)
+        got = get_curvature_filter(torch.from_numpy(field).cuda(), sigma=sigma, threshold=threshold, direction=direction)
+        assert isinstance(got, torch.Tensor) and _same(got.cpu().numpy(), want)
+        assert 0 < want.sum() < want.size                      # a non-trivial filter
+    with pytest.raises(ValueError):
+        get_curvature_filter(torch.from_numpy(field).cuda(), direction="sideways")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_nan_gaussian_filter_device_path_equals_scipy_path(scene, dtype):
+    import torch
+    from tobac_flow_amd.detection import nan_gaussian_filter
+    rng = np.random.default_rng(5)
+    a = scene["bt"].astype(dtype)
+    a[rng.random(a.shape) < 0.05] = np.nan
+    a[1, 20:60, 30:90] = np.nan                               # a hole wider than the kernel: 0 / 0 -> NaN branch
+    for propagate in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = nan_gaussian_filter(a, (0, 2, 2), propagate_nan=propagate)
+        got = nan_gaussian_filter(torch.from_numpy(a).cuda(), (0, 2, 2), propagate_nan=propagate).cpu().numpy()
+        assert _same(got, want), f"{int((~np.isclose(got, want, equal_nan=True, rtol=0, atol=0)).sum())} differ"
+    assert np.isnan(want[1, 40, 60])
+
+
+def _growing_wvd(scene, minutes):
+    """WVD-like field: the cold blobs of the scene are MAXIMA that intensify with time (only they exceed -5)"""
+    bt = scene["bt"]
+    ramp = np.linspace(0.6, 1.2, bt.shape[0], dtype=np.float32)[:, None, None]
+    field = ramp * np.clip(250.0 - bt, 0, None) / 3 - 8 + np.clip(250.0 - bt, None, 0) / 40
+    return FakeDataArray(field.astype(np.float32), minutes=minutes)
+
+
+def test_detect_growth_markers_device_resident_equals_scipy_glue(scene):
+    """detect_growth_markers keeps every intermediate in HBM; the variant that runs the reference's SciPy glue on the
+    host between the same device operators must give the same derivative field and the same labels.  The field is
+    chosen so that every filter removes something and something survives."""
+    from tobac_flow_amd.detection import _detect_growth_markers_host, detect_growth_markers
+    wvd = _growing_wvd(scene, minutes=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_diff, want_labels = _detect_growth_markers_host(scene["flow"], wvd)
+        got_diff, got_labels = detect_growth_markers(scene["flow"], wvd)
+    want_labels, got_labels = np.asarray(want_labels), np.asarray(got_labels)
+    assert want_labels.max() >= 2 and 0 < (want_diff >= 0.5).sum() < (want_diff >= 0.25).sum() < want_diff.size / 4
+    assert _same(np.asarray(got_diff), np.asarray(want_diff))
+    assert _same(got_labels, want_labels)
+
+
+def test_detect_growth_markers_without_survivors_behaves_like_the_reference(scene):
+    """When no marker lasts three time steps the reference passes SciPy an empty label range
+    (analysis.py:78-86); with this SciPy that is a ValueError.  Both variants must do the same thing."""
+    from tobac_flow_amd.detection import _detect_growth_markers_host, detect_growth_markers
+    wvd = _growing_wvd(scene, minutes=5)
+    outcome = []
+    for fn in (_detect_growth_markers_host, detect_growth_markers):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                outcome.append(("ok", np.asarray(fn(scene["flow"], wvd)[1])))
+            except Exception as e:                                   # noqa: BLE001 - the type is what is compared
+                outcome.append(("raised", type(e)))
+    assert outcome[0][0] == outcome[1][0]
+    if outcome[0][0] == "raised":
+        assert outcome[0][1] is outcome[1][1] is ValueError
+    else:
+        assert np.array_equal(outcome[0][1], outcome[1][1]) and outcome[0][1].max() == 0

@@ -66,8 +66,35 @@ def filtered_tdiff(flow, raw_diff):
     return flow.convolve(raw_diff, structure=_time_struct(), func=_nanmean0)
 
 
+def _get_curvature_filter_dev(field, sigma, threshold, direction):
+    """get_curvature_filter on a device tensor: same operations, same dtypes (second differences in the field's
+    dtype, comparison in float64 against the zero-initialised float64 arrays the reference assigns into)."""
+    from tobac_flow_amd import ndimage_dev as nd
+    t = _lib.torch()
+    if direction not in ("negative", "positive"):
+        raise ValueError("Direction must be either positive or negative")
+    smooth = nd.gaussian_filter(field, (0, sigma, sigma))
+    x_diff = t.zeros(field.shape, dtype=t.float64, device=field.device)
+    y_diff = t.zeros(field.shape, dtype=t.float64, device=field.device)
+    if field.shape[2] > 2:
+        d1 = smooth[:, :, 1:] - smooth[:, :, :-1]                      # np.diff(n=2) = diff of the diff
+        x_diff[:, :, 1:-1] = (d1[:, :, 1:] - d1[:, :, :-1]).to(t.float64)
+    if field.shape[1] > 2:
+        d1 = smooth[:, 1:] - smooth[:, :-1]
+        y_diff[:, 1:-1] = (d1[:, 1:] - d1[:, :-1]).to(t.float64)
+    if direction == "negative":
+        both = (x_diff < -threshold) & (y_diff < -threshold)
+    else:
+        both = (x_diff > threshold) & (y_diff > threshold)
+    s = _plane_struct()
+    return nd.binary_opening(nd.binary_fill_holes(both, s), s)
+
+
 def get_curvature_filter(field, sigma=2, threshold=0, direction="negative"):
-    """Where the smoothed field curves down (or up) in both x and y (reference: detection.py:64-94)."""
+    """Where the smoothed field curves down (or up) in both x and y (reference: detection.py:64-94).
+    A GPU tensor runs on the device (ndimage_dev) and returns a bool tensor."""
+    if isinstance(field, _lib.torch().Tensor):
+        return _get_curvature_filter_dev(field, sigma, threshold, direction)
     smooth = ndi.gaussian_filter(field, (0, sigma, sigma))
     x_diff = np.zeros(field.shape)
     x_diff[:, :, 1:-1] = np.diff(smooth, n=2, axis=2)
@@ -84,7 +111,40 @@ def get_curvature_filter(field, sigma=2, threshold=0, direction="negative"):
 
 
 def detect_growth_markers(flow, wvd):
-    """Growth markers from the WVD field alone (reference: detection.py:98-125)."""
+    """Growth markers from the WVD field alone (reference: detection.py:98-125).  numpy / DataArray in and out like the
+    reference; in between the field is uploaded once and every step (semi-Lagrangian derivative, moving average, grey
+    opening, curvature filter, opening, flow labelling, label filters) stays in HBM.  The SciPy-glue variant
+    _detect_growth_markers_host gives identical results (tests/test_gpu_detection.py)."""
+    from tobac_flow_amd import ndimage_dev as nd
+    t = _lib.torch()
+    vals = np.ascontiguousarray(_values(wvd))
+    wvd_d = _lib.to_dev(vals)
+    dt = t.from_numpy(np.asarray(get_time_diff_from_coord(wvd.t))).to(wvd_d.device)[:, None, None]
+    wvd_diff_raw = flow.diff(wvd_d, method="linear") / dt              # float32 / float64 -> float64, as in numpy
+    wvd_diff_smoothed = filtered_tdiff(flow, wvd_diff_raw)
+    s2 = ndi.generate_binary_structure(2, 1)[np.newaxis, ...]
+    s2_3d = _plane_struct()
+    filtered = nd.grey_opening(wvd_diff_smoothed, s2) * get_curvature_filter(wvd_d)
+    marker_labels = flow.label(nd.binary_opening(filtered >= 0.25, s2_3d))
+    lengths, _ = nd.label_extent(marker_labels)
+    marker_labels = nd.remap_labels(marker_labels, lengths >= 3)
+    for mask in (filtered >= 0.5, wvd_d >= -5):
+        if int(marker_labels.max().item()) == 0:
+            # nothing survived: the reference hands SciPy an empty label range here (analysis.py:78-86), which this
+            # SciPy rejects with a ValueError.  Run that very call so that the behaviour is the reference's, whatever it is
+            marker_labels = _lib.to_dev(filter_labels_by_mask(marker_labels.cpu().numpy(), mask.cpu().numpy()))
+            continue
+        _, hit = nd.label_extent(marker_labels, mask)
+        marker_labels = nd.remap_labels(marker_labels, hit)
+    wvd_diff_smoothed, marker_labels = wvd_diff_smoothed.cpu().numpy(), marker_labels.cpu().numpy()
+    if _is_dataarray(wvd):
+        import xarray as xr
+        marker_labels = xr.DataArray(marker_labels, wvd.coords, wvd.dims)
+    return wvd_diff_smoothed, marker_labels
+
+
+def _detect_growth_markers_host(flow, wvd):
+    """detect_growth_markers with the reference's own SciPy glue between the device operators."""
     wvd_diff_raw = _rate(flow, wvd)
     wvd_diff_smoothed = filtered_tdiff(flow, wvd_diff_raw)
     s2 = ndi.generate_binary_structure(2, 1)[np.newaxis, ...]
@@ -100,7 +160,19 @@ def detect_growth_markers(flow, wvd):
 
 
 def nan_gaussian_filter(a, *args, propagate_nan=True, **kwargs):
-    """Gaussian filter that ignores NaNs (normalised convolution) (reference: detection.py:128-146)."""
+    """Gaussian filter that ignores NaNs (normalised convolution) (reference: detection.py:128-146).
+    A GPU tensor runs on the device: nan_gaussian_filter(tensor, sigma[, truncate=...])."""
+    if isinstance(a, _lib.torch().Tensor):
+        from tobac_flow_amd import ndimage_dev as nd
+        t = _lib.torch()
+        nan = t.isnan(a)
+        filled = t.where(nan, t.zeros_like(a), a)
+        weight = t.where(nan, t.zeros_like(a), t.ones_like(a))
+        num = nd.gaussian_filter(filled, *args, **kwargs)
+        den = nd.gaussian_filter(weight, *args, **kwargs)
+        den = t.where(den == 0, t.full_like(den, float("nan")), den)
+        out = num / den
+        return t.where(nan, t.full_like(out, float("nan")), out) if propagate_nan else out
     nan = np.isnan(a)
     filled = a.copy()
     filled[nan] = 0
