@@ -2,6 +2,7 @@
 operators (ports of /root/reference/tests/test_flow.py:53-194 and tests/test_detection.py:36-60).
 These are the only golden values the reference holds at the cv2 boundary."""
 import numpy as np
+import pytest
 
 from oracle import np_ops
 
@@ -84,3 +85,74 @@ def test_farneback_oracle_recovers_translation():
     assert n == 3          # 160 x 200 -> 40 x 50, 80 x 100, full
     c = out[40:120, 50:150].mean((0, 1))
     assert abs(c[0] + 2) < 0.05 and abs(c[1] - 1) < 0.05
+
+
+# ----------------------------------------------------------------------------- Farnebaeck: identities of the method
+# cv2 is not available, so the restated Farnebaeck stages (oracle/c/farneback.c) cannot be compared with OpenCV's
+# output.  What CAN be checked without cv2 are the identities the method is derived from (Farnebaeck 2003): the
+# polynomial expansion of an exactly quadratic image returns its coefficients, and for two quadratic images that differ
+# by a translation d the very first iteration returns d.  They tie the tap tables, the inverse-metric constants, the
+# channel order, the 1/2 factors of UpdateMatrices, the sign convention of the flow and the determinant regulariser
+# to the mathematics rather than to a recollection of optflowgf.cpp.
+def _fb_stage_lib():
+    import ctypes
+    from oracle import _lib as ol
+    return ol, ol.lib(), ctypes
+
+
+def _quadratic(h, w, c, p, q, r, s, u, dx=0.0, dy=0.0):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    xx, yy = xx - dx, yy - dy
+    return c + p * xx + q * yy + r * xx * xx + s * yy * yy + u * xx * yy
+
+
+def _poly_exp(img, n=5, sigma=1.1):
+    ol, L, ctypes = _fb_stage_lib()
+    h, w = img.shape
+    out = np.zeros((h, w, 5), np.float32)
+    L.oracle_poly_exp(ol.ptr(np.ascontiguousarray(img, np.float32), ctypes.c_float), h, w, ol.ptr(out, ctypes.c_float), n,
+                      ctypes.c_double(sigma))
+    return out
+
+
+@pytest.mark.parametrize("scale", [0.004, 0.05, 0.5, 3.0])
+def test_farneback_polynomial_expansion_is_exact_on_quadratics(scale):
+    h, w, n = 64, 80, 5
+    c, p, q, r, s, u = 100.0, 0.8, -0.5, 1.0 * scale, -0.75 * scale, 0.5 * scale
+    img = _quadratic(h, w, c, p, q, r, s, u)
+    got = _poly_exp(img, n).astype(np.float64)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    # local expansion around (x0, y0); channel order [y, x, yy, xx, xy] as FarnebackUpdateMatrices reads it
+    want = np.stack([q + 2 * s * yy + u * xx, p + 2 * r * xx + u * yy, np.full_like(xx, s), np.full_like(xx, r),
+                     np.full_like(xx, u)], -1)
+    inner = (slice(n, h - n), slice(n, w - n))
+    # the vertical pass accumulates in float32: the error floor is the float32 spacing at the image's largest value
+    # (measured: 0.4 - 0.7 of it over a 750x range of curvature); 4x leaves margin for other libm / compilers
+    tol = 4 * np.spacing(np.float32(np.abs(img).max()))
+    assert np.abs(got - want)[inner].max() <= tol
+    # the replicate border breaks the polynomial: the check above is not satisfied trivially
+    assert np.abs(got - want)[0].max() > 100 * tol
+
+
+@pytest.mark.parametrize("scale,d", [(3.0, (0.7, -0.4)), (3.0, (-1.3, 0.9)), (0.5, (0.7, -0.4)), (0.5, (-1.3, 0.9)), (3.0, (0.0, 0.0))])
+def test_farneback_first_iteration_returns_the_translation_of_a_quadratic(scale, d):
+    ol, L, ctypes = _fb_stage_lib()
+    F = ctypes.c_float
+    h, w, win = 64, 80, 13
+    r, s, u = 1.0 * scale, 0.75 * scale, 0.3 * scale
+    r0 = _poly_exp(_quadratic(h, w, 50.0, 0.8, -0.5, r, s, u))
+    r1 = _poly_exp(_quadratic(h, w, 50.0, 0.8, -0.5, r, s, u, dx=d[0], dy=d[1]))       # next(x) = prev(x - d)
+    flow = np.zeros((h, w, 2), np.float32)
+    m = np.zeros((h, w, 5), np.float32)
+    L.oracle_update_matrices(ol.ptr(r0, F), ol.ptr(r1, F), ol.ptr(flow, F), ol.ptr(m, F), h, w)
+    L.oracle_update_flow_blur(ol.ptr(r0, F), ol.ptr(r1, F), ol.ptr(flow, F), ol.ptr(m, F), h, w, win, 0)
+    inner = (slice(win + 1, h - win - 1), slice(win + 1, w - win - 1))
+    err = np.abs(flow[inner] - np.array(d, np.float32)).max()
+    if d == (0.0, 0.0):
+        assert err == 0.0
+        return
+    # flow = (G h) / (det G + 1e-3) with G = A^T A, A = [[s, u/2], [u/2, r]]: relative bias 1e-3 / det(A)^2
+    bias = 1e-3 / (r * s - (u / 2) ** 2) ** 2 * max(abs(d[0]), abs(d[1]))
+    assert err <= 2 * bias + 1e-5, (err, bias)          # measured: err / bias = 0.98 - 1.3
+    if bias > 1e-3:
+        assert err >= 0.5 * bias, (err, bias)           # ... and the regulariser really is 1e-3 on the window MEANS
