@@ -158,3 +158,33 @@ def test_watershed_custom_structure_and_inf_field(tf):
     got = tf.watershed(fwd, bwd, field, markers, connectivity=st)
     want = ws_oracle.watershed(fwd, bwd, field, markers, None, st)
     assert np.array_equal(got, want)
+
+
+def test_watershed_ex_rejects_unknown_flags_and_chain_depth_one_ignores_the_hint(tf):
+    """C ABI: flags other than TF_WS_SKIP_FAST_PATH are TF_EINVAL; with chain_depth 1 there are no chain phases to
+    skip to, so the hint is ignored and the root phase runs."""
+    import torch
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    rng = np.random.default_rng(4)
+    shape = (2, 12, 14)
+    T, H, W = shape
+    f = torch.from_numpy(rand_field(rng, shape).astype(np.float32)).cuda()
+    m = torch.from_numpy(seeds(rng, shape, 3).astype(np.int32)).cuda()
+    fl = torch.zeros(shape + (2,), dtype=torch.float32, device="cuda")
+    out = torch.empty(shape, dtype=torch.int32, device="cuda")
+    nbr = np.ascontiguousarray(neighbour_offsets(1, 3), np.int8)
+    L = _lib.lib()
+    ws = torch.empty(L.tf_watershed_workspace_bytes(T, H, W, len(nbr), 3, 0), dtype=torch.uint8, device="cuda")
+    st = np.zeros(8, np.int64)
+    args = lambda flags: (_lib.ptr(f), _lib.ptr(m), None, _lib.ptr(fl), _lib.ptr(fl), T, H, W, nbr.ctypes.data_as(_lib._P),
+                          len(nbr), 3, flags, _lib.ptr(out), _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), None)
+    assert L.tf_watershed_ex(*args(2)) == -1 and b"unknown flag" in L.tf_last_error()
+    assert L.tf_watershed_ex(*args(0)) == 0
+    probe = out.cpu().numpy().copy()
+    assert L.tf_watershed_ex(*args(1)) == 0 and st[5] == -1 and st[1] == 0
+    assert np.array_equal(out.cpu().numpy(), probe)
+    st1 = {}
+    depth1 = watershed_dev(fl, fl, f, m, None, nbr, 1, st1, expect_conflict=True).cpu().numpy()
+    assert st1["sweeps"][1] > 0 and st1["sweeps"][5] == 0        # root phase ran, nothing skipped
+    assert np.array_equal(depth1[m.cpu().numpy() != 0], m.cpu().numpy()[m.cpu().numpy() != 0])

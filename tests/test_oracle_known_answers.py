@@ -156,3 +156,54 @@ def test_farneback_first_iteration_returns_the_translation_of_a_quadratic(scale,
     assert err <= 2 * bias + 1e-5, (err, bias)          # measured: err / bias = 0.98 - 1.3
     if bias > 1e-3:
         assert err >= 0.5 * bias, (err, bias)           # ... and the regulariser really is 1e-3 on the window MEANS
+
+
+# ----------------------------------------------------------------------------- remap: properties of the restated sampler
+# Regression guards on oracle/c/remap.c.  They follow from the restated definitions (1/32-pixel coordinate table,
+# bilinear weights, cubic kernel with A = -0.75); they do not add evidence about OpenCV itself.
+def _grid_locs(h, w, dx, dy):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    return np.stack([xx + np.float32(dx), yy + np.float32(dy)], -1)
+
+
+@pytest.mark.parametrize("method", ["nearest", "linear", "cubic"])
+def test_remap_reproduces_constants_and_integer_shifts(method):
+    rng = np.random.default_rng(3)
+    h, w = 20, 27
+    const = np.full((h, w), 3.25, np.float32)
+    out = np_ops.remap(const, _grid_locs(h, w, 0.37, -0.81), method, np.nan)
+    inner = out[3:-3, 3:-3]
+    assert np.all(np.abs(inner - 3.25) <= 2e-6)              # weights sum to one (float32 rounding of 16 products)
+    img = rng.normal(size=(h, w)).astype(np.float32)
+    out = np_ops.remap(img, _grid_locs(h, w, 2, -1), method, np.nan)
+    assert np.array_equal(out[4:-4, 4:-4], img[3:-5, 6:-2])  # integer coordinates return the pixel itself
+    assert np.isnan(out[0, -1])                              # outside the image: the NaN border value
+    # x = w - 4 samples source column w - 2: inside for nearest / linear, but the 4-wide cubic patch reaches column w,
+    # and a NaN border tap poisons the sum even at weight zero (the NaN rims of the reference's warped fields)
+    assert np.isnan(out[8, w - 4]) == (method == "cubic")
+
+
+def test_remap_linear_is_affine_exact_on_the_32nd_pixel_grid():
+    """cv2.remap interpolates at coordinates rounded to 1/32 pixel: a ramp sampled at x + 0.37 returns
+    x + round(0.37 * 32) / 32 = x + 0.375, not x + 0.37."""
+    h, w = 16, 40
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    ramp = (2 * xx - 3 * yy + 5).astype(np.float32)
+    out = np_ops.remap(ramp, _grid_locs(h, w, 0.37, 0.2), "linear", np.nan)
+    qx, qy = round(0.37 * 32) / 32, round(0.2 * 32) / 32
+    want = 2 * (xx + qx) - 3 * (yy + qy) + 5
+    assert np.abs(out - want)[2:-2, 2:-2].max() <= 1e-5
+    exact = 2 * (xx + 0.37) - 3 * (yy + 0.2) + 5
+    assert np.abs(out - exact)[2:-2, 2:-2].min() > 5e-3      # ... and visibly not the unquantised value
+
+
+def test_remap_cubic_kernel_has_unit_sum_but_no_linear_precision():
+    """A = -0.75 (OpenCV's constant) gives a partition of unity but, unlike Keys' A = -0.5, does not reproduce
+    ramps: at a fraction of 1/4 the first moment is 0.296875.  A sampler that returned x + 0.25 here would be a
+    different kernel."""
+    h, w = 12, 40
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    out = np_ops.remap(xx.copy(), _grid_locs(h, w, 0.25, 0.0), "cubic", np.nan)
+    assert np.abs(out - (xx + 0.296875))[3:-3, 3:-3].max() <= 2e-5
+    half = np_ops.remap(xx.copy(), _grid_locs(h, w, 0.5, 0.0), "cubic", np.nan)
+    assert np.abs(half - (xx + 0.5))[3:-3, 3:-3].max() <= 2e-5   # symmetric at one half
