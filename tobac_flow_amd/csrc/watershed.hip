@@ -191,6 +191,14 @@ __device__ __forceinline__ void ws_flush(WsStage &st, int *__restrict__ qout, in
 }
 
 // ---- phase A: K2 and M1 ------------------------------------------------------------------------
+// Memory-level parallelism.  A queue entry used to walk its out-edges one at a time: neighbour id -> its value
+// and keys -> atomics, about twenty DEPENDENT round trips per entry, and a large sweep ran at the latency of that
+// chain (0.45 ns per entry = a few hundred GB/s).  The edges of one pixel are independent, so they are now handled
+// WS_NB at a time in three waves of independent accesses: all neighbour ids (issued together with the in-queue
+// exchange), then all neighbour values / keys, then all atomics.  Same operations, same decisions on the values the
+// atomics return; the plain reads were already only pre-filters (keys only decrease, a stale value is larger).
+#define WS_NB 8
+
 __global__ void __launch_bounds__(256)
 k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in, int *__restrict__ qout,
              int *__restrict__ cnt_out, int *__restrict__ inq, int qcap)
@@ -204,30 +212,45 @@ k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in,
     for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n_pad; i0 += (int64_t)gridDim.x * 256) {
         const int64_t i = i0 + threadIdx.x;
         const bool act = i < n_in;
-        int p = 0; u64 kp = WS_INF;
-        if (act) {
-            p = qin ? qin[i] : (int)i;
-            // relaxed L2 atomics only: the load below is issued after the exchange has returned
-            const int was = atomicExch(&inq[p], 0);
-            kp = was == 0x7fffffff ? WS_INF : ws_load(&c.K2[p]);
-        }
-        const u64 lp = kp >> 32;
-        for (int s = 0; s < c.n_nbr; s++) {
-            bool enq = false; int n = -1;
-            if (act) {
-                n = c.nbr[(int64_t)p * c.n_nbr + s];
-                if (n >= 0) {
-                    const u64 vn = c.val[n];
-                    const u64 cand = vn > lp ? ((vn << 32) | 1ull) : (vn == lp ? kp + 1ull : kp);
+        const int p = act ? (qin ? qin[i] : (int)i) : 0;
+        const int *np = c.nbr + (int64_t)p * c.n_nbr;
+        u64 kp = WS_INF;
+        for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
+            int n[WS_NB];
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) n[j] = (act && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
+            if (s0 == 0 && act) {
+                // relaxed L2 atomics only: the key is loaded after the exchange has returned (the flag is cleared BEFORE
+                // the key is read, so a later decrease re-queues the pixel); the id loads above are already in flight
+                const int was = atomicExch(&inq[p], 0);
+                kp = was == 0x7fffffff ? WS_INF : ws_load(&c.K2[p]);
+            }
+            const u64 lp = kp >> 32;
+            u64 vn[WS_NB], m1[WS_NB], k2[WS_NB];
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) {
+                const int q = n[j] >= 0 ? n[j] : 0;
+                vn[j] = c.val[q]; m1[j] = c.M1[q]; k2[j] = c.K2[q];
+            }
+            u64 cand[WS_NB], old[WS_NB];
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) {
+                cand[j] = vn[j] > lp ? ((vn[j] << 32) | 1ull) : (vn[j] == lp ? kp + 1ull : kp);
+                old[j] = 0ull;                                             // "no improvement"
+                if (n[j] >= 0) {
                     // keys only decrease, so a (possibly stale, i.e. larger) plain read is a safe pre-filter
-                    if (kp < c.M1[n]) atomicMin(&c.M1[n], kp);
-                    if (cand < c.K2[n]) {
-                        const u64 old = atomicMin(&c.K2[n], cand);
-                        if (cand < old) enq = atomicExch(&inq[n], 1) == 0;
-                    }
+                    if (kp < m1[j]) atomicMin(&c.M1[n[j]], kp);
+                    if (cand[j] < k2[j]) old[j] = atomicMin(&c.K2[n[j]], cand[j]);
                 }
             }
-            ws_stage(st, enq, n);
+            int was_q[WS_NB];                                              // raw returns: consumed only after all are issued
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) {
+                was_q[j] = 1;
+                if (n[j] >= 0 && cand[j] < old[j]) was_q[j] = atomicExch(&inq[n[j]], 1);
+            }
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) ws_stage(st, was_q[j] == 0, n[j]);
         }
         ws_flush(st, qout, cnt_out, qcap);
     }
@@ -251,38 +274,55 @@ k_ws_sweep_chain(WsC c, int k, int depth, const int *__restrict__ qin, const int
     u64 *dst = k == depth ? c.Rt : c.C[k];
     for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n_pad; i0 += (int64_t)gridDim.x * 256) {
         const int64_t i = i0 + threadIdx.x;
-        const bool act = i < n_in;
-        int p = 0; u64 kp = WS_INF, own = WS_INF;
-        if (act) {
-            p = qin ? qin[i] : (int)i;
-            const int was = atomicExch(&inq[p], 0);
-            kp = c.K2[p];                        // final since phase A
-            own = was == 0x7fffffff ? WS_INF : ws_load(&dst[p]);
-        }
-        for (int s = 0; s < c.n_nbr; s++) {
-            bool enq = false; int n = -1;
-            if (act && kp != WS_INF) {
-                n = c.nbr[(int64_t)p * c.n_nbr + s];
-                if (n >= 0 && c.M1[n] == kp) {
-                    const u64 kn = c.K2[n];
-                    const bool entry = (kn >> 32) == (u64)c.val[n] && (kn & 0xFFFFFFFFull) == 1ull;
+        const bool act0 = i < n_in;
+        const int p = act0 ? (qin ? qin[i] : (int)i) : 0;
+        const int *np = c.nbr + (int64_t)p * c.n_nbr;
+        u64 kp = WS_INF, own = WS_INF;
+        u64 cp[WS_MAX_DEPTH];                        // C_j[p], j < k: final since their own phases, read once per entry
+        bool act = false;
+        for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
+            int n[WS_NB];
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) n[j] = (act0 && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
+            if (s0 == 0 && act0) {
+                const int was = atomicExch(&inq[p], 0);
+                kp = c.K2[p];                        // final since phase A
+                own = was == 0x7fffffff ? WS_INF : ws_load(&dst[p]);
+                for (int j = 1; j < k; j++) cp[j] = c.C[j][p];
+                act = kp != WS_INF;
+            }
+            u64 m1[WS_NB], kn[WS_NB], dn[WS_NB]; unsigned vn[WS_NB];
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) {
+                const int q = n[j] >= 0 ? n[j] : 0;
+                m1[j] = c.M1[q]; kn[j] = c.K2[q]; vn[j] = c.val[q]; dn[j] = dst[q];
+            }
+            u64 offered[WS_NB], old[WS_NB];
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) {
+                offered[j] = WS_INF; old[j] = 0ull;
+                if (act && n[j] >= 0 && m1[j] == kp) {
+                    const bool entry = (kn[j] >> 32) == (u64)vn[j] && (kn[j] & 0xFFFFFFFFull) == 1ull;
                     bool match = true;
-                    for (int j = 1; j < k && match; j++) {
-                        const u64 offered_j = entry ? (j == 1 ? kp : c.C[j - 1][p]) : c.C[j][p];
-                        match = offered_j == c.C[j][n];
+                    for (int l = 1; l < k && match; l++) {
+                        const u64 offered_l = entry ? (l == 1 ? kp : cp[l - 1]) : cp[l];
+                        match = offered_l == c.C[l][n[j]];
                     }
                     if (match) {
-                        u64 offered;
-                        if (k == depth) offered = own;                                    // root: copied along every edge
-                        else offered = entry ? (k == 1 ? kp : c.C[k - 1][p]) : own;
-                        if (offered != WS_INF && offered < dst[n]) {
-                            const u64 old = atomicMin(&dst[n], offered);
-                            if (offered < old) enq = atomicExch(&inq[n], 1) == 0;
-                        }
+                        if (k == depth) offered[j] = own;                                 // root: copied along every edge
+                        else offered[j] = entry ? (k == 1 ? kp : cp[k - 1]) : own;
+                        if (offered[j] != WS_INF && offered[j] < dn[j]) old[j] = atomicMin(&dst[n[j]], offered[j]);
                     }
                 }
             }
-            ws_stage(st, enq, n);
+            int was_q[WS_NB];
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) {
+                was_q[j] = 1;
+                if (offered[j] < old[j]) was_q[j] = atomicExch(&inq[n[j]], 1);
+            }
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) ws_stage(st, was_q[j] == 0, n[j]);
         }
         ws_flush(st, qout, cnt_out, qcap);
     }
