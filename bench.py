@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: do not record HIP events around the library's launches in the timed region "
+                         "(roofline = null); the difference to a default run is what the instrumentation costs")
     a = ap.parse_args()
 
     import numpy as np
@@ -131,7 +134,7 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    _lib.profile_enable(True)
+    _lib.profile_enable(not a.no_kernel_events)
     _lib.profile_collect()
     t0 = time.perf_counter()
     for _ in range(a.steps):
