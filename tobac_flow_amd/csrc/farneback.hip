@@ -365,40 +365,55 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 #define FBI_M 6
 #define FBI_WIN (2 * FBI_M + 1)
 #define FBI_OW (256 - 2 * FBI_M)
-#define FBI_HS 128
+#define FBI_HS 512                  // tallest strip; halved until the grid has >= 1536 workgroups
 // R[img] / fin[q] / fout[q] are the pointers of batch item 0; item b adds b * the matching stride
 struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2]; };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
 
+// Addressing: per-thread 64-bit byte offsets from per-item base pointers.  (A variant with wave-uniform bases + 32-bit
+// offsets, the global_load "saddr + voffset" form, saves 7 % of the VALU instructions and runs 12 % SLOWER at 5424^2:
+// measured, not pursued.)
+typedef int64_t fb_off_t;
+
 struct FbIterCtx {
-    const float *R0, *R1, *fin; float *fout;
-    int H, W; int64_t plane; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale;
+    const char *R0, *R0e, *fin; char *fout;                      // R*: float4 plane {y, x, yy, xx};  R*e: float plane {xy}
+    // the four corners of the bilinear gather share ONE per-thread offset: the corner displacement (+1 element,
+    // +1 row, both) is folded into four wave-uniform base pointers
+    const char *R1c[4], *R1ec[4];
+    int H, W; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale;
 };
 
 struct FbTaps { float4 q0, c00, c01, c10, c11; float2 e0, e1; float q04, dx, dy; };
 
+template <typename T, typename OFF>
+__device__ __forceinline__ T fb_ld(const char *base, OFF byte_off) { return *(const T *)(base + byte_off); }
+
 __device__ __forceinline__ float2 fb_iter_flow_at(const FbIterCtx &c, int s)
 {
-    return ((const float2 *)c.fin)[(int64_t)tf_clampi(s, 0, c.H - 1) * c.W + c.xc];
+    typedef fb_off_t off_t;
+    const off_t o = (off_t)tf_clampi(s, 0, c.H - 1) * (off_t)c.W + (off_t)c.xc;
+    return fb_ld<float2>(c.fin, o * 8);
 }
 
 // issue every load of one M evaluation (same arithmetic as fb_matrix_at, branch-free)
 __device__ __forceinline__ void fb_taps_load(const FbIterCtx &c, int s, float2 fl, FbTaps &t)
 {
+    typedef fb_off_t off_t;
     const int y = tf_clampi(s, 0, c.H - 1);
-    const int64_t o = (int64_t)y * c.W + c.xc;
+    const off_t o = (off_t)y * (off_t)c.W + (off_t)c.xc;
     t.dx = fl.x; t.dy = fl.y;
     const float fx = c.xc + t.dx, fy = y + t.dy;
     const int x1 = tf_cvfloor(fx), y1 = tf_cvfloor(fy);
     const bool inb = (unsigned)x1 < (unsigned)(c.W - 1) && (unsigned)y1 < (unsigned)(c.H - 1);
-    const int64_t q = inb ? (int64_t)y1 * c.W + x1 : 0;
-    const int sx = inb ? 1 : 0, sy = inb ? c.W : 0;                   // dummy taps all read element 0
-    const float4 *P4 = (const float4 *)c.R1 + q;
-    const float *P1 = c.R1 + 4 * c.plane + q;
-    t.q0 = ((const float4 *)c.R0)[o];
-    t.q04 = c.R0[4 * c.plane + o];
-    t.c00 = P4[0]; t.c01 = P4[sx]; t.c10 = P4[sy]; t.c11 = P4[sy + sx];
-    t.e0.x = P1[0]; t.e0.y = P1[sx]; t.e1.x = P1[sy]; t.e1.y = P1[sy + sx];
+    // out of the image: the patch at element 0 is read instead (always valid, see the base pointers) and discarded
+    const off_t q = inb ? (off_t)y1 * (off_t)c.W + (off_t)x1 : (off_t)0;
+    const off_t q16 = q * 16, q4 = q * 4;
+    t.q0 = fb_ld<float4>(c.R0, o * 16);
+    t.q04 = fb_ld<float>(c.R0e, o * 4);
+    t.c00 = fb_ld<float4>(c.R1c[0], q16); t.c01 = fb_ld<float4>(c.R1c[1], q16);
+    t.c10 = fb_ld<float4>(c.R1c[2], q16); t.c11 = fb_ld<float4>(c.R1c[3], q16);
+    t.e0.x = fb_ld<float>(c.R1ec[0], q4); t.e0.y = fb_ld<float>(c.R1ec[1], q4);
+    t.e1.x = fb_ld<float>(c.R1ec[2], q4); t.e1.y = fb_ld<float>(c.R1ec[3], q4);
 }
 
 __device__ __forceinline__ void fb_taps_eval(const FbIterCtx &c, int s, const FbTaps &t, float (&m)[5])
@@ -446,6 +461,7 @@ __device__ __forceinline__ void fb_taps_eval(const FbIterCtx &c, int s, const Fb
 // four 2x2 solves.  The four windows share the ten middle terms.
 __device__ __forceinline__ void fb_iter_quad(const FbIterCtx &c, int yo, int g, int q, const double *vrow)
 {
+    typedef fb_off_t off_t;
     const int x0 = c.x_strip + 4 * q;
     if (yo < c.y0 || yo >= c.y1 || x0 >= c.W) return;
     const double *base = vrow + (g * 5) * FBI_VS + 5 * q;
@@ -455,7 +471,7 @@ __device__ __forceinline__ void fb_iter_quad(const FbIterCtx &c, int yo, int g, 
         double v[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = base[ch * FBI_VS + k + (k >> 2)];
-        // balanced tree over the ten shared terms (short dependency chains: two waves per SIMD do not hide a serial sum)
+        // balanced tree over the ten shared terms
         const double T = (((v[3] + v[4]) + (v[5] + v[6])) + ((v[7] + v[8]) + (v[9] + v[10]))) + (v[11] + v[12]);
         const double lo = v[1] + v[2], hi = v[13] + v[14];
         sum[ch][0] = v[0] + lo + T;
@@ -463,7 +479,7 @@ __device__ __forceinline__ void fb_iter_quad(const FbIterCtx &c, int yo, int g, 
         sum[ch][2] = v[2] + T + hi;
         sum[ch][3] = T + hi + v[15];
     }
-    float2 *out = (float2 *)c.fout + (int64_t)yo * c.W + x0;
+    float2 *out = (float2 *)(c.fout + ((off_t)yo * (off_t)c.W + (off_t)x0) * 8);
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const double g11 = sum[0][u], g12 = sum[1][u], g22 = sum[2][u], h1 = sum[3][u], h2 = sum[4][u];
@@ -479,10 +495,15 @@ __device__ __forceinline__ void fb_iter_quad(const FbIterCtx &c, int yo, int g, 
     }
 }
 
-// non-pipelined variant: NB rows at a time, flows of the next group fetched before the barrier
+// one group of G consecutive window rows s0 .. s0+G-1 with STATIC ring slots K0 .. K0+G-1:
+//   1. evaluate M for NB rows at a time (their loads in flight together), slide the 13-row column sums,
+//      park them in LDS,
+//   2. fetch the flow of the next group's GN rows,
+//   3. one barrier, then the horizontal phase: thread t takes (row t / 61, quad t % 61).
+// ABL 1 (development aid, env TF_FBI_ABLATE=1): synthetic M instead of the gathers.
 template <int K0, int G, int GN, int NB, int ABL>
-__device__ __forceinline__ void fb_iter_group_np(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
-                                                 float2 (&fl)[FBI_G], double *vrow)
+__device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
+                                              float2 (&fl)[FBI_G], double *vrow)
 {
 #pragma unroll
     for (int g0 = 0; g0 < G; g0 += NB) {
@@ -496,12 +517,6 @@ __device__ __forceinline__ void fb_iter_group_np(const FbIterCtx &c, int s0, flo
             if (g0 + r < G) {
                 const int g = g0 + r, s = s0 + g;
                 if (ABL == 1) { m[r][0] = (float)s; m[r][1] = (float)c.xc; m[r][2] = 1.f; m[r][3] = 2.f; m[r][4] = (float)(s + c.xc); }
-                else if (ABL == 3) {
-                    const FbTaps &q = t[r];
-                    m[r][0] = q.q0.x + q.c00.x + q.c01.x + q.c10.x + q.c11.x; m[r][1] = q.q0.y + q.c00.y + q.c01.y + q.c10.y + q.c11.y;
-                    m[r][2] = q.q0.z + q.c00.z + q.c01.z + q.c10.z + q.c11.z; m[r][3] = q.q0.w + q.c00.w + q.c01.w + q.c10.w + q.c11.w;
-                    m[r][4] = q.q04 + q.e0.x + q.e0.y + q.e1.x + q.e1.y;
-                }
                 else fb_taps_eval(c, s, t[r], m[r]);
 #pragma unroll
                 for (int ch = 0; ch < 5; ch++) {
@@ -515,74 +530,15 @@ __device__ __forceinline__ void fb_iter_group_np(const FbIterCtx &c, int s0, flo
         for (int g = 0; g < GN; g++) fl[g] = fb_iter_flow_at(c, s0 + G + g);
     }
     __syncthreads();
-    if (ABL == 2 || ABL == 3) {
-        // no horizontal phase: every thread stores its own column sums
-        const int yo = s0 + G - 1 - FBI_M, xo = c.x_strip + c.j - FBI_M;
-        if (yo >= c.y0 && yo < c.y1 && c.j >= FBI_M && c.j < 256 - FBI_M && xo < c.W)
-            ((float2 *)c.fout)[(int64_t)yo * c.W + xo] = make_float2((float)(S[0] + S[1] + S[2]), (float)(S[3] + S[4]));
-    } else {
-        if (c.j < G * FBI_Q) fb_iter_quad(c, s0 + c.tg - FBI_M, c.tg, c.tq, vrow);
-        if (G * FBI_Q > 256 && c.j < G * FBI_Q - 256) fb_iter_quad(c, s0 + 4 - FBI_M, 4, c.j + 256 - 4 * FBI_Q, vrow);
-    }
-    __syncthreads();
-}
-
-// one group of G consecutive window rows s0 .. s0+G-1 with STATIC ring slots K0 .. K0+G-1, software
-// pipelined in batches of NB rows: the loads of batch i+1 are issued before batch i is evaluated, and the
-// first batch of the NEXT group is issued before this group's last batch is evaluated, so it is in flight
-// across the barriers and the horizontal phase.
-//   on entry : T[P] holds the taps of rows [0, NB) of this group, fl the flows of its rows;
-//   on exit  : T[P ^ (nbatch & 1)] holds the first batch of the next group, fl the next group's flows.
-template <int K0, int G, int GN, int NB, int P, int ABL>
-__device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
-                                              float2 (&fl)[FBI_G], FbTaps (&T)[2][NB], double *vrow)
-{
-    constexpr int nbatch = (G + NB - 1) / NB;
-    float2 fln[FBI_G];
-#pragma unroll
-    for (int bi = 0; bi < nbatch; bi++) {
-        const int cur = (P + bi) & 1, nxt = cur ^ 1;
-        if (ABL != 1) {
-            if (bi + 1 < nbatch) {
-#pragma unroll
-                for (int r = 0; r < NB; r++)
-                    if ((bi + 1) * NB + r < G) fb_taps_load(c, s0 + (bi + 1) * NB + r, fl[(bi + 1) * NB + r], T[nxt][r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < NB; r++) fb_taps_load(c, s0 + G + r, fln[r], T[nxt][r]);
-            }
-            if (bi == 0) {
-#pragma unroll
-                for (int g = 0; g < GN; g++) fln[g] = fb_iter_flow_at(c, s0 + G + g);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NB; r++)
-            if (bi * NB + r < G) {
-                const int g = bi * NB + r, s = s0 + g;
-                float m[5];
-                if (ABL != 1) fb_taps_eval(c, s, T[cur][r], m);
-                else { m[0] = (float)s; m[1] = (float)c.xc; m[2] = 1.f; m[3] = 2.f; m[4] = (float)(s + c.xc); }
-#pragma unroll
-                for (int ch = 0; ch < 5; ch++) {
-                    S[ch] += (double)(m[ch] - ring[K0 + g][ch]); ring[K0 + g][ch] = m[ch];
-                    vrow[(g * 5 + ch) * FBI_VS + c.dj] = S[ch];
-                }
-            }
-    }
-#pragma unroll
-    for (int g = 0; g < FBI_G; g++) fl[g] = fln[g];
-    __syncthreads();
     if (c.j < G * FBI_Q) fb_iter_quad(c, s0 + c.tg - FBI_M, c.tg, c.tq, vrow);
     if (G * FBI_Q > 256 && c.j < G * FBI_Q - 256) fb_iter_quad(c, s0 + 4 - FBI_M, 4, c.j + 256 - 4 * FBI_Q, vrow);
     __syncthreads();
 }
 
-template <int NB, int PIPE, int ABL>
+template <int NB, int ABL>
 __global__ void __launch_bounds__(256)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
 {
-    static_assert(NB == 2 || !PIPE, "group sizes 4 + 4 + 5 are pipelined in batches of two rows");
     __shared__ double vrow[FBI_G * 5 * FBI_VS];
     // Work-item order.  Both directions of one strip read the same two R images (each is the other's gather
     // target), so they are placed on the SAME XCD (block ids that differ by 8 share an XCD under the observed
@@ -597,9 +553,21 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
     const int b = blockIdx.z;
     const int d = a.dir[q];                                            // 0: prev -> next, 1: next -> prev
     FbIterCtx c;
-    c.R0 = a.R[d] + b * a.bs_R; c.R1 = a.R[1 - d] + b * a.bs_R;
-    c.fin = a.fin[q] + b * a.bs_fin[q]; c.fout = a.fout[q] + b * a.bs_fout[q];
-    c.H = H; c.W = W; c.plane = plane;
+    const float *R0 = a.R[d] + b * a.bs_R, *R1 = a.R[1 - d] + b * a.bs_R;
+    c.R0 = (const char *)R0; c.R0e = (const char *)(R0 + 4 * plane);
+    {
+        // corner displacements in elements; a level narrower / shorter than two pixels has no in-image patch at all
+        // (inb is never true): all four corners then alias element 0 so that the discarded reads stay in bounds
+        const bool patch = W >= 2 && H >= 2;
+        const int64_t dcorner[4] = {0, patch ? 1 : 0, patch ? W : 0, patch ? (int64_t)W + 1 : 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c.R1c[k] = (const char *)R1 + dcorner[k] * 16;
+            c.R1ec[k] = (const char *)(R1 + 4 * plane) + dcorner[k] * 4;
+        }
+    }
+    c.fin = (const char *)(a.fin[q] + b * a.bs_fin[q]); c.fout = (char *)(a.fout[q] + b * a.bs_fout[q]);
+    c.H = H; c.W = W;
     c.j = threadIdx.x;
     c.dj = c.j + (c.j >> 2);
     c.tg = c.j / FBI_Q; c.tq = c.j - c.tg * FBI_Q;
@@ -623,26 +591,11 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
     const int s_first = c.y0 - FBI_M, s_last = c.y1 - 1 + FBI_M;       // window rows needed (inclusive)
 #pragma unroll
     for (int g = 0; g < FBI_G; g++) fl[g] = (ABL != 1) ? fb_iter_flow_at(c, s_first + g) : make_float2(0.f, 0.f);
-    if (!PIPE) {
-        for (int base = s_first; base <= s_last; base += FBI_WIN) {
-            fb_iter_group_np<0, 4, 4, NB, ABL>(c, base, ring, S, fl, vrow);
-            fb_iter_group_np<4, 4, 5, NB, ABL>(c, base + 4, ring, S, fl, vrow);
-            fb_iter_group_np<8, 5, 4, NB, ABL>(c, base + 8, ring, S, fl, vrow);
-        }
-        return;
-    }
-    FbTaps T[2][NB];
-    if (ABL != 1) {
-#pragma unroll
-        for (int r = 0; r < NB; r++) fb_taps_load(c, s_first + r, fl[r], T[0][r]);
-    }
     // rows past s_last are evaluated (clamped, harmless) but never produce output
     for (int base = s_first; base <= s_last; base += FBI_WIN) {
-        fb_iter_group<0, 4, 4, NB, 0, ABL>(c, base, ring, S, fl, T, vrow);          // 2 batches: parity kept
-        fb_iter_group<4, 4, 5, NB, 0, ABL>(c, base + 4, ring, S, fl, T, vrow);
-        fb_iter_group<8, 5, 4, NB, 0, ABL>(c, base + 8, ring, S, fl, T, vrow);      // 3 batches: next batch in T[1]
-#pragma unroll
-        for (int r = 0; r < NB; r++) T[0][r] = T[1][r];
+        fb_iter_group<0, 4, 4, NB, ABL>(c, base, ring, S, fl, vrow);
+        fb_iter_group<4, 4, 5, NB, ABL>(c, base + 4, ring, S, fl, vrow);
+        fb_iter_group<8, 5, 4, NB, ABL>(c, base + 8, ring, S, fl, vrow);
     }
 }
 
@@ -905,14 +858,8 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 {
                     TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd * B, s);
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
-                    static const int nb = getenv("TF_FBI_NB") ? atoi(getenv("TF_FBI_NB")) : 4;
-                    static const int pipe = getenv("TF_FBI_PIPE") ? atoi(getenv("TF_FBI_PIPE")) : 0;
-                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<4, 0, 1>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<4, 0, 2>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else if (abl == 3) hipLaunchKernelGGL((k_fb_iter<4, 0, 3>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else if (pipe) hipLaunchKernelGGL((k_fb_iter<2, 1, 0>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else if (nb == 2) hipLaunchKernelGGL((k_fb_iter<2, 0, 0>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else hipLaunchKernelGGL((k_fb_iter<4, 0, 0>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<4, 1>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    else hipLaunchKernelGGL((k_fb_iter<4, 0>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
                 }
                 for (int q = 0; q < nd; q++) cur[dirs[q]] = 1 - cur[dirs[q]];
             }
