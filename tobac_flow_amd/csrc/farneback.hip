@@ -535,8 +535,12 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float 
     __syncthreads();
 }
 
+// Occupancy is two waves per SIMD by construction (65 ring registers + the 72 of the horizontal phase; 64 KB of LDS):
+// the launch bound says so, which lets the compiler schedule for the 256-register budget (5 % faster than the
+// default bound).  Forcing three waves spills the ring (+70 %); row groups 4 + 4 + 4 + 1 with 51 KB of LDS cost
+// 2 % for the extra barrier pair and gain nothing while the registers hold the kernel at two waves.
 template <int NB, int ABL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
 {
     __shared__ double vrow[FBI_G * 5 * FBI_VS];
