@@ -97,6 +97,26 @@ def test_farneback_odd_sizes_match_oracle(tf, shape):
     assert np.max(np.abs(bk - _oracle_farneback(b, a))) <= 1e-4
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (7, 1), (2, 2), (3, 5), (13, 13), (5, 40), (40, 6), (40, 9), (9, 40),
+                                   (7, 8), (9, 9), (40, 11), (12, 300), (300, 12)])
+def test_farneback_tiny_and_degenerate_images_match_oracle(tf, shape):
+    """Images smaller than the 13 x 13 window, than the expansion radius, and one pixel wide / tall (no bilinear patch
+    exists: every gather takes the out-of-image branch).  Below 10 pixels OpenCV's border attenuation test
+    (unsigned)(x - 5) >= (unsigned)(W - 10) wraps around and skips some border columns / rows: the widths and heights
+    6 ... 11 pin that behaviour (a kernel that scaled every border column was 1.4 px off here)."""
+    from test_gpu_parity import _oracle_farneback
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    big = ndi.gaussian_filter(rng.normal(size=(shape[0] + 8, shape[1] + 8)), 1.5)
+    big = ((big - big.min()) / (np.ptp(big) + 1e-9) * 255).astype(np.uint8)
+    a = np.ascontiguousarray(big[4:4 + shape[0], 4:4 + shape[1]])
+    b = np.ascontiguousarray(big[3:3 + shape[0], 5:5 + shape[1]])           # shifted by (1, -1)
+    f, bk = tf.calculate_flow_frame(a, b, tf.select_of_model("Farneback"))
+    want_f, want_b = _oracle_farneback(a, b), _oracle_farneback(b, a)
+    assert f.shape == shape + (2,) and np.isfinite(f).all() and np.isfinite(bk).all()
+    assert np.max(np.abs(f - want_f)) <= 1e-4 * max(1.0, np.abs(want_f).max())
+    assert np.max(np.abs(bk - want_b)) <= 1e-4 * max(1.0, np.abs(want_b).max())
+
+
 def test_create_flow_short_series(tf):
     rng = np.random.default_rng(1)
     two = rng.normal(size=(2, 40, 48)).astype(np.float32)

@@ -380,7 +380,7 @@ struct FbIterCtx {
     // the four corners of the bilinear gather share ONE per-thread offset: the corner displacement (+1 element,
     // +1 row, both) is folded into four wave-uniform base pointers
     const char *R1c[4], *R1ec[4];
-    int H, W; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale;
+    int H, W; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale; bool xborder;
 };
 
 struct FbTaps { float4 q0, c00, c01, c10, c11; float2 e0, e1; float q04, dx, dy; };
@@ -440,10 +440,14 @@ __device__ __forceinline__ void fb_taps_eval(const FbIterCtx &c, int s, const Fb
     r3 = (t.q0.y - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
-    // border attenuation: (x factor, fixed per thread) * y factors (uniform), == 1 in the interior
-    const float b0 = y == 0 ? 0.14f : (y == 1 ? 0.14f : 0.4472f), yb = c.H - 1 - y;
+    // border attenuation: (x factors, fixed per thread) * (y factors, uniform).  It is applied under OpenCV's own
+    // test, (unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10), whose unsigned
+    // wrap-around leaves some border columns / rows of images narrower than 10 pixels UNscaled: reproduced as is
+    const int yb = c.H - 1 - y;
+    const float b0 = y == 0 ? 0.14f : (y == 1 ? 0.14f : 0.4472f);
     const float b1 = yb == 0 ? 0.14f : (yb == 1 ? 0.14f : 0.4472f);
-    const float scale = c.xscale * (y < 5 ? b0 : 1.f) * (yb < 5 ? b1 : 1.f);
+    const bool in_border = c.xborder || (unsigned)(y - 5) >= (unsigned)(c.H - 10);
+    const float scale = in_border ? c.xscale * (y < 5 ? b0 : 1.f) * (yb < 5 ? b1 : 1.f) : 1.f;
     r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     m[0] = r4 * r4 + r6 * r6;
     m[1] = (r4 + r5) * r6;
@@ -586,6 +590,7 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
 #pragma unroll
         for (int k = 0; k < 5; k++) { lo = c.xc == k ? border[k] : lo; hi = xb == k ? border[k] : hi; }
         c.xscale = lo * hi;
+        c.xborder = (unsigned)(c.xc - 5) >= (unsigned)(W - 10);
     }
     float ring[FBI_WIN][5];
 #pragma unroll
