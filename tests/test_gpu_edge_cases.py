@@ -208,3 +208,20 @@ def test_watershed_ex_rejects_unknown_flags_and_chain_depth_one_ignores_the_hint
     depth1 = watershed_dev(fl, fl, f, m, None, nbr, 1, st1, expect_conflict=True).cpu().numpy()
     assert st1["sweeps"][1] > 0 and st1["sweeps"][5] == 0        # root phase ran, nothing skipped
     assert np.array_equal(depth1[m.cpu().numpy() != 0], m.cpu().numpy()[m.cpu().numpy() != 0])
+
+
+def test_apply_global_lut_gpu_equals_host_path_and_keeps_negative_ids():
+    """The relabelling step of the multi-GPU stitch (parallel.apply_global_lut): the library's one-pass gather on the GPU
+    must equal the torch implementation the gloo rehearsals use, including zero and negative ids."""
+    import torch
+    from tobac_flow_amd.parallel import apply_global_lut
+    rng = np.random.default_rng(12)
+    labels = rng.integers(-3, 40, size=(3, 33, 41)).astype(np.int32)
+    lut = np.concatenate([[0], rng.permutation(np.arange(1, 40))]).astype(np.int64)
+    want = apply_global_lut(torch.from_numpy(labels), lut).numpy()
+    got = apply_global_lut(torch.from_numpy(labels).cuda(), lut).cpu().numpy()
+    assert got.dtype == np.int32 and np.array_equal(got, want)
+    assert np.array_equal(got[labels <= 0], labels[labels <= 0]) and (labels < 0).any()
+    nonneg = np.abs(labels)
+    assert np.array_equal(apply_global_lut(torch.from_numpy(nonneg).cuda(), lut).cpu().numpy(),
+                          apply_global_lut(torch.from_numpy(nonneg), lut).numpy())

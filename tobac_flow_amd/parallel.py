@@ -107,8 +107,27 @@ def stitch_labels(labels, group=None, min_overlap=1):
     dist.all_gather(gathered, padded, group=group)
     pairs = [gathered[r][:n_all[r]].cpu().numpy() for r in range(world - 1)]
     lut = stitch_lut(counts, pairs)[rank]
-    lut_t = torch.from_numpy(lut.astype(np.int32)).to(dev)
-    pos = labels > 0
-    out = labels.clone()
-    out[pos] = lut_t[labels[pos].to(torch.int64)]
+    return apply_global_lut(labels, lut)
+
+
+def apply_global_lut(labels, lut):
+    """labels -> lut[labels] for the positive ids, zero and negative ids kept.  GPU tensors go through the library's
+    one-pass gather (tf_apply_lut: 4 B read + 4 B written per voxel; a boolean-mask update in torch would compact and
+    scatter several GB of int64 temporaries for a 12 x 5424^2 window); CPU tensors (gloo rehearsals) use torch."""
+    import torch
+    lut = np.asarray(lut)
+    if not labels.is_cuda:
+        lut_t = torch.from_numpy(lut.astype(np.int32))
+        pos = labels > 0
+        out = labels.clone()
+        out[pos] = lut_t[labels[pos].to(torch.int64)]
+        return out
+    from tobac_flow_amd import _lib
+    lab = labels.to(torch.int32).contiguous()
+    lut_t = torch.from_numpy(np.ascontiguousarray(lut, np.int32)).to(lab.device)
+    out = torch.empty_like(lab)
+    _lib.check(_lib.lib().tf_apply_lut(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut_t.numel(), _lib.ptr(out),
+                                       _lib.stream_ptr()), "tf_apply_lut")
+    if bool((lab.min() < 0).item()):                 # tf_apply_lut maps ids outside the table to 0: put negatives back
+        out = torch.where(lab < 0, lab, out)
     return out
