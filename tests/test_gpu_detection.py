@@ -367,3 +367,47 @@ def test_detect_growth_markers_without_survivors_behaves_like_the_reference(scen
         assert outcome[0][1] is outcome[1][1] is ValueError
     else:
         assert np.array_equal(outcome[0][1], outcome[1][1]) and outcome[0][1].max() == 0
+
+
+def test_peak_local_max_2d_on_device_equals_scikit_image_goldens():
+    """GPU candidate mask + shared selection against scikit-image 0.18.3's own output (tests/golden/peak_local_max_skimage.npz)"""
+    import os
+    import torch
+    from tobac_flow_amd import ndimage_dev as nd
+    from tobac_flow_amd.utils.peak_utils import peak_local_max
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "peak_local_max_skimage.npz"))
+    n = 0
+    for name in z["names"]:
+        img = z[f"{name}/image"]
+        for d in (1, 3, 10):
+            got = nd.peak_local_max_2d(torch.from_numpy(img).cuda(), d).reshape(-1, 2)
+            host = np.asarray(peak_local_max(img, min_distance=d)).reshape(-1, 2)
+            assert np.array_equal(got, host), f"{name} d={d}: device differs from the host function"
+            if str(name) != "quantised":                      # tie order depends on the numpy version (see test_host_logic)
+                assert np.array_equal(got, z[f"{name}/peaks_d{d}"]), f"{name} d={d}: differs from scikit-image"
+            n += len(got)
+    assert n > 4000
+
+
+@pytest.mark.parametrize("direction", ["negative", "positive"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_peak_filter_device_path_equals_host_path(scene, direction, dtype):
+    """get_peak_filter (detection.py:149-168) on a device tensor against the numpy / SciPy path, including a frame with a
+    NaN (numpy's min makes the threshold NaN: no peak at all) and a constant frame; a peak-free frame gets the corner
+    SciPy's distance transform produces when there is no background."""
+    import torch
+    from tobac_flow_amd.detection import get_peak_filter
+    field = (-scene["bt"]).astype(dtype).copy()
+    field[2, 30, 40] = np.nan
+    field[4] = 1.5
+    for sigma in (2, 0.5):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = get_peak_filter(field, sigma=sigma, direction=direction)
+        got = get_peak_filter(torch.from_numpy(field).cuda(), sigma=sigma, direction=direction)
+        assert isinstance(got, torch.Tensor) and _same(got.cpu().numpy(), want)
+        corner = np.zeros(field.shape[1:], bool)
+        yy, xx = np.mgrid[0:field.shape[1], 0:field.shape[2]]
+        corner[(yy + 1) ** 2 + xx ** 2 < 25] = True
+        assert np.array_equal(want[2].astype(bool), corner) and np.array_equal(want[4].astype(bool), corner)
+        assert want[0].sum() > corner.sum()                    # ordinary frames do have peaks

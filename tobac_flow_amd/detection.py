@@ -192,8 +192,17 @@ def get_peak_filter(field, sigma=2, min_distance=10, direction="negative"):
     like the reference, peak_local_max is always called with min_distance=10)."""
     if direction not in ("negative", "positive"):
         raise ValueError("Direction must be either positive or negative")
-    smooth = ndi.gaussian_filter(field, (0, sigma, sigma))
     sign = 1 if direction == "negative" else -1
+    if isinstance(field, _lib.torch().Tensor):       # device-resident: only the candidate peaks visit the host
+        from tobac_flow_amd import ndimage_dev as nd
+        t = _lib.torch()
+        smooth = nd.gaussian_filter(field, (0, sigma, sigma))
+        out = t.zeros(field.shape, dtype=t.int32, device=field.device)
+        for i in range(field.shape[0]):
+            locs = nd.peak_local_max_2d(sign * smooth[i], min_distance=10)
+            out[i] = nd.within_distance(locs, tuple(field.shape[1:]), 5, field.device).to(t.int32)
+        return out
+    smooth = ndi.gaussian_filter(field, (0, sigma, sigma))
     out = np.zeros(field.shape, dtype=np.int32)
     for i in range(field.shape[0]):
         locs = peak_local_max(sign * smooth[i], min_distance=10).T

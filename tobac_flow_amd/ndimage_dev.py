@@ -218,3 +218,70 @@ def binary_fill_holes(x, structure):
     _lib.check(_lib.lib().tf_apply_lut(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut.size, _lib.ptr(reached),
                                        _lib.stream_ptr()), "tf_apply_lut")
     return ~(reached != 0)
+
+
+def peak_local_max_2d(image, min_distance=1):
+    """skimage.feature.peak_local_max(image2d, min_distance=d) (scikit-image 0.18, every other argument at its default)
+    for a 2-D float device tensor; returns the (n, 2) int64 numpy array utils.peak_utils.peak_local_max returns.
+    The candidate mask (separable maximum filter, threshold = image minimum, border exclusion) is built on the GPU;
+    the few candidates go to the host, where the SAME selection code as the host function orders and thins them."""
+    import torch.nn.functional as F
+    from tobac_flow_amd.utils.peak_utils import select_peaks
+    t = _lib.torch()
+    _float_type(image)
+    if image.dim() != 2:
+        raise ValueError("peak_local_max_2d: a 2-D tensor is required")
+    d = int(min_distance)
+    H, W = image.shape
+    threshold = image.min()                                   # NaN anywhere -> NaN threshold -> no peak, as in numpy
+    size = 2 * d + 1
+    if size == 1 or image.numel() == 1:
+        mask = image > threshold
+    else:
+        # maximum_filter(footprint = ones, mode = 'constant', cval = 0): zero padding, then max over the window
+        padded = F.pad(image[None, None], (d, d, d, d), mode="constant", value=0.0)
+        mx = F.max_pool2d(F.max_pool2d(padded, kernel_size=(1, size), stride=1), kernel_size=(size, 1), stride=1)[0, 0]
+        mask = image == mx
+        if bool(mask.all().item()):
+            mask = t.zeros_like(mask)
+        mask = mask & (image > threshold)
+    if d:
+        mask = mask.clone()
+        mask[:d] = False
+        mask[-d:] = False
+        mask[:, :d] = False
+        mask[:, -d:] = False
+    coords = t.nonzero(mask)                                  # row-major, like np.nonzero
+    vals = image[coords[:, 0], coords[:, 1]] if coords.shape[0] else image.new_zeros(0)
+    return select_peaks(coords.cpu().numpy(), vals.cpu().numpy(), d)
+
+
+_DISC_CACHE = {}
+
+
+def within_distance(points, shape, radius, device):
+    """scipy.ndimage.distance_transform_edt(~peaks) < radius for a 2-D frame whose only non-zero pixels are `points`
+    ((n, 2) int array): squared distances are integers, so this is the union of the discs dy^2 + dx^2 < radius^2.
+    A frame WITHOUT any point has no background for the transform; SciPy (1.7 and 1.15 alike) then returns
+    sqrt((y + 1)^2 + x^2), i.e. the test marks a small corner at the origin -- reproduced as is."""
+    t = _lib.torch()
+    H, W = shape
+    r2 = float(radius) ** 2
+    out = t.zeros((H, W), dtype=t.bool, device=device)
+    pts = np.asarray(points, np.int64).reshape(-1, 2)
+    if len(pts) == 0:
+        yy = t.arange(H, device=device)[:, None] + 1
+        xx = t.arange(W, device=device)[None, :]
+        return (yy * yy + xx * xx).to(t.float64) < r2
+    key = float(radius)
+    if key not in _DISC_CACHE:
+        k = int(np.ceil(radius))
+        dy, dx = np.mgrid[-k:k + 1, -k:k + 1]
+        keep = (dy * dy + dx * dx) < r2
+        _DISC_CACHE[key] = np.stack([dy[keep], dx[keep]], 1).astype(np.int64)
+    offs = _DISC_CACHE[key]
+    cells = (pts[:, None, :] + offs[None, :, :]).reshape(-1, 2)
+    ok = (cells[:, 0] >= 0) & (cells[:, 0] < H) & (cells[:, 1] >= 0) & (cells[:, 1] < W)
+    cells = t.from_numpy(cells[ok]).to(device)
+    out[cells[:, 0], cells[:, 1]] = True
+    return out

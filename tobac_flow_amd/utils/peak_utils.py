@@ -31,9 +31,16 @@ def peak_local_max(image, min_distance=1, threshold_abs=None, threshold_rel=None
             sl[ax] = slice(-border, None)
             mask[tuple(sl)] = False
     coords = np.transpose(np.nonzero(mask))
+    return select_peaks(coords, image[tuple(coords.T)], min_distance, num_peaks)
+
+
+def select_peaks(coords, intensities, min_distance, num_peaks=np.inf):
+    """Second half of peak_local_max (scikit-image 0.18 `_get_high_intensity_peaks` + `ensure_spacing`): candidates
+    in C order with their intensities -> highest first, greedily dropping anything closer than min_distance."""
+    coords = np.asarray(coords)
     if len(coords) == 0:
         return coords
-    coords = coords[np.argsort(-image[tuple(coords.T)])]
+    coords = coords[np.argsort(-np.asarray(intensities))]
     keep, kept = np.ones(len(coords), bool), []
     for i, c in enumerate(coords):            # highest first; drop anything closer than min_distance (Chebyshev)
         if kept and np.min(np.max(np.abs(np.array(kept) - c), axis=1)) < min_distance:
@@ -44,4 +51,4 @@ def peak_local_max(image, min_distance=1, threshold_abs=None, threshold_rel=None
     return coords[:int(num_peaks)] if len(coords) > num_peaks else coords
 
 
-__all__ = ("peak_local_max",)
+__all__ = ("peak_local_max", "select_peaks")
