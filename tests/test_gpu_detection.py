@@ -411,3 +411,22 @@ def test_peak_filter_device_path_equals_host_path(scene, direction, dtype):
         corner[(yy + 1) ** 2 + xx ** 2 < 25] = True
         assert np.array_equal(want[2].astype(bool), corner) and np.array_equal(want[4].astype(bool), corner)
         assert want[0].sum() > corner.sum()                    # ordinary frames do have peaks
+
+
+@pytest.mark.parametrize("use_wvd", [True, False])
+def test_combined_filters_device_resident_equals_host_recipe(scene, use_wvd):
+    """get_combined_filters (detection.py:301-354) with GPU tensors: curvature + peak filters, semi-Lagrangian `any`
+    over t+-1, fill holes, opening, SWD ramp -- nothing but the candidate peaks leaves HBM."""
+    import torch
+    from tobac_flow_amd.detection import get_combined_filters
+    bt = scene["bt"].astype(np.float32)
+    wvd = ((250.0 - bt) / 8 - 6).astype(np.float32)
+    swd = ((bt - 214.0) / 8).astype(np.float32)                     # spans the 2.5 ... 7.5 ramp
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = get_combined_filters(scene["flow"], bt, wvd, swd, use_wvd=use_wvd)
+    got = get_combined_filters(scene["flow"], torch.from_numpy(bt).cuda(), torch.from_numpy(wvd).cuda(),
+                               torch.from_numpy(swd).cuda(), use_wvd=use_wvd)
+    assert isinstance(got, torch.Tensor) and _same(got.cpu().numpy(), np.asarray(want))
+    frac = (np.asarray(want) > 0).mean()
+    assert 0.01 < frac < 0.9 and len(np.unique(np.asarray(want))) > 10   # a non-trivial, graded filter

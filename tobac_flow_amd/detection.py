@@ -248,6 +248,21 @@ def get_combined_filters(flow, bt, wvd, swd, use_wvd=True):
     t_struct = np.zeros([3, 3, 3], dtype=bool)
     t_struct[:, 1, 1] = True
     s = _plane_struct()
+    if isinstance(bt, _lib.torch().Tensor):          # device-resident recipe (same operators, same dtypes)
+        from tobac_flow_amd import ndimage_dev as nd
+        t = _lib.torch()
+
+        def channel_dev(field, direction):
+            seed = (get_curvature_filter(field, direction=direction)
+                    | (get_peak_filter(field, sigma=0.5, direction=direction) != 0)).to(t.int32)
+            return flow.convolve(seed, structure=t_struct, method="nearest", fill_value=False, dtype=np.int32,
+                                 func=partial(np.any, axis=0))
+
+        combined = channel_dev(bt, "positive") != 0
+        if use_wvd:
+            combined = combined | (channel_dev(wvd, "negative") != 0)
+        combined = nd.binary_opening(nd.binary_fill_holes(combined, s), s)
+        return combined.to(t.float64) * (1 - nd.linearise_field(swd, 2.5, 7.5))
 
     def channel(field, direction):
         seed = np.logical_or(get_curvature_filter(field, direction=direction),
