@@ -70,6 +70,38 @@ def test_farneback_full_frame_recovers_translation():
     assert float((f[core] + b[core]).abs().median()) < 0.1          # antisymmetry away from the wrap seam
 
 
+def test_farneback_full_frame_matches_oracle_without_strip_seams():
+    """One full-disk-sized pair (5424 x 5424: 23 column strips x 11 row strips of the fused iteration kernel, all six
+    pyramid resolutions) against the CPU oracle, forward direction (the oracle needs ~15 - 30 s).  float32 stages with
+    different summation orders: typical difference 4e-6; a handful of low-texture spots amplify it to ~1.5e-4, hence the
+    percentile form of the tolerance.  The difference must not depend on the position inside a 244-column strip or a
+    row strip: that is what a tiling seam would look like."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from test_gpu_parity import _oracle_farneback
+    H, W = F
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((1, 1, H + 16, W + 16), device="cuda", generator=g)
+    for _ in range(4):
+        x = torch.nn.functional.avg_pool2d(x, 7, stride=1, padding=3)
+    big = ((x - x.min()) / (x.max() - x.min()) * 255)[0, 0].to(torch.uint8)
+    a = big[8:8 + H, 8:8 + W].contiguous().cpu().numpy()
+    b = big[6:6 + H, 11:11 + W].contiguous().cpu().numpy()                       # content shifted by (dy, dx) = (2, -3)
+    got, _ = tf.calculate_flow_frame(a, b, tf.select_of_model("Farneback"))
+    want = _oracle_farneback(a, b)
+    assert abs(float(np.median(want[..., 0])) + 3) < 0.1 and abs(float(np.median(want[..., 1])) - 2) < 0.1
+    d = np.abs(got - want)
+    assert d.mean() <= 2e-5 and np.percentile(d, 99.99) <= 1e-4 and d.max() <= 1e-3, (d.mean(), np.percentile(d, 99.99), d.max())
+    per_col = d.sum(-1).mean(0)
+    xl = np.arange(W) % 244
+    per_row = d.sum(-1).mean(1)
+    overall = per_col.mean()
+    for lo in (0, 6, 232):                                                        # strip edges and their halo overlap
+        assert per_col[(xl >= lo) & (xl < lo + 12)].mean() <= 1.5 * overall
+    yl = np.arange(H) % 128                                                       # one pair: 128-row strips (every 512-row seam is one too)
+    assert per_row[(yl < 13) | (yl >= 115)].mean() <= 1.5 * overall
+
+
 def test_sobel_full_frame_power_of_two_linearity(full):
     """sobel(4 x) == 4 sobel(x) bit for bit (scaling by a power of two commutes with every rounding)"""
     import torch
