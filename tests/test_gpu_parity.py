@@ -243,6 +243,28 @@ def test_create_flow_matches_oracle_pipeline(tf):
     assert np.array_equal(np.isnan(fl.forward_flow), np.isnan(fw))
 
 
+def test_farneback_batch_is_bit_identical_to_single_pairs(tf):
+    """tf_farneback_batch (B pairs per launch, strided inputs / outputs) against tf_farneback_pair one pair at a time:
+    the same kernels on the same data, so the flows must be identical bit for bit, both directions."""
+    import torch
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow
+    rng = np.random.default_rng(17)
+    B, H, W = 5, 150, 270
+    base = ndi.gaussian_filter(rng.normal(size=(H + 2 * B, W + 2 * B)), 2.5)
+    base = ((base - base.min()) / np.ptp(base) * 255).astype(np.uint8)
+    frames = np.stack([base[i:i + H, 2 * B - i:2 * B - i + W] for i in range(B + 1)])          # drifting content
+    fr = torch.from_numpy(frames).cuda()
+    model = FarnebackFlow()
+    fwd = torch.full((B + 1, H, W, 2), float("nan"), dtype=torch.float32, device="cuda")
+    bwd = torch.full_like(fwd, float("nan"))
+    model.calc_batch_dev(fr[:-1].contiguous(), fr[1:].contiguous(), fwd[:B], bwd[1:])          # views into bigger arrays
+    for i in range(B):
+        f1, b1 = model.calc_pair_dev(fr[i], fr[i + 1])
+        assert torch.equal(fwd[i], f1) and torch.equal(bwd[i + 1], b1), f"pair {i}"
+    assert torch.isnan(fwd[B]).all() and torch.isnan(bwd[0]).all()                              # untouched slots stay untouched
+    assert float(fwd[:B].abs().max()) > 0.5
+
+
 # ----------------------------------------------------------------------------- watershed
 EXACT_VS_REFERENCE = ["A_cont_c1", "B_cont_mask_c2", "B_cont_mask_c3", "D_anvil_like_c1", "F_zero_flow_c1", "G_big_flow_c1"]
 
