@@ -199,6 +199,50 @@ __device__ __forceinline__ void ws_flush(WsStage &st, int *__restrict__ qout, in
 // atomics return; the plain reads were already only pre-filters (keys only decrease, a stale value is larger).
 #define WS_NB 8
 
+// one queue entry of phase A: pop p, relax its out-edges WS_NB at a time, stage the pixels whose key it lowered
+__device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, bool act, int p, int *__restrict__ inq)
+{
+    const int *np = c.nbr + (int64_t)p * c.n_nbr;
+    u64 kp = WS_INF;
+    for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
+        int n[WS_NB];
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) n[j] = (act && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
+        if (s0 == 0 && act) {
+            // relaxed L2 atomics only: the key is loaded after the exchange has returned (the flag is cleared BEFORE
+            // the key is read, so a later decrease re-queues the pixel); the id loads above are already in flight
+            const int was = atomicExch(&inq[p], 0);
+            kp = was == 0x7fffffff ? WS_INF : ws_load(&c.K2[p]);
+        }
+        const u64 lp = kp >> 32;
+        u64 vn[WS_NB], m1[WS_NB], k2[WS_NB];
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) {
+            const int q = n[j] >= 0 ? n[j] : 0;
+            vn[j] = c.val[q]; m1[j] = c.M1[q]; k2[j] = c.K2[q];
+        }
+        u64 cand[WS_NB], old[WS_NB];
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) {
+            cand[j] = vn[j] > lp ? ((vn[j] << 32) | 1ull) : (vn[j] == lp ? kp + 1ull : kp);
+            old[j] = 0ull;                                             // "no improvement"
+            if (n[j] >= 0) {
+                // keys only decrease, so a (possibly stale, i.e. larger) plain read is a safe pre-filter
+                if (kp < m1[j]) atomicMin(&c.M1[n[j]], kp);
+                if (cand[j] < k2[j]) old[j] = atomicMin(&c.K2[n[j]], cand[j]);
+            }
+        }
+        int was_q[WS_NB];                                              // raw returns: consumed only after all are issued
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) {
+            was_q[j] = 1;
+            if (n[j] >= 0 && cand[j] < old[j]) was_q[j] = atomicExch(&inq[n[j]], 1);
+        }
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) ws_stage(st, was_q[j] == 0, n[j]);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in, int *__restrict__ qout,
              int *__restrict__ cnt_out, int *__restrict__ inq, int qcap)
@@ -213,45 +257,7 @@ k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in,
         const int64_t i = i0 + threadIdx.x;
         const bool act = i < n_in;
         const int p = act ? (qin ? qin[i] : (int)i) : 0;
-        const int *np = c.nbr + (int64_t)p * c.n_nbr;
-        u64 kp = WS_INF;
-        for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
-            int n[WS_NB];
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) n[j] = (act && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
-            if (s0 == 0 && act) {
-                // relaxed L2 atomics only: the key is loaded after the exchange has returned (the flag is cleared BEFORE
-                // the key is read, so a later decrease re-queues the pixel); the id loads above are already in flight
-                const int was = atomicExch(&inq[p], 0);
-                kp = was == 0x7fffffff ? WS_INF : ws_load(&c.K2[p]);
-            }
-            const u64 lp = kp >> 32;
-            u64 vn[WS_NB], m1[WS_NB], k2[WS_NB];
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) {
-                const int q = n[j] >= 0 ? n[j] : 0;
-                vn[j] = c.val[q]; m1[j] = c.M1[q]; k2[j] = c.K2[q];
-            }
-            u64 cand[WS_NB], old[WS_NB];
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) {
-                cand[j] = vn[j] > lp ? ((vn[j] << 32) | 1ull) : (vn[j] == lp ? kp + 1ull : kp);
-                old[j] = 0ull;                                             // "no improvement"
-                if (n[j] >= 0) {
-                    // keys only decrease, so a (possibly stale, i.e. larger) plain read is a safe pre-filter
-                    if (kp < m1[j]) atomicMin(&c.M1[n[j]], kp);
-                    if (cand[j] < k2[j]) old[j] = atomicMin(&c.K2[n[j]], cand[j]);
-                }
-            }
-            int was_q[WS_NB];                                              // raw returns: consumed only after all are issued
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) {
-                was_q[j] = 1;
-                if (n[j] >= 0 && cand[j] < old[j]) was_q[j] = atomicExch(&inq[n[j]], 1);
-            }
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) ws_stage(st, was_q[j] == 0, n[j]);
-        }
+        ws_entry_a(c, st, act, p, inq);
         ws_flush(st, qout, cnt_out, qcap);
     }
 }
@@ -262,6 +268,59 @@ k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in,
 //     iff K2[n] = (value(n), 1): its chain is [K2 n, chain(p)]   -> offered_j = C_{j-1}[p]
 //   otherwise n continues p's run / descent: chain = [K2 n, tail(p)] -> offered_j = C_j[p]
 // The candidate must agree with n on every level j < k.
+__device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u64 *__restrict__ dst, WsStage &st,
+                                               bool act0, int p, int *__restrict__ inq)
+{
+    const int *np = c.nbr + (int64_t)p * c.n_nbr;
+    u64 kp = WS_INF, own = WS_INF;
+    u64 cp[WS_MAX_DEPTH];                        // C_j[p], j < k: final since their own phases, read once per entry
+    bool act = false;
+    for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
+        int n[WS_NB];
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) n[j] = (act0 && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
+        if (s0 == 0 && act0) {
+            const int was = atomicExch(&inq[p], 0);
+            kp = c.K2[p];                        // final since phase A
+            own = was == 0x7fffffff ? WS_INF : ws_load(&dst[p]);
+            for (int j = 1; j < k; j++) cp[j] = c.C[j][p];
+            act = kp != WS_INF;
+        }
+        u64 m1[WS_NB], kn[WS_NB], dn[WS_NB]; unsigned vn[WS_NB];
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) {
+            const int q = n[j] >= 0 ? n[j] : 0;
+            m1[j] = c.M1[q]; kn[j] = c.K2[q]; vn[j] = c.val[q]; dn[j] = dst[q];
+        }
+        u64 offered[WS_NB], old[WS_NB];
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) {
+            offered[j] = WS_INF; old[j] = 0ull;
+            if (act && n[j] >= 0 && m1[j] == kp) {
+                const bool entry = (kn[j] >> 32) == (u64)vn[j] && (kn[j] & 0xFFFFFFFFull) == 1ull;
+                bool match = true;
+                for (int l = 1; l < k && match; l++) {
+                    const u64 offered_l = entry ? (l == 1 ? kp : cp[l - 1]) : cp[l];
+                    match = offered_l == c.C[l][n[j]];
+                }
+                if (match) {
+                    if (k == depth) offered[j] = own;                                 // root: copied along every edge
+                    else offered[j] = entry ? (k == 1 ? kp : cp[k - 1]) : own;
+                    if (offered[j] != WS_INF && offered[j] < dn[j]) old[j] = atomicMin(&dst[n[j]], offered[j]);
+                }
+            }
+        }
+        int was_q[WS_NB];
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) {
+            was_q[j] = 1;
+            if (offered[j] < old[j]) was_q[j] = atomicExch(&inq[n[j]], 1);
+        }
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) ws_stage(st, was_q[j] == 0, n[j]);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_ws_sweep_chain(WsC c, int k, int depth, const int *__restrict__ qin, const int *__restrict__ cnt_in,
                  int *__restrict__ qout, int *__restrict__ cnt_out, int *__restrict__ inq, int qcap)
@@ -276,54 +335,7 @@ k_ws_sweep_chain(WsC c, int k, int depth, const int *__restrict__ qin, const int
         const int64_t i = i0 + threadIdx.x;
         const bool act0 = i < n_in;
         const int p = act0 ? (qin ? qin[i] : (int)i) : 0;
-        const int *np = c.nbr + (int64_t)p * c.n_nbr;
-        u64 kp = WS_INF, own = WS_INF;
-        u64 cp[WS_MAX_DEPTH];                        // C_j[p], j < k: final since their own phases, read once per entry
-        bool act = false;
-        for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
-            int n[WS_NB];
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) n[j] = (act0 && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
-            if (s0 == 0 && act0) {
-                const int was = atomicExch(&inq[p], 0);
-                kp = c.K2[p];                        // final since phase A
-                own = was == 0x7fffffff ? WS_INF : ws_load(&dst[p]);
-                for (int j = 1; j < k; j++) cp[j] = c.C[j][p];
-                act = kp != WS_INF;
-            }
-            u64 m1[WS_NB], kn[WS_NB], dn[WS_NB]; unsigned vn[WS_NB];
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) {
-                const int q = n[j] >= 0 ? n[j] : 0;
-                m1[j] = c.M1[q]; kn[j] = c.K2[q]; vn[j] = c.val[q]; dn[j] = dst[q];
-            }
-            u64 offered[WS_NB], old[WS_NB];
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) {
-                offered[j] = WS_INF; old[j] = 0ull;
-                if (act && n[j] >= 0 && m1[j] == kp) {
-                    const bool entry = (kn[j] >> 32) == (u64)vn[j] && (kn[j] & 0xFFFFFFFFull) == 1ull;
-                    bool match = true;
-                    for (int l = 1; l < k && match; l++) {
-                        const u64 offered_l = entry ? (l == 1 ? kp : cp[l - 1]) : cp[l];
-                        match = offered_l == c.C[l][n[j]];
-                    }
-                    if (match) {
-                        if (k == depth) offered[j] = own;                                 // root: copied along every edge
-                        else offered[j] = entry ? (k == 1 ? kp : cp[k - 1]) : own;
-                        if (offered[j] != WS_INF && offered[j] < dn[j]) old[j] = atomicMin(&dst[n[j]], offered[j]);
-                    }
-                }
-            }
-            int was_q[WS_NB];
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) {
-                was_q[j] = 1;
-                if (offered[j] < old[j]) was_q[j] = atomicExch(&inq[n[j]], 1);
-            }
-#pragma unroll
-            for (int j = 0; j < WS_NB; j++) ws_stage(st, was_q[j] == 0, n[j]);
-        }
+        ws_entry_chain(c, k, depth, dst, st, act0, p, inq);
         ws_flush(st, qout, cnt_out, qcap);
     }
 }
