@@ -179,7 +179,7 @@ def main():
         out["watershed"] = {"sweeps_per_phase_last_step": timed[-1][:5], "relevant_pixels": timed[-1][6],
                             "timed_steps_probing": sum(1 for t_ in timed if t_[5] >= 0),
                             "timed_steps_skipping_root_phase": sum(1 for t_ in timed if t_[5] < 0)}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:             # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(20240601)
         print(json.dumps(out))
     if dist is not None:
