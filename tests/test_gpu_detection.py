@@ -12,12 +12,29 @@ from helpers import blob_sequence, rand_flow
 pytestmark = pytest.mark.gpu
 
 
+class FakeCoord:
+    """the part of an xarray coordinate the recipes touch: `.values` / `.data` give the datetime64 array
+    (a plain ndarray would not do: ndarray.data is the raw buffer, which numpy refuses for datetime64)"""
+
+    def __init__(self, values):
+        self.values = self.data = values
+
+    def __array__(self, dtype=None, copy=None):
+        return self.values if dtype is None else self.values.astype(dtype)
+
+    def __len__(self):
+        return len(self.values)
+
+    def __getitem__(self, i):
+        return self.values[i]
+
+
 class FakeDataArray(np.ndarray):
     """ndarray with the two xarray attributes the recipes touch: `.t` (time coordinate) and `.to_numpy()`"""
 
     def __new__(cls, data, minutes=10):
         obj = np.asarray(data).view(cls)
-        obj.t = np.datetime64("2020-06-01T00:00") + np.arange(obj.shape[0]) * np.timedelta64(minutes, "m")
+        obj.t = FakeCoord(np.datetime64("2020-06-01T00:00") + np.arange(obj.shape[0]) * np.timedelta64(minutes, "m"))
         return obj
 
     def __array_finalize__(self, obj):
@@ -430,3 +447,66 @@ def test_combined_filters_device_resident_equals_host_recipe(scene, use_wvd):
     assert isinstance(got, torch.Tensor) and _same(got.cpu().numpy(), np.asarray(want))
     frac = (np.asarray(want) > 0).mean()
     assert 0.01 < frac < 0.9 and len(np.unique(np.asarray(want))) > 10   # a non-trivial, graded filter
+
+
+def _core_scene(minutes, scale=1.0, T=8):
+    """Intensifying cold blobs: BT falls inside them, WVD rises above -5 there, SWD is small there"""
+    import tobac_flow_amd.flow as tf
+    rng = np.random.default_rng(42)
+    bt0 = blob_sequence(rng, T, 96, 120, n_blobs=5, vmax=2.0, noise=0.5)
+    flow = tf.create_flow(bt0, smoothing_passes=1, interp_method="cubic")
+    ramp = np.linspace(0.5, 1.4, T, dtype=np.float32)[:, None, None]
+    cold = np.clip(250.0 - bt0, 0, None)
+    bt = FakeDataArray((290.0 - ramp * cold * scale).astype(np.float32), minutes=minutes)
+    wvd = FakeDataArray((ramp * cold * scale / 6 - 8).astype(np.float32), minutes=minutes)
+    swd = FakeDataArray(np.clip(8 - cold / 8, 0, None).astype(np.float32), minutes=minutes)
+    return flow, bt, wvd, swd
+
+
+@pytest.mark.parametrize("minutes,use_wvd", [(2, True), (5, True), (2, False)])
+def test_detect_cores_device_resident_equals_host_glue_and_meets_its_own_criteria(minutes, use_wvd, capsys):
+    """detect_cores (detection.py:372-482).  (1) The variant that keeps everything up to the labels in HBM equals the
+    variant with the reference's numpy / SciPy glue.  (2) The criteria of the recipe, recomputed independently on the
+    result: every core lasts more than min_length steps, touches WVD > -5 and cools by >= 0.5 K / min over some
+    min_length-step interval of its per-step mean BT."""
+    from tobac_flow_amd.detection import _detect_cores_host, detect_cores
+    flow, bt, wvd, swd = _core_scene(minutes)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = np.asarray(_detect_cores_host(flow, bt, wvd, swd, use_wvd=use_wvd))
+        host_log = capsys.readouterr().out
+        got = np.asarray(detect_cores(flow, bt, wvd, swd, use_wvd=use_wvd))
+        dev_log = capsys.readouterr().out
+    assert _same(got, want) and host_log == dev_log               # same labels and the same progress report
+    n = int(want.max())
+    assert n >= 1 and set(np.unique(want)) == set(range(n + 1))   # dense labels
+    btv, wv = np.asarray(bt), np.asarray(wvd)
+    for k in range(1, n + 1):
+        where = want == k
+        steps = np.nonzero(where.any((1, 2)))[0]
+        assert steps[-1] - steps[0] + 1 > 3 and (wv[where] > -5).any()
+        mean_bt = np.array([np.nanmean(btv[t][where[t]]) for t in steps])
+        drop = (mean_bt[:-3] - mean_bt[3:]) / (3.0 * minutes)
+        assert np.nanmax(drop) >= 0.5 - 1e-4, (k, drop)
+    assert "Initial core count" in host_log
+
+
+def test_detect_cores_without_candidates_behaves_like_the_reference():
+    """Sampled every 15 minutes the same scene grows too slowly per minute: no marker at all.  The reference then hands
+    ndi.labeled_comprehension an empty label range in its statistics stage (detection.py:434-446), which this SciPy
+    rejects with a ValueError -- a window without growing cloud makes detect_cores raise.  Both variants do the same."""
+    from tobac_flow_amd.detection import _detect_cores_host, detect_cores
+    flow, bt, wvd, swd = _core_scene(15)
+    outcome = []
+    for fn in (_detect_cores_host, detect_cores):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                outcome.append(("ok", np.asarray(fn(flow, bt, wvd, swd))))
+            except Exception as e:                                   # noqa: BLE001 - the type is what is compared
+                outcome.append(("raised", type(e)))
+    assert outcome[0][0] == outcome[1][0]
+    if outcome[0][0] == "raised":
+        assert outcome[0][1] is outcome[1][1] is ValueError
+    else:
+        assert outcome[0][1].max() == 0 and np.array_equal(outcome[0][1], outcome[1][1])

@@ -281,7 +281,66 @@ def get_combined_filters(flow, bt, wvd, swd, use_wvd=True):
                      cell_measures="area: area")
 def detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overlap=0.5, absolute_overlap=4,
                  subsegment_shrink=0.0, min_length=3, use_wvd=True):
-    """Growing cores from BT, WVD and SWD (reference: detection.py:372-482)."""
+    """Growing cores from BT, WVD and SWD (reference: detection.py:372-482).  DataArray / numpy in and out like the
+    reference.  The three fields are uploaded once; filters, growth rates, markers, flow labelling and the length / WVD
+    label filters stay in HBM; the labels come back once for the per-core cooling-rate statistics, which are host numpy
+    exactly as in the reference (their float32 means feed a threshold).  Same result as _detect_cores_host."""
+    from tobac_flow_amd import ndimage_dev as nd
+    t = _lib.torch()
+    bt_d, wvd_d, swd_d = (_lib.to_dev(np.ascontiguousarray(_values(x))) for x in (bt, wvd, swd))
+    combined_filter = get_combined_filters(flow, bt_d, wvd_d, swd_d, use_wvd=use_wvd)
+    s = ndi.generate_binary_structure(3, 1)
+    s *= np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
+
+    def growth(field_d, coord):
+        dt = t.from_numpy(np.asarray(get_time_diff_from_coord(coord))).to(field_d.device)[:, None, None]
+        rate = flow.diff(field_d, method="cubic") / dt
+        return flow.convolve(rate, structure=_plane_struct(), func=_nanmean0, method="cubic")
+
+    bt_markers = (growth(-bt_d, bt.t) * combined_filter) > bt_threshold
+    if use_wvd:
+        wvd_markers = (growth(wvd_d, wvd.t) * combined_filter) > wvd_threshold
+        combined_markers = nd.binary_opening(wvd_markers | bt_markers, s)
+        print("WVD growth above threshold: area =", int(wvd_markers.sum().item()))
+    else:
+        combined_markers = nd.binary_opening(bt_markers, s)
+    print("BT growth above threshold: area =", int(bt_markers.sum().item()))
+    print("Detected markers: area =", int(combined_markers.sum().item()))
+    core_labels = flow.label(combined_markers, overlap=overlap, absolute_overlap=absolute_overlap,
+                             subsegment_shrink=subsegment_shrink)
+    print("Initial core count:", int(core_labels.max().item()))
+    lengths, wvd_ok = nd.label_extent(core_labels, wvd_d > -5)
+    print("Core labels meeting length threshold:", np.sum(lengths > min_length))
+    print("Core labels meeting WVD threshold:", np.sum(wvd_ok))
+    core_labels = nd.remap_labels(core_labels, np.logical_and(lengths > min_length, wvd_ok)).cpu().numpy()
+    return _core_cooling_filter(core_labels, bt, min_length)
+
+
+def _core_cooling_filter(core_labels, bt, min_length):
+    """Last stage of detect_cores (reference: detection.py:434-482): keep the cores whose per-step mean BT falls by at
+    least 0.5 K per minute over some min_length-step interval.  Host numpy / SciPy, as in the reference."""
+    step_labels = slice_labels(core_labels)
+    step_core = labeled_comprehension(core_labels, step_labels, lambda x: stats.mode(x, keepdims=False)[0], default=0)
+    step_bt = labeled_comprehension(_values(bt), step_labels, np.nanmean, default=np.nan)
+    step_t = labeled_comprehension(np.asarray(bt.t.data)[:, np.newaxis, np.newaxis], step_labels, np.nanmin, default=0)
+
+    def max_cooling(bt_vals, pos):
+        when = step_t[pos]
+        order = np.argsort(when)
+        bt_vals, when = bt_vals[order], when[order]
+        rate = (bt_vals[:-min_length] - bt_vals[min_length:]) / (
+            (when[min_length:] - when[:-min_length]).astype("timedelta64[s]").astype("int") / 60)
+        return np.nanmax(rate) if rate.size > 0 else 0
+
+    cooling = labeled_comprehension(step_bt, step_core, max_cooling, default=0, pass_positions=True)
+    valid = cooling >= 0.5
+    print("Core labels meeting cooling rate threshold:", np.sum(valid))
+    return remap_labels(core_labels, valid)
+
+
+def _detect_cores_host(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overlap=0.5, absolute_overlap=4,
+                       subsegment_shrink=0.0, min_length=3, use_wvd=True):
+    """detect_cores with the reference's own numpy / SciPy glue between the device operators."""
     combined_filter = get_combined_filters(flow, bt, wvd, swd, use_wvd=use_wvd)
     s = ndi.generate_binary_structure(3, 1)
     s *= np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
@@ -303,24 +362,7 @@ def detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overl
     print("Core labels meeting WVD threshold:", np.sum(wvd_ok))
     core_labels = remap_labels(core_labels, np.logical_and(lengths > min_length, wvd_ok))
 
-    # cooling-rate test on the per-step mean BT of every core
-    step_labels = slice_labels(core_labels)
-    step_core = labeled_comprehension(core_labels, step_labels, lambda x: stats.mode(x, keepdims=False)[0], default=0)
-    step_bt = labeled_comprehension(_values(bt), step_labels, np.nanmean, default=np.nan)
-    step_t = labeled_comprehension(np.asarray(bt.t.data)[:, np.newaxis, np.newaxis], step_labels, np.nanmin, default=0)
-
-    def max_cooling(bt_vals, pos):
-        when = step_t[pos]
-        order = np.argsort(when)
-        bt_vals, when = bt_vals[order], when[order]
-        rate = (bt_vals[:-min_length] - bt_vals[min_length:]) / (
-            (when[min_length:] - when[:-min_length]).astype("timedelta64[s]").astype("int") / 60)
-        return np.nanmax(rate) if rate.size > 0 else 0
-
-    cooling = labeled_comprehension(step_bt, step_core, max_cooling, default=0, pass_positions=True)
-    valid = cooling >= 0.5
-    print("Core labels meeting cooling rate threshold:", np.sum(valid))
-    return remap_labels(core_labels, valid)
+    return _core_cooling_filter(core_labels, bt, min_length)
 
 
 @configure_dataarray(name="anvil_marker_label", drop_attrs=_DROP, long_name="labels for anvil markers", units="",
