@@ -434,3 +434,88 @@ def test_flow_link_overlap_matches_oracle(tf):
     got = tf.Flow(fwd, bwd).link_overlap(step, overlap=0.5, absolute_overlap=5)
     want = np_label.flow_link_overlap(fwd, bwd, step, overlap=0.5, absolute_overlap=5)
     assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------------------- flow API scenarios of the reference's tests
+def _reference_blob(tf):
+    xx, yy = np.meshgrid(np.arange(15), np.arange(10))
+    return tf.to_8bit((7 ** 2 - (xx - 7) ** 2) * (4.5 ** 2 - (yy - 4.5) ** 2))
+
+
+def test_calculate_flow_and_create_flow_agree_like_in_the_reference_tests(tf):
+    """tests/test_flow.py:298-361 with the model that exists here: calculate_flow returns (forward, backward) for the
+    stack, create_flow wraps the same vectors (clipped to +-20) in a Flow, identical frames give the flow the oracle
+    gives for identical frames (close to zero)."""
+    blob = _reference_blob(tf).astype(np.float32)
+    stack = np.stack([np.roll(blob, -1, (0, 1)), blob, np.roll(blob, 1, (0, 1))])
+    fwd, bwd = tf.calculate_flow(stack, "Farneback")
+    obj = tf.create_flow(stack, "Farneback")
+    assert isinstance(obj, tf.Flow) and obj.shape == stack.shape
+    assert fwd.shape == stack.shape + (2,) and fwd.dtype == np.float32
+    assert np.array_equal(np.clip(fwd, -20, 20), obj.forward_flow) and np.array_equal(np.clip(bwd, -20, 20), obj.backward_flow)
+    assert np.array_equal(fwd[-1], -bwd[-1]) and np.array_equal(bwd[0], -fwd[0])        # mirrored end frames (flow.py:425-426)
+    for i in range(2):                                                                  # pair i against the oracle
+        a, b = (np_ops_to8(stack[i], stack[i + 1]))
+        assert np.max(np.abs(fwd[i] - _oracle_farneback(a, b))) <= 1e-4
+        assert np.max(np.abs(bwd[i + 1] - _oracle_farneback(b, a))) <= 1e-4
+    same = tf.calculate_flow(np.stack([blob] * 3), "Farneback")
+    assert np.allclose(same[0], 0, atol=0.05) and np.allclose(same[1], 0, atol=0.05)
+
+
+def np_ops_to8(x, y):
+    from oracle import np_ops
+    pair = np_ops.to_8bit(np_ops.linear_norm(np.stack([x, y])), 0, 1)
+    return np.ascontiguousarray(pair[0]), np.ascontiguousarray(pair[1])
+
+
+def test_calculate_flow_2_pairs_two_stacks(tf):
+    """calculate_flow_2 (flow.py:431-496): flow from a[i] to b[i] on the jointly normalised pair -- with the
+    reference's own indexing, which it shares with calculate_flow: only the first T - 1 pairs are computed, the forward
+    flow of pair i is stored at i and its BACKWARD flow at i + 1, then forward[-1] = -backward[-1] and
+    backward[0] = -forward[0]."""
+    rng = np.random.default_rng(21)
+    a = ndi.gaussian_filter(rng.normal(size=(3, 60, 90)), (0, 3, 3)).astype(np.float32)
+    b = np.roll(a, (1, -2), (1, 2))
+    fwd, bwd = tf.calculate_flow_2(a, b, "Farneback")
+    T = a.shape[0]
+    assert fwd.shape == a.shape + (2,) and bwd.shape == a.shape + (2,)
+    for i in range(T - 1):
+        p, n = np_ops_to8(a[i], b[i])
+        f, bk = tf.calculate_flow_frame(p, n, tf.select_of_model("Farneback"))
+        assert np.array_equal(fwd[i], f) and np.array_equal(bwd[i + 1], bk)
+        assert np.max(np.abs(f - _oracle_farneback(p, n))) <= 1e-4
+    assert np.array_equal(fwd[T - 1], -bwd[T - 1]) and np.array_equal(bwd[0], -fwd[0])
+
+
+def test_vr_steps_warn_and_return_the_unrefined_flow(tf):
+    """cv2.VariationalRefinement has no implementation here: vr_steps > 0 must say so and
+    leave the Farnebaeck flow untouched (tests/test_flow.py:265-279, 323-333 are the reference's scenarios)."""
+    blob = _reference_blob(tf)
+    nxt = np.roll(blob, -1, [0, 1])
+    model = tf.select_of_model("Farneback")
+    plain = tf.calculate_flow_frame(blob, nxt, model)
+    with pytest.warns(RuntimeWarning, match="VariationalRefinement"):
+        refined = tf.calculate_flow_frame(blob, nxt, model, vr_steps=1)
+    assert np.array_equal(plain[0], refined[0]) and np.array_equal(plain[1], refined[1])
+    stack = np.stack([np.roll(blob, -1, (0, 1)), blob, np.roll(blob, 1, (0, 1))]).astype(np.float32)
+    with pytest.warns(RuntimeWarning, match="VariationalRefinement"):
+        with_vr = tf.calculate_flow(stack, "Farneback", vr_steps=1)
+    without = tf.calculate_flow(stack, "Farneback")
+    assert np.array_equal(with_vr[0], without[0]) and np.array_equal(with_vr[1], without[1])
+
+
+def test_calculate_flow_frame_smoothing_steps_match_oracle(tf):
+    """smoothing_steps of calculate_flow_frame (flow.py:519-525) = that many smooth_flow_step passes"""
+    from oracle import np_ops
+    rng = np.random.default_rng(5)
+    a = ndi.gaussian_filter(rng.normal(size=(70, 100)), 3)
+    a = ((a - a.min()) / np.ptp(a) * 255).astype(np.uint8)
+    b = np.roll(a, (2, -1), (0, 1))
+    model = tf.select_of_model("Farneback")
+    f0, b0 = tf.calculate_flow_frame(a, b, model)
+    for steps, method in [(1, "linear"), (2, "cubic")]:
+        f, bk = tf.calculate_flow_frame(a, b, model, smoothing_steps=steps, interp_method=method)
+        wf, wb = f0, b0
+        for _ in range(steps):
+            wf, wb = np_ops.smooth_flow_step(wf, wb, method)
+        assert np.max(np.abs(f - wf)) <= 1e-5 and np.max(np.abs(bk - wb)) <= 1e-5
