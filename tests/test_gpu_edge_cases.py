@@ -225,3 +225,39 @@ def test_apply_global_lut_gpu_equals_host_path_and_keeps_negative_ids():
     nonneg = np.abs(labels)
     assert np.array_equal(apply_global_lut(torch.from_numpy(nonneg).cuda(), lut).cpu().numpy(),
                           apply_global_lut(torch.from_numpy(nonneg), lut).numpy())
+
+
+def test_flow_diagnostics_run_and_satisfy_their_identities(tf):
+    """get_forward_warp / flow_diff_mse_estimate / get_flow_residual / flow_residual_mse_estimate / time_flow
+    (reference: flow.py:571-640): thin wrappers over convolve and calculate_flow_2, exercised on a drifting field."""
+    class DA:                                              # the one xarray attribute these helpers touch
+        def __init__(self, data):
+            self.data = data
+
+    rng = np.random.default_rng(31)
+    base = ndi.gaussian_filter(rng.normal(size=(70, 100)), 3).astype(np.float32) * 40 + 260
+    stack = np.stack([np.roll(base, (i, -2 * i), (0, 1)) for i in range(4)])
+    flow = tf.create_flow(stack, smoothing_passes=1)
+    da = DA(stack)
+    fw = tf.get_forward_warp(da, flow)
+    one_tap = np.zeros([3, 3, 3], bool)
+    one_tap[2, 1, 1] = True
+    assert fw.shape == stack.shape and np.array_equal(np.nan_to_num(fw), np.nan_to_num(flow.convolve(stack, one_tap)[0]))
+    win = (slice(None), slice(15, -15), slice(15, -15))
+    aligned = np.nanmean(np.abs(fw[:3][win] - stack[:3][win]))          # next frame pulled back along the flow vs this frame
+    unaligned = np.mean(np.abs(stack[1:][win] - stack[:3][win]))
+    assert unaligned > 0.5 and aligned < 0.25 * unaligned               # (integer drift + 1/32 px coordinate grid: often exactly 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        all_mse, cold_mse = tf.flow_diff_mse_estimate(da, flow)
+        resid = tf.get_flow_residual(da, flow, vr_steps=0)
+        r_all, r_cold = tf.flow_residual_mse_estimate(da, flow, vr_steps=0)
+    assert np.isfinite(all_mse) and all_mse >= 0 and (np.isnan(cold_mse) or cold_mse >= 0)
+    assert resid.shape == stack.shape + (2,) and np.isfinite(r_all) and r_all >= 0
+    zero = tf.Flow(np.zeros(stack.shape + (2,), np.float32), np.zeros(stack.shape + (2,), np.float32))
+    fw0 = tf.get_forward_warp(da, zero)
+    # zero flow: the forward warp is the next frame -- except the last row and column, where the bilinear patch
+    # reaches outside and the NaN border value poisons the sum even at weight zero (cv2.remap, BORDER_CONSTANT)
+    assert np.array_equal(fw0[:-1, :-1, :-1], stack[1:, :-1, :-1])
+    assert np.isnan(fw0[:-1, -1, :]).all() and np.isnan(fw0[:-1, :, -1]).all() and np.isnan(fw0[-1]).all()
+    assert tf.time_flow(stack, vr_steps=0, smoothing_passes=0) > 0

@@ -259,3 +259,94 @@ def test_core_cooling_filter_keeps_only_fast_cooling_cores():
     bt[:, 2:6, 12:18] = 280.0 - 0.5 * minutes * steps[:, :, :1]
     out = _core_cooling_filter(labels.copy(), bt, min_length=3)
     assert out.max() == 2 and np.array_equal(out == 2, labels == 2)
+
+
+# ----------------------------------------------------------------------------- label filters of analysis.py
+def _random_labels(seed, shape=(7, 24, 30), n=14):
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(seed)
+    blobs = ndi.gaussian_filter(rng.normal(size=shape), (0.6, 1.0, 1.0)) > 0.09     # 13 - 22 components for seeds 0 - 2
+    labels, count = ndi.label(blobs)
+    assert count >= 5
+    return labels.astype(np.int32), rng
+
+
+def _brute_filter(labels, keep):
+    out = np.zeros_like(labels)
+    nxt = 0
+    for k in range(1, labels.max() + 1):
+        if keep(k):
+            nxt += 1
+            out[labels == k] = nxt
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_label_filters_match_brute_force_and_their_legacy_forms(seed):
+    """analysis.filter_labels_by_* (reference: analysis.py:66-201): keep the labels that last >= min_length steps along
+    axis 0 and / or touch the mask(s), renumbered densely in ascending order; the *_legacy forms do the same in place."""
+    from tobac_flow_amd import analysis as an
+    labels, rng = _random_labels(seed)
+    mask = rng.random(labels.shape) < 0.01
+    mask2 = rng.random(labels.shape) < 0.02
+
+    def length(k):
+        tt = np.nonzero((labels == k).any((1, 2)))[0]
+        return tt[-1] - tt[0] + 1
+
+    def hits(k, m):
+        return bool(m[labels == k].any())
+
+    min_length = 3
+    want_len = _brute_filter(labels, lambda k: length(k) >= min_length)
+    want_mask = _brute_filter(labels, lambda k: hits(k, mask))
+    want_both = _brute_filter(labels, lambda k: length(k) >= min_length and hits(k, mask))
+    want_multi = _brute_filter(labels, lambda k: hits(k, mask) and hits(k, mask2))
+    want_len_multi = _brute_filter(labels, lambda k: length(k) >= min_length and hits(k, mask) and hits(k, mask2))
+    assert 0 < want_len.max() < labels.max() and 0 < want_mask.max() < labels.max()      # the filters do remove something
+    assert np.array_equal(an.filter_labels_by_length(labels, min_length), want_len)
+    assert np.array_equal(an.filter_labels_by_mask(labels, mask), want_mask)
+    assert np.array_equal(an.filter_labels_by_length_and_mask(labels, mask, min_length), want_both)
+    assert np.array_equal(an.filter_labels_by_multimask(labels, [mask, mask2]), want_multi)
+    assert np.array_equal(an.filter_labels_by_length_and_multimask(labels, [mask, mask2], min_length), want_len_multi)
+    for legacy, args, want in [(an.filter_labels_by_length_legacy, (min_length,), want_len),
+                               (an.filter_labels_by_length_and_mask_legacy, (mask, min_length), want_both),
+                               (an.filter_labels_by_length_and_multimask_legacy, ([mask, mask2], min_length), want_len_multi)]:
+        work = labels.copy()
+        out = legacy(work, *args)
+        assert out is work and np.array_equal(out, want)                                 # in place, same answer
+    for fn in (an.filter_labels_by_multimask, an.filter_labels_by_length_and_multimask_legacy):
+        with pytest.raises(ValueError):
+            fn(labels.copy(), mask, *(() if fn is an.filter_labels_by_multimask else (min_length,)))
+
+
+def test_find_neighbour_labels_and_find_overlapping_labels():
+    """label.find_neighbour_labels / label_utils.find_overlapping_labels (reference: label.py:178-245,
+    label_utils.py:352-376): labels whose overlap with the given label's pixels exceeds `absolute_overlap` pixels AND
+    reaches `overlap` x the smaller of the two areas are pushed once onto the stack."""
+    from tobac_flow_amd.label import find_neighbour_labels
+    from tobac_flow_amd.utils.label_utils import find_overlapping_labels
+    labels = np.zeros((12, 12), np.int32)
+    labels[1:5, 1:5] = 1                                   # 16 px
+    labels[6:9, 6:9] = 2                                   # 9 px
+    labels[10:12, 0:3] = 3                                 # 6 px
+    fwd = np.zeros_like(labels)                            # "warped labels of the next step"
+    fwd[1:5, 1:3] = 2                                      # covers 8 px of label 1
+    fwd[1:2, 4:5] = 3                                      # covers 1 px of label 1
+    bwd = np.zeros_like(labels)
+    bwd[3:5, 3:5] = 3                                      # covers 4 px of label 1
+    bins = np.cumsum(np.bincount(labels.ravel()))
+    args = np.argsort(labels.ravel())
+    locs = args[bins[0]:bins[1]]
+    assert sorted(locs.tolist()) == sorted(np.flatnonzero(labels.ravel() == 1).tolist())
+    assert find_overlapping_labels(fwd, locs, bins, overlap=0, absolute_overlap=0) == [2, 3]
+    assert find_overlapping_labels(fwd, locs, bins, overlap=0, absolute_overlap=1) == [2]          # 1 px is not > 1
+    assert find_overlapping_labels(fwd, locs, bins, overlap=0.9, absolute_overlap=0) == []         # 8 < 0.9 * min(16, 9)
+    assert find_overlapping_labels(fwd, locs, bins, overlap=0.8, absolute_overlap=0) == [2]        # 8 >= 0.8 * 9
+    assert find_overlapping_labels(fwd, np.array([], int), bins) == []
+    stack, seen = [], np.zeros(4, bool)
+    seen[1] = True
+    find_neighbour_labels(1, stack, bins, args, seen, fwd, bwd, overlap=0, absolute_overlap=1)
+    assert stack == [2, 3] and seen.tolist() == [False, True, True, True]                          # 2 via t+1, 3 via t-1 (4 px)
+    find_neighbour_labels(1, stack, bins, args, seen, fwd, bwd, overlap=0, absolute_overlap=1)
+    assert stack == [2, 3]                                                                         # nothing is pushed twice
