@@ -519,3 +519,31 @@ def test_calculate_flow_frame_smoothing_steps_match_oracle(tf):
         for _ in range(steps):
             wf, wb = np_ops.smooth_flow_step(wf, wb, method)
         assert np.max(np.abs(f - wf)) <= 1e-5 and np.max(np.abs(bk - wb)) <= 1e-5
+
+
+@pytest.mark.parametrize("method,kwargs", [("inverse_log", {}), ("z_score", {"max_std": 2}), ("uniform", {"quantiles": 64}),
+                                           ("local_linear", {"size": 25}), ("log", {})])
+def test_calculate_flow_with_other_normalisation_methods(tf, method, kwargs):
+    """calculate_flow(normalisation_method=...) (flow.py:362-428): the pair is normalised jointly by the chosen method,
+    quantised with to_8bit(., 0, 1) and handed to the flow model; equal to doing exactly that by hand per pair."""
+    from tobac_flow_amd.utils.normalisation_utils import select_normalisation_method
+    rng = np.random.default_rng(9)
+    base = ndi.gaussian_filter(rng.normal(size=(64, 96)), 3) * 30 + 250
+    stack = np.stack([np.roll(base, (i, -i), (0, 1)) for i in range(3)]).astype(np.float32)
+    fwd, bwd = tf.calculate_flow(stack, "Farneback", normalisation_method=method, **kwargs)
+    norm = select_normalisation_method(method)
+    model = tf.select_of_model("Farneback")
+    for i in range(2):
+        p8 = tf.to_8bit(norm(np.stack([stack[i], stack[i + 1]], 0), **kwargs), 0, 1)
+        f, b = tf.calculate_flow_frame(np.ascontiguousarray(p8[0]), np.ascontiguousarray(p8[1]), model)
+        assert np.array_equal(fwd[i], f) and np.array_equal(bwd[i + 1], b), (method, i)
+    # for a brightness-temperature-like field the reference's log_norm gives all zeros and its inverse_log_norm a
+    # range of ~5 / 300 (two bits after to_8bit): no or almost no flow signal survives (see test_host_logic)
+    if method == "log":
+        assert not fwd.any()
+    elif method == "inverse_log":
+        assert np.abs(fwd).max() < 0.1
+    else:
+        assert np.abs(fwd[0]).max() > 0.3
+    with pytest.raises(ValueError):
+        tf.calculate_flow(stack, "Farneback", normalisation_method="quadratic")

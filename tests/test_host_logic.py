@@ -350,3 +350,73 @@ def test_find_neighbour_labels_and_find_overlapping_labels():
     assert stack == [2, 3] and seen.tolist() == [False, True, True, True]                          # 2 via t+1, 3 via t-1 (4 px)
     find_neighbour_labels(1, stack, bins, args, seen, fwd, bwd, overlap=0, absolute_overlap=1)
     assert stack == [2, 3]                                                                         # nothing is pushed twice
+
+
+# ----------------------------------------------------------------------------- normalisation methods and small utilities
+def test_normalisation_methods_have_their_defining_properties():
+    """utils.normalisation_utils (reference: normalisation_utils.py:59-160): every method maps into [0, 1]; linear / log /
+    z_score / uniform are non-decreasing in the data, inverse_log non-increasing; known values."""
+    from tobac_flow_amd.utils import normalisation_utils as nu
+    rng = np.random.default_rng(3)
+    x = (rng.gamma(2.0, 10.0, size=(2, 40, 50)) + 200).astype(np.float32)
+    order = np.argsort(x.ravel())
+    for name, sign in [("linear", 1), ("log", 1), ("z_score", 1), ("uniform", 1), ("inverse_log", -1)]:
+        y = nu.select_normalisation_method(name)(x)
+        assert y.shape == x.shape and y.min() >= 0 and y.max() <= 1, name
+        assert np.all(sign * np.diff(y.ravel()[order]) >= 0), name
+    assert np.array_equal(nu.linear_norm(np.array([2.0, 4.0, 6.0])), [0.0, 0.5, 1.0])
+    assert np.array_equal(nu.linear_norm(np.array([5.0, 5.0])), [0.0, 0.0])                     # flat input: factor 0
+    assert np.array_equal(nu.linear_norm(np.array([0.0, 10.0]), vmin=2, vmax=6), [0.0, 1.0])   # clipped
+    # log_norm (:75-79) overwrites vmin with the DATA minimum and then uses it as the lower bound of the LOG values:
+    # log([1, e, e^2] - 1 + 1) = [0, 1, 2] normalised from 1 to 2 -> [0, 0, 1].  Reproduced as is; with data whose minimum
+    # exceeds its largest log value (any brightness temperature field) the upper bound falls below the lower one and
+    # everything maps to 0.
+    assert np.array_equal(nu.log_norm(np.array([1.0, np.e, np.e ** 2])), [0.0, 0.0, 1.0])
+    assert not nu.log_norm(x).any()
+    inv = nu.inverse_log_norm(np.array([1.0, 2.0, 3.0]))       # log(3 - x + 1) = log([3, 2, 1]) from its minimum to the DATA maximum 3
+    assert np.allclose(inv, (np.log([3.0, 2.0, 1.0]) - 0.0) / 3.0)
+    z = nu.z_norm(np.array([-10.0, 0.0, 10.0]), max_std=1)
+    assert np.array_equal(z, [0.0, 0.5, 1.0])
+    u = nu.uniform_norm(np.arange(1000.0), quantiles=4)
+    assert set(np.unique(u)) == {0.0, 1 / 3, 2 / 3, 1.0} and np.allclose(np.bincount((u * 3).round().astype(int)), 250, atol=1)
+    ll = nu.local_linear_norm(np.tile(np.arange(50.0), (50, 1)), size=5)
+    assert ll.min() == 0 and ll.max() == 1 and ll[10, 10] == 0.5                                # centre of a 5-wide ramp
+    nan_in = np.tile(np.arange(20.0), (20, 1))
+    nan_in[3, 3] = np.nan
+    assert np.isfinite(nu.local_linear_norm(nan_in, size=3)).all() and np.isnan(nan_in[3, 3])   # NaNs filled on a copy
+    with pytest.raises(ValueError):
+        nu.select_normalisation_method("quadratic")
+
+
+def test_small_utilities_known_answers():
+    from datetime import datetime, timedelta
+    from tobac_flow_amd.utils import mse
+    from tobac_flow_amd.utils.datetime_utils import get_datetime_from_coord, get_time_diff_from_coord, time_diff
+    from tobac_flow_amd.utils.flow_utils import select_border_mode, select_interp_mode
+    from tobac_flow_amd.utils.label_utils import get_step_labels_for_label, make_step_labels, relabel_objects
+    assert mse(np.array([1.0, 2.0, 4.0]), np.array([1.0, 0.0, 1.0])) == pytest.approx((0 + 4 + 9) / 3)
+    t0 = datetime(2020, 6, 1)
+    times = [t0, t0 + timedelta(minutes=5), t0 + timedelta(minutes=15), t0 + timedelta(minutes=20)]
+    assert time_diff(times) == [5.0, 7.5, 7.5, 5.0]            # one-sided at the ends, centred (halved) inside
+    coord = np.array(times, dtype="datetime64[s]")
+    assert get_datetime_from_coord(coord) == times
+    assert np.array_equal(get_time_diff_from_coord(coord), [5.0, 7.5, 7.5, 5.0])
+    assert select_interp_mode("nearest") == 0 and select_interp_mode("linear") == 1 and select_interp_mode("cubic") == 2
+    for bad, err in [("lanczos", NotImplementedError), ("spline", ValueError)]:
+        with pytest.raises(err):
+            select_interp_mode(bad)
+    assert select_border_mode("constant") == "constant"
+    for bad, err in [("reflect", NotImplementedError), ("edge", ValueError)]:
+        with pytest.raises(err):
+            select_border_mode(bad)
+    labels = np.array([[[0, 4, 4], [0, 0, 9]], [[4, 4, 0], [9, 0, 0]]])
+    assert np.array_equal(relabel_objects(labels), np.array([[[0, 1, 1], [0, 0, 2]], [[1, 1, 0], [2, 0, 0]]]))
+    steps = make_step_labels(labels)
+    per_label = get_step_labels_for_label(labels, steps)     # one entry per label value 1 .. max, None where absent
+    assert len(per_label) == labels.max()
+    for lab in range(1, labels.max() + 1):
+        if lab in (4, 9):
+            assert np.array_equal(per_label[lab - 1], np.unique(steps[labels == lab]))
+            assert len(per_label[lab - 1]) == 2            # both labels live in two time steps
+        else:
+            assert per_label[lab - 1] is None
