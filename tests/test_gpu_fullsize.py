@@ -156,6 +156,27 @@ def test_watershed_full_frame_properties(full):
     assert bool((lab2 == lab).all())
 
 
+def test_watershed_full_disk_frames_bit_exact_vs_reference_twin(full):
+    """3 x 5424 x 5424 (88 M voxels) with the detect_anvils-style edge field and markers: the HIP flood against the
+    line-by-line twin of the reference's Cython heap flood (oracle/c/ws_heap.c, itself checked against the compiled
+    reference on the golden cases).  The twin needs ~10 s here.  Should equal-valued markers compete in some future
+    input, the idealised-order oracle is the contract and is consulted instead."""
+    import torch
+    from oracle import ws_oracle
+    fl, lin, markers = full["flow"], full["lin"], full["markers"]
+    e = fl.sobel(lin, direction="uphill", method="cubic")
+    e = (torch.where(e > 0, e + 1, e) - lin).to(torch.float32)
+    got = fl.watershed(e, markers, connectivity=1).cpu().numpy()
+    fw, bw = fl.forward_flow.cpu().numpy(), fl.backward_flow.cpu().numpy()
+    en, mn = e.cpu().numpy(), markers.cpu().numpy()
+    assert 0.01 < (mn == 0).mean() < 0.2
+    twin = ws_oracle.watershed(fw, bw, en, mn, None, 1)
+    if not np.array_equal(got, twin):
+        ideal = ws_oracle.watershed(fw, bw, en, mn, None, 1, tie_mode=1)
+        assert np.array_equal(got, ideal), f"{int((got != ideal).sum())} px differ from the idealised-order oracle"
+    assert (got == 0).sum() == 0
+
+
 def test_watershed_config_c_frame_bit_exact_vs_oracle():
     """config C frame size (1500 x 2500), 3 frames: direct comparison with the sequential oracle"""
     import torch
