@@ -16,20 +16,57 @@ __device__ __forceinline__ float key2f(unsigned k) {
 
 __global__ void k_minmax_init(unsigned *mm) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; mm[2] = 0u; }
 
+__device__ __forceinline__ void mm_take(float v, float &lo, float &hi, unsigned &seen) {
+    if (v == v) { lo = fminf(lo, v); hi = fmaxf(hi, v); seen = 1; }
+}
+
+// NaN-ignoring min / max of one frame: scalar head up to 16-byte alignment, float4 body with two loads in flight per
+// thread, scalar tail.  min / max are exact and order-independent, so any traversal gives the same pair.
+__device__ __forceinline__ void mm_span(const float *__restrict__ p, int64_t n, int64_t tid, int64_t nthreads,
+                                        float &lo, float &hi, unsigned &seen)
+{
+    int64_t head = (int64_t)((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    if (head > n) head = n;
+    const int64_t nvec = (n - head) / 4, tail0 = head + nvec * 4;
+    if (tid < head) mm_take(p[tid], lo, hi, seen);
+    if (tid < n - tail0) mm_take(p[tail0 + tid], lo, hi, seen);
+    const float4 *v = (const float4 *)(p + head);
+    int64_t i = tid;
+    for (; i + nthreads < nvec; i += 2 * nthreads) {
+        const float4 x = v[i], y = v[i + nthreads];
+        mm_take(x.x, lo, hi, seen); mm_take(x.y, lo, hi, seen); mm_take(x.z, lo, hi, seen); mm_take(x.w, lo, hi, seen);
+        mm_take(y.x, lo, hi, seen); mm_take(y.y, lo, hi, seen); mm_take(y.z, lo, hi, seen); mm_take(y.w, lo, hi, seen);
+    }
+    if (i < nvec) {
+        const float4 x = v[i];
+        mm_take(x.x, lo, hi, seen); mm_take(x.y, lo, hi, seen); mm_take(x.z, lo, hi, seen); mm_take(x.w, lo, hi, seen);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_minmax(const float *__restrict__ a, const float *__restrict__ b, int64_t n, unsigned *__restrict__ mm)
 {
     float lo = INFINITY, hi = -INFINITY; unsigned seen = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += stride) {
-        float v = i < n ? a[i] : b[i - n];
-        if (v == v) { lo = fminf(lo, v); hi = fmaxf(hi, v); seen = 1; }
-    }
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    mm_span(a, n, tid, nthreads, lo, hi, seen);
+    mm_span(b, n, tid, nthreads, lo, hi, seen);
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); seen |= __shfl_xor(seen, o);
     }
-    if ((threadIdx.x & 63) == 0 && seen) {
-        atomicMin(&mm[0], f2key(lo)); atomicMax(&mm[1], f2key(hi)); atomicOr(&mm[2], 1u);
+    // one result per workgroup, and an atomic only when it can still change the global value: thousands of
+    // atomics on the three words of one cache line used to cost more than reading the two frames
+    __shared__ float s_lo[4], s_hi[4]; __shared__ unsigned s_seen[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[w] = lo; s_hi[w] = hi; s_seen[w] = seen; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { lo = fminf(lo, s_lo[k]); hi = fmaxf(hi, s_hi[k]); seen |= s_seen[k]; }
+        if (seen) {
+            const unsigned klo = f2key(lo), khi = f2key(hi);
+            if (klo < __hip_atomic_load(&mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mm[0], klo);
+            if (khi > __hip_atomic_load(&mm[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[1], khi);
+            if (__hip_atomic_load(&mm[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(&mm[2], 1u);
+        }
     }
 }
 
@@ -73,7 +110,7 @@ extern "C" int tf_to8bit_pair(const float *frame0, const float *frame1, int64_t 
     hipStream_t s = (hipStream_t)stream;
     unsigned *mm = (unsigned *)ws;
     const int64_t n = H * W;
-    int blocks = (int)((2 * n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
     TfProfScope ps(TFK_TO8BIT, 18.0 * n, s);
     hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, s, mm);
     hipLaunchKernelGGL(k_minmax, dim3(blocks), dim3(256), 0, s, frame0, frame1, n, mm);
