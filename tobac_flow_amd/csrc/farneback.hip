@@ -75,6 +75,29 @@ k_fb_blur_cols(const float *__restrict__ src, int H, int W, const FbKernel kk, f
     dst[(int64_t)y * W + x] = s;
 }
 
+// 3 x 3 Gaussian blur in one pass (the kernel size of pyramid levels 0 and 1 with the default pyr_scale): every thread
+// forms the three row sums its column pass needs, with exactly the expressions of k_fb_blur_rows / k_fb_blur_cols, so the
+// result is bit-identical to the two-pass form while the float intermediate (4 B written + 4 B read per pixel) never
+// exists: 1 B read + 4 B written per pixel instead of 13.
+template <typename TIn>
+__global__ void __launch_bounds__(256)
+k_fb_blur3_fused(const TIn *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst, int64_t bs_src, int64_t bs_dst)
+{
+    src += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const float *k = kk.k;
+    const int xl = fb_reflect101(x - 1, W), xr = fb_reflect101(x + 1, W);
+    const int yu = fb_reflect101(y - 1, H), yd = fb_reflect101(y + 1, H);
+    const TIn *S0 = src + (int64_t)y * W, *Su = src + (int64_t)yu * W, *Sd = src + (int64_t)yd * W;
+    const float r0 = (float)S0[x] * k[1] + ((float)S0[xl] + (float)S0[xr]) * k[0];
+    const float ru = (float)Su[x] * k[1] + ((float)Su[xl] + (float)Su[xr]) * k[0];
+    const float rd = (float)Sd[x] * k[1] + ((float)Sd[xl] + (float)Sd[xr]) * k[0];
+    float s = k[1] * r0;
+    s += k[2] * (rd + ru);                                    // k_fb_blur_cols: k[r + 1] * (tmp[y + 1] + tmp[y - 1])
+    dst[(int64_t)y * W + x] = s;
+}
+
 // ---- cv::resize INTER_LINEAR (cn interleaved channels), optional post-scale ---------------------
 __global__ void __launch_bounds__(256)
 k_fb_resize_linear(const float *__restrict__ src, int sh, int sw, int cn, float *__restrict__ dst, int dh, int dw,
@@ -801,9 +824,15 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
             const bool area2 = !same && fabs(rsx - irx) < DBL_EPSILON && fabs(rsy - iry) < DBL_EPSILON && irx == 2 && iry == 2;
             if (same || area2) {
                 {
-                    TfProfScope ps(TFK_FB_BLUR, 13.0 * n * B, s);     // u8 r + f32 w, then f32 r + f32 w
-                    hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp, img_stride, bs_tmp);
-                    hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur, bs_tmp, bs_n);
+                    static const bool two_pass = getenv("TF_FB_BLUR_TWOPASS") != nullptr;    // development aid
+                    if (hk.ksize == 3 && !two_pass) {
+                        TfProfScope ps(TFK_FB_BLUR, 5.0 * n * B, s);  // u8 r + f32 w
+                        hipLaunchKernelGGL(k_fb_blur3_fused<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, blur, img_stride, bs_n);
+                    } else {
+                        TfProfScope ps(TFK_FB_BLUR, 13.0 * n * B, s); // u8 r + f32 w, then f32 r + f32 w
+                        hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp, img_stride, bs_tmp);
+                        hipLaunchKernelGGL(k_fb_blur_cols, gfull, block, 0, s, tmp, H, W, hk, blur, bs_tmp, bs_n);
+                    }
                 }
                 if (area2) {
                     TfProfScope ps(TFK_FB_RESIZE, (4.0 * n + 4.0 * plane) * B, s);
