@@ -98,6 +98,42 @@ k_fb_blur3_fused(const TIn *__restrict__ src, int H, int W, const FbKernel kk, f
     dst[(int64_t)y * W + x] = s;
 }
 
+// 3 x 3 Gaussian blur followed by the exact-2x INTER_AREA resize (pyramid level 1), in one pass: a thread of the
+// half-resolution grid forms the four blurred values of its 2 x 2 block with the expressions of k_fb_blur3_fused and
+// averages them in k_fb_resize_area2's order.  Bit-identical to blur-then-resize; the full-resolution float image of
+// this level (4 B written + 4 B read per pixel) never exists.
+template <typename TIn>
+__global__ void __launch_bounds__(256)
+k_fb_blur3_area2(const TIn *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst, int dh, int dw,
+                 int64_t bs_src, int64_t bs_dst)
+{
+    src += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    const float *k = kk.k;
+    const int x0 = 2 * dx, y0 = 2 * dy;
+    const int xs[4] = {fb_reflect101(x0 - 1, W), x0, x0 + 1, fb_reflect101(x0 + 2, W)};
+    const int ys[4] = {fb_reflect101(y0 - 1, H), y0, y0 + 1, fb_reflect101(y0 + 2, H)};
+    float r[4][2];                                            // row sums of rows ys[j] at columns x0, x0 + 1
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const TIn *S = src + (int64_t)ys[j] * W;
+        const float v0 = (float)S[xs[0]], v1 = (float)S[xs[1]], v2 = (float)S[xs[2]], v3 = (float)S[xs[3]];
+        r[j][0] = v1 * k[1] + (v0 + v2) * k[0];               // column x0:     S[x] k1 + (S[x-1] + S[x+1]) k0
+        r[j][1] = v2 * k[1] + (v1 + v3) * k[0];               // column x0 + 1
+    }
+    float b[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float s0 = k[1] * r[1][c]; s0 += k[2] * (r[2][c] + r[0][c]);        // row y0:     k1 tmp[y] + k2 (tmp[y+1] + tmp[y-1])
+        float s1 = k[1] * r[2][c]; s1 += k[2] * (r[3][c] + r[1][c]);        // row y0 + 1
+        b[0][c] = s0; b[1][c] = s1;
+    }
+    float sum = 0;
+    sum += b[0][0] + b[0][1] + b[1][0] + b[1][1];
+    dst[(int64_t)dy * dw + dx] = sum * 0.25f;
+}
+
 // ---- cv::resize INTER_LINEAR (cn interleaved channels), optional post-scale ---------------------
 __global__ void __launch_bounds__(256)
 k_fb_resize_linear(const float *__restrict__ src, int sh, int sw, int cn, float *__restrict__ dst, int dh, int dw,
@@ -822,9 +858,13 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
             const int irx = (int)(rsx + 0.5), iry = (int)(rsy + 0.5);
             const bool same = (w == W && h == H);
             const bool area2 = !same && fabs(rsx - irx) < DBL_EPSILON && fabs(rsy - iry) < DBL_EPSILON && irx == 2 && iry == 2;
-            if (same || area2) {
+            static const bool two_pass = getenv("TF_FB_BLUR_TWOPASS") != nullptr;            // development aid
+            if (area2 && hk.ksize == 3 && !two_pass && W >= 2 && H >= 2 && 2 * w <= W && 2 * h <= H) {
+                TfProfScope ps(TFK_FB_BLUR, (1.0 * n + 4.0 * plane) * B, s);                   // u8 r + quarter-size f32 w
+                hipLaunchKernelGGL(k_fb_blur3_area2<uint8_t>, glev, block, 0, s, img[i], H, W, hk, I, h, w, img_stride, bs_n);
+                Ik = I;
+            } else if (same || area2) {
                 {
-                    static const bool two_pass = getenv("TF_FB_BLUR_TWOPASS") != nullptr;    // development aid
                     if (hk.ksize == 3 && !two_pass) {
                         TfProfScope ps(TFK_FB_BLUR, 5.0 * n * B, s);  // u8 r + f32 w
                         hipLaunchKernelGGL(k_fb_blur3_fused<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, blur, img_stride, bs_n);
