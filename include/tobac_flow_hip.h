@@ -139,6 +139,15 @@ int tf_convolve(const void *data, int data_type, int64_t T, int64_t H, int64_t W
  * out_type TF_F64 (the function's own result) or TF_F32 (the cast tobac_flow/watershed.py:64-65 applies). */
 int tf_edge_field(const double *sobel, const float *field, int64_t n, void *out, int out_type, void *stream);
 
+/* tf_sobel_edge_field: the same result in ONE kernel -- tobac_flow/detection.py:620-642 get_combined_edge_field:
+ *   edges = Flow.sobel(field, direction="uphill", method=interp)     (float64 stack, sobel.py:89-143, fill NaN)
+ *   edges[edges > 0] += 1;  edges = edges - field;  edges[isnan(field)] = inf;   stored as out_type
+ * (TF_F32 rounds the finished value the way watershed.py:64-65 would).  Bit-identical to
+ * tf_convolve(func = TF_FUNC_SOBEL_UPHILL, out_type = TF_F64) followed by tf_edge_field; the float64 Sobel volume
+ * (8 B written + 8 B read per voxel) is never stored. */
+int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int64_t W, const float *fwd, const float *bwd,
+                        int interp, void *out, int out_type, void *stream);
+
 /* ---- a14/a15: semi-Lagrangian marker-controlled watershed -------------------------------------
  * replaces tobac_flow/watershed.py:17-168 (wrapper) and tobac_flow/_watershed.pyx:222-344
  * (watershed_raveled, the reference's only native kernel; compactness = 0, wsl = False).

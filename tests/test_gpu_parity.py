@@ -547,3 +547,34 @@ def test_calculate_flow_with_other_normalisation_methods(tf, method, kwargs):
         assert np.abs(fwd[0]).max() > 0.3
     with pytest.raises(ValueError):
         tf.calculate_flow(stack, "Farneback", normalisation_method="quadratic")
+
+
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic"])
+def test_sobel_edge_field_fused_is_bit_identical_to_the_two_kernel_form(tf, interp):
+    """tf_sobel_edge_field against tf_convolve(SOBEL_UPHILL, float64) + tf_edge_field (the two-kernel form of
+    detection.py:620-642), float32 and float64 outputs, NaNs in the field, first / last frame (missing neighbours)."""
+    import torch
+    from tobac_flow_amd import _lib
+    rng = np.random.default_rng(12)
+    shape = (4, 45, 70)
+    field = rand_field(rng, shape).astype(np.float32)
+    field[rng.random(shape) < 0.03] = np.nan
+    fwd, bwd = rand_flow(rng, shape, 2.5), rand_flow(rng, shape, 2.5)
+    T, H, W = shape
+    L = _lib.lib()
+    f = torch.from_numpy(field).cuda()
+    fw, bw = torch.from_numpy(fwd).cuda(), torch.from_numpy(bwd).cuda()
+    code = _lib.INTERP[interp]
+    struct = np.ones(27, np.uint8)
+    sob = torch.empty(shape, dtype=torch.float64, device="cuda")
+    _lib.check(L.tf_convolve(_lib.ptr(f), _lib.TF_F32, T, H, W, _lib.ptr(fw), _lib.ptr(bw), struct.ctypes.data_as(_lib._P), code,
+                             float("nan"), 2, _lib.ptr(sob), _lib.TF_F64, 0, T, _lib.stream_ptr()), "tf_convolve")
+    for dt, ty in ((torch.float64, _lib.TF_F64), (torch.float32, _lib.TF_F32)):
+        two = torch.empty(shape, dtype=dt, device="cuda")
+        one = torch.empty(shape, dtype=dt, device="cuda")
+        _lib.check(L.tf_edge_field(_lib.ptr(sob), _lib.ptr(f), sob.numel(), _lib.ptr(two), ty, _lib.stream_ptr()), "tf_edge_field")
+        _lib.check(L.tf_sobel_edge_field(_lib.ptr(f), T, H, W, _lib.ptr(fw), _lib.ptr(bw), code, _lib.ptr(one), ty,
+                                         _lib.stream_ptr()), "tf_sobel_edge_field")
+        a, b = one.cpu().numpy(), two.cpu().numpy()
+        assert np.array_equal(a, b, equal_nan=True), f"{interp} {dt}: {int((a != b).sum())} differ"
+        assert np.isposinf(a[np.isnan(field)]).all() and np.isfinite(a).any()

@@ -44,6 +44,7 @@ _PROTOS = {
     "tf_convolve": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int,
                                _c.c_double, _c.c_int, _P, _c.c_int, _c.c_int64, _c.c_int64, _P]),
     "tf_edge_field": (_c.c_int, [_P, _P, _c.c_int64, _P, _c.c_int, _P]),
+    "tf_sobel_edge_field": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _c.c_int, _P, _c.c_int, _P]),
     "tf_watershed_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int64]),
     "tf_watershed": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int,
                                 _P, _P, _c.c_size_t, _P, _P]),

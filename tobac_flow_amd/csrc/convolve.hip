@@ -239,7 +239,9 @@ __device__ __forceinline__ void sobel_accumulate(TS v, TS c, int wx, int wy, int
     if (wt) gt += dd * (double)wt;
 }
 
-template <int METHOD, typename TS, int DIR>
+// EDGE: the tail of detection.py:638-642 (get_combined_edge_field) is applied to the float64 magnitude before it is
+// stored -- edges[edges > 0] += 1; edges -= field; edges[isnan(field)] = inf -- exactly k_edge_field's expressions.
+template <int METHOD, typename TS, int DIR, bool EDGE = false>
 __global__ void __launch_bounds__(256)
 k_sobel27(const float *__restrict__ data, const float *__restrict__ fwd, const float *__restrict__ bwd,
           int64_t T, int H, int W, double fill, void *__restrict__ out, int out_type, int64_t t0)
@@ -295,7 +297,15 @@ k_sobel27(const float *__restrict__ data, const float *__restrict__ fwd, const f
     m += gt * gt;
     double r = sqrt(m);
     if (centre != centre) r = fill;
-    store_out<double>(out, out_type, pix, r);
+    if (EDGE) {
+        double e = r;
+        if (e > 0) e += 1.0;
+        e = e - (double)centre;
+        if (centre != centre) e = INFINITY;
+        store_out<double>(out, out_type, pix, e);
+    } else {
+        store_out<double>(out, out_type, pix, r);
+    }
 }
 
 template <int METHOD, typename TS>
@@ -563,6 +573,28 @@ k_edge_field(const double *__restrict__ sob, const float *__restrict__ field, in
     e = e - (double)f;
     if (f != f) e = INFINITY;
     if (out_type == TF_F64) ((double *)out)[i] = e; else ((float *)out)[i] = (float)e;
+}
+
+extern "C" int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int64_t W, const float *fwd, const float *bwd,
+                                   int interp, void *out, int out_type, void *stream)
+{
+    TF_REQUIRE(field && fwd && bwd && out, "tf_sobel_edge_field: null pointer");
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_sobel_edge_field: bad shape");
+    TF_REQUIRE(interp >= TF_INTERP_NEAREST && interp <= TF_INTERP_CUBIC, "tf_sobel_edge_field: bad interp");
+    TF_REQUIRE(out_type == TF_F32 || out_type == TF_F64, "tf_sobel_edge_field: out_type must be f32 or f64");
+    hipStream_t s = (hipStream_t)stream;
+    const double fill = NAN;                                  // Flow.sobel's default fill_value
+    TfProfScope ps(TFK_SOBEL, (4.0 + 16.0 + (out_type == TF_F64 ? 8.0 : 4.0)) * (double)H * W * (double)T, s);
+    dim3 block(64, 4, 1), grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
+    // the Sobel stack is float64 (Flow.sobel(dtype=None)); only the finished edge value is rounded to out_type
+    if (interp == TF_INTERP_NEAREST)
+        hipLaunchKernelGGL((k_sobel27<TF_INTERP_NEAREST, double, TF_FUNC_SOBEL_UPHILL, true>), grid, block, 0, s, field, fwd, bwd, T, (int)H, (int)W, fill, out, out_type, (int64_t)0);
+    else if (interp == TF_INTERP_LINEAR)
+        hipLaunchKernelGGL((k_sobel27<TF_INTERP_LINEAR, double, TF_FUNC_SOBEL_UPHILL, true>), grid, block, 0, s, field, fwd, bwd, T, (int)H, (int)W, fill, out, out_type, (int64_t)0);
+    else
+        hipLaunchKernelGGL((k_sobel27<TF_INTERP_CUBIC, double, TF_FUNC_SOBEL_UPHILL, true>), grid, block, 0, s, field, fwd, bwd, T, (int)H, (int)W, fill, out, out_type, (int64_t)0);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
 }
 
 extern "C" int tf_edge_field(const double *sobel, const float *field, int64_t n, void *out, int out_type, void *stream)

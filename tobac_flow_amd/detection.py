@@ -459,11 +459,15 @@ def get_combined_edge_field(flow, field, **kwargs):
         # rounded the way watershed.py:64-65 would round it
         out_dtype = kwargs.get("dtype", np.float64)
         f32 = field.to(t.float32).contiguous()
-        edges = flow.sobel(f32, direction="uphill", method="cubic")
-        out = _lib.empty(tuple(edges.shape), t.float32 if np.dtype(out_dtype) == np.float32 else t.float64)
-        _lib.check(_lib.lib().tf_edge_field(_lib.ptr(edges), _lib.ptr(f32), edges.numel(), _lib.ptr(out),
-                                            _lib.TF_F32 if out.dtype == t.float32 else _lib.TF_F64, _lib.stream_ptr()),
-                   "tf_edge_field")
+        if f32.dim() != 3 or tuple(f32.shape) != tuple(flow.shape):
+            raise ValueError("field must have the shape of the flow (t, y, x)")
+        T, H, W = f32.shape
+        fw, bw = flow._dev_flows()
+        out = _lib.empty((T, H, W), t.float32 if np.dtype(out_dtype) == np.float32 else t.float64)
+        # Sobel (float64 stack) and the edge-field tail in one kernel: the float64 Sobel volume is never stored
+        _lib.check(_lib.lib().tf_sobel_edge_field(_lib.ptr(f32), T, H, W, _lib.ptr(fw), _lib.ptr(bw), _lib.INTERP["cubic"],
+                                                  _lib.ptr(out), _lib.TF_F32 if out.dtype == t.float32 else _lib.TF_F64,
+                                                  _lib.stream_ptr()), "tf_sobel_edge_field")
         return out
     edges = flow.sobel(field, direction="uphill", method="cubic")
     edges[edges > 0] += 1
