@@ -103,9 +103,16 @@ k_ws_relevant(const uint8_t *__restrict__ cls, const float *__restrict__ fwd, co
     if (c == 2) {
         const float2 fw = ((const float2 *)fwd)[p], bw = ((const float2 *)bwd)[p];
         const int fx = ws_round_flow(fw.x), fy = ws_round_flow(fw.y), bx = ws_round_flow(bw.x), by = ws_round_flow(bw.y);
-        for (int i = 0; i < g.n_nbr && !f; i++) {
-            const int64_t n = ws_neighbour(g, t, y, x, fx, fy, bx, by, i);
-            if (n >= 0 && cls[n] == 1) f = 1;
+        // eight neighbour classes in flight at a time (a marker inside a marker region has to look at all of them)
+        for (int i0 = 0; i0 < g.n_nbr && !f; i0 += 8) {
+            uint8_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int64_t n = i0 + j < g.n_nbr ? ws_neighbour(g, t, y, x, fx, fy, bx, by, i0 + j) : -1;
+                v[j] = n >= 0 ? cls[n] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) f |= v[j] == 1;
         }
     }
     flag[p] = f;
