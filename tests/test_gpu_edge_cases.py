@@ -261,3 +261,23 @@ def test_flow_diagnostics_run_and_satisfy_their_identities(tf):
     assert np.array_equal(fw0[:-1, :-1, :-1], stack[1:, :-1, :-1])
     assert np.isnan(fw0[:-1, -1, :]).all() and np.isnan(fw0[:-1, :, -1]).all() and np.isnan(fw0[-1]).all()
     assert tf.time_flow(stack, vr_steps=0, smoothing_passes=0) > 0
+
+
+def test_stitch_window_list_on_gpu_equals_host_result():
+    """the single-process window stitch with GPU tensors (tf_apply_lut relabelling) against the same call on CPU tensors"""
+    import torch
+    from tobac_flow_amd.parallel import stitch_window_list, window_bounds
+    rng = np.random.default_rng(3)
+    truth, n = ndi.label(ndi.gaussian_filter(rng.normal(size=(10, 40, 50)), (1.0, 1.5, 1.5)) > 0.03)
+    assert n >= 4
+    wins = []
+    for a, b in window_bounds(10, 3):
+        w = truth[a:b].astype(np.int32)
+        ids = np.unique(w[w > 0])
+        perm = np.zeros(w.max() + 1, np.int32)
+        perm[ids] = rng.permutation(len(ids)) + 1
+        wins.append(perm[w])
+    host = [x.numpy() for x in stitch_window_list([torch.from_numpy(w) for w in wins])]
+    dev = [x.cpu().numpy() for x in stitch_window_list([torch.from_numpy(w).cuda() for w in wins])]
+    for h, d in zip(host, dev):
+        assert d.dtype == np.int32 and np.array_equal(h, d)

@@ -420,3 +420,41 @@ def test_small_utilities_known_answers():
             assert len(per_label[lab - 1]) == 2            # both labels live in two time steps
         else:
             assert per_label[lab - 1] is None
+
+
+@pytest.mark.parametrize("n_windows", [1, 2, 4])
+def test_stitch_window_list_reassembles_a_labelling(n_windows):
+    """parallel.stitch_window_list: cut a labelled (t, y, x) volume into windows that share one frame, renumber every
+    window independently, stitch: the result is the original labelling up to renumbering in order of first appearance
+    (the single-process form of the multi-GPU stitch, reference scheme: linking.py:49-161)."""
+    import scipy.ndimage as ndi
+    import torch
+    from tobac_flow_amd.parallel import stitch_window_list, window_bounds
+    rng = np.random.default_rng(8)
+    blobs = ndi.gaussian_filter(rng.normal(size=(13, 30, 36)), (1.2, 1.5, 1.5)) > 0.03
+    truth, n = ndi.label(blobs)
+    assert n >= 4
+    truth = truth.astype(np.int32)
+    truth[0, 0, 0] = -7                                        # negative ids pass through untouched
+    windows = []
+    for a, b in window_bounds(truth.shape[0], n_windows):
+        w = truth[a:b].copy()
+        ids = np.unique(w[w > 0])
+        perm = np.zeros(max(w.max(), 0) + 1, np.int32)
+        perm[ids] = rng.permutation(len(ids)) + 1              # what an independent per-window labelling would give
+        w[w > 0] = perm[w[w > 0]]
+        windows.append(torch.from_numpy(w))
+    out = [x.numpy() for x in stitch_window_list(windows)]
+    bounds = window_bounds(truth.shape[0], n_windows)
+    for (a, b), w in zip(bounds, out):                          # shared frames agree between neighbours
+        assert w.shape == truth[a:b].shape
+    for i in range(n_windows - 1):
+        assert np.array_equal(out[i][-1], out[i + 1][0])
+    whole = np.concatenate([out[0]] + [w[1:] for w in out[1:]])
+    assert whole[0, 0, 0] == -7 and np.array_equal(whole == 0, truth == 0)
+    # same partition: a bijection between the stitched ids and the true ids
+    pos = truth > 0
+    pairs = np.unique(np.stack([truth[pos], whole[pos]], 1), axis=0)
+    assert len(pairs) == len(np.unique(truth[pos])) == len(np.unique(whole[pos]))
+    assert sorted(np.unique(whole[pos]).tolist()) == list(range(1, len(pairs) + 1))
+    assert stitch_window_list([]) == []

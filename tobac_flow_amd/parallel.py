@@ -53,6 +53,35 @@ def stitch_lut(counts, pairs_per_boundary):
     return [np.concatenate([[0], new[offs[r] + 1: offs[r + 1] + 1]]) for r in range(len(counts))]
 
 
+def boundary_pairs(left_last, right_first, base, min_overlap=1):
+    """(id_left, id_right) pairs of positive labels that coincide in the frame two consecutive windows share, seen in at
+    least `min_overlap` pixels; `base` > the largest id of the right window.  Tensors (CPU or GPU), (k, 2) int64 out."""
+    import torch
+    a, b = left_last.reshape(-1).to(torch.int64), right_first.reshape(-1).to(torch.int64)
+    both = (a > 0) & (b > 0)
+    key, cnt = torch.unique(a[both] * base + b[both], return_counts=True)
+    key = key[cnt >= min_overlap]
+    return torch.stack([key // base, key % base], 1)
+
+
+def stitch_window_list(windows, min_overlap=1):
+    """Single-process form of stitch_labels: `windows` is a list of (T_w, H, W) int32 label tensors (CPU or GPU), window
+    w + 1 starting with the frame window w ends with (e.g. a 144-frame stack processed as twelve windows on one GPU,
+    window_bounds).  Returns the relabelled windows: positive ids made globally consistent (contiguous from 1 in order
+    of first appearance), zero and negative ids kept.  Same LUT logic as the distributed version."""
+    import torch
+    if len(windows) == 0:
+        return []
+    counts = [int(torch.clamp(w.max(), min=0).item()) if w.numel() else 0 for w in windows]
+    pairs = []
+    for r in range(len(windows) - 1):
+        if windows[r].shape[1:] != windows[r + 1].shape[1:]:
+            raise ValueError("windows must share their spatial shape")
+        pairs.append(boundary_pairs(windows[r][-1], windows[r + 1][0], counts[r + 1] + 1, min_overlap).cpu().numpy())
+    luts = stitch_lut(counts, pairs)
+    return [apply_global_lut(w, lut) for w, lut in zip(windows, luts)]
+
+
 def stitch_labels(labels, group=None, min_overlap=1):
     """Make the positive label IDs of per-rank windows globally consistent.
 
@@ -88,12 +117,7 @@ def stitch_labels(labels, group=None, min_overlap=1):
         req.wait()
     # pairs on my right boundary
     if rank < world - 1:
-        a, b = labels[-1].reshape(-1).to(torch.int64), right_first.reshape(-1).to(torch.int64)
-        both = (a > 0) & (b > 0)
-        base = counts[rank + 1] + 1
-        key, cnt = torch.unique(a[both] * base + b[both], return_counts=True)
-        key = key[cnt >= min_overlap]
-        mine = torch.stack([key // base, key % base], 1)
+        mine = boundary_pairs(labels[-1], right_first, counts[rank + 1] + 1, min_overlap)
     else:
         mine = torch.zeros((0, 2), dtype=torch.int64, device=dev)
     n_mine = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)
