@@ -458,3 +458,26 @@ def test_stitch_window_list_reassembles_a_labelling(n_windows):
     assert len(pairs) == len(np.unique(truth[pos])) == len(np.unique(whole[pos]))
     assert sorted(np.unique(whole[pos]).tolist()) == list(range(1, len(pairs) + 1))
     assert stitch_window_list([]) == []
+
+
+def test_apply_func_to_labels_behaviours():
+    """utils.label_utils.apply_func_to_labels beyond the reference's own test (tests/test_label_utils.py:5-75): explicit
+    index incl. absent and unordered labels, broadcasting, sequence defaults, multi-valued func, region values in C order."""
+    from tobac_flow_amd.utils.label_utils import apply_func_to_labels
+    labels = np.array([[0, 2, 2, 0], [5, 5, 0, 2], [0, 0, 0, 5]])
+    data = np.arange(12.0).reshape(3, 4)
+    assert np.array_equal(apply_func_to_labels(labels, data, func=np.sum, default=-1.0), [-1, 1 + 2 + 7, -1, -1, 4 + 5 + 11])
+    assert np.array_equal(apply_func_to_labels(labels, data, func=np.sum, index=[5, 3, 2], default=0.0), [20.0, 0.0, 10.0])
+    # values reach func in C order of the pixels
+    assert apply_func_to_labels(labels, data, func=lambda v: v[0] * 100 + v[-1], index=[2])[()] == 1 * 100 + 7
+    # broadcasting of a lower-dimensional field
+    row = np.array([10.0, 20.0, 30.0, 40.0])
+    assert np.array_equal(apply_func_to_labels(labels, row, func=np.max, index=[2, 5]), [40.0, 40.0])
+    # multi-valued func: scalar default repeated, one-element sequence unwrapped, full sequence used as given
+    mm = lambda v: (v.min(), v.max())
+    assert np.array_equal(apply_func_to_labels(labels, data, func=mm, index=[2, 4], default=np.nan),
+                          [[1.0, np.nan], [7.0, np.nan]], equal_nan=True)
+    assert np.array_equal(apply_func_to_labels(labels, data, func=mm, index=[4, 5], default=(-1.0, -2.0)), [[-1.0, 4.0], [-2.0, 11.0]])
+    assert np.array_equal(apply_func_to_labels(labels, data, func=np.sum, index=[4, 5], default=[9.0]), [9.0, 20.0])
+    with pytest.raises(IndexError):
+        apply_func_to_labels(np.zeros((2, 2), int), np.zeros((2, 2)), func=np.sum, index=[1], default=0.0)

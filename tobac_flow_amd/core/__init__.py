@@ -1,2 +1,4 @@
-"""Core: abstract classes (reference: tobac_flow/core/__init__.py)."""
-from tobac_flow_amd.core.abstracts import *  # noqa: F401,F403
+"""Abstract contract of the package's central object (see abstracts.py)."""
+from tobac_flow_amd.core.abstracts import FLOW_CONTRACT, AbstractFlow
+
+__all__ = ("AbstractFlow", "FLOW_CONTRACT")

@@ -56,55 +56,87 @@ def linearise_field(field, lower_threshold, upper_threshold):
     return np.maximum(np.minimum((field - lower_threshold) / (upper_threshold - lower_threshold), 1), 0)
 
 
+# ---- joint normalisation of a frame pair before the 8-bit quantisation ----------------------------------------------
+# Six methods, selected by name (calculate_flow's `normalisation_method`).  They are kept value-for-value equal to the
+# reference's formulas (tobac_flow/utils/normalisation_utils.py:59-160), including the way log_norm / inverse_log_norm
+# reuse the data minimum / maximum as a bound of the LOG values (tests/test_host_logic.py spells out the consequence);
+# what is shared between them is factored out: the NaN-ignoring bounds, the unit clip, the log compression.
+def _clip_unit(values):
+    return np.maximum(np.minimum(values, 1), 0)
+
+
+def _bounds(array, vmin, vmax):
+    lower = np.nanmin(array) if vmin is None else vmin
+    upper = np.nanmax(array) if vmax is None else vmax
+    return lower, upper
+
+
+def _log_compress(distance):
+    return np.log(distance + 1)
+
+
 def linear_norm(array, vmin=None, vmax=None):
-    """(array - vmin) / (vmax - vmin) clipped to [0, 1]; NaN-ignoring range (reference: :59-72)."""
-    if vmin is None:
-        vmin = np.nanmin(array)
-    if vmax is None:
-        vmax = np.nanmax(array)
-    factor = 1 / (vmax - vmin) if vmax > vmin else 0
-    return np.maximum(np.minimum((array - vmin) * factor, 1), 0)
+    """Position of each value between vmin and vmax (defaults: the NaN-ignoring range), clipped to [0, 1];
+    an empty or inverted range maps everything to 0."""
+    lower, upper = _bounds(array, vmin, vmax)
+    scale = 1 / (upper - lower) if upper > lower else 0
+    return _clip_unit((array - lower) * scale)
 
 
 def log_norm(array, vmin=None, vmax=None):
-    vmin = np.nanmin(array)
-    return linear_norm(np.log(array - vmin + 1), vmin=vmin, vmax=vmax)
+    """linear_norm of log(distance above the data minimum + 1); the data minimum doubles as the lower bound."""
+    floor = np.nanmin(array)
+    return linear_norm(_log_compress(array - floor), vmin=floor, vmax=vmax)
 
 
 def inverse_log_norm(array, vmin=None, vmax=None):
-    vmax = np.nanmax(array)
-    return linear_norm(np.log(vmax - array + 1), vmin=vmin, vmax=vmax)
+    """linear_norm of log(distance below the data maximum + 1); the data maximum doubles as the upper bound."""
+    ceiling = np.nanmax(array)
+    return linear_norm(_log_compress(ceiling - array), vmin=vmin, vmax=ceiling)
 
 
 def z_norm(array, max_std=3):
-    return linear_norm((array - np.nanmean(array)) / np.nanstd(array), vmin=-max_std, vmax=max_std)
+    """Standard score, with +-max_std standard deviations spanning [0, 1]."""
+    score = (array - np.nanmean(array)) / np.nanstd(array)
+    return linear_norm(score, vmin=-max_std, vmax=max_std)
 
 
 def uniform_norm(array, quantiles=256):
+    """Histogram equalisation: the index of the quantile bin a value falls into, rescaled to [0, 1]."""
     edges = np.quantile(array, np.linspace(0, 1, quantiles + 1))
-    edges[-1] = edges[-1] + 1
+    edges[-1] = edges[-1] + 1                       # the maximum belongs to the last bin, not to one beyond it
     return linear_norm(np.digitize(array, edges))
 
 
 def local_linear_norm(data, size=100):
+    """Position of each value between the minimum and maximum of its size^n neighbourhood (0 where that
+    neighbourhood is flat); NaNs are first replaced by the mean, on a copy."""
     if not np.all(np.isfinite(data)):
         data = np.copy(data)
         data[np.isnan(data)] = np.nanmean(data)
-    vmax, vmin = ndi.maximum_filter(data, size), ndi.minimum_filter(data, size)
-    span = vmax - vmin
+    lowest, highest = ndi.minimum_filter(data, size), ndi.maximum_filter(data, size)
+    span = highest - lowest
     flat = span == 0
-    span[flat] = 1
-    inv = 1 / span
-    inv[flat] = 0
-    return (data - vmin) * inv
+    scale = np.where(flat, 0, 1 / np.where(flat, 1, span))
+    return (data - lowest) * scale
+
+
+NORMALISATION_METHODS = {
+    "linear": linear_norm,
+    "log": log_norm,
+    "inverse_log": inverse_log_norm,
+    "z_score": z_norm,
+    "uniform": uniform_norm,
+    "local_linear": local_linear_norm,
+}
 
 
 def select_normalisation_method(method: str) -> Callable:
-    methods = {"linear": linear_norm, "log": log_norm, "inverse_log": inverse_log_norm,
-               "z_score": z_norm, "uniform": uniform_norm, "local_linear": local_linear_norm}
-    if method in methods:
-        return methods[method]
-    raise ValueError(f"{method} not an acceptable normalisation method, method must be one of {list(methods.keys())}")
+    try:
+        return NORMALISATION_METHODS[method]
+    except KeyError:
+        raise ValueError(f"{method} not an acceptable normalisation method, method must be one of "
+                         f"{list(NORMALISATION_METHODS)}") from None
 
 
 __all__ = ("to_8bit", "linearise_field", "linear_norm", "log_norm", "inverse_log_norm", "z_norm",
