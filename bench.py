@@ -24,6 +24,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def _fullres_traffic():
+    """HBM bytes of the dominant kernel's full-resolution launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes (profiles/round1_pmc_traffic_fullres_pair_v10.json).  `traffic` itself stays null: the counter passes crash
+    on the whole benchmark on this stack, and a per-launch figure for its mix of pyramid levels cannot be measured."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic_fullres_pair_v10.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    return {"launch": t["launch"], "fetch_bytes_raw": t["fetch_bytes_raw"],
+            "fetch_bytes_corrected": t["fetch_bytes_wide_read_corrected"], "write_bytes": t["write_bytes"],
+            "algorithmic_bytes": t["algorithmic_bytes"], "launch_us": t["launch_us_same_box"],
+            "source": "profiles/round1_pmc_traffic_fullres_pair_v10.json"}
+
+
 def cpu_baseline(seed):
     """The oracle (CPU restatement of the reference's cv2/numpy/Cython path, kind = "port") timed on ONE
     host core on a bounded sample of the same workload: a 5 x 1536 x 1536 stack."""
@@ -157,6 +173,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": calls,
                     "avg_launch_us": round(ms * 1e3 / calls, 2),
                     "share_of_step": round(ms / (dt * 1e3), 4),
+                    "traffic_fullres_pair": _fullres_traffic(),
                     "all_kernels": {k: {"ms_per_step": round(v[1] / a.steps, 3),
                                         "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[2] > 0 else None}
                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
