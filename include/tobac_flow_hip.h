@@ -31,6 +31,8 @@ extern "C" {
 #define TF_ENOMEM (-2)   /* workspace too small                               */
 #define TF_EHIP (-3)     /* a HIP runtime call or kernel launch failed        */
 #define TF_ENOCONV (-4)  /* an iterative kernel hit its sweep limit           */
+#define TF_EDEPTH (-5)   /* tf_watershed*: ties left at the deepest chain level the workspace allows; output written,
+                            but not guaranteed to equal the reference at the reported pixels */
 
 /* interpolation of the semi-Lagrangian gathers: cv2.INTER_NEAREST / _LINEAR / _CUBIC as selected
  * by tobac_flow/convolve.py:47-54 and tobac_flow/utils/flow_utils.py:22-34 */
@@ -157,8 +159,8 @@ int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int64_t W, con
  *   fwd, bwd (T, H, W, 2) float; rounded half-to-even to integer pixel offsets (watershed.py:121-141)
  *   nbr_host n_nbr x 3 int8 (dt, dy, dx) neighbour list IN THE REFERENCE'S ORDER
  *            (skimage _offsets_to_raveled_neighbors, watershed.py:114-116)
- *   chain_depth  number of tie-break levels of the pop-order key (>= 1; 3 is exact for tie-free
- *            fields and for the plateau structure of detect_anvils)
+ *   chain_depth  number of tie-break levels of the pop-order key (>= 1; 3 suffices for tie-free
+ *            fields and for the plateau structure of detect_anvils; see DESIGN.md and the contract below)
  *   labels   (T, H, W) int32 out
  * No padding is needed: out-of-volume neighbours are rejected by coordinate tests, which is what
  * the reference's zero-padded mask achieves (watershed.py:111-113).
@@ -168,7 +170,26 @@ int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int64_t W, con
  * TF_ENOMEM and stats_host[6] holds the exact count to size a retry with.
  * stats_host (optional, 8 x int64): [0] sweeps phase A, [1] sweeps root phase (fast path),
  * [2..4] sweeps of the chain phases when the fast path found a label conflict, [5] conflict flag,
- * [6] relevant pixel count.  This call synchronises the stream. */
+ * [6] relevant pixel count.  This call synchronises the stream.
+ *
+ * EXACTNESS CONTRACT (never a silent wrong label).  After the root phase the library checks, on the device, every
+ * pixel whose label was decided by the last-resort rule "smallest root index among candidates that tie on all
+ * compared chain levels":
+ *   - ties caused only by the cut-off at `chain_depth` levels are removed by computing further levels, up to
+ *     `max_depth` (tf_watershed_ex2; tf_watershed / tf_watershed_ex have max_depth = chain_depth).  If some remain:
+ *     return TF_EDEPTH (labels are still written);
+ *   - ties that remain with COMPLETE chains are ties between EQUAL-VALUED MARKERS.  The reference pushes all markers
+ *     with age 0 (_watershed.pyx:278-284), so their pop order is a by-product of its binary heap's array mechanics
+ *     (:67-152), which no order-free formulation reproduces.  The library resolves them by push order (raster index
+ *     of the marker = the reference's own marker_locations order) and returns TF_WS_AMBIGUOUS (> 0, not an error)
+ *     when at least one pixel's LABEL depends on that; tf_watershed_ex2 reports which pixels.
+ *   Return TF_OK therefore means: bit-identical to the reference's output for this input, whatever the tie-breaks. */
+#define TF_WS_AMBIGUOUS 1      /* success; stats[9] pixels carry a label that depends on the order of equal-valued markers */
+#define TF_WS_MAX_DEPTH 12     /* largest chain depth (levels of the pop-order key) */
+#define TF_WS_NSTATS 16
+#define TF_WS_AMB_DEPENDS 1    /* `ambiguous` bits: label depends on a last-resort tie-break ...                        */
+#define TF_WS_AMB_MARKER_TIE 2 /* ... the tie arises HERE, between chains that end in equal-valued markers            */
+#define TF_WS_AMB_DEPTH 4      /* ... the tie arises HERE because the chains are cut off at the final depth (TF_EDEPTH) */
 size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int n_nbr, int chain_depth,
                                     int64_t max_relevant);
 int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
@@ -177,15 +198,28 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
                  void *ws, size_t ws_bytes, int64_t *stats_host, void *stream);
 /* tf_watershed_ex = tf_watershed + `flags`.
  * TF_WS_SKIP_FAST_PATH: after phase A go straight to the chain phases instead of first trying the
- *   K2-only root phase + conflict test.  The labels are IDENTICAL either way (the fast path is only
+ *   K2-only root phase + exactness check.  The labels are IDENTICAL either way (the fast path is only
  *   taken when no tie-break can matter); the flag is a scheduling hint for inputs known to contain
  *   label conflicts (exact plateaus, as in detect_anvils), where the speculative root phase is wasted
- *   work.  With the flag stats_host[1] = 0 and stats_host[5] = -1 (conflict test not evaluated). */
+ *   work.  With the flag stats_host[1] = 0 and stats_host[5] = -1 (speculative phase not run). */
 #define TF_WS_SKIP_FAST_PATH 1
 int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
                     const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                     const int8_t *nbr_host, int n_nbr, int chain_depth, int flags, int32_t *labels,
                     void *ws, size_t ws_bytes, int64_t *stats_host, void *stream);
+/* tf_watershed_ex2: the full form.
+ *   chain_depth  depth the chain phases start at (when the speculative phase is skipped or rejected)
+ *   max_depth    deepest level the call may go to on its own (chain_depth <= max_depth <= TF_WS_MAX_DEPTH); the
+ *                workspace must be sized for it: tf_watershed_workspace_bytes(..., max_depth, ...)
+ *   ambiguous    (T, H, W) uint8 out or NULL: TF_WS_AMB_* bits per voxel (0 everywhere when the call returns TF_OK)
+ *   stats_host   TF_WS_NSTATS x int64 or NULL: [0..7] as above, [8] chain depth the labels were computed at,
+ *                [9] pixels whose label depends on a last-resort tie-break, [10] origins of such ties between
+ *                equal-valued markers, [11] origins left by the depth cut-off (> 0 <=> TF_EDEPTH), [12] root phases run */
+int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *mask,
+                     const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                     const int8_t *nbr_host, int n_nbr, int chain_depth, int max_depth, int flags,
+                     int32_t *labels, uint8_t *ambiguous, void *ws, size_t ws_bytes,
+                     int64_t *stats_host, void *stream);
 
 /* ---- section 8f-2: scipy.ndimage glue of the detection recipes (bit-exact with SciPy) ---------------------
  * tf_binary_morph: scipy.ndimage.binary_erosion (op 0) / binary_dilation (op 1) of a (T, H, W) uint8 volume with a

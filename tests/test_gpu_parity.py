@@ -277,19 +277,81 @@ def test_watershed_golden_bit_exact(tf, golden_ws, name):
     assert np.array_equal(got, c["labels"]), f"{int((got != c['labels']).sum())} px differ from the reference"
 
 
-@pytest.mark.parametrize("name,depth,max_vs_ref", [("C_quant4_c1", 3, 21), ("C_quant32_c1", 6, 0), ("E_const_plateau_c1", 3, 37)])
-def test_watershed_tie_heavy_goldens(tf, golden_ws, name, depth, max_vs_ref):
-    """Tie-heavy inputs: the HIP flood equals the oracle under the idealised marker order
-    (value, age, push sequence) bit for bit; against the reference itself the only differences are
-    where equal-valued markers (age 0) compete, which the reference resolves by heap-internal order."""
+@pytest.mark.parametrize("name,final_depth", [("C_quant4_c1", 3), ("C_quant32_c1", 6), ("E_const_plateau_c1", 3)])
+def test_watershed_tie_heavy_goldens(tf, golden_ws, name, final_depth):
+    """Tie-heavy inputs, default arguments.  The library deepens the chain comparison on its own (C_quant32 needs six
+    levels) and REPORTS the pixels whose label hangs on the order of equal-valued markers -- the one thing the
+    reference decides by the internal state of its heap.  Checked here: the labels equal the sequential flood under
+    the idealised marker order bit for bit; every pixel that differs from the reference's own output is reported; and
+    the report is exactly the one the numpy model of the contract computes (tests/ws_parallel_model.py)."""
+    import sys, os, warnings
+    sys.path.insert(0, os.path.dirname(__file__))
+    import ws_parallel_model as M
     from oracle import ws_oracle
+    from tobac_flow_amd.watershed import WatershedAmbiguityWarning
     c = golden_ws[name]
     conn = int(c["conn"])
-    got = tf.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], mask=c.get("mask"), connectivity=conn,
-                       chain_depth=depth)
+    with pytest.warns(WatershedAmbiguityWarning):
+        got, rep = tf.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], mask=c.get("mask"), connectivity=conn,
+                                return_ambiguous=True)
     ideal = ws_oracle.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn, tie_mode=1)
     assert np.array_equal(got, ideal), f"{int((got != ideal).sum())} px differ from the idealised-order oracle"
-    assert int((got != c["labels"]).sum()) <= max_vs_ref
+    differs = got != c["labels"]
+    assert not (differs & ((rep & 1) == 0)).any(), "a pixel differs from the reference without being reported"
+    assert not (rep & 4).any()                                   # nothing left by the depth cut-off
+    want, info = M.run(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn, depth=final_depth)
+    assert np.array_equal(got, want) and np.array_equal(rep, info["report"])
+    assert int(differs.sum()) == {"C_quant4_c1": 21, "C_quant32_c1": 0, "E_const_plateau_c1": 37}[name]
+
+
+def test_watershed_reports_the_depth_it_needed_and_refuses_a_silent_cut_off(tf, golden_ws):
+    """Nested exact plateaus (32-level quantised field): three chain levels are not enough.  With room to deepen the
+    call ends at depth 6 with the reference's labels; confined to depth 3 it raises instead of returning labels that
+    differ from the reference (38 px) with a clean return code -- and `on_ambiguous="ignore"` still warns."""
+    import torch
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.watershed import (WatershedAmbiguityWarning, WatershedDepthError, neighbour_offsets,
+                                          watershed_dev)
+    c = golden_ws["C_quant32_c1"]
+    fw, bw = _lib.to_dev(c["fwd"], torch.float32), _lib.to_dev(c["bwd"], torch.float32)
+    f, m = _lib.to_dev(c["field"], torch.float32), _lib.to_dev(c["markers"], torch.int32)
+    nbr = neighbour_offsets(int(c["conn"]), 3)
+    for expect_conflict in (None, True, False):
+        st = {}
+        lab = watershed_dev(fw, bw, f, m, None, nbr, 3, st, expect_conflict=expect_conflict, on_ambiguous="ignore")
+        assert st["chain_depth"] == 6 and st["depth_origins"] == 0
+        assert np.array_equal(lab.cpu().numpy(), c["labels"])
+    with pytest.raises(WatershedDepthError):
+        watershed_dev(fw, bw, f, m, None, nbr, 3, max_chain_depth=3)
+    st = {}
+    with pytest.warns(WatershedAmbiguityWarning, match="still tie at chain depth 3"):
+        lab, rep = watershed_dev(fw, bw, f, m, None, nbr, 3, st, max_chain_depth=3, on_ambiguous="ignore",
+                                 return_ambiguous=True)
+    lab, rep = lab.cpu().numpy(), rep.cpu().numpy()
+    assert st["depth_origins"] > 0 and (rep & 4).any()
+    differs = lab != c["labels"]
+    assert differs.sum() == 38 and not (differs & ((rep & 1) == 0)).any()
+    # the C ABI itself: TF_EDEPTH, never 0, when the cut-off decided a label
+    L = _lib.lib()
+    T, H, W = c["field"].shape
+    ws = torch.empty(L.tf_watershed_workspace_bytes(T, H, W, len(nbr), 3, 0), dtype=torch.uint8, device="cuda")
+    out = torch.empty((T, H, W), dtype=torch.int32, device="cuda")
+    rc = L.tf_watershed(_lib.ptr(f), _lib.ptr(m), None, _lib.ptr(fw), _lib.ptr(bw), T, H, W, nbr.ctypes.data_as(_lib._P),
+                        len(nbr), 3, _lib.ptr(out), _lib.ptr(ws), ws.numel(), None, None)
+    assert rc == -5 and b"still tie at chain depth 3" in L.tf_last_error()
+
+
+@pytest.mark.parametrize("name", ["A_cont_c1", "B_cont_mask_c2", "B_cont_mask_c3", "D_anvil_like_c1", "F_zero_flow_c1",
+                                  "G_big_flow_c1"])
+def test_watershed_clean_return_means_no_tie_break_mattered(tf, golden_ws, name):
+    """TF_OK <=> nothing was decided by a last-resort rule: no warning, an all-zero report, the reference's labels."""
+    import warnings
+    c = golden_ws[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got, rep = tf.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], mask=c.get("mask"),
+                                connectivity=int(c["conn"]), return_ambiguous=True, on_ambiguous="raise")
+    assert not rep.any() and np.array_equal(got, c["labels"])
 
 
 @pytest.mark.parametrize("seed", range(6))

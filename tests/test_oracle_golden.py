@@ -64,3 +64,33 @@ def test_parallel_model_equals_idealised_oracle(golden_ws):
         got, _ = M.run(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn, depth=depth)
         ideal = ws_oracle.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn, tie_mode=1)
         assert np.array_equal(got, ideal), name
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_exactness_report_of_the_parallel_model_covers_every_difference_from_the_reference(golden_ws, name):
+    """The contract the HIP flood reports against (include/tobac_flow_hip.h, tf_watershed_ex2), checked on its numpy
+    model: (1) whatever the depth, every pixel that differs from the REFERENCE's labels is reported as depending on
+    a last-resort tie-break; (2) no origin left by the depth cut-off <=> equal to the idealised-order flood;
+    (3) deepening on its own ends with the reference's labels everywhere outside the reported marker ties."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import ws_parallel_model as M
+    c = golden_ws[name]
+    conn = int(c["conn"])
+    args = (c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn)
+    ideal = ws_oracle.watershed(*args, tie_mode=1)
+    for depth in (1, 2, 3):
+        got, info = M.run(*args, depth=depth)
+        rep = info["report"]
+        assert not ((got != c["labels"]) & ((rep & 1) == 0)).any(), depth
+        assert not ((got != ideal) & ((rep & 1) == 0)).any(), depth
+        if not (rep & 4).any():
+            assert np.array_equal(got, ideal), depth
+    got, info = M.run_auto(*args, depth=1)
+    assert np.array_equal(got, ideal)
+    assert not (info["report"] & 4).any()
+    assert info["depth"] == {"C_quant32_c1": 6, "C_quant4_c1": 3, "D_anvil_like_c1": 3, "E_const_plateau_c1": 2}.get(name, 1)
+    differs = got != c["labels"]
+    assert not (differs & ((info["report"] & 1) == 0)).any()
+    if name not in ("C_quant4_c1", "C_quant32_c1", "E_const_plateau_c1"):
+        assert not info["report"].any() and not differs.any()

@@ -88,18 +88,36 @@ def model(p, depth=3, max_sweeps=100000):
     R = np.full(N, INF, np.uint64)
     R[is_marker] = np.arange(int(is_marker.sum()), dtype=np.uint64)   # idealised: push order
     mloc = idx[is_marker]
+    # label set [lo, hi] over the roots of ALL fully matching candidates (the exactness check of the library)
+    BIG = np.int64(1) << 40
+    lo = np.full(N, BIG, np.int64)
+    hi = np.full(N, -BIG, np.int64)
+    lo[is_marker] = out[is_marker]
+    hi[is_marker] = out[is_marker]
     while True:
         offered = np.where(match, R[EPc], INF)
         new = R.copy()
         np.minimum.at(new, ENc, offered)
+        nlo = lo.copy()
+        np.minimum.at(nlo, ENc, np.where(match, lo[EPc], BIG))
+        nhi = hi.copy()
+        np.maximum.at(nhi, ENc, np.where(match, hi[EPc], -BIG))
         total_sweeps += 1
-        if np.array_equal(new, R):
+        if np.array_equal(new, R) and np.array_equal(nlo, lo) and np.array_equal(nhi, hi):
             break
-        R = new
+        R, lo, hi = new, nlo, nhi
     lab = out.copy()
     ok = reached & (R != INF)
     lab[ok] = out[mloc[R[ok].astype(np.int64)]]
-    return lab, dict(sweeps_A=sweeps, sweeps_total=total_sweeps)
+    # report: bit 0 label depends on a last-resort tie-break; bit 1 origin between complete chains (equal-valued
+    # markers); bit 2 origin between chains cut off at `depth`
+    joins = match & ((lo[EPc] != lo[ENc]) | (hi[EPc] != hi[ENc]))
+    complete = ((C[depth - 1] & np.uint64(0xFFFFFFFF)) == 0) if depth >= 2 else np.zeros(N, bool)
+    origin = np.zeros(N, bool)
+    origin[ENc[joins]] = True
+    report = (ok & (lo != hi)).astype(np.uint8) | ((origin & complete).astype(np.uint8) << 1) \
+        | ((origin & ~complete).astype(np.uint8) << 2)
+    return lab, dict(sweeps_A=sweeps, sweeps_total=total_sweeps, report=report)
 
 
 def run(fwd, bwd, field, markers, mask=None, conn=1, depth=3):
@@ -107,5 +125,20 @@ def run(fwd, bwd, field, markers, mask=None, conn=1, depth=3):
     p = ws_oracle.prepare(fwd, bwd, field, markers, mask, conn)
     lab, info = model(p, depth)
     pd = p["pad"]
-    o = lab.reshape(p["out"].shape)
-    return o[pd[0]:o.shape[0] - pd[0], pd[1]:o.shape[1] - pd[1], pd[2]:o.shape[2] - pd[2]].copy(), info
+
+    def crop(a):
+        o = a.reshape(p["out"].shape)
+        return o[pd[0]:o.shape[0] - pd[0], pd[1]:o.shape[1] - pd[1], pd[2]:o.shape[2] - pd[2]].copy()
+
+    info["report"] = crop(info["report"])
+    return crop(lab), info
+
+
+def run_auto(fwd, bwd, field, markers, mask=None, conn=1, depth=3, max_depth=12):
+    """What the library does on its own: deepen until no origin is left by the depth cut-off."""
+    while True:
+        lab, info = run(fwd, bwd, field, markers, mask, conn, depth)
+        info["depth"] = depth
+        if not (info["report"] & 4).any() or depth >= max_depth:
+            return lab, info
+        depth += 1

@@ -50,6 +50,8 @@ _PROTOS = {
                                 _P, _P, _c.c_size_t, _P, _P]),
     "tf_watershed_ex": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int,
                                    _c.c_int, _P, _P, _c.c_size_t, _P, _P]),
+    "tf_watershed_ex2": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int,
+                                    _c.c_int, _c.c_int, _P, _P, _P, _c.c_size_t, _P, _P]),
     "tf_binary_morph": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "tf_correlate1d_sym": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int, _P, _P]),
     "tf_grey_morph": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _P, _P]),

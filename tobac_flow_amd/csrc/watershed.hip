@@ -40,7 +40,7 @@ typedef unsigned long long u64;
 #define WS_INF 0xFFFFFFFFFFFFFFFFull
 #define WS_MARKER_BIT 0x8000000000000000ull
 #define WS_MAX_NBR 26
-#define WS_MAX_DEPTH 8
+#define WS_MAX_DEPTH TF_WS_MAX_DEPTH
 #define WS_BATCH 32
 
 struct WsGeom {
@@ -53,6 +53,7 @@ struct WsC {               // compact arrays
     int64_t R; int n_nbr;
     const u64 *pix; const unsigned *val; const int *nbr;
     u64 *K2, *M1, *C[WS_MAX_DEPTH], *Rt;
+    int *Llo, *Lhi;        // smallest / largest label among the roots of all fully matching candidates (root phase)
 };
 
 __device__ __forceinline__ unsigned ws_ordkey(float v) {
@@ -63,6 +64,11 @@ __device__ __forceinline__ unsigned ws_ordkey(float v) {
 __device__ __forceinline__ u64 ws_load(const u64 *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Ordering by data dependency.  The in-queue flag of a pixel must be cleared BEFORE its key is read (otherwise a
+// decrease that lands between the read and the clear is never propagated).  Both are relaxed agent-scope accesses to
+// different addresses, which the memory system may perform out of order; so the key's address takes the exchange's
+// return value (0 or 1) as a term the compiler cannot fold: ws_after(x) is 0 for every value the flag can hold.
+__device__ __forceinline__ int ws_after(int was) { asm volatile("" : "+v"(was)); return was >> 2; }
 __device__ __forceinline__ int ws_round_flow(float f) {
     // np.round(flow).astype(int32), watershed.py:121-141 (half to even); NaN -> 0
     return (f == f) ? __float2int_rn(f) : 0;
@@ -169,6 +175,20 @@ k_ws_init_level(const u64 *__restrict__ pix, u64 *__restrict__ dst, int64_t R, i
     dst[i] = marker ? (is_root ? (px & ~WS_MARKER_BIT) : 0ull) : WS_INF;
 }
 
+// root phase start: a marker's label set is its own label, everything else starts empty
+__global__ void __launch_bounds__(256)
+k_ws_init_labelset(const u64 *__restrict__ pix, const int32_t *__restrict__ markers, int *__restrict__ lo,
+                   int *__restrict__ hi, int64_t R)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const u64 px = pix[i];
+    const bool marker = (px & WS_MARKER_BIT) != 0ull;
+    const int32_t l = marker ? markers[px & ~WS_MARKER_BIT] : 0;
+    lo[i] = marker ? l : 0x7fffffff;
+    hi[i] = marker ? l : (int)0x80000000;
+}
+
 // ---- frontier queues ---------------------------------------------------------------------------
 // A sweep processes the queue of pixels whose key changed (qin) and appends every pixel whose key it
 // lowers to qout.  inq[n] = 1 while n sits in a queue and has not been processed since: the flag is
@@ -218,8 +238,8 @@ __device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, bool act, 
         if (s0 == 0 && act) {
             // relaxed L2 atomics only: the key is loaded after the exchange has returned (the flag is cleared BEFORE
             // the key is read, so a later decrease re-queues the pixel); the id loads above are already in flight
-            const int was = atomicExch(&inq[p], 0);
-            kp = was == 0x7fffffff ? WS_INF : ws_load(&c.K2[p]);
+            const int dep = ws_after(atomicExch(&inq[p], 0));
+            kp = ws_load(&c.K2[p] + dep);
         }
         const u64 lp = kp >> 32;
         u64 vn[WS_NB], m1[WS_NB], k2[WS_NB];
@@ -275,11 +295,17 @@ k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in,
 //     iff K2[n] = (value(n), 1): its chain is [K2 n, chain(p)]   -> offered_j = C_{j-1}[p]
 //   otherwise n continues p's run / descent: chain = [K2 n, tail(p)] -> offered_j = C_j[p]
 // The candidate must agree with n on every level j < k.
+__device__ __forceinline__ int ws_load_i(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u64 *__restrict__ dst, WsStage &st,
                                                bool act0, int p, int *__restrict__ inq)
 {
     const int *np = c.nbr + (int64_t)p * c.n_nbr;
+    const bool root = k == depth;
     u64 kp = WS_INF, own = WS_INF;
+    int own_lo = 0x7fffffff, own_hi = (int)0x80000000;   // label set of p (root phase only)
     u64 cp[WS_MAX_DEPTH];                        // C_j[p], j < k: final since their own phases, read once per entry
     bool act = false;
     for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
@@ -287,22 +313,28 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) n[j] = (act0 && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
         if (s0 == 0 && act0) {
-            const int was = atomicExch(&inq[p], 0);
+            // the in-queue flag is cleared BEFORE p's own keys are read (the loads take the exchange's
+            // return value as an address term), so a later decrease re-queues p: no lost update
+            const int dep = ws_after(atomicExch(&inq[p], 0));
             kp = c.K2[p];                        // final since phase A
-            own = was == 0x7fffffff ? WS_INF : ws_load(&dst[p]);
+            own = ws_load(&dst[p] + dep);
+            if (root) { own_lo = ws_load_i(&c.Llo[p] + dep); own_hi = ws_load_i(&c.Lhi[p] + dep); }
             for (int j = 1; j < k; j++) cp[j] = c.C[j][p];
             act = kp != WS_INF;
         }
         u64 m1[WS_NB], kn[WS_NB], dn[WS_NB]; unsigned vn[WS_NB];
+        int lon[WS_NB], hin[WS_NB];
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) {
             const int q = n[j] >= 0 ? n[j] : 0;
             m1[j] = c.M1[q]; kn[j] = c.K2[q]; vn[j] = c.val[q]; dn[j] = dst[q];
+            lon[j] = root ? c.Llo[q] : 0; hin[j] = root ? c.Lhi[q] : 0;
         }
         u64 offered[WS_NB], old[WS_NB];
+        int olo[WS_NB], ohi[WS_NB];              // raw atomic returns of the label-set relaxations
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) {
-            offered[j] = WS_INF; old[j] = 0ull;
+            offered[j] = WS_INF; old[j] = 0ull; olo[j] = (int)0x80000000; ohi[j] = 0x7fffffff;
             if (act && n[j] >= 0 && m1[j] == kp) {
                 const bool entry = (kn[j] >> 32) == (u64)vn[j] && (kn[j] & 0xFFFFFFFFull) == 1ull;
                 bool match = true;
@@ -311,9 +343,14 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
                     match = offered_l == c.C[l][n[j]];
                 }
                 if (match) {
-                    if (k == depth) offered[j] = own;                                 // root: copied along every edge
+                    if (root) offered[j] = own;                                       // root: copied along every edge
                     else offered[j] = entry ? (k == 1 ? kp : cp[k - 1]) : own;
                     if (offered[j] != WS_INF && offered[j] < dn[j]) old[j] = atomicMin(&dst[n[j]], offered[j]);
+                    if (root) {
+                        // label set of n = union over its fully matching candidates (monotone min / max relaxations)
+                        if (own_lo < lon[j]) olo[j] = atomicMin(&c.Llo[n[j]], own_lo);
+                        if (own_hi > hin[j]) ohi[j] = atomicMax(&c.Lhi[n[j]], own_hi);
+                    }
                 }
             }
         }
@@ -321,7 +358,8 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) {
             was_q[j] = 1;
-            if (offered[j] < old[j]) was_q[j] = atomicExch(&inq[n[j]], 1);
+            const bool improved = offered[j] < old[j] || (root && (own_lo < olo[j] || own_hi > ohi[j]));
+            if (improved) was_q[j] = atomicExch(&inq[n[j]], 1);
         }
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) ws_stage(st, was_q[j] == 0, n[j]);
@@ -347,37 +385,88 @@ k_ws_sweep_chain(WsC c, int k, int depth, const int *__restrict__ qin, const int
     }
 }
 
-// after the K2-only root phase: does any candidate edge join two different labels?
+// ---- exactness check after a root phase at depth d ------------------------------------------------------------
+// The root phase also computed, for every reached pixel n, [Llo(n), Lhi(n)]: the range of labels over the roots of
+// ALL candidates whose chain agrees with n's on the d compared levels.  Llo == Lhi: whichever of those candidates the
+// reference pops first, n gets this label -- the result does not depend on any tie-break.  Llo != Lhi: the decision
+// was made by the last-resort rule (smallest root index), which is the reference's order only if ...
+//   * the compared chains are COMPLETE (they ended in a marker key within d levels: low word of C_{d-1}(n) is 0) --
+//     then the candidates tie on everything down to EQUAL-VALUED MARKERS, which the reference pops in an order fixed
+//     by the array mechanics of its binary heap (_watershed.pyx:278-284 pushes every marker with age 0; :67-152).
+//     No order-free formulation reproduces that; the library uses the push order (raster index) and REPORTS the pixel;
+//   * otherwise the chains were cut off at d levels (depth exhausted) and the tie is an artefact: the caller deepens.
+// An ORIGIN is a pixel where two label sets meet (a fully matching edge p -> n with a different set at p); every
+// other ambiguous pixel inherited its set.  org[n]: bit 0 = origin with complete chains, bit 1 = origin cut off.
 __global__ void __launch_bounds__(256)
-k_ws_conflicts(WsC c, const int32_t *__restrict__ markers, int *__restrict__ conflict)
+k_ws_origins(WsC c, int depth, int *__restrict__ org)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= c.R) return;
     const u64 kp = c.K2[p];
-    if (kp == WS_INF) return;
-    const u64 rp = c.Rt[p];
-    if (rp == WS_INF) return;
-    const int32_t lp = markers[rp];
-    bool bad = false;
+    if (kp == WS_INF || c.Rt[p] == WS_INF) return;
+    const int lo = c.Llo[p], hi = c.Lhi[p];
+    u64 cp[WS_MAX_DEPTH];
+    for (int j = 1; j < depth; j++) cp[j] = c.C[j][p];
     for (int i = 0; i < c.n_nbr; i++) {
         const int n = c.nbr[p * c.n_nbr + i];
         if (n < 0 || c.M1[n] != kp) continue;
-        const u64 rn = c.Rt[n];
-        bad |= rn == WS_INF || markers[rn] != lp;
+        const u64 kn = c.K2[n];
+        const bool entry = (kn >> 32) == (u64)c.val[n] && (kn & 0xFFFFFFFFull) == 1ull;
+        bool match = true;
+        for (int l = 1; l < depth && match; l++) {
+            const u64 offered_l = entry ? (l == 1 ? kp : cp[l - 1]) : cp[l];
+            match = offered_l == c.C[l][n];
+        }
+        if (!match) continue;
+        if (c.Llo[n] != lo || c.Lhi[n] != hi) {
+            const bool complete = depth >= 2 && (c.C[depth - 1][n] & 0xFFFFFFFFull) == 0ull;
+            atomicOr(&org[n], complete ? 1 : 2);
+        }
     }
-    if (bad) *conflict = 1;
 }
 
+// cnt[0] = pixels whose label depends on a last-resort tie-break, cnt[1] = origins between equal-valued markers,
+// cnt[2] = origins whose chains were cut off at the current depth
+__global__ void __launch_bounds__(256)
+k_ws_count_ambiguous(WsC c, const int *__restrict__ org, unsigned long long *__restrict__ cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int a = 0, t = 0, e = 0;
+    if (i < c.R && c.Rt[i] != WS_INF && !(c.pix[i] & WS_MARKER_BIT)) {
+        a = c.Llo[i] != c.Lhi[i];
+        const int o = org[i];
+        t = o & 1; e = (o >> 1) & 1;
+    }
+    const unsigned long long ma = __ballot(a), mt = __ballot(t), me = __ballot(e);
+    if ((threadIdx.x & 63) == 0) {
+        if (ma) atomicAdd(&cnt[0], (unsigned long long)__popcll(ma));
+        if (mt) atomicAdd(&cnt[1], (unsigned long long)__popcll(mt));
+        if (me) atomicAdd(&cnt[2], (unsigned long long)__popcll(me));
+    }
+}
+
+// labels; optionally the per-voxel report: bit 0 = label depends on a last-resort tie-break (TF_WS_AMB_DEPENDS),
+// bit 1 = origin between equal-valued markers (TF_WS_AMB_MARKER_TIE), bit 2 = origin cut off at the final depth
+// (TF_WS_AMB_DEPTH)
 __global__ void __launch_bounds__(256)
 k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, const u64 *__restrict__ Rt,
-            int32_t *__restrict__ labels, int64_t n)
+            const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ org,
+            int32_t *__restrict__ labels, uint8_t *__restrict__ amb, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int32_t l = markers[i];
     const int c = cid[i];
-    if (l == 0 && c >= 0) { const u64 r = Rt[c]; if (r != WS_INF) l = markers[r]; }
+    uint8_t a = 0;
+    if (l == 0 && c >= 0) {
+        const u64 r = Rt[c];
+        if (r != WS_INF) {
+            l = markers[r];
+            if (amb) a = (uint8_t)((lo[c] != hi[c] ? 1 : 0) | ((org[c] & 3) << 1));
+        }
+    }
     labels[i] = l;
+    if (amb) amb[i] = a;
 }
 
 struct WsU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
@@ -399,7 +488,8 @@ static size_t ws_compact_bytes(int64_t R, int n_nbr, int depth) {
     // pix + val + nbr + keys + queues
     return tf_align_up((size_t)R * 8, 256) + tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 4 * n_nbr, 256)
          + (size_t)(depth + 2) * tf_align_up((size_t)R * 8, 256)          // K2, M1, C_1..C_{d-1}, Rt
-         + 2 * tf_align_up((size_t)R * 8 + 256, 256) + tf_align_up((size_t)R * 4, 256) + 4096;   // two queues (2R ints), inq
+         + 2 * tf_align_up((size_t)R * 8 + 256, 256) + tf_align_up((size_t)R * 4, 256)           // two queues (2R ints), inq
+         + 3 * tf_align_up((size_t)R * 4, 256) + 4096;                                            // Llo, Lhi, org
 }
 
 extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int n_nbr, int chain_depth, int64_t max_relevant)
@@ -475,65 +565,56 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
     return TF_OK;
 }
 
-extern "C" int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
-                               const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
-                               const int8_t *nbr_host, int n_nbr, int chain_depth, int flags, int32_t *labels,
-                               void *ws, size_t ws_bytes, int64_t *stats_host, void *stream)
+// One call = classification / compaction, phase A, then root phases at increasing chain depth until the exactness
+// check finds no origin whose chains were cut off (or depth_max is reached).
+static int ws_run(const float *field, const int32_t *markers, const int8_t *mask,
+                  const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                  const int8_t *nbr_host, int n_nbr, int depth0, int depth_max, int flags, int32_t *labels,
+                  uint8_t *amb_out, void *ws, size_t ws_bytes, int64_t *st, void *stream)
 {
     TF_REQUIRE((flags & ~TF_WS_SKIP_FAST_PATH) == 0, "tf_watershed: unknown flag");
     TF_REQUIRE(field && markers && fwd && bwd && nbr_host && labels && ws, "tf_watershed: null pointer");
     TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15) && T < 65536, "tf_watershed: bad shape");
     TF_REQUIRE(n_nbr > 0 && n_nbr <= WS_MAX_NBR, "tf_watershed: bad neighbour count");
-    TF_REQUIRE(chain_depth >= 1 && chain_depth <= WS_MAX_DEPTH, "tf_watershed: bad chain_depth");
+    TF_REQUIRE(depth0 >= 1 && depth0 <= depth_max && depth_max <= WS_MAX_DEPTH, "tf_watershed: bad chain_depth");
     const int64_t N = T * H * W;
-    TF_REQUIRE(N <= 0x7fffffffll * 2, "tf_watershed: volume too large for one call (use time windows)");
-    if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(1, n_nbr, chain_depth)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
+    TF_REQUIRE(N <= 0x7fffffffll, "tf_watershed: more than 2^31 - 1 voxels per call (use time windows)");
+    if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(1, n_nbr, depth_max)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
     hipStream_t s = (hipStream_t)stream;
     WsGeom g; g.T = T; g.H = (int)H; g.W = (int)W; g.plane = H * W; g.n_nbr = n_nbr;
     for (int i = 0; i < n_nbr; i++) {
         g.dt[i] = nbr_host[i * 3]; g.dy[i] = nbr_host[i * 3 + 1]; g.dx[i] = nbr_host[i * 3 + 2];
         TF_REQUIRE(abs(g.dt[i]) <= 1 && abs(g.dy[i]) <= 1 && abs(g.dx[i]) <= 1, "tf_watershed: neighbour offset out of range");
     }
-    int64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = 0;
     TfArena ar(ws, ws_bytes);
     uint8_t *cls = ar.take<uint8_t>(N), *flag = ar.take<uint8_t>(N);
     int *scan = ar.take<int>(N), *cid = ar.take<int>(N);
     const size_t scan_bytes = ws_scan_temp_bytes(N);
     char *scan_tmp = ar.take<char>(scan_bytes ? scan_bytes : 1);
     int *d_flags = ar.take<int>(WS_BATCH + 8);
+    unsigned long long *d_cnt = ar.take<unsigned long long>(4);
     if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
 
     dim3 block(64, 4, 1), grid((g.W + 63) / 64, (g.H + 3) / 4, (unsigned)T);
     const unsigned nb1 = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
-    hipLaunchKernelGGL(k_ws_relevant, grid, block, 0, s, cls, fwd, bwd, g, flag);
-    TF_CHECK_LAUNCH();
-    // exclusive scan of the flags in chunks of < 2^31 elements (carry added on the host side of the loop)
     int64_t R = 0;
     {
-        // N <= 2^32-2: at most two chunks
-        int64_t done = 0;
-        while (done < N) {
-            const int64_t len = (N - done > 0x7fffffffll) ? 0x7fffffffll : (N - done);
-            size_t tb = scan_bytes;
-            WsFlagIter it(flag + done, WsU8ToInt());
-            TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, it, scan + done, (int)len, s));
-            int last_scan = 0; uint8_t last_flag = 0;
-            TF_CHECK_HIP(hipMemcpyAsync(&last_scan, scan + done + len - 1, sizeof(int), hipMemcpyDeviceToHost, s));
-            TF_CHECK_HIP(hipMemcpyAsync(&last_flag, flag + done + len - 1, 1, hipMemcpyDeviceToHost, s));
-            TF_CHECK_HIP(hipStreamSynchronize(s));
-            const int64_t cnt = (int64_t)last_scan + last_flag;
-            if (done > 0 && R > 0) {
-                // second chunk: its ids must continue after the first chunk's
-                TF_REQUIRE(false, "tf_watershed: more than 2^31 voxels per call is not supported yet");
-            }
-            R += cnt; done += len;
-        }
+        TfProfScope ps(TFK_WS_SETUP, 29.0 * (double)N, s);
+        hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
+        hipLaunchKernelGGL(k_ws_relevant, grid, block, 0, s, cls, fwd, bwd, g, flag);
+        TF_CHECK_LAUNCH();
+        size_t tb = scan_bytes;
+        WsFlagIter it(flag, WsU8ToInt());
+        TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, it, scan, (int)N, s));
+        int last_scan = 0; uint8_t last_flag = 0;
+        TF_CHECK_HIP(hipMemcpyAsync(&last_scan, scan + N - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipMemcpyAsync(&last_flag, flag + N - 1, 1, hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipStreamSynchronize(s));
+        R = (int64_t)last_scan + last_flag;
     }
     st[6] = R;
-    if (R >= 0x7fffffffll) { tf_set_error("tf_watershed: too many floodable pixels for 32-bit compact ids"); return TF_EINVAL; }
-    if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(R > 0 ? R : 1, n_nbr, chain_depth)) {
-        if (stats_host) { for (int i = 0; i < 8; i++) stats_host[i] = st[i]; }
+    if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(R > 0 ? R : 1, n_nbr, depth_max)) {
         tf_set_error("tf_watershed: workspace too small for %lld relevant pixels", (long long)R);
         return TF_ENOMEM;
     }
@@ -542,58 +623,108 @@ extern "C" int tf_watershed_ex(const float *field, const int32_t *markers, const
     int h_cnt[WS_BATCH + 8];
     WsC c; memset(&c, 0, sizeof(c));
     c.R = R; c.n_nbr = n_nbr;
+    int *org = nullptr;
+    int depth = 0;
+    unsigned long long h_amb[4] = {0, 0, 0, 0};
     if (R > 0) {
         u64 *pix = ar.take<u64>(R); unsigned *val = ar.take<unsigned>(R); int *nbr = ar.take<int>(R * n_nbr);
         c.pix = pix; c.val = val; c.nbr = nbr;
         c.K2 = ar.take<u64>(R); c.M1 = ar.take<u64>(R);
-        for (int k = 1; k < chain_depth; k++) c.C[k] = ar.take<u64>(R);
+        for (int k = 1; k < depth_max; k++) c.C[k] = ar.take<u64>(R);
         c.Rt = ar.take<u64>(R);
+        c.Llo = ar.take<int>(R); c.Lhi = ar.take<int>(R); org = ar.take<int>(R);
         WsQueues Q;
         Q.qcap = (int)(2 * R < 0x7fffff00ll ? 2 * R : 0x7fffff00ll);
         Q.q[0] = ar.take<int>(2 * R + 64); Q.q[1] = ar.take<int>(2 * R + 64); Q.inq = ar.take<int>(R);
         Q.cnt = d_flags; Q.h_cnt = h_cnt; Q.processed = &st[7];
         if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
-        hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1);
+        {
+            TfProfScope ps(TFK_WS_SETUP, 0.0, s);
+            hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1);
+        }
         TF_CHECK_LAUNCH();
         const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
         const int64_t max_sweeps = 4096 + 512 * (T + H + W);
-        int rc = ws_run_phase(c, 0, chain_depth, Q, s, max_sweeps, &st[0]);
+        int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0]);
         if (rc) return rc;
-        // fast path: root phase matched on K2 only, then the conflict test (skipped on the caller's hint:
-        // the chain phases below give the same labels whenever the fast path would have been accepted)
-        const bool speculate = !((flags & TF_WS_SKIP_FAST_PATH) && chain_depth > 1);
-        int conflict = speculate ? 0 : -1;
-        if (speculate) {
-            hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1);
-            TF_CHECK_LAUNCH();
-            rc = ws_run_phase(c, 1, 1, Q, s, max_sweeps, &st[1]);
-            if (rc) return rc;
-        }
-        if (speculate && chain_depth > 1) {
-            TF_CHECK_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), s));
-            hipLaunchKernelGGL(k_ws_conflicts, dim3(nbr_blocks), dim3(256), 0, s, c, markers, d_flags);
-            TF_CHECK_LAUNCH();
-            TF_CHECK_HIP(hipMemcpyAsync(&conflict, d_flags, sizeof(int), hipMemcpyDeviceToHost, s));
-            TF_CHECK_HIP(hipStreamSynchronize(s));
-        }
-        st[5] = conflict;
-        if (conflict) {
-            for (int k = 1; k <= chain_depth; k++) {
-                u64 *dst = k == chain_depth ? c.Rt : c.C[k];
-                hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, dst, R, k == chain_depth ? 1 : 0);
+        // Speculative start: a root phase on K2 alone (depth 1).  If its exactness check finds no origin at all the
+        // labelling cannot depend on any tie-break and is final (tie-free fields).  The caller's hint skips it for
+        // inputs known to contain exact plateaus: the labels are the same either way, only the work differs.
+        const bool speculate = !((flags & TF_WS_SKIP_FAST_PATH) && depth0 > 1);
+        st[5] = speculate ? 0 : -1;
+        depth = speculate ? 1 : depth0;
+        int levels_done = 0;                        // C_1 .. C_levels_done are final
+        for (;;) {
+            for (int k = levels_done + 1; k < depth; k++) {
+                hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.C[k], R, 0);
                 TF_CHECK_LAUNCH();
                 int64_t sw = 0;
-                rc = ws_run_phase(c, k, chain_depth, Q, s, max_sweeps, &sw);
+                rc = ws_run_phase(c, k, depth_max + 1, Q, s, max_sweeps, &sw);      // k < "depth": a chain level
                 if (rc) return rc;
                 st[2 + (k < 3 ? k - 1 : 2)] += sw;
+                levels_done = k;
             }
+            hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1);
+            hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, markers, c.Llo, c.Lhi, R);
+            TF_CHECK_LAUNCH();
+            int64_t sw = 0;
+            rc = ws_run_phase(c, depth, depth, Q, s, max_sweeps, &sw);              // k == depth: the root phase
+            if (rc) return rc;
+            if (speculate && depth == 1) st[1] = sw; else st[2 + (depth < 3 ? depth - 1 : 2)] += sw;
+            st[12] += 1;
+            TF_CHECK_HIP(hipMemsetAsync(org, 0, (size_t)R * sizeof(int), s));
+            TF_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(k_ws_origins, dim3(nbr_blocks), dim3(256), 0, s, c, depth, org);
+            hipLaunchKernelGGL(k_ws_count_ambiguous, dim3(nbr_blocks), dim3(256), 0, s, c, org, d_cnt);
+            TF_CHECK_LAUNCH();
+            TF_CHECK_HIP(hipMemcpyAsync(h_amb, d_cnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            if (speculate && depth == 1) st[5] = h_amb[2] != 0;
+            if (h_amb[2] == 0 || depth >= depth_max) break;
+            depth = depth < depth0 ? depth0 : depth + 1;
         }
     }
-    hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, labels, N);
+    st[8] = depth; st[9] = (int64_t)h_amb[0]; st[10] = (int64_t)h_amb[1]; st[11] = (int64_t)h_amb[2];
+    {
+        TfProfScope ps(TFK_WS_LABELS, 12.0 * (double)N, s);
+        hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, c.Llo, c.Lhi, org, labels,
+                           R > 0 ? amb_out : nullptr, N);
+    }
     TF_CHECK_LAUNCH();
+    if (R == 0 && amb_out) TF_CHECK_HIP(hipMemsetAsync(amb_out, 0, (size_t)N, s));
     TF_CHECK_HIP(hipStreamSynchronize(s));
+    if (st[11] > 0) {
+        tf_set_error("tf_watershed: %lld pixel(s) still tie at chain depth %d (the compared chains are cut off); "
+                     "labels written, but they may differ from the reference there: raise max_depth",
+                     (long long)st[11], depth);
+        return TF_EDEPTH;
+    }
+    return st[9] > 0 ? TF_WS_AMBIGUOUS : TF_OK;
+}
+
+extern "C" int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *mask,
+                                const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                                const int8_t *nbr_host, int n_nbr, int chain_depth, int max_depth, int flags,
+                                int32_t *labels, uint8_t *ambiguous, void *ws, size_t ws_bytes,
+                                int64_t *stats_host, void *stream)
+{
+    int64_t st[TF_WS_NSTATS];
+    const int rc = ws_run(field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, chain_depth, max_depth, flags, labels,
+                          ambiguous, ws, ws_bytes, st, stream);
+    if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = st[i];
+    return rc;
+}
+
+extern "C" int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
+                               const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                               const int8_t *nbr_host, int n_nbr, int chain_depth, int flags, int32_t *labels,
+                               void *ws, size_t ws_bytes, int64_t *stats_host, void *stream)
+{
+    int64_t st[TF_WS_NSTATS];
+    const int rc = ws_run(field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, chain_depth, chain_depth, flags, labels,
+                          nullptr, ws, ws_bytes, st, stream);
     if (stats_host) for (int i = 0; i < 8; i++) stats_host[i] = st[i];
-    return TF_OK;
+    return rc;
 }
 
 extern "C" int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,

@@ -6,6 +6,8 @@ ValueErrors).  The reference pads the volume and calls its Cython heap flood
 include/tobac_flow_hip.h) on the unpadded volume: out-of-volume neighbours are rejected by
 coordinate tests, which is what the zero-padded mask achieves in the reference.
 """
+import warnings
+
 import numpy as np
 import scipy.ndimage as ndi
 
@@ -27,6 +29,21 @@ _NEIGHBOUR_ORDER = {
 }
 
 DEFAULT_CHAIN_DEPTH = 3
+MAX_CHAIN_DEPTH = 12              # TF_WS_MAX_DEPTH
+TF_WS_AMBIGUOUS, TF_EDEPTH = 1, -5
+AMB_DEPENDS, AMB_MARKER_TIE, AMB_DEPTH = 1, 2, 4
+
+
+class WatershedAmbiguityWarning(UserWarning):
+    """Some labels depend on the order in which the reference's heap pops equal-valued markers."""
+
+
+class WatershedAmbiguityError(RuntimeError):
+    """on_ambiguous="raise": some labels depend on the order of equal-valued markers."""
+
+
+class WatershedDepthError(RuntimeError):
+    """Ties remain at the deepest chain level: the labels may differ from the reference there."""
 
 
 def neighbour_offsets(connectivity, ndim=3):
@@ -64,42 +81,80 @@ TF_WS_SKIP_FAST_PATH = 1
 
 
 def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
-                  expect_conflict=None):
+                  expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="warn", return_ambiguous=False):
     """Device-resident core: torch tensors in (field f32, markers i32, mask i8 or None), labels out.
-    expect_conflict: True / False force the scheduling hint, None (default) uses the per-shape memo."""
+
+    expect_conflict: True / False force the scheduling hint, None (default) uses the per-shape memo.
+    Exactness contract (include/tobac_flow_hip.h, tf_watershed_ex2): the library deepens the chain comparison on its
+    own up to `max_chain_depth` and reports every pixel whose label still hangs on a last-resort tie-break.
+      * ties between equal-valued markers (the reference resolves them by the internal state of its heap): labels
+        follow the markers' raster order; `on_ambiguous` = "warn" (default) / "raise" / "ignore";
+      * ties left by the depth cut-off at `max_chain_depth`: WatershedDepthError (a warning with "ignore").
+    return_ambiguous: also return the (T, H, W) uint8 report (AMB_* bits)."""
+    if on_ambiguous not in ("warn", "raise", "ignore"):
+        raise ValueError("on_ambiguous must be 'warn', 'raise' or 'ignore'")
     t = _lib.torch()
     L = _lib.lib()
     T, H, W = field.shape
     labels = _lib.empty((T, H, W), t.int32)
+    amb = _lib.empty((T, H, W), t.uint8) if return_ambiguous else None
     nbr = np.ascontiguousarray(nbr, np.int8)
+    chain_depth = int(chain_depth)
+    max_chain_depth = max(chain_depth, min(int(max_chain_depth), MAX_CHAIN_DEPTH))
     # the flood keys are compact over the relevant pixels: size the workspace from a cheap count of
     # the floodable pixels and retry once with the exact number if boundary markers exceed the slack
     floodable = (markers == 0) if mask is None else ((markers == 0) & (mask != 0))
     guess = min(T * H * W, int(floodable.sum().item() * 1.5) + 4096)
     del floodable
-    st = np.zeros(8, np.int64)
+    st = np.zeros(16, np.int64)
     key = (T, H, W, len(nbr), chain_depth)
     memo = _conflict_memo.setdefault(key, [False, 0])          # [last probe conflicted, calls since that probe]
     skip = expect_conflict if expect_conflict is not None else (memo[0] and memo[1] < _REPROBE)
     flags = TF_WS_SKIP_FAST_PATH if (skip and chain_depth > 1) else 0
-    for attempt in range(2):
-        nbytes = L.tf_watershed_workspace_bytes(T, H, W, len(nbr), chain_depth, guess)
+    # levels beyond chain_depth are rarely needed: the first call gets room for two more, a second one for all
+    start, cap = chain_depth, min(max_chain_depth, chain_depth + 2)
+    probed = None
+    while True:
+        nbytes = L.tf_watershed_workspace_bytes(T, H, W, len(nbr), cap, guess)
         ws = _lib.workspace(nbytes, "watershed")
-        rc = L.tf_watershed_ex(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
-                               T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), chain_depth, flags, _lib.ptr(labels),
-                               _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr())
-        if rc == -2 and attempt == 0 and st[6] > guess:
+        rc = L.tf_watershed_ex2(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
+                                T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), start, cap, flags, _lib.ptr(labels),
+                                _lib.ptr(amb), _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr())
+        if rc == -2 and st[6] > guess:
             guess = int(st[6])
             continue
+        if probed is None and rc in (0, TF_WS_AMBIGUOUS, TF_EDEPTH):
+            probed = int(st[5])
+        if rc == TF_EDEPTH and cap < max_chain_depth:
+            start, cap, flags = cap + 1, max_chain_depth, TF_WS_SKIP_FAST_PATH
+            continue
         break
-    _lib.check(rc, "tf_watershed")
-    if st[5] >= 0:
-        memo[0], memo[1] = bool(st[5]), 0                      # this call probed
+    if rc not in (TF_WS_AMBIGUOUS, TF_EDEPTH):
+        _lib.check(rc, "tf_watershed")
+    if probed is not None and probed >= 0:
+        memo[0], memo[1] = bool(probed), 0                     # this call probed
     else:
         memo[1] += 1
     if stats is not None:
-        stats["sweeps"] = st.tolist()
-    return labels
+        stats["sweeps"] = st[:8].tolist()
+        stats["chain_depth"] = int(st[8])
+        stats["ambiguous_pixels"] = int(st[9])
+        stats["marker_tie_origins"] = int(st[10])
+        stats["depth_origins"] = int(st[11])
+    if rc == TF_EDEPTH:
+        msg = (f"watershed: {int(st[11])} pixel(s) still tie at chain depth {int(st[8])} (the deepest allowed); "
+               f"{int(st[9])} label(s) may differ from the reference")
+        if on_ambiguous == "ignore":
+            warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=2)
+        else:
+            raise WatershedDepthError(msg)
+    elif rc == TF_WS_AMBIGUOUS and on_ambiguous != "ignore":
+        msg = (f"watershed: the labels of {int(st[9])} pixel(s) depend on the order in which the reference's binary heap "
+               f"pops equal-valued markers ({int(st[10])} tie point(s)); resolved by the markers' raster order")
+        if on_ambiguous == "raise":
+            raise WatershedAmbiguityError(msg)
+        warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=2)
+    return (labels, amb) if return_ambiguous else labels
 
 
 def watershed(
@@ -111,9 +166,15 @@ def watershed(
     connectivity: int | np.ndarray = 1,
     _dev_flows=None,
     chain_depth: int = DEFAULT_CHAIN_DEPTH,
+    max_chain_depth: int = MAX_CHAIN_DEPTH,
+    on_ambiguous: str = "warn",
+    return_ambiguous: bool = False,
 ) -> np.ndarray:
     """Watershed segmentation of a sequence of images in a semi-Lagrangian framework
-    (reference: watershed.py:17-168).  Returns int32 labels with the shape of `field`."""
+    (reference: watershed.py:17-168).  Returns int32 labels with the shape of `field`.
+
+    The keyword arguments after `connectivity` are not in the reference: see watershed_dev for the exactness
+    contract they control (`return_ambiguous=True` returns (labels, uint8 report))."""
     t = _lib.torch()
     on_device = isinstance(field, t.Tensor)
     if hasattr(field, "to_numpy") and not isinstance(field, (np.ndarray, t.Tensor)):
@@ -138,8 +199,12 @@ def watershed(
         fwd, bwd = _lib.to_dev(forward_flow, t.float32), _lib.to_dev(backward_flow, t.float32)
     if tuple(fwd.shape) != tuple(field.shape) + (2,):
         raise ValueError("flow vectors must have shape field.shape + (2,)")
-    out = watershed_dev(fwd, bwd, f, m, k, nbr, chain_depth)
+    out = watershed_dev(fwd, bwd, f, m, k, nbr, chain_depth, max_chain_depth=max_chain_depth,
+                        on_ambiguous=on_ambiguous, return_ambiguous=return_ambiguous)
+    if return_ambiguous:
+        return out if on_device else (out[0].cpu().numpy(), out[1].cpu().numpy())
     return out if on_device else out.cpu().numpy()
 
 
-__all__ = ("watershed", "watershed_dev", "neighbour_offsets")
+__all__ = ("watershed", "watershed_dev", "neighbour_offsets", "WatershedAmbiguityWarning", "WatershedAmbiguityError",
+           "WatershedDepthError")

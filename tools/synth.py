@@ -5,7 +5,10 @@ import math
 import numpy as np
 
 
-def blob_stack(T, H, W, seed=20240601, device="cuda", nan_every=12):
+def blob_stack(T, H, W, seed=20240601, device="cuda", nan_every=12, t0=0):
+    """Frames t0 .. t0 + T - 1 of ONE endless synthetic sequence: frame content depends on (seed, global frame index)
+    only, so two windows cut from the same sequence (e.g. the overlapping windows of adjacent ranks) share their common
+    frames bit for bit."""
     import torch
     g = np.random.default_rng(seed)
     K = max(8, H * W // 65536)
@@ -14,10 +17,11 @@ def blob_stack(T, H, W, seed=20240601, device="cuda", nan_every=12):
     amp, sig = g.uniform(20, 60, K), g.uniform(6, 40, K)
     out = torch.full((T, H, W), 290.0, dtype=torch.float32, device=device)
     gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
     F = torch.nn.functional
-    for t in range(T):
-        frame = out[t]
+    for ti in range(T):
+        t = t0 + ti
+        frame = out[ti]
+        gen.manual_seed(seed * 1000003 + t)
         for k in range(K):
             y0, x0 = cy[k] + vy[k] * t, cx[k] + vx[k] * t
             rad = int(4 * sig[k]) + 1
@@ -35,7 +39,8 @@ def blob_stack(T, H, W, seed=20240601, device="cuda", nan_every=12):
         frame += n[0, 0] * 16.0
         if nan_every and t % nan_every == nan_every // 2:
             hh, ww = max(H // 10, 1), max(W // 10, 1)
-            y1, x1 = int(g.integers(0, H - hh + 1)), int(g.integers(0, W - ww + 1))
+            gt = np.random.default_rng([seed, t])
+            y1, x1 = int(gt.integers(0, H - hh + 1)), int(gt.integers(0, W - ww + 1))
             frame[y1:y1 + hh, x1:x1 + ww] = float("nan")
     return out
 
