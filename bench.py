@@ -3,13 +3,16 @@
 marker-controlled watershed) on 5424 x 5424 GOES-16 full-disk-sized frames, one process per GPU.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...): the
+  ranks come from RANK / LOCAL_RANK / WORLD_SIZE.  N > 1 WITHOUT a launcher: this process stays off the GPU, starts N
+  fresh rank processes itself (one per GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line.
 
 A step is one pass of the hot path over one window of `--frames` synthetic frames resident in HBM:
 create_flow(Farneback, smoothing_passes=1, interp_method="cubic")  ->  Flow.sobel(uphill, cubic,
 float64)  ->  combined edge field  ->  Flow.watershed(conn 1) with the detect_anvils marker recipe.
-Frame windows are independent units: every rank processes its own window (weak scaling) and the
-label IDs are stitched at the end of each step with one all-gather (tobac_flow_amd/parallel.py).
+Frame windows are independent units: every rank processes its own window of ONE synthetic sequence (weak scaling;
+consecutive windows share `--overlap` frames, bit for bit) and the label IDs are stitched at the end of each step by
+the reference's overlap rule with one all-gather (tobac_flow_amd/parallel.py, linking.py:49-161).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -41,12 +44,15 @@ def _fullres_traffic():
 
 
 def cpu_baseline(seed):
-    """The oracle (CPU restatement of the reference's cv2/numpy/Cython path, kind = "port") timed on ONE
-    host core on a bounded sample of the same workload: a 5 x 1536 x 1536 stack."""
+    """The oracle (CPU restatement of the reference's cv2/numpy/Cython path, kind = "port") timed on the host cores of
+    this box on a bounded sample of the same workload: a 5 x 1536 x 1536 stack.  The order-independent stages run on a
+    thread pool (Farneback: one task per frame pair and direction; Sobel: one task per frame -- the C restatements and
+    numpy release the GIL); the heap flood is sequential by construction (one thread, like the reference's)."""
     import numpy as np
     import scipy.ndimage as ndi
     import ctypes
     import warnings
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import blob_sequence
     from oracle import _lib as ol, np_ops, ws_oracle
@@ -55,8 +61,10 @@ def cpu_baseline(seed):
     bt = blob_sequence(rng, T, H, W, n_blobs=36)
     L = ol.lib()
     L.oracle_farneback.restype = ctypes.c_int
+    threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 2 * (T - 1)))
 
-    def fb(a, b):
+    def fb(ab):
+        a, b = ab
         out = np.zeros((H, W, 2), np.float32)
         L.oracle_farneback(ol.ptr(np.ascontiguousarray(a), ctypes.c_uint8), ol.ptr(np.ascontiguousarray(b), ctypes.c_uint8),
                            H, W, ol.ptr(out, ctypes.c_float), 5, ctypes.c_double(0.5), 13, 10, 5, ctypes.c_double(1.1))
@@ -64,26 +72,89 @@ def cpu_baseline(seed):
     t0 = time.perf_counter()
     fw = np.full((T, H, W, 2), np.nan, np.float32)
     bw = np.full((T, H, W, 2), np.nan, np.float32)
-    with warnings.catch_warnings():
+    with warnings.catch_warnings(), ThreadPoolExecutor(threads) as pool:
         warnings.simplefilter("ignore")
-        for i in range(T - 1):
-            p8 = np_ops.to_8bit(np_ops.linear_norm(bt[i:i + 2].copy()), 0, 1)
-            f, b = np_ops.smooth_flow_step(fb(p8[0], p8[1]), fb(p8[1], p8[0]), "cubic")
+        p8 = [np_ops.to_8bit(np_ops.linear_norm(bt[i:i + 2].copy()), 0, 1) for i in range(T - 1)]
+        raw = list(pool.map(fb, [(p[0], p[1]) for p in p8] + [(p[1], p[0]) for p in p8]))
+        sm = list(pool.map(lambda i: np_ops.smooth_flow_step(raw[i], raw[T - 1 + i], "cubic"), range(T - 1)))
+        for i, (f, b) in enumerate(sm):
             fw[i], bw[i + 1] = f, b
         fw[-1], bw[0] = -bw[-1], -fw[0]
         fw, bw = np.clip(fw, -20, 20), np.clip(bw, -20, 20)
+        t_flow = time.perf_counter() - t0
         lin = np.clip((bt - 270.0) / (250.0 - 270.0), 0, 1).astype(np.float32)
-        edges = np_ops.sobel(lin, fw, bw, "cubic", None, np.nan, "uphill")
+
+        def sobel_frame(i):                                  # frame i needs frames i-1 .. i+1 (convolve.py:305-330)
+            lo, hi = max(i - 1, 0), min(i + 2, T)
+            return np_ops.sobel(lin[lo:hi], fw[lo:hi], bw[lo:hi], "cubic", None, np.nan, "uphill")[i - lo]
+        edges = np.stack(list(pool.map(sobel_frame, range(T))))
         edges[edges > 0] += 1
         edges = edges - lin
+        t_sobel = time.perf_counter() - t0 - t_flow
         s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
         markers = (lin >= 1) * ndi.binary_erosion(lin >= 1, structure=s).astype(np.int32)
         markers[ndi.binary_erosion(lin <= 0, structure=np.ones([3, 3, 3]), border_value=1)] = -1
         ws_oracle.watershed(fw, bw, edges, markers.astype(np.int32), None, 1)
     dt = time.perf_counter() - t0
-    return {"value": round(T * H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+    return {"value": round(T * H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": threads, "kind": "port",
             "sample": f"{T}x{H}x{W} synthetic stack, same stage sequence, oracle (C/numpy restatement of the "
-                      f"cv2+scipy+Cython path), single thread, {dt:.1f} s; host has {os.cpu_count()} cores"}
+                      f"cv2+scipy+Cython path): flow {t_flow:.1f} s and Sobel {t_sobel:.1f} s on {threads} threads, flood "
+                      f"{dt - t_flow - t_sobel:.1f} s on one (sequential heap), {dt:.1f} s in all; host has {os.cpu_count()} cores"}
+
+
+def cv2_parity(seed=20240601):
+    """SURVEY.md section 7 hard part 2 / section 8d: Farneback and remap values are pinned only where OpenCV exists.  If
+    this box has cv2 with the optflow module, compare the library with it on one synthetic frame pair and report the
+    largest differences; otherwise say so."""
+    try:
+        import cv2
+        cv2.optflow.createOptFlow_Farneback
+    except Exception as e:                                   # ImportError, or a cv2 build without contrib modules
+        return {"status": "parity unpinned", "reason": f"cv2.optflow unavailable on this box ({type(e).__name__})"}
+    import numpy as np
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow, warp_flow
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import blob_sequence
+    rng = np.random.default_rng(seed)
+    bt = blob_sequence(rng, 2, 768, 1024, n_blobs=24)
+    lo, hi = np.nanmin(bt), np.nanmax(bt)
+    p8 = np.clip((bt - lo) / (hi - lo) * 255, 0, 255).astype(np.uint8)
+    ref = cv2.optflow.createOptFlow_Farneback().calc(p8[0], p8[1], None)
+    got = FarnebackFlow().calc(p8[0], p8[1], None)
+    out = {"status": "pinned", "cv2": cv2.__version__, "farneback_max_abs_diff": float(np.abs(ref - got).max())}
+    img = bt[0].astype(np.float32)
+    locs = ref.copy()                                        # the map as utils/flow_utils.py:84-87 builds it
+    locs[:, :, 0] += np.arange(img.shape[1])
+    locs[:, :, 1] += np.arange(img.shape[0])[:, np.newaxis]
+    for name, inter in (("nearest", cv2.INTER_NEAREST), ("linear", cv2.INTER_LINEAR), ("cubic", cv2.INTER_CUBIC)):
+        want = cv2.remap(img, locs, None, inter, None, cv2.BORDER_CONSTANT, np.nan)
+        have = warp_flow(img, ref, method=name)
+        both = np.isfinite(want) & np.isfinite(have)
+        out[f"remap_{name}_max_abs_diff"] = float(np.abs(want - have)[both].max())
+        out[f"remap_{name}_nan_mask_equal"] = bool(np.array_equal(np.isnan(want), np.isnan(have)))
+    return out
+
+
+def launch_ranks(a):
+    """--gpus N > 1 without a launcher: start N rank processes (fresh interpreters; this parent never touches the GPU)
+    and relay their output.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
 
 
 def main():
@@ -92,6 +163,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=12, help="frames per window (per GPU, per step)")
+    ap.add_argument("--overlap", type=int, default=4,
+                    help="frames consecutive windows (ranks) share; the stitch compares all but the first and last of them")
     ap.add_argument("--height", type=int, default=5424)
     ap.add_argument("--width", type=int, default=5424)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,12 +174,16 @@ def main():
                     help="diagnostic: do not record HIP events around the library's launches in the timed region "
                          "(roofline = null); the difference to a default run is what the instrumentation costs")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
 
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the two must agree")
     if a.single_device:
         local = 0
     torch.cuda.set_device(local)
@@ -127,7 +204,8 @@ def main():
     from tools.synth import anvil_inputs, blob_stack
 
     T, H, W = a.frames, a.height, a.width
-    bt = blob_stack(T, H, W, seed=20240601 + rank)          # resident in HBM before the timed region
+    # rank r holds frames r * (T - overlap) ... of ONE sequence: its last `overlap` frames are rank r + 1's first ones
+    bt = blob_stack(T, H, W, seed=20240601, t0=rank * (T - a.overlap))      # resident in HBM before the timed region
     lin, markers = anvil_inputs(bt)
     nbr = neighbour_offsets(1)
     ws_stats = []                                            # tf_watershed stats of every step (warmup included)
@@ -138,9 +216,9 @@ def main():
         e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
         st = {}
-        labels = watershed_dev(fw, bw, e, markers, None, nbr, stats=st)
-        ws_stats.append(st["sweeps"])
-        return stitch_labels(labels) if world > 1 else labels
+        labels = watershed_dev(fw, bw, e, markers, None, nbr, stats=st, on_ambiguous="ignore")
+        ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
+        return stitch_labels(labels, overlap=a.overlap) if world > 1 else labels
 
     def barrier():
         if dist is not None:
@@ -179,7 +257,8 @@ def main():
                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
         out = {"metric": "Mpix/s end-to-end flow+sobel+watershed, 5424^2 frames" if (H, W) == (5424, 5424)
                else f"Mpix/s end-to-end flow+sobel+watershed, {H}x{W} frames (rehearsal size)", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
-               "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "unit": "Mpix/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist is not None else 1,
+               "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": (f"GOES-16 ABI full-disk-sized window: {T}x{H}x{W} float32 frames per GPU per step "
@@ -188,16 +267,21 @@ def main():
                                        f"REDUCED rehearsal window (not the benchmark configuration): {T}x{H}x{W} float32 frames per GPU per step"),
                           "stages": "create_flow(Farneback, vr_steps=0, smoothing_passes=1, cubic) + Flow.sobel(uphill, cubic, f64) "
                                     "+ edge field + Flow.watershed(connectivity 1, detect_anvils markers)",
-                          "sharding": "one time window per GPU, label IDs stitched by all-gather"},
+                          "sharding": f"one time window per GPU cut from one sequence, consecutive windows share {a.overlap} frames; "
+                                      "label IDs stitched by the reference's overlap rule (>= 5 px and >= 0.5, linking.py:49-161) "
+                                      "with one all-gather of pair lists"},
                "roofline": roof}
         # which watershed schedule the timed steps ran: stats[5] = 1 / 0 probe (speculative root phase + conflict test,
         # conflict found / not found), -1 = root phase skipped on the conflict memo of watershed.py (identical labels)
         timed = ws_stats[a.warmup:]
         out["watershed"] = {"sweeps_per_phase_last_step": timed[-1][:5], "relevant_pixels": timed[-1][6],
+                            "chain_depth_used": timed[-1][8], "pixels_depending_on_equal_valued_marker_order": timed[-1][9],
+                            "marker_tie_points": timed[-1][10], "ties_left_by_depth_cut_off": timed[-1][11],
                             "timed_steps_probing": sum(1 for t_ in timed if t_[5] >= 0),
                             "timed_steps_skipping_root_phase": sum(1 for t_ in timed if t_[5] < 0)}
         if not a.no_cpu_baseline and world == 1:             # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(20240601)
+            out["cv2_parity"] = cv2_parity()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

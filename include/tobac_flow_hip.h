@@ -101,6 +101,24 @@ int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B, int6
                        float *flow_fwd, float *flow_bwd, int64_t flow_stride,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* ---- a5 tail / section 8f-1: variational refinement of one flow field -------------------------------------
+ * replaces cv2.VariationalRefinement.create().calc(I0, I1, flow) as tobac_flow/flow.py:359 creates it and
+ * tobac_flow/flow.py:513-519 calls it once per direction when vr_steps > 0 (OpenCV defaults: fixedPointIterations 5,
+ * sorIterations 5, alpha 20, delta 5, gamma 10, omega 1.6).  I0, I1: (H, W) uint8; flow: (H, W, 2) float (dx, dy),
+ * refined IN PLACE.  params NULL = defaults.  Parity with OpenCV itself is unpinned. */
+typedef struct {
+    int fixed_point_iterations;   /* 5   */
+    int sor_iterations;           /* 5   */
+    float alpha;                  /* 20  smoothness term weight        */
+    float delta;                  /* 5   colour constancy weight       */
+    float gamma;                  /* 10  gradient constancy weight     */
+    float omega;                  /* 1.6 SOR relaxation factor         */
+} tf_varref_params;
+void tf_varref_default_params(tf_varref_params *p);
+size_t tf_varref_workspace_bytes(int64_t H, int64_t W);
+int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
+              float *flow, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- a6: forward/backward consistency smoothing ----------------------------------------------
  * replaces tobac_flow/flow.py:530-568 smooth_flow_step (4 x cv2.remap via
  * tobac_flow/utils/flow_utils.py:80-99 + np.nanmean).  Outputs must not alias inputs. */
@@ -256,6 +274,44 @@ int tf_apply_lut(const int32_t *labels, int64_t n, const int32_t *lut, int n_lut
 size_t tf_label_workspace_bytes(int64_t T, int64_t H, int64_t W);
 int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
              int32_t *labels, int *n_labels_host, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- a16: flow-aware labelling (tobac_flow/label.py:84-321) and section 8e/8f-3: cross-window linking ----------
+ * tf_pair_counts: for two int32 volumes of n voxels, every distinct pair (a[i], b[i]) with a[i] > 0 and b[i] > 0
+ *   (b[i] >= 0 when include_b_zero) and how often it occurs, sorted by (a, b) -- the counting the reference does per
+ *   label with np.bincount / np.unique (tobac_flow/utils/label_utils.py:352-376, tobac_flow/linking.py:33-47).
+ *   out_a / out_b / out_count: device arrays of max_pairs entries; *n_pairs_host = number of pairs.  The workspace is
+ *   sized for at most max_runs runs of equal consecutive pairs (0 = worst case n); with more the call returns
+ *   TF_ENOMEM and *n_pairs_host = the run count to size a retry with.  Synchronises the stream.
+ * tf_label_sizes: np.bincount(labels) for ids 0 .. n_labels (device int64[n_labels + 1]).
+ * tf_flow_link_overlap: tobac_flow/label.py:249-321 -- links per-step labels `flat_labels` (T, H, W) into objects:
+ *   nearest-neighbour warps of the labels to t-1 / t+1 (structure * [1, 0, 1]; exactly one tap per outer plane, as the
+ *   reference's tuple unpacking requires), overlap counts, the criterion `count > absolute_overlap and count >=
+ *   overlap * min(n_locs, size(other))`, and the reference's first-come-first-served grouping in ascending label order
+ *   (forward neighbours before backward ones).  out may alias nothing.  *n_objects_host = number of objects.
+ * tf_flow_label: tobac_flow/label.py:84-175 with subsegment_shrink = 0: flat_label (utils/label_utils.py:143-180 =
+ *   scipy.ndimage.label with the structure's t-planes zeroed) followed by the linking above.  mask: (T, H, W) uint8.
+ * tf_window_overlap_pairs: tobac_flow/linking.py:49-93 / :96-140 -- `left` / `right` are the labels two consecutive
+ *   time windows give to the frames they share (first and last common frame already dropped, linking.py:55-56);
+ *   returns on the HOST the (left id, right id) pairs with count >= atol (count > 0 if atol == 0) and, if rtol > 0,
+ *   max(count / pixels(left id), count / pixels(right id)) >= rtol; the reference uses atol = 5, rtol = 0.5.
+ *   pairs_host: 2 * max_pairs int32.  Connected components of these pairs are the stitched objects (linking.py:153-161). */
+size_t tf_pair_counts_workspace_bytes(int64_t n, int64_t max_runs);
+int tf_pair_counts(const int32_t *a, const int32_t *b, int64_t n, int include_b_zero,
+                   int32_t *out_a, int32_t *out_b, int64_t *out_count, int64_t max_pairs,
+                   int64_t *n_pairs_host, void *ws, size_t ws_bytes, void *stream);
+int tf_label_sizes(const int32_t *labels, int64_t n, int64_t n_labels, int64_t *sizes, void *stream);
+size_t tf_flow_link_workspace_bytes(int64_t T, int64_t H, int64_t W, int64_t max_runs);
+int tf_flow_link_overlap(const int32_t *flat_labels, const float *fwd, const float *bwd,
+                         int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
+                         double overlap, int64_t absolute_overlap, int32_t *out, int *n_objects_host,
+                         void *ws, size_t ws_bytes, void *stream);
+size_t tf_flow_label_workspace_bytes(int64_t T, int64_t H, int64_t W, int64_t max_runs);
+int tf_flow_label(const uint8_t *mask, const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                  const uint8_t *structure_host, double overlap, int64_t absolute_overlap,
+                  int32_t *labels, int *n_objects_host, void *ws, size_t ws_bytes, void *stream);
+int tf_window_overlap_pairs(const int32_t *left, const int32_t *right, int64_t n, int64_t atol, double rtol,
+                            int32_t *pairs_host, int64_t max_pairs, int64_t *n_pairs_host,
+                            void *ws, size_t ws_bytes, void *stream);
 
 /* ---- measurement aid (bench.py's roofline figure) ---------------------------------------------
  * tf_profile_enable(1): every kernel launch of the library is bracketed by HIP events on its own

@@ -73,3 +73,39 @@ def flow_label(fwd, bwd, mask, structure=ndi.generate_binary_structure(3, 1), dt
 def flow_link_overlap(fwd, bwd, flat_labels, structure=ndi.generate_binary_structure(3, 1), dtype=np.int32, overlap=0.0,
                       absolute_overlap=0):
     return _link(np.asarray(flat_labels), fwd, bwd, structure, dtype, overlap, absolute_overlap)
+
+
+# ---- cross-window linking: /root/reference/tobac_flow/linking.py:33-47 (find_overlaps), :49-93
+# (find_overlap_between_cores; :96-140 is the same for anvils), :153-161 (find_new_labels) ----------------------
+def find_overlaps(x, atol, rtol, max_label, label_counts):
+    overlap_counts = np.bincount(x, minlength=max_label + 1)
+    wh_overlap = overlap_counts >= atol if atol > 0 else overlap_counts > 0
+    if rtol > 0:
+        wh_overlap = np.logical_and(
+            wh_overlap, np.maximum(overlap_counts / x.size, overlap_counts / label_counts) >= rtol)
+    wh_overlap[0] = False
+    return np.where(wh_overlap)[0]
+
+
+def link_overlap_pairs(current_overlap, next_overlap, atol=5, rtol=0.5):
+    """current_overlap / next_overlap: the labels two consecutive windows give to their common frames, the first and the
+    last common frame already dropped (linking.py:55-56 `t_overlap[1:-1]`).  Returns (x, y): left ids repeated per
+    linked right id, as linking.py:78-91 builds them."""
+    from functools import partial
+    cur = np.asarray(current_overlap)
+    nxt = np.asarray(next_overlap)
+    max_label = int(nxt.max()) if nxt.size else 0
+    index = np.unique(cur[cur > 0])                                   # current_ds.core.values: the labels of the window
+    label_counts = np.maximum(np.bincount(nxt.ravel(), minlength=max_label + 1), 1)
+    comp = partial(find_overlaps, atol=atol, rtol=rtol, max_label=max_label, label_counts=label_counts)
+    overlap_labels = ndi.labeled_comprehension(nxt.ravel(), cur.ravel(), index, comp, list, [[]])
+    x = np.repeat(index, [len(n) for n in overlap_labels])
+    y = np.concatenate([np.asarray(n, np.int64) for n in overlap_labels]) if len(overlap_labels) else np.zeros(0, np.int64)
+    return x.astype(np.int64), y.astype(np.int64)
+
+
+def find_new_labels(x, y, size):
+    import scipy.sparse
+    import scipy.sparse.csgraph
+    graph = scipy.sparse.coo_array((np.ones(x.size), (x, y)), shape=(size, size))
+    return scipy.sparse.csgraph.connected_components(graph, directed=False)[1]

@@ -227,3 +227,23 @@ def smooth_flow_step(fwd, bwd, method="linear"):
         b2 = np.nanmean([bwd, np.stack([-warp_flow_single(fwd[..., 0], bwd, method),
                                         -warp_flow_single(fwd[..., 1], bwd, method)], -1)], 0)
     return f2, b2
+
+
+def variational_refinement(I0, I1, flow, fixed_point_iterations=5, sor_iterations=5, alpha=20.0, delta=5.0, gamma=10.0,
+                           omega=1.6):
+    """cv2.VariationalRefinement.create().calc(I0, I1, flow) (flow.py:359, 513-519; oracle/c/varref.c, parity
+    unpinned).  I0 / I1 uint8 (H, W); returns the refined copy of flow (H, W, 2) float32."""
+    I0 = np.ascontiguousarray(I0, np.uint8)
+    I1 = np.ascontiguousarray(I1, np.uint8)
+    out = np.array(flow, np.float32, order="C", copy=True)
+    H, W = I0.shape
+    assert I1.shape == (H, W) and out.shape == (H, W, 2)
+    L = _lib.lib()
+    L.oracle_variational_refinement.restype = ctypes.c_int
+    rc = L.oracle_variational_refinement(_lib.ptr(I0, ctypes.c_uint8), _lib.ptr(I1, ctypes.c_uint8), H, W,
+                                         _lib.ptr(out, ctypes.c_float), int(fixed_point_iterations), int(sor_iterations),
+                                         ctypes.c_float(alpha), ctypes.c_float(delta), ctypes.c_float(gamma),
+                                         ctypes.c_float(omega))
+    if rc:
+        raise MemoryError("oracle_variational_refinement")
+    return out

@@ -27,7 +27,7 @@ def _worker(rank, world, port, volume, bounds, out_dir):
     a, b = bounds[rank]
     local = ndi.label(volume[a:b] > 0)[0].astype(np.int32)      # window-local IDs
     local[volume[a:b] < 0] = -1                                 # background seeds survive untouched
-    got = stitch_labels(torch.from_numpy(local))
+    got = stitch_labels(torch.from_numpy(local), min_overlap=1)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), got.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -65,3 +65,71 @@ def test_two_rank_label_stitch_equals_global_labelling(tmp_path, world):
     want = ndi.label(vol > 0)[0]
     want[vol < 0] = -1
     assert np.array_equal(_canonical(merged), _canonical(want))
+
+
+def _ws_worker(rank, world, port, field, markers, bounds, overlap, out_dir):
+    """One rank = one time window: its own flood (here the CPU oracle stands in for the HIP flood, which needs a GPU) with
+    WINDOW-LOCAL marker ids, then the distributed stitch with the reference's linking rule."""
+    import torch
+    import torch.distributed as dist
+    from oracle import ws_oracle
+    from tobac_flow_amd.parallel import stitch_labels
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = bounds[rank]
+    local_markers = ndi.label(markers[a:b] > 0)[0].astype(np.int32)
+    local_markers[markers[a:b] < 0] = -1
+    zero = np.zeros(field[a:b].shape + (2,), np.float32)
+    lab = ws_oracle.watershed(zero, zero, field[a:b], local_markers, None, 1)
+    got = stitch_labels(torch.from_numpy(lab), overlap=overlap)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), got.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stitched_watershed_windows_equal_the_whole_volume_flood_away_from_the_seams(tmp_path, world):
+    """The production scheme end to end: overlapping time windows flooded independently, label ids
+    stitched over gloo by the reference's overlap rule (linking.py:49-161: >= 5 px and >= 0.5, the outer common frames
+    dropped).  Every window is then compared with the flood of the WHOLE volume on the frames that are at least two
+    steps away from a cut: same partition, and one global id per object across all windows."""
+    import torch.multiprocessing as mp
+    from oracle import ws_oracle
+    from tobac_flow_amd.parallel import window_bounds
+    rng = np.random.default_rng(11)
+    T, H, W, overlap = 6 * world + 4, 48, 64, 4
+    yy, xx = np.mgrid[0:H, 0:W]
+    field = np.zeros((T, H, W), np.float32)
+    markers = np.zeros((T, H, W), np.int32)
+    for k in range(8):                                   # drifting blobs on a 2 x 4 grid of cells (their seeds never meet),
+        cy = 12 + 24 * (k // 4) + rng.uniform(-2, 2)     # each seeded in every frame it lives in
+        cx = 8 + 16 * (k % 4) + rng.uniform(-2, 2)
+        vy, vx = rng.uniform(-0.2, 0.2, 2)
+        t0, t1 = (0, T) if k < 3 else sorted(rng.integers(0, T, 2))
+        for t in range(t0, max(t1, t0 + 3)):
+            if t >= T:
+                break
+            y, x = cy + vy * t, cx + vx * t
+            field[t] -= np.exp(-((yy - y) ** 2 + (xx - x) ** 2) / 24.0).astype(np.float32)
+            if 1 <= y < H - 2 and 1 <= x < W - 2:
+                markers[t, int(y):int(y) + 2, int(x):int(x) + 2] = 1
+    field += ndi.gaussian_filter(rng.normal(size=field.shape), (0, 1, 1)).astype(np.float32) * 0.02
+    markers[field > -0.01] = -1                          # background seed
+    bounds = window_bounds(T, world, overlap)
+    mp.spawn(_ws_worker, args=(world, _free_port(), field, markers, bounds, overlap, str(tmp_path)), nprocs=world, join=True)
+    glob_markers = ndi.label(markers > 0)[0].astype(np.int32)
+    glob_markers[markers < 0] = -1
+    zero = np.zeros(field.shape + (2,), np.float32)
+    whole = ws_oracle.watershed(zero, zero, field, glob_markers, None, 1)
+    mapping = {}
+    for r, (a, b) in enumerate(bounds):
+        part = np.load(tmp_path / f"r{r}.npy")
+        lo = 0 if r == 0 else 2                          # frames at least two steps from a cut
+        hi = (b - a) if r == world - 1 else (b - a) - 2
+        got, want = part[lo:hi], whole[a + lo:a + hi]
+        assert np.array_equal(got <= 0, want <= 0) and np.array_equal(got[got < 0], want[got < 0])
+        pairs = np.unique(np.stack([want[want > 0], got[want > 0]], 1), axis=0)
+        for w_id, g_id in pairs:                         # one stitched id per object of the whole-volume flood, everywhere
+            assert mapping.setdefault(int(w_id), int(g_id)) == int(g_id), (r, w_id, g_id)
+    assert len(set(mapping.values())) == len(mapping)    # ... and different objects keep different ids

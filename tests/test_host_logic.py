@@ -444,7 +444,7 @@ def test_stitch_window_list_reassembles_a_labelling(n_windows):
         perm[ids] = rng.permutation(len(ids)) + 1              # what an independent per-window labelling would give
         w[w > 0] = perm[w[w > 0]]
         windows.append(torch.from_numpy(w))
-    out = [x.numpy() for x in stitch_window_list(windows)]
+    out = [x.numpy() for x in stitch_window_list(windows, min_overlap=1)]
     bounds = window_bounds(truth.shape[0], n_windows)
     for (a, b), w in zip(bounds, out):                          # shared frames agree between neighbours
         assert w.shape == truth[a:b].shape
@@ -481,3 +481,47 @@ def test_apply_func_to_labels_behaviours():
     assert np.array_equal(apply_func_to_labels(labels, data, func=np.sum, index=[4, 5], default=[9.0]), [9.0, 20.0])
     with pytest.raises(IndexError):
         apply_func_to_labels(np.zeros((2, 2), int), np.zeros((2, 2)), func=np.sum, index=[1], default=0.0)
+
+
+def test_window_linking_rule_equals_the_reference_statement():
+    """parallel._overlap_pairs_host (the CPU-tensor path of the stitch, and the statement the GPU kernel is tested against)
+    against the loop form of linking.py:33-93 (oracle/np_label.link_overlap_pairs: bincount per left label through
+    scipy.ndimage.labeled_comprehension, atol / rtol as the reference applies them)."""
+    import scipy.ndimage as ndi
+    from oracle import np_label
+    from tobac_flow_amd.parallel import _overlap_pairs_host, compare_frames
+    rng = np.random.default_rng(0)
+    for trial in range(12):
+        a = ndi.label(ndi.gaussian_filter(rng.normal(size=(2, 40, 50)), (0, 1.5, 1.5)) > 0.2)[0]
+        b = ndi.label(ndi.gaussian_filter(rng.normal(size=(2, 40, 50)), (0, 1.5, 1.5)) > 0.2)[0]
+        if trial % 2:
+            b = np.roll(a, (1, 2), (1, 2))
+            b[b > 0] = (b[b > 0] * 7) % 31 + 1
+        for atol, rtol in ((5, 0.5), (0, 0), (1, 0), (3, 0.9), (0, 0.3)):
+            x, y = np_label.link_overlap_pairs(a, b, atol, rtol)
+            assert np.array_equal(_overlap_pairs_host(a, b, atol, rtol), np.stack([x, y], 1)), (trial, atol, rtol)
+    assert _overlap_pairs_host(np.zeros((1, 3, 3), int), np.ones((1, 3, 3), int), 5, 0.5).shape == (0, 2)
+    # linking.py:55-56: of the common frames the first and the last are not compared
+    assert compare_frames(4) == slice(1, 3) and compare_frames(24) == slice(1, 23) and compare_frames(1) == slice(0, 1)
+
+
+def test_stitch_with_the_reference_rule_joins_only_well_overlapping_labels():
+    """Two windows sharing four frames: an object seen alike by both is joined; one that the right window sees shifted
+    so that < 50 % of either footprint coincides is not, nor is one that coincides in < 5 pixels (linking.py:70-76)."""
+    import torch
+    from tobac_flow_amd.parallel import stitch_window_list
+    left = np.zeros((6, 20, 40), np.int32)
+    right = np.zeros((6, 20, 40), np.int32)
+    left[:, 2:8, 2:8] = 1
+    right[:, 2:8, 2:8] = 3                  # same footprint: joined
+    left[:, 10:16, 2:8] = 2
+    right[:, 10:16, 6:12] = 1               # 2 of 6 columns in common: 1/3 of either -> not joined
+    left[:, 2:4, 20:22] = 3
+    right[:, 2:4, 20:22] = 2                # 4 px per frame x 2 compared frames = 8 >= 5 and identical: joined
+    left[:, 10:11, 30:32] = 4
+    right[:, 10:11, 30:32] = 4              # 2 px x 2 frames = 4 < 5: not joined
+    out = stitch_window_list([torch.from_numpy(left), torch.from_numpy(right)], overlap=4)
+    l, r = out[0].numpy(), out[1].numpy()
+    assert l[0, 2, 2] == r[0, 2, 2] and l[0, 2, 20] == r[0, 2, 20]
+    assert l[0, 10, 2] != r[0, 10, 6] and l[0, 10, 30] != r[0, 10, 30]
+    assert sorted(np.unique(np.concatenate([l[l > 0], r[r > 0]])).tolist()) == [1, 2, 3, 4, 5, 6]

@@ -207,3 +207,118 @@ def test_remap_cubic_kernel_has_unit_sum_but_no_linear_precision():
     assert np.abs(out - (xx + 0.296875))[3:-3, 3:-3].max() <= 2e-5
     half = np_ops.remap(xx.copy(), _grid_locs(h, w, 0.5, 0.0), "cubic", np.nan)
     assert np.abs(half - (xx + 0.5))[3:-3, 3:-3].max() <= 2e-5   # symmetric at one half
+
+
+# ---- variational refinement (oracle/c/varref.c; OpenCV restated, parity unpinned): the method's own identities ----
+def _texture(rng, shape, smooth=2.5):
+    import scipy.ndimage as ndi
+    a = ndi.gaussian_filter(rng.normal(size=shape), smooth)
+    return (a - a.min()) / np.ptp(a) * 255
+
+
+def test_variational_refinement_leaves_a_perfect_flow_of_identical_frames_alone():
+    """I0 == I1 and zero flow: Iz = 0, so b = 0 and dW = 0 is the exact solution of every SOR step."""
+    from oracle import np_ops
+    img = _texture(np.random.default_rng(1), (37, 53)).astype(np.uint8)
+    out = np_ops.variational_refinement(img, img, np.zeros((37, 53, 2), np.float32))
+    assert np.array_equal(out, np.zeros_like(out))
+
+
+def test_variational_refinement_on_textureless_frames_only_smooths():
+    """Constant images: every derivative vanishes, the data term is zeta^2 * I with b = 0, and what is left is the
+    regulariser: the refined flow has less total variation, its range does not grow."""
+    from oracle import np_ops
+    rng = np.random.default_rng(2)
+    img = np.full((40, 48), 90, np.uint8)
+    flow = rng.normal(size=(40, 48, 2)).astype(np.float32)
+    out = np_ops.variational_refinement(img, img, flow)
+    tv = lambda f: np.abs(np.diff(f, axis=0)).sum() + np.abs(np.diff(f, axis=1)).sum()
+    assert tv(out) < 0.5 * tv(flow)
+    assert out.max() <= flow.max() + 1e-5 and out.min() >= flow.min() - 1e-5
+
+
+@pytest.mark.parametrize("d", [(0.6, -0.3), (-1.25, 0.5)])
+def test_variational_refinement_pulls_a_wrong_flow_towards_the_true_translation(d):
+    """I1(x) = I0(x - d): starting from zero flow (an error of |d|), the default 5 x 5 iterations bring the interior flow
+    closer to d, a second application closer still (each call linearises around its input); starting AT d it stays
+    there (residual data term only from uint8 rounding)."""
+    import scipy.ndimage as ndi
+    from oracle import np_ops
+    rng = np.random.default_rng(3)
+    base = _texture(rng, (96, 128), 3.0)
+    i0 = base.astype(np.uint8)
+    i1 = ndi.shift(base, (d[1], d[0]), order=3, mode="nearest").astype(np.uint8)
+    inner = (slice(12, -12), slice(12, -12))
+    truth = np.array(d, np.float32)
+    start = np.zeros((96, 128, 2), np.float32)
+    out = np_ops.variational_refinement(i0, i1, start)
+    err0 = np.linalg.norm(start[inner] - truth, axis=-1).mean()
+    err1 = np.linalg.norm(out[inner] - truth, axis=-1).mean()
+    again = np_ops.variational_refinement(i0, i1, out)
+    err2 = np.linalg.norm(again[inner] - truth, axis=-1).mean()
+    assert err1 < 0.8 * err0 and err2 < 0.8 * err1
+    at = np.broadcast_to(truth, (96, 128, 2)).copy()
+    stay = np_ops.variational_refinement(i0, i1, at)
+    assert np.linalg.norm(stay[inner] - truth, axis=-1).mean() < 0.1
+
+
+def test_variational_refinement_sor_solves_the_system_it_assembles():
+    """Internal consistency of the restatement: with ONE fixed-point iteration and many SOR sweeps dW converges to the
+    solution of the linear system (A - smoothness Laplacian) dW = b that the same code assembled -- recomputed here in
+    numpy from the published formulas (weights from the input flow, replicated borders, edges absent at the image
+    border)."""
+    from oracle import np_ops
+    rng = np.random.default_rng(4)
+    H, W = 24, 31
+    i0 = _texture(rng, (H, W)).astype(np.uint8)
+    i1 = np.roll(i0, (1, -1), (0, 1))
+    flow = (rng.normal(size=(H, W, 2)) * 0.3).astype(np.float32)
+    out = np_ops.variational_refinement(i0, i1, flow, fixed_point_iterations=1, sor_iterations=400)
+    dW = (out - flow).astype(np.float64)
+    # --- the system in float64
+    yy, xx = np.mgrid[0:H, 0:W]
+    mx, my = xx + flow[..., 0].astype(np.float64), yy + flow[..., 1].astype(np.float64)
+    fx, fy = np.rint(mx.astype(np.float32) * 32).astype(int), np.rint(my.astype(np.float32) * 32).astype(int)
+    sx, sy, ax, ay = fx >> 5, fy >> 5, (fx & 31) / 32.0, (fy & 31) / 32.0
+    g = lambda y, x: i1[np.clip(y, 0, H - 1), np.clip(x, 0, W - 1)].astype(np.float64)
+    warped = (g(sy, sx) * (1 - ay) * (1 - ax) + g(sy, sx + 1) * (1 - ay) * ax + g(sy + 1, sx) * ay * (1 - ax)
+              + g(sy + 1, sx + 1) * ay * ax)
+    avg, Iz = (i0 + warped) / 2, warped - i0
+    dx = lambda a: a[:, np.clip(np.arange(W) + 1, 0, W - 1)] - a[:, np.clip(np.arange(W) - 1, 0, W - 1)]
+    dy = lambda a: a[np.clip(np.arange(H) + 1, 0, H - 1)] - a[np.clip(np.arange(H) - 1, 0, H - 1)]
+    Ix, Iy, Ixz, Iyz = dx(avg), dy(avg), dx(Iz), dy(Iz)
+    Ixx, Ixy, Iyy = dx(Ix), dy(Ix), dy(Iy)
+    z2, e2 = 0.01, 1e-6
+    n0 = Ix ** 2 + Iy ** 2 + z2
+    w = 2.5 / np.sqrt(Iz ** 2 / n0 + e2)                       # dW = 0 at the start of the only fixed-point iteration
+    A11, A12, A22 = w * Ix * Ix / n0 + z2, w * Ix * Iy / n0, w * Iy * Iy / n0 + z2
+    b1, b2 = -w * Iz * Ix / n0, -w * Iz * Iy / n0
+    n1, n2 = Ixx ** 2 + Ixy ** 2 + z2, Iyy ** 2 + Ixy ** 2 + z2
+    w = 5.0 / np.sqrt(Ixz ** 2 / n1 + Iyz ** 2 / n2 + e2)
+    A11 += w * (Ixx ** 2 / n1 + Ixy ** 2 / n2)
+    A12 += w * (Ixx * Ixy / n1 + Ixy * Iyy / n2)
+    A22 += w * (Ixy ** 2 / n1 + Iyy ** 2 / n2)
+    b1 -= w * (Ixx * Ixz / n1 + Ixy * Iyz / n2)
+    b2 -= w * (Ixy * Ixz / n1 + Iyy * Iyz / n2)
+    u, v = flow[..., 0].astype(np.float64), flow[..., 1].astype(np.float64)
+    fwd_x = lambda a: np.concatenate([a[:, 1:] - a[:, :-1], np.zeros((H, 1))], 1)
+    fwd_y = lambda a: np.concatenate([a[1:] - a[:-1], np.zeros((1, W))], 0)
+    wt = 5.0 / np.sqrt(fwd_x(u) ** 2 + fwd_x(v) ** 2 + fwd_y(u) ** 2 + fwd_y(v) ** 2 + e2)
+    ex = wt.copy(); ex[:, -1] = 0                               # edge (p, right) exists except in the last column
+    ey = wt.copy(); ey[-1] = 0                                  # edge (p, down) exists except in the last row
+    exl = np.concatenate([np.zeros((H, 1)), ex[:, :-1]], 1)     # weight of the edge to the left / upper neighbour
+    eyu = np.concatenate([np.zeros((1, W)), ey[:-1]], 0)
+    diag = ex + exl + ey + eyu
+
+    def lap(a):                                                 # sum over edges of weight * (neighbour - self)
+        r = np.zeros_like(a)
+        r[:, :-1] += ex[:, :-1] * (a[:, 1:] - a[:, :-1])
+        r[:, 1:] += ex[:, :-1] * (a[:, :-1] - a[:, 1:])
+        r[:-1] += ey[:-1] * (a[1:] - a[:-1])
+        r[1:] += ey[:-1] * (a[:-1] - a[1:])
+        return r
+    # (A + diag) du + A12 dv - sum_w dW_nbr = b + lap(W)   <=>   A du + A12 dv - lap(du) = b + lap(u)
+    r1 = A11 * dW[..., 0] + A12 * dW[..., 1] - lap(dW[..., 0]) - (b1 + lap(u))
+    r2 = A22 * dW[..., 1] + A12 * dW[..., 0] - lap(dW[..., 1]) - (b2 + lap(v))
+    scale = np.abs(b1 + lap(u)).max() + np.abs(b2 + lap(v)).max()
+    assert diag.min() > 0 and max(np.abs(r1).max(), np.abs(r2).max()) < 2e-3 * scale

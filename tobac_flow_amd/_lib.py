@@ -16,6 +16,11 @@ TF_F32, TF_F64, TF_I32 = 0, 1, 2
 FUNC_STACK, FUNC_SOBEL, FUNC_SOBEL_UPHILL, FUNC_SOBEL_DOWNHILL, FUNC_NANMEAN, FUNC_DIFF, FUNC_ANY, FUNC_NANMAX = range(8)
 
 
+class VarRefParams(ctypes.Structure):
+    _fields_ = [("fixed_point_iterations", ctypes.c_int), ("sor_iterations", ctypes.c_int), ("alpha", ctypes.c_float),
+                ("delta", ctypes.c_float), ("gamma", ctypes.c_float), ("omega", ctypes.c_float)]
+
+
 class FarnebackParams(ctypes.Structure):
     _fields_ = [("num_levels", ctypes.c_int), ("pyr_scale", ctypes.c_double), ("win_size", ctypes.c_int),
                 ("num_iters", ctypes.c_int), ("poly_n", ctypes.c_int), ("poly_sigma", ctypes.c_double)]
@@ -38,6 +43,9 @@ _PROTOS = {
     "tf_farneback_workspace_bytes_batch": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams)]),
     "tf_farneback_batch": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                       _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),
+    "tf_varref_default_params": (None, [_c.POINTER(VarRefParams)]),
+    "tf_varref_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    "tf_varref": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.POINTER(VarRefParams), _P, _P, _c.c_size_t, _P]),
     "tf_smooth_flow_step": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P, _P]),
     "tf_warp_flow": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P]),
     "tf_flow_finalize": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float, _P]),
@@ -60,6 +68,17 @@ _PROTOS = {
     "tf_apply_lut": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int, _P, _P]),
     "tf_label_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64]),
     "tf_label": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _c.c_size_t, _P]),
+    "tf_pair_counts_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    "tf_pair_counts": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_int64, _P, _P, _c.c_size_t, _P]),
+    "tf_label_sizes": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P]),
+    "tf_flow_link_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64]),
+    "tf_flow_link_overlap": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_double, _c.c_int64, _P, _P,
+                                        _P, _c.c_size_t, _P]),
+    "tf_flow_label_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64]),
+    "tf_flow_label": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_double, _c.c_int64, _P, _P,
+                                 _P, _c.c_size_t, _P]),
+    "tf_window_overlap_pairs": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_double, _P, _c.c_int64, _P, _P,
+                                           _c.c_size_t, _P]),
     "tf_profile_enable": (_c.c_int, [_c.c_int]),
     "tf_profile_kernel_count": (_c.c_int, []),
     "tf_profile_kernel_name": (_c.c_char_p, [_c.c_int]),

@@ -1,0 +1,462 @@
+// Label-overlap graphs on gfx950: the counting half of the reference's flow-aware labelling and of its
+// cross-window linking.
+//
+//   tf_pair_counts        histogram of coinciding (a[i], b[i]) label pairs of two int32 volumes -- what the reference
+//                         computes per label with np.bincount / np.unique over that label's pixels
+//                         (tobac_flow/utils/label_utils.py:352-376 find_overlapping_labels, tobac_flow/linking.py:33-47
+//                         find_overlaps)
+//   tf_label_sizes        np.bincount(labels.ravel()) (label.py:139, linking.py:62-65)
+//   tf_flow_link_overlap  tobac_flow/label.py:249-321 flow_link_overlap (and :127-175, the second half of flow_label)
+//   tf_flow_label         tobac_flow/label.py:84-175 flow_label with subsegment_shrink = 0
+//   tf_window_overlap_pairs  tobac_flow/linking.py:49-93 / :96-140: which labels of two windows are the same object,
+//                         judged on the frames both windows hold
+//
+// Pair counting.  Labels are spatially coherent, so in raster order the key stream (a << 32 | b) consists of long
+// runs.  One run-length pass (hipcub) turns N voxels into n_runs (key, length) records -- typically N / 50 -- which
+// are radix-sorted by key and reduced by key.  HBM traffic: 8 B read per voxel once; everything after that works on
+// the run records.  The label GRAPH (a few thousand nodes) is walked on the host in the reference's own visiting
+// order, because that order decides the numbering (label.py:145-170: first come, first served).
+#include "tf_common.h"
+#include <hipcub/hipcub.hpp>
+#include <vector>
+#include <algorithm>
+
+typedef unsigned long long u64;
+#define PC_INVALID 0xFFFFFFFFFFFFFFFFull
+
+struct PairKey {
+    const int32_t *a, *b;
+    int min_b;                                   // 1: pairs need b > 0; 0: b >= 0 is kept (b == 0 counts towards sizes)
+    __host__ __device__ __forceinline__ u64 operator()(int64_t i) const {
+        const int32_t x = a[i], y = b[i];
+        return (x > 0 && y >= min_b) ? (((u64)(uint32_t)x << 32) | (uint32_t)y) : PC_INVALID;
+    }
+};
+typedef hipcub::CountingInputIterator<int64_t> PcCount;
+typedef hipcub::TransformInputIterator<u64, PairKey, PcCount> PcKeyIter;
+
+// number of runs of the key stream (runs of the invalid key included)
+__global__ void __launch_bounds__(256)
+k_pc_count_runs(PairKey key, int64_t n, unsigned long long *__restrict__ n_runs)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool head = false;
+    if (i < n) head = i == 0 || key(i) != key(i - 1);
+    const unsigned long long m = __ballot(head);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_runs, (unsigned long long)__popcll(m));
+}
+
+__global__ void __launch_bounds__(256)
+k_pc_widen(const int *__restrict__ in, int64_t n, int64_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_pc_unpack(const u64 *__restrict__ keys, const int64_t *__restrict__ cnt, int64_t n, int32_t *__restrict__ oa,
+            int32_t *__restrict__ ob, int64_t *__restrict__ oc)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 k = keys[i];
+    oa[i] = (int32_t)(k >> 32); ob[i] = (int32_t)(k & 0xFFFFFFFFull); oc[i] = cnt[i];
+}
+
+struct PcSizes { size_t rle, sort, reduce, runs_bytes; };
+static PcSizes pc_temp_sizes(int64_t n, int64_t max_runs)
+{
+    PcSizes z; z.rle = z.sort = z.reduce = 0;
+    PairKey pk{nullptr, nullptr, 1};
+    PcKeyIter it(PcCount(0), pk);
+    (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, z.rle, it, (u64 *)nullptr, (int *)nullptr, (int *)nullptr, (int)n);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, z.sort, (const u64 *)nullptr, (u64 *)nullptr, (const int64_t *)nullptr,
+                                             (int64_t *)nullptr, (int)max_runs);
+    (void)hipcub::DeviceReduce::ReduceByKey(nullptr, z.reduce, (const u64 *)nullptr, (u64 *)nullptr, (const int64_t *)nullptr,
+                                            (int64_t *)nullptr, (int *)nullptr, hipcub::Sum(), (int)max_runs);
+    return z;
+}
+
+extern "C" size_t tf_pair_counts_workspace_bytes(int64_t n, int64_t max_runs)
+{
+    if (n <= 0 || n > 0x7fffffffll) return 0;
+    if (max_runs <= 0 || max_runs > n) max_runs = n;
+    const PcSizes z = pc_temp_sizes(n, max_runs);
+    const size_t temp = std::max(z.rle, std::max(z.sort, z.reduce));
+    // run keys + run lengths (int) + widened lengths, sorted keys + sorted lengths, reduced keys + sums, counters
+    return tf_align_up(temp, 256) + 3 * tf_align_up((size_t)max_runs * 8, 256) + 3 * tf_align_up((size_t)max_runs * 8, 256)
+         + tf_align_up((size_t)max_runs * 4, 256) + 4096;
+}
+
+// Device-side result (keys sorted by (a, b), int64 counts) left in the workspace; host copies / unpacks as needed.
+struct PcResult { const u64 *keys; const int64_t *counts; int64_t n_pairs; };
+
+// number of runs of the (a, b) key stream: what the scratch of pc_run has to hold
+static int pc_count(const int32_t *a, const int32_t *b, int64_t n, int min_b, void *ws, size_t ws_bytes, hipStream_t s,
+                    int64_t *runs)
+{
+    TF_REQUIRE(a && b && n > 0 && n <= 0x7fffffffll, "tf_pair_counts: bad arguments");
+    if (ws_bytes < 64) { tf_set_error("tf_pair_counts: workspace too small"); return TF_ENOMEM; }
+    unsigned long long *d_cnt = (unsigned long long *)ws;
+    PairKey pk{a, b, min_b};
+    TF_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_pc_count_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pk, n, d_cnt);
+    TF_CHECK_LAUNCH();
+    unsigned long long h = 0;
+    TF_CHECK_HIP(hipMemcpyAsync(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    *runs = (int64_t)h;
+    return TF_OK;
+}
+
+// does a workspace of ws_bytes hold pc_run's scratch for `runs` runs of an n-voxel stream?
+static bool pc_fits(int64_t n, int64_t runs, size_t ws_bytes)
+{
+    const PcSizes z = pc_temp_sizes(n, runs);
+    const size_t temp = std::max(z.rle, std::max(z.sort, z.reduce));
+    const size_t need = 256 + tf_align_up(temp ? temp : 1, 256) + 3 * tf_align_up((size_t)runs * 8, 256)
+                      + 3 * tf_align_up((size_t)runs * 8, 256) + tf_align_up((size_t)runs * 4, 256) + 2048;
+    return need <= ws_bytes;
+}
+
+static int pc_run(const int32_t *a, const int32_t *b, int64_t n, int min_b, void *ws, size_t ws_bytes, hipStream_t s,
+                  PcResult *res, int64_t *runs_needed)
+{
+    TF_REQUIRE(a && b && n > 0 && n <= 0x7fffffffll, "tf_pair_counts: bad arguments");
+    PairKey pk{a, b, min_b};
+    TfArena ar(ws, ws_bytes);
+    unsigned long long *d_cnt = ar.take<unsigned long long>(8);
+    if (!ar.ok()) { tf_set_error("tf_pair_counts: workspace too small"); return TF_ENOMEM; }
+    TF_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 8 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_pc_count_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pk, n, d_cnt);
+    TF_CHECK_LAUNCH();
+    unsigned long long h_runs = 0;
+    TF_CHECK_HIP(hipMemcpyAsync(&h_runs, d_cnt, sizeof(h_runs), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    const int64_t runs = (int64_t)h_runs;
+    if (runs_needed) *runs_needed = runs;
+    const PcSizes z = pc_temp_sizes(n, runs);
+    const size_t temp = std::max(z.rle, std::max(z.sort, z.reduce));
+    char *tmp = ar.take<char>(temp ? temp : 1);
+    u64 *rk = ar.take<u64>(runs), *sk = ar.take<u64>(runs), *uk = ar.take<u64>(runs);
+    int *rl = ar.take<int>(runs);
+    int64_t *rl64 = ar.take<int64_t>(runs), *sl = ar.take<int64_t>(runs), *us = ar.take<int64_t>(runs);
+    if (!ar.ok()) {
+        tf_set_error("tf_pair_counts: workspace too small for %lld runs", (long long)runs);
+        return TF_ENOMEM;
+    }
+    int *d_nruns = (int *)(d_cnt + 2), *d_npairs = (int *)(d_cnt + 4);
+    PcKeyIter it(PcCount(0), pk);
+    size_t tb = temp;
+    TF_CHECK_HIP(hipcub::DeviceRunLengthEncode::Encode(tmp, tb, it, rk, rl, d_nruns, (int)n, s));
+    hipLaunchKernelGGL(k_pc_widen, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, s, rl, runs, rl64);
+    TF_CHECK_LAUNCH();
+    tb = temp;
+    TF_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, (const u64 *)rk, sk, (const int64_t *)rl64, sl, (int)runs, 0, 64, s));
+    tb = temp;
+    TF_CHECK_HIP(hipcub::DeviceReduce::ReduceByKey(tmp, tb, (const u64 *)sk, uk, (const int64_t *)sl, us, d_npairs,
+                                                   hipcub::Sum(), (int)runs, s));
+    int h_npairs = 0; u64 last_key = 0;
+    TF_CHECK_HIP(hipMemcpyAsync(&h_npairs, d_npairs, sizeof(int), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    if (h_npairs > 0) {
+        TF_CHECK_HIP(hipMemcpyAsync(&last_key, uk + (h_npairs - 1), sizeof(u64), hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipStreamSynchronize(s));
+        if (last_key == PC_INVALID) h_npairs -= 1;            // the invalid key sorts last
+    }
+    res->keys = uk; res->counts = us; res->n_pairs = h_npairs;
+    return TF_OK;
+}
+
+extern "C" int tf_pair_counts(const int32_t *a, const int32_t *b, int64_t n, int include_b_zero,
+                              int32_t *out_a, int32_t *out_b, int64_t *out_count, int64_t max_pairs,
+                              int64_t *n_pairs_host, void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(n_pairs_host && ws, "tf_pair_counts: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    PcResult r; int64_t runs = 0;
+    const int rc = pc_run(a, b, n, include_b_zero ? 0 : 1, ws, ws_bytes, s, &r, &runs);
+    if (rc == TF_ENOMEM) { *n_pairs_host = runs; return rc; }
+    if (rc) return rc;
+    *n_pairs_host = r.n_pairs;
+    if (r.n_pairs > max_pairs) { tf_set_error("tf_pair_counts: %lld pairs, room for %lld", (long long)r.n_pairs, (long long)max_pairs); return TF_ENOMEM; }
+    if (r.n_pairs > 0) {
+        TF_REQUIRE(out_a && out_b && out_count, "tf_pair_counts: null output");
+        hipLaunchKernelGGL(k_pc_unpack, dim3((unsigned)((r.n_pairs + 255) / 256)), dim3(256), 0, s, r.keys, r.counts, r.n_pairs,
+                           out_a, out_b, out_count);
+        TF_CHECK_LAUNCH();
+    }
+    return TF_OK;
+}
+
+// ---- np.bincount ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_label_sizes(const int32_t *__restrict__ labels, int64_t n, int64_t n_labels, unsigned long long *__restrict__ sizes)
+{
+    // one atomic per run of equal labels inside a thread's 8 consecutive voxels
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    int32_t cur = -1; unsigned long long run = 0;
+    for (int j = 0; j < 8 && i0 + j < n; j++) {
+        const int32_t l = labels[i0 + j];
+        if (l == cur) { run++; continue; }
+        if (run && cur >= 0 && cur <= n_labels) atomicAdd(&sizes[cur], run);
+        cur = l; run = 1;
+    }
+    if (run && cur >= 0 && cur <= n_labels) atomicAdd(&sizes[cur], run);
+}
+
+extern "C" int tf_label_sizes(const int32_t *labels, int64_t n, int64_t n_labels, int64_t *sizes, void *stream)
+{
+    TF_REQUIRE(labels && sizes && n > 0 && n_labels >= 0, "tf_label_sizes: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    TF_CHECK_HIP(hipMemsetAsync(sizes, 0, (size_t)(n_labels + 1) * sizeof(int64_t), s));
+    hipLaunchKernelGGL(k_label_sizes, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, labels, n, n_labels,
+                       (unsigned long long *)sizes);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+__global__ void __launch_bounds__(256)
+k_label_max(const int32_t *__restrict__ labels, int64_t n, int *__restrict__ out)
+{
+    int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = max(m, labels[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+static int label_max(const int32_t *labels, int64_t n, int *d_tmp, hipStream_t s, int *out)
+{
+    TF_CHECK_HIP(hipMemsetAsync(d_tmp, 0, sizeof(int), s));
+    const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_label_max, dim3(nb), dim3(256), 0, s, labels, n, d_tmp);
+    TF_CHECK_LAUNCH();
+    TF_CHECK_HIP(hipMemcpyAsync(out, d_tmp, sizeof(int), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    return TF_OK;
+}
+
+// ---- flow_link_overlap ------------------------------------------------------------------------------------------
+// label.py:268-321.  back / forward = the per-step labels of t-1 / t+1 warped to t with the backward / forward
+// flow (nearest neighbour; Flow.convolve with the t-planes of `structure` reduced to their centre column, i.e.
+// structure * [1, 0, 1]).  For label L with n pixels, a warped label M != 0 is a neighbour iff
+//   count(L, M) > absolute_overlap  and  count(L, M) >= overlap * min(n, size(M))          (label_utils.py:352-376)
+// Groups: labels in ascending order; an unvisited label opens a group and absorbs, breadth first, the unvisited
+// neighbours of every member -- forward neighbours (ascending) before backward ones (label.py:208-245).
+extern "C" size_t tf_flow_link_workspace_bytes(int64_t T, int64_t H, int64_t W, int64_t max_runs)
+{
+    const int64_t N = T * H * W;
+    if (T <= 0 || H <= 0 || W <= 0 || N > 0x7fffffffll) return 0;
+    return 2 * tf_align_up((size_t)N * 4, 256) + tf_pair_counts_workspace_bytes(N, max_runs) + 4096;
+}
+
+static void link_groups(int n_lab, const std::vector<int64_t> &sizes, const std::vector<u64> keys[2],
+                        const std::vector<int64_t> cnts[2], double overlap, int64_t absolute_overlap, std::vector<int32_t> &lut)
+{
+    // adjacency per direction (0 = forward, 1 = backward), CSR over the sorted keys
+    std::vector<int64_t> start[2];
+    std::vector<int32_t> nb[2];
+    for (int d = 0; d < 2; d++) {
+        start[d].assign(n_lab + 2, 0);
+        for (size_t i = 0; i < keys[d].size(); i++) {
+            const int32_t a = (int32_t)(keys[d][i] >> 32), b = (int32_t)(keys[d][i] & 0xFFFFFFFFull);
+            if (a < 1 || a > n_lab || b < 1 || b > n_lab) continue;
+            const int64_t c = cnts[d][i];
+            const int64_t m = std::min(sizes[a], sizes[b]);
+            if (c > absolute_overlap && (double)c >= overlap * (double)m) { nb[d].push_back(b); start[d][a + 1]++; }
+        }
+        for (int l = 1; l <= n_lab + 1; l++) start[d][l] += start[d][l - 1];
+    }
+    std::vector<char> seen(n_lab + 1, 0);
+    lut.assign(n_lab + 1, 0);
+    std::vector<int32_t> stack;
+    int32_t n_groups = 0;
+    for (int label = 1; label <= n_lab; label++) {
+        if (seen[label]) continue;
+        n_groups++;
+        stack.clear(); stack.push_back(label); seen[label] = 1;
+        for (size_t i = 0; i < stack.size(); i++) {
+            const int cur = stack[i];
+            if (sizes[cur] == 0) continue;                      // label.py:218: labels without pixels have no neighbours
+            for (int d = 0; d < 2; d++)
+                for (int64_t e = start[d][cur]; e < start[d][cur + 1]; e++) {
+                    const int32_t m = nb[d][e];
+                    if (!seen[m]) { seen[m] = 1; stack.push_back(m); }
+                }
+        }
+        for (int32_t m : stack) lut[m] = sizes[m] > 0 ? n_groups : 0;
+    }
+}
+
+extern "C" int tf_flow_link_overlap(const int32_t *flat_labels, const float *fwd, const float *bwd,
+                                    int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
+                                    double overlap, int64_t absolute_overlap, int32_t *out, int *n_objects_host,
+                                    void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(flat_labels && fwd && bwd && structure_host && out && ws, "tf_flow_link_overlap: null pointer");
+    const int64_t N = T * H * W;
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && N <= 0x7fffffffll, "tf_flow_link_overlap: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    TfArena ar(ws, ws_bytes);
+    int32_t *warped = ar.take<int32_t>(2 * N);
+    int *d_tmp = ar.take<int>(64);
+    if (!ar.ok()) { tf_set_error("tf_flow_link_overlap: workspace too small"); return TF_ENOMEM; }
+    // structure * [1, 0, 1] along t (label.py:266)
+    uint8_t st[27];
+    for (int i = 0; i < 27; i++) st[i] = (i / 9 == 1) ? 0 : (structure_host[i] ? 1 : 0);
+    int n_taps_prev = 0, n_taps_next = 0;
+    for (int i = 0; i < 9; i++) { n_taps_prev += st[i]; n_taps_next += st[18 + i]; }
+    TF_REQUIRE(n_taps_prev == 1 && n_taps_next == 1, "tf_flow_link_overlap: the structure must have exactly one tap in each "
+               "of its t-1 and t+1 planes (the reference unpacks Flow.convolve's stack into back_labels, forward_labels)");
+    int rc = tf_convolve(flat_labels, TF_I32, T, H, W, fwd, bwd, st, TF_INTERP_NEAREST, 0.0, TF_FUNC_STACK, warped, TF_I32, 0, T, stream);
+    if (rc) return rc;
+    int n_lab = 0;
+    rc = label_max(flat_labels, N, d_tmp, s, &n_lab);
+    if (rc) return rc;
+    std::vector<int64_t> sizes(n_lab + 1, 0);
+    std::vector<u64> keys[2];
+    std::vector<int64_t> cnts[2];
+    char *rest = (char *)ws + tf_align_up(ar.used, 256);
+    const size_t rest_bytes = ws_bytes - tf_align_up(ar.used, 256);
+    if (n_lab > 0) {
+        // scratch check for all three counting passes at once, so that ONE retry with the reported run count suffices
+        int64_t need = 0;
+        for (int d = 0; d < 3; d++) {
+            const int32_t *b = d == 0 ? warped + N : (d == 1 ? warped : flat_labels);
+            int64_t runs = 0;
+            rc = pc_count(flat_labels, b, N, 1, rest, rest_bytes, s, &runs);
+            if (rc) return rc;
+            need = std::max(need, runs);
+        }
+        if (!pc_fits(N, need, rest_bytes)) {
+            if (n_objects_host) *n_objects_host = (int)std::min<int64_t>(need, 0x7fffffff);
+            tf_set_error("tf_flow_link_overlap: workspace too small for %lld label runs", (long long)need);
+            return TF_ENOMEM;
+        }
+        // bincount of the labels themselves = pair counts of (label, label)
+        for (int d = 0; d < 3; d++) {
+            const int32_t *b = d == 0 ? warped + N /* forward */ : (d == 1 ? warped /* back */ : flat_labels);
+            PcResult r; int64_t runs = 0;
+            rc = pc_run(flat_labels, b, N, 1, rest, rest_bytes, s, &r, &runs);
+            if (rc) { if (rc == TF_ENOMEM && n_objects_host) *n_objects_host = (int)std::min<int64_t>(runs, 0x7fffffff); return rc; }
+            std::vector<u64> k(r.n_pairs); std::vector<int64_t> c(r.n_pairs);
+            if (r.n_pairs) {
+                TF_CHECK_HIP(hipMemcpyAsync(k.data(), r.keys, r.n_pairs * sizeof(u64), hipMemcpyDeviceToHost, s));
+                TF_CHECK_HIP(hipMemcpyAsync(c.data(), r.counts, r.n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+                TF_CHECK_HIP(hipStreamSynchronize(s));
+            }
+            if (d < 2) { keys[d].swap(k); cnts[d].swap(c); }
+            else for (int64_t i = 0; i < r.n_pairs; i++) sizes[(int32_t)(k[i] >> 32)] = c[i];
+        }
+    }
+    std::vector<int32_t> lut;
+    link_groups(n_lab, sizes, keys, cnts, overlap, absolute_overlap, lut);
+    int32_t n_groups = 0;
+    for (int32_t v : lut) n_groups = std::max(n_groups, v);
+    if (n_objects_host) *n_objects_host = n_groups;
+    // relabel: the LUT goes through the (now free) pair-count scratch
+    int32_t *d_lut = (int32_t *)rest;
+    if (rest_bytes < (size_t)(n_lab + 1) * 4) { tf_set_error("tf_flow_link_overlap: workspace too small"); return TF_ENOMEM; }
+    TF_CHECK_HIP(hipMemcpyAsync(d_lut, lut.data(), (size_t)(n_lab + 1) * 4, hipMemcpyHostToDevice, s));
+    rc = tf_apply_lut(flat_labels, N, d_lut, n_lab + 1, out, stream);
+    if (rc) return rc;
+    TF_CHECK_HIP(hipStreamSynchronize(s));                       // lut (host vector) is read by the copy above
+    return TF_OK;
+}
+
+extern "C" size_t tf_flow_label_workspace_bytes(int64_t T, int64_t H, int64_t W, int64_t max_runs)
+{
+    const size_t a = tf_flow_link_workspace_bytes(T, H, W, max_runs), b = tf_label_workspace_bytes(T, H, W);
+    if (!a || !b) return 0;
+    return tf_align_up((size_t)(T * H * W) * 4, 256) + std::max(a, b) + 256;
+}
+
+extern "C" int tf_flow_label(const uint8_t *mask, const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                             const uint8_t *structure_host, double overlap, int64_t absolute_overlap,
+                             int32_t *labels, int *n_objects_host, void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(mask && structure_host && labels && ws, "tf_flow_label: null pointer");
+    const int64_t N = T * H * W;
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && N <= 0x7fffffffll, "tf_flow_label: bad shape");
+    TfArena ar(ws, ws_bytes);
+    int32_t *flat = ar.take<int32_t>(N);
+    if (!ar.ok()) { tf_set_error("tf_flow_label: workspace too small"); return TF_ENOMEM; }
+    char *rest = (char *)ws + tf_align_up(ar.used, 256);
+    const size_t rest_bytes = ws_bytes - tf_align_up(ar.used, 256);
+    uint8_t st[27];                                              // label_utils.py:170-172: no connection across t
+    for (int i = 0; i < 27; i++) st[i] = (i / 9 == 1) ? structure_host[i] : 0;
+    int n_flat = 0;
+    int rc = tf_label(mask, T, H, W, st, flat, &n_flat, rest, rest_bytes, stream);
+    if (rc) return rc;
+    return tf_flow_link_overlap(flat, fwd, bwd, T, H, W, structure_host, overlap, absolute_overlap, labels, n_objects_host,
+                                rest, rest_bytes, stream);
+}
+
+// ---- cross-window linking -----------------------------------------------------------------------------------------
+// linking.py:49-93 (cores) / :96-140 (anvils): `left` and `right` are the labels two consecutive windows assign to
+// the SAME frames (the caller has already dropped the first and the last common frame, linking.py:55-56).  For every
+// left label L (n pixels in these frames) and right label M != 0 (size(M) pixels in these frames):
+//   linked  iff  count >= atol (count > 0 when atol == 0)  and  (rtol <= 0 or max(count / n, count / size(M)) >= rtol)
+// Output: the linked (L, M) pairs sorted by (L, M), on the HOST (they are few and feed the union-find / all-gather).
+extern "C" int tf_window_overlap_pairs(const int32_t *left, const int32_t *right, int64_t n, int64_t atol, double rtol,
+                                       int32_t *pairs_host, int64_t max_pairs, int64_t *n_pairs_host,
+                                       void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(left && right && n_pairs_host && ws && n > 0, "tf_window_overlap_pairs: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    PcResult r; int64_t runs = 0, runs2 = 0;
+    int rc = pc_count(left, right, n, 0, ws, ws_bytes, s, &runs);
+    if (!rc) rc = pc_count(right, right, n, 1, ws, ws_bytes, s, &runs2);
+    if (rc) return rc;
+    if (!pc_fits(n, std::max(runs, runs2), ws_bytes)) {
+        *n_pairs_host = std::max(runs, runs2);
+        tf_set_error("tf_window_overlap_pairs: workspace too small for %lld label runs", (long long)*n_pairs_host);
+        return TF_ENOMEM;
+    }
+    rc = pc_run(left, right, n, 0, ws, ws_bytes, s, &r, &runs);           // right == 0 kept: it counts towards n
+    if (rc == TF_ENOMEM) { *n_pairs_host = runs; return rc; }
+    if (rc) return rc;
+    std::vector<u64> k(r.n_pairs); std::vector<int64_t> c(r.n_pairs);
+    if (r.n_pairs) {
+        TF_CHECK_HIP(hipMemcpyAsync(k.data(), r.keys, r.n_pairs * sizeof(u64), hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipMemcpyAsync(c.data(), r.counts, r.n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    // size of every right label over ALL voxels of these frames (linking.py:62-65), i.e. also where left == 0
+    PcResult rr;
+    rc = pc_run(right, right, n, 1, ws, ws_bytes, s, &rr, &runs);
+    if (rc == TF_ENOMEM) { *n_pairs_host = runs; return rc; }
+    if (rc) return rc;
+    std::vector<u64> rk(rr.n_pairs); std::vector<int64_t> rc_(rr.n_pairs);
+    if (rr.n_pairs) {
+        TF_CHECK_HIP(hipMemcpyAsync(rk.data(), rr.keys, rr.n_pairs * sizeof(u64), hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipMemcpyAsync(rc_.data(), rr.counts, rr.n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    auto right_size = [&](uint32_t m) -> int64_t {
+        const u64 key = ((u64)m << 32) | m;
+        auto it = std::lower_bound(rk.begin(), rk.end(), key);
+        return (it != rk.end() && *it == key) ? std::max<int64_t>(rc_[it - rk.begin()], 1) : 1;
+    };
+    int64_t out = 0;
+    for (size_t i = 0; i < k.size();) {
+        size_t j = i; int64_t n_left = 0;
+        const uint32_t L = (uint32_t)(k[i] >> 32);
+        while (j < k.size() && (uint32_t)(k[j] >> 32) == L) { n_left += c[j]; j++; }
+        for (size_t e = i; e < j; e++) {
+            const uint32_t M = (uint32_t)(k[e] & 0xFFFFFFFFull);
+            if (M == 0) continue;
+            const int64_t cnt = c[e];
+            bool ok = atol > 0 ? cnt >= atol : cnt > 0;
+            if (ok && rtol > 0) ok = std::max((double)cnt / (double)n_left, (double)cnt / (double)right_size(M)) >= rtol;
+            if (!ok) continue;
+            if (out < max_pairs && pairs_host) { pairs_host[2 * out] = (int32_t)L; pairs_host[2 * out + 1] = (int32_t)M; }
+            out++;
+        }
+        i = j;
+    }
+    *n_pairs_host = out;
+    if (out > max_pairs) { tf_set_error("tf_window_overlap_pairs: %lld pairs, room for %lld", (long long)out, (long long)max_pairs); return TF_ENOMEM; }
+    return TF_OK;
+}

@@ -60,7 +60,8 @@ __device__ __forceinline__ int tf_clampi(int v, int lo, int hi) { return v < lo 
 // returns calls / total ms / total algorithmic bytes per kernel id.  Disabled: zero overhead.
 enum TfKernelId {
     TFK_TO8BIT = 0, TFK_FB_BLUR, TFK_FB_RESIZE, TFK_FB_POLYEXP, TFK_FB_MATRICES, TFK_FB_BLUR_SOLVE, TFK_FB_ITER,
-    TFK_SMOOTH, TFK_CONVOLVE, TFK_SOBEL, TFK_WS_SETUP, TFK_WS_RELAX, TFK_WS_LABELS, TFK_COUNT
+    TFK_SMOOTH, TFK_CONVOLVE, TFK_SOBEL, TFK_WS_SETUP, TFK_WS_RELAX, TFK_WS_LABELS, TFK_VR_PREPARE, TFK_VR_SYSTEM, TFK_VR_SOR,
+    TFK_COUNT
 };
 extern bool g_tf_prof_on;
 void tf_prof_record(int id, double bytes, hipStream_t s, bool start);

@@ -1,0 +1,254 @@
+// Variational refinement of a dense flow field on gfx950.
+//
+// Replaces cv2.VariationalRefinement.create().calc(I0, I1, flow) as the reference issues it once per direction when
+// vr_steps > 0 (/root/reference/tobac_flow/flow.py:359, 513-519), with OpenCV's defaults: fixedPointIterations 5,
+// sorIterations 5, alpha 20, delta 5, gamma 10, omega 1.6 (internal zeta 0.1, epsilon 0.001) --
+// modules/video/src/variational_refinement.cpp, restated from the published algorithm (SURVEY.md Appendix A.2;
+// PARITY UNPINNED: no OpenCV in the build image, the reference holds no vectors for this stage).
+//
+//   k_vr_prepare   I1 warped by the flow (bilinear, coordinates quantised to 1/32 px, replicated border), averaged
+//                  image, Iz, and all first / second central differences (Sobel ksize 1, replicated border) on ONE LDS
+//                  tile with a 2-pixel halo: the eight derivative planes are written once (32 B / px), nothing else
+//                  touches HBM
+//   k_vr_weights   smoothness weights of the current flow W + dW (forward differences, replicated border)
+//   k_vr_system    the 2x2 system of every pixel: data term (robust colour- and gradient-constancy weights) plus the
+//                  smoothness contributions of its four edges, accumulated in OpenCV's pass order (red before black,
+//                  horizontal before vertical -- the order at a pixel depends on its colour)
+//   k_vr_sor       one half sweep (one colour) of red-black SOR on dW
+// Every float expression is evaluated as written (-ffp-contract=off, correctly rounded divide / sqrt), so the result
+// is bit-identical to the oracle's C restatement (oracle/c/varref.c).
+//
+// HBM layout (planar, per flow direction): D1 = float4 {Ix, Iy, Ixz, Iyz}, D2 = float4 {Ixx, Ixy, Iyy, Iz},
+// S = float4 {A11, A22, b1, b2}, A12 float, wt float, W float2 (the input flow), dW float2.
+#include "tf_common.h"
+
+struct VrP { float alpha2, delta2, gamma2, omega, zeta2, eps2; };
+
+__device__ __forceinline__ int vr_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+#define VR_TW 64
+#define VR_TH 16
+#define VR_LW (VR_TW + 4)
+#define VR_LH (VR_TH + 4)
+
+__global__ void __launch_bounds__(256)
+k_vr_prepare(const uint8_t *__restrict__ I0, const uint8_t *__restrict__ I1, const float2 *__restrict__ flow,
+             int H, int W, float4 *__restrict__ D1, float4 *__restrict__ D2)
+{
+    __shared__ float s_avg[VR_LH][VR_LW], s_iz[VR_LH][VR_LW], s_ix[VR_LH][VR_LW], s_iy[VR_LH][VR_LW];
+    const int x0 = blockIdx.x * VR_TW - 2, y0 = blockIdx.y * VR_TH - 2;
+    // warped / averaged image and Iz on the tile + 2 halo (in-image positions only; neighbours are clamped later)
+    for (int i = threadIdx.x; i < VR_LW * VR_LH; i += 256) {
+        const int ly = i / VR_LW, lx = i - ly * VR_LW;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        const int64_t p = (int64_t)y * W + x;
+        const float2 f = flow[p];
+        const float mx = (float)x + f.x, my = (float)y + f.y;
+        const int fx = tf_cvround(mx * 32.f), fy = tf_cvround(my * 32.f);
+        const int sx = tf_sat_short(fx >> 5), sy = tf_sat_short(fy >> 5);
+        const int ax = fx & 31, ay = fy & 31;
+        const float tx1 = (float)ax * (1.f / 32.f), tx0 = 1.f - tx1, ty1 = (float)ay * (1.f / 32.f), ty0 = 1.f - ty1;
+        const float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
+        const int xa = vr_clampi(sx, W - 1), xb = vr_clampi(sx + 1, W - 1), ya = vr_clampi(sy, H - 1), yb = vr_clampi(sy + 1, H - 1);
+        const float v0 = (float)I1[(int64_t)ya * W + xa], v1 = (float)I1[(int64_t)ya * W + xb];
+        const float v2 = (float)I1[(int64_t)yb * W + xa], v3 = (float)I1[(int64_t)yb * W + xb];
+        const float warped = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+        const float i0 = (float)I0[p];
+        s_avg[ly][lx] = (i0 + warped) * 0.5f;
+        s_iz[ly][lx] = warped - i0;
+    }
+    __syncthreads();
+    // first differences of the averaged image on the tile + 1 halo (replicated border = clamped neighbour coordinates)
+    for (int i = threadIdx.x; i < VR_LW * VR_LH; i += 256) {
+        const int ly = i / VR_LW, lx = i - ly * VR_LW;
+        if (lx < 1 || ly < 1 || lx >= VR_LW - 1 || ly >= VR_LH - 1) continue;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        const int xr = vr_clampi(x + 1, W - 1) - x0, xl = vr_clampi(x - 1, W - 1) - x0;
+        const int yd = vr_clampi(y + 1, H - 1) - y0, yu = vr_clampi(y - 1, H - 1) - y0;
+        s_ix[ly][lx] = s_avg[ly][xr] - s_avg[ly][xl];
+        s_iy[ly][lx] = s_avg[yd][lx] - s_avg[yu][lx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < VR_TW * VR_TH; i += 256) {
+        const int ty = i / VR_TW, tx = i - ty * VR_TW;
+        const int lx = tx + 2, ly = ty + 2;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= W || y >= H) continue;
+        const int xr = vr_clampi(x + 1, W - 1) - x0, xl = vr_clampi(x - 1, W - 1) - x0;
+        const int yd = vr_clampi(y + 1, H - 1) - y0, yu = vr_clampi(y - 1, H - 1) - y0;
+        const float ixz = s_iz[ly][xr] - s_iz[ly][xl], iyz = s_iz[yd][lx] - s_iz[yu][lx];
+        const float ixx = s_ix[ly][xr] - s_ix[ly][xl], ixy = s_ix[yd][lx] - s_ix[yu][lx];
+        const float iyy = s_iy[yd][lx] - s_iy[yu][lx];
+        const int64_t p = (int64_t)y * W + x;
+        D1[p] = make_float4(s_ix[ly][lx], s_iy[ly][lx], ixz, iyz);
+        D2[p] = make_float4(ixx, ixy, iyy, s_iz[ly][lx]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_vr_weights(const float2 *__restrict__ Wf, const float2 *__restrict__ dW, int H, int W, VrP P, float *__restrict__ wt)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int64_t j = (int64_t)y * W + x;
+    const int64_t jr = x + 1 < W ? j + 1 : j, jd = y + 1 < H ? j + W : j;
+    const float2 w0 = Wf[j], d0 = dW[j], wr = Wf[jr], dr = dW[jr], wd = Wf[jd], dd = dW[jd];
+    const float cu = w0.x + d0.x, cv = w0.y + d0.y;
+    const float ux = (wr.x + dr.x) - cu, vx = (wr.y + dr.y) - cv, uy = (wd.x + dd.x) - cu, vy = (wd.y + dd.y) - cv;
+    wt[j] = P.alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + P.eps2);
+}
+
+__global__ void __launch_bounds__(256)
+k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const float2 *__restrict__ Wf,
+            const float2 *__restrict__ dW, const float *__restrict__ wt, int H, int W, VrP P,
+            float4 *__restrict__ S, float *__restrict__ A12o)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int64_t j = (int64_t)y * W + x;
+    const float4 d1 = D1[j], d2 = D2[j];
+    const float Ix = d1.x, Iy = d1.y, Ixz = d1.z, Iyz = d1.w, Ixx = d2.x, Ixy = d2.y, Iyy = d2.z, Iz = d2.w;
+    const float2 d = dW[j];
+    const float du = d.x, dv = d.y;
+    // ComputeDataTerm
+    float derivNorm = Ix * Ix + Iy * Iy + P.zeta2;
+    const float Ik1z = Iz + Ix * du + Iy * dv;
+    float weight = P.delta2 / sqrtf(Ik1z * Ik1z / derivNorm + P.eps2);
+    float A11 = weight * (Ix * Ix / derivNorm) + P.zeta2;
+    float A12 = weight * (Ix * Iy / derivNorm);
+    float A22 = weight * (Iy * Iy / derivNorm) + P.zeta2;
+    float b1 = -weight * (Iz * Ix / derivNorm);
+    float b2 = -weight * (Iz * Iy / derivNorm);
+    derivNorm = Ixx * Ixx + Ixy * Ixy + P.zeta2;
+    const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + P.zeta2;
+    const float Ik1zx = Ixz + Ixx * du + Ixy * dv;
+    const float Ik1zy = Iyz + Ixy * du + Iyy * dv;
+    weight = P.gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + P.eps2);
+    A11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
+    A12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
+    A22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
+    b1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
+    b2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+    // smoothness: each edge (p, right) / (p, down) carries the weight of its upper-left end
+    const bool has_r = x + 1 < W, has_l = x > 0, has_d = y + 1 < H, has_u = y > 0;
+    const float wp = wt[j], wl = has_l ? wt[j - 1] : 0.f, wu = has_u ? wt[j - W] : 0.f;
+    const float2 w0 = Wf[j];
+    const float2 wr = has_r ? Wf[j + 1] : w0, wlf = has_l ? Wf[j - 1] : w0, wd = has_d ? Wf[j + W] : w0, wuf = has_u ? Wf[j - W] : w0;
+    // own edge terms as the horizontal / vertical passes form them at p, neighbour edge terms as they form them at the
+    // left / upper neighbour
+    const float own_ux = wp * (wr.x - w0.x), own_vx = wp * (wr.y - w0.y);
+    const float lft_ux = wl * (w0.x - wlf.x), lft_vx = wl * (w0.y - wlf.y);
+    const float own_uy = wp * (wd.x - w0.x), own_vy = wp * (wd.y - w0.y);
+    const float up_uy = wu * (w0.x - wuf.x), up_vy = wu * (w0.y - wuf.y);
+    const bool red = ((x + y) & 1) == 0;
+    if (red) {
+        if (has_r) { b1 += own_ux; A11 += wp; b2 += own_vx; A22 += wp; }
+        if (has_l) { b1 -= lft_ux; A11 += wl; b2 -= lft_vx; A22 += wl; }
+        if (has_d) { b1 += own_uy; A11 += wp; b2 += own_vy; A22 += wp; }
+        if (has_u) { b1 -= up_uy; A11 += wu; b2 -= up_vy; A22 += wu; }
+    } else {
+        if (has_l) { b1 -= lft_ux; A11 += wl; b2 -= lft_vx; A22 += wl; }
+        if (has_r) { b1 += own_ux; A11 += wp; b2 += own_vx; A22 += wp; }
+        if (has_u) { b1 -= up_uy; A11 += wu; b2 -= up_vy; A22 += wu; }
+        if (has_d) { b1 += own_uy; A11 += wp; b2 += own_vy; A22 += wp; }
+    }
+    S[j] = make_float4(A11, A22, b1, b2);
+    A12o[j] = A12;
+}
+
+// one colour of one red-black SOR sweep: thread -> the pixel of that colour in its pixel pair
+__global__ void __launch_bounds__(256)
+k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W, int colour,
+         float omega, float2 *__restrict__ dW)
+{
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = 2 * (blockIdx.x * 64 + (threadIdx.x & 63)) + ((y + colour) & 1);
+    if (x >= W || y >= H) return;
+    const int64_t j = (int64_t)y * W + x;
+    const float2 z = make_float2(0.f, 0.f);
+    const float wp = wt[j], wl = x > 0 ? wt[j - 1] : 0.f, wu = y > 0 ? wt[j - W] : 0.f;
+    const float2 dl = x > 0 ? dW[j - 1] : z, dr = x + 1 < W ? dW[j + 1] : z, du_ = y > 0 ? dW[j - W] : z, dd = y + 1 < H ? dW[j + W] : z;
+    const float4 s = S[j];
+    const float a12 = A12[j];
+    float2 d = dW[j];
+    const float sigmaU = wl * dl.x + wp * dr.x + wu * du_.x + wp * dd.x;
+    const float sigmaV = wl * dl.y + wp * dr.y + wu * du_.y + wp * dd.y;
+    d.x += omega * ((sigmaU + s.z - d.y * a12) / s.x - d.x);
+    d.y += omega * ((sigmaV + s.w - d.x * a12) / s.y - d.y);
+    dW[j] = d;
+}
+
+__global__ void __launch_bounds__(256)
+k_vr_finish(const float2 *__restrict__ Wf, const float2 *__restrict__ dW, int64_t n, float2 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 w = Wf[i], d = dW[i];
+    out[i] = make_float2(w.x + d.x, w.y + d.y);
+}
+
+extern "C" void tf_varref_default_params(tf_varref_params *p)
+{
+    p->fixed_point_iterations = 5; p->sor_iterations = 5;
+    p->alpha = 20.f; p->delta = 5.f; p->gamma = 10.f; p->omega = 1.6f;
+}
+
+extern "C" size_t tf_varref_workspace_bytes(int64_t H, int64_t W)
+{
+    if (H <= 0 || W <= 0) return 0;
+    const size_t n = (size_t)H * W;
+    // D1, D2, S (float4), A12, wt (float), W copy, dW (float2)
+    return 3 * tf_align_up(n * 16, 256) + 2 * tf_align_up(n * 4, 256) + 2 * tf_align_up(n * 8, 256) + 4096;
+}
+
+extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
+                         float *flow, void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(I0 && I1 && flow && ws, "tf_varref: null pointer");
+    TF_REQUIRE(H > 0 && W > 0 && H < 32768 && W < 32768, "tf_varref: bad shape");
+    tf_varref_params dp;
+    if (!params) { tf_varref_default_params(&dp); params = &dp; }
+    TF_REQUIRE(params->fixed_point_iterations >= 0 && params->sor_iterations >= 0, "tf_varref: bad iteration counts");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = H * W;
+    TfArena ar(ws, ws_bytes);
+    float4 *D1 = ar.take<float4>(n), *D2 = ar.take<float4>(n), *S = ar.take<float4>(n);
+    float *A12 = ar.take<float>(n), *wt = ar.take<float>(n);
+    float2 *Wf = ar.take<float2>(n), *dW = ar.take<float2>(n);
+    if (!ar.ok()) { tf_set_error("tf_varref: workspace too small"); return TF_ENOMEM; }
+    VrP P;
+    P.alpha2 = params->alpha / 4; P.delta2 = params->delta / 2; P.gamma2 = params->gamma / 2; P.omega = params->omega;
+    P.zeta2 = 0.1f * 0.1f; P.eps2 = 0.001f * 0.001f;
+    TF_CHECK_HIP(hipMemcpyAsync(Wf, flow, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    TF_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)n * 8, s));
+    const int iH = (int)H, iW = (int)W;
+    {
+        TfProfScope ps(TFK_VR_PREPARE, (1.0 + 1.0 + 8.0 + 32.0) * (double)n, s);
+        hipLaunchKernelGGL(k_vr_prepare, dim3((iW + VR_TW - 1) / VR_TW, (iH + VR_TH - 1) / VR_TH), dim3(256), 0, s,
+                           I0, I1, (const float2 *)Wf, iH, iW, D1, D2);
+    }
+    TF_CHECK_LAUNCH();
+    const dim3 g1((iW + 63) / 64, (iH + 3) / 4), g2(((iW + 1) / 2 + 63) / 64, (iH + 3) / 4);
+    for (int it = 0; it < params->fixed_point_iterations; it++) {
+        {
+            TfProfScope ps(TFK_VR_SYSTEM, (16.0 + 4.0 + 32.0 + 16.0 + 4.0 + 20.0) * (double)n, s);
+            hipLaunchKernelGGL(k_vr_weights, g1, dim3(256), 0, s, (const float2 *)Wf, (const float2 *)dW, iH, iW, P, wt);
+            hipLaunchKernelGGL(k_vr_system, g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, (const float2 *)Wf,
+                               (const float2 *)dW, (const float *)wt, iH, iW, P, S, A12);
+        }
+        TF_CHECK_LAUNCH();
+        {
+            TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + 8.0 + 8.0) * (double)n * params->sor_iterations, s);
+            for (int k = 0; k < params->sor_iterations; k++) {
+                hipLaunchKernelGGL(k_vr_sor, g2, dim3(256), 0, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW, 0, P.omega, dW);
+                hipLaunchKernelGGL(k_vr_sor, g2, dim3(256), 0, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW, 1, P.omega, dW);
+            }
+        }
+        TF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_vr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float2 *)Wf, (const float2 *)dW, n, (float2 *)flow);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}

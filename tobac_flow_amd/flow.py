@@ -5,9 +5,10 @@ Same public names, signatures, defaults and exceptions as the reference: `create
 diagnostics.  cv2's Farnebaeck / remap calls are replaced by the HIP library
 (include/tobac_flow_hip.h); numpy inputs give numpy outputs, torch GPU tensors stay on the device.
 
-Not built yet: cv2.VariationalRefinement (`vr_steps > 0`, flow.py:359,513-519).  A
-RuntimeWarning is raised and the refinement step is skipped.
+cv2.VariationalRefinement (`vr_steps > 0`, flow.py:359, 513-519) is tf_varref (csrc/varref.hip); like the reference,
+any vr_steps > 0 runs exactly ONE refinement per direction.
 """
+import ctypes
 import os
 import warnings
 from datetime import datetime
@@ -113,16 +114,73 @@ class Flow(AbstractFlow):
                                  absolute_overlap=absolute_overlap)
 
 
-class _VariationalRefinementStub:
-    """Placeholder for cv2.VariationalRefinement.create() (flow.py:359): not built yet."""
+class VariationalRefinement:
+    """Stand-in for the object cv2.VariationalRefinement.create() returns (reference: flow.py:359): `.calc(I0, I1,
+    flow)` refines a dense flow field by OpenCV's variational refinement (tf_varref, include/tobac_flow_hip.h; defaults
+    fixedPointIterations 5, sorIterations 5, alpha 20, delta 5, gamma 10, omega 1.6 -- the getters / setters OpenCV
+    exposes are plain attributes here).  Like OpenCV it updates `flow` in place and also returns it (numpy in -> the
+    numpy array is written back; device tensor in -> refined on the device)."""
 
-    def calc(self, prev, nxt, flow):
-        warnings.warn("VariationalRefinement has no HIP implementation yet: flow returned unrefined",
-                      RuntimeWarning)
+    def __init__(self):
+        p = _lib.VarRefParams()
+        _lib.lib().tf_varref_default_params(ctypes.byref(p))
+        self.fixedPointIterations, self.sorIterations = p.fixed_point_iterations, p.sor_iterations
+        self.alpha, self.delta, self.gamma, self.omega = p.alpha, p.delta, p.gamma, p.omega
+
+    @classmethod
+    def create(cls):
+        return cls()
+
+    def _params(self):
+        return _lib.VarRefParams(int(self.fixedPointIterations), int(self.sorIterations), float(self.alpha),
+                                 float(self.delta), float(self.gamma), float(self.omega))
+
+    def calc_dev(self, i0, i1, flow):
+        """uint8 device frames (H, W), float32 device flow (H, W, 2) refined in place (may be a view with contiguous
+        rows, e.g. one frame of a (T, H, W, 2) array)."""
+        L = _lib.lib()
+        H, W = i0.shape
+        assert flow.is_contiguous() and tuple(flow.shape) == (H, W, 2)
+        ws = _lib.workspace(L.tf_varref_workspace_bytes(H, W), "varref")
+        p = self._params()
+        _lib.check(L.tf_varref(_lib.ptr(i0), _lib.ptr(i1), H, W, ctypes.byref(p), _lib.ptr(flow), _lib.ptr(ws), ws.numel(),
+                               _lib.stream_ptr()), "tf_varref")
         return flow
 
+    def calc(self, I0, I1, flow):
+        t = _lib.torch()
+        i0, i1 = _lib.to_dev(I0), _lib.to_dev(I1)
+        if i0.dtype != t.uint8 or i1.dtype != t.uint8:
+            raise ValueError("VariationalRefinement input frames must be uint8")
+        if i0.dim() != 2 or i0.shape != i1.shape:
+            raise ValueError("I0 and I1 must be 2-D arrays of the same shape")
+        if tuple(flow.shape) != tuple(i0.shape) + (2,):
+            raise ValueError("flow must have shape I0.shape + (2,)")
+        if isinstance(flow, t.Tensor):
+            f = flow if (flow.is_cuda and flow.dtype == t.float32 and flow.is_contiguous()) else _lib.to_dev(flow, t.float32)
+            self.calc_dev(i0, i1, f)
+            if f is not flow:
+                flow.copy_(f)
+            return flow
+        f = self.calc_dev(i0, i1, _lib.to_dev(np.asarray(flow), t.float32).clone()).cpu().numpy()
+        if isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.flags.writeable:
+            flow[...] = f
+            return flow
+        return f
 
-vr_model = _VariationalRefinementStub()
+
+class _LazyVariationalRefinement:
+    """`vr_model` (flow.py:359) is created at import time in the reference; here the library is loaded on first use so
+    that importing the module does not need the built .so."""
+    _obj = None
+
+    def __getattr__(self, name):
+        if _LazyVariationalRefinement._obj is None:
+            _LazyVariationalRefinement._obj = VariationalRefinement()
+        return getattr(_LazyVariationalRefinement._obj, name)
+
+
+vr_model = _LazyVariationalRefinement()
 
 
 def _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_steps, interp_method, tag="farneback"):
@@ -131,9 +189,9 @@ def _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_steps, interp_me
     t = _lib.torch()
     interp = select_interp_mode(interp_method) if smoothing_steps > 0 else 1
     fwd, bwd = of_model.calc_pair_dev(prev8, next8, tag=tag)
-    if vr_steps > 0:
-        fwd = vr_model.calc(prev8, next8, fwd)
-        bwd = vr_model.calc(next8, prev8, bwd)
+    if vr_steps > 0:                             # flow.py:513-519: ONE refinement per direction whatever the value
+        fwd = vr_model.calc_dev(prev8, next8, fwd)
+        bwd = vr_model.calc_dev(next8, prev8, bwd)
     H, W = prev8.shape
     for _ in range(smoothing_steps):
         f2, b2 = t.empty_like(fwd), t.empty_like(bwd)
@@ -155,8 +213,6 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     # Frame pairs are independent units: they are processed in batches of TF_FLOW_BATCH pairs per set of
     # kernel launches (tf_farneback_batch), which keeps the coarse pyramid levels busy on all CUs.
     linear = norm_name == "linear" and not normalisation_kwargs
-    if vr_steps > 0:
-        vr_model.calc(None, None, None)        # warns once: VariationalRefinement is not built yet
     interp = select_interp_mode(interp_method) if smoothing_passes > 0 else 1
     chunk = max(1, int(os.environ.get("TF_FLOW_BATCH", "8")))
     for i0 in range(0, T - 1, chunk):
@@ -174,10 +230,18 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                 next8[b].copy_(_lib.to_dev(p8[1]))
         if smoothing_passes == 0:
             of_model.calc_batch_dev(prev8, next8, forward[i0:i0 + B], backward[i0 + 1:i0 + 1 + B])
+            if vr_steps > 0:                     # flow.py:513-519
+                for b in range(B):
+                    vr_model.calc_dev(prev8[b], next8[b], forward[i0 + b])
+                    vr_model.calc_dev(next8[b], prev8[b], backward[i0 + 1 + b])
         else:
             f = _lib.empty((B, H, W, 2), t.float32)
             bk = _lib.empty((B, H, W, 2), t.float32)
             of_model.calc_batch_dev(prev8, next8, f, bk)
+            if vr_steps > 0:                     # flow.py:513-519, before the smoothing (flow.py:521-525)
+                for b in range(B):
+                    vr_model.calc_dev(prev8[b], next8[b], f[b])
+                    vr_model.calc_dev(next8[b], prev8[b], bk[b])
             for b in range(B):
                 fi, bi = f[b], bk[b]
                 for k in range(smoothing_passes):

@@ -1,89 +1,93 @@
 """Flow-aware labelling (mirrors /root/reference/tobac_flow/label.py:84-321).
 
-What the reference does per label in a Python loop (a bincount / unique over the label's pixels in the
-two nearest-neighbour-warped label volumes, label.py:139-170 + utils/label_utils.py:352-376) is done
-once for the whole volume:
-  * the two label warps run on the GPU (Flow.convolve, int32 / nearest -> tf_convolve),
-  * the overlap counts of every (label, warped label) pair come from one sort/unique of packed keys,
-  * the grouping keeps the reference's semantics exactly: labels are visited in ascending order, each
-    unvisited label starts a group and absorbs, breadth first, every not-yet-visited label it overlaps
-    (the relation is DIRECTED -- the relative criterion uses min(size of the current label, size of
-    the other) but the count is taken over the current label's pixels -- so first come, first served).
+The whole of it runs behind two C-ABI entry points of the HIP library (include/tobac_flow_hip.h):
+tf_flow_label (label.py:84-175: per-step connected components, then the linking) and tf_flow_link_overlap
+(label.py:249-321).  What the reference does per label in a Python loop -- a bincount / unique over the label's
+pixels in the two nearest-neighbour-warped label volumes (label.py:139-170, utils/label_utils.py:352-376) -- is one
+run-length / sort / reduce-by-key pass over the volume on the GPU; the small label graph is then walked in the
+reference's own order inside the library (labels ascending, each unvisited label opens a group and absorbs, breadth
+first, every not-yet-visited label it overlaps, forward neighbours before backward ones; the relation is DIRECTED, so
+first come, first served).
 `subsegment_labels` (label.py:13-80, needs scikit-image) is outside the hot path: production passes
 subsegment_shrink=0.
 """
+import ctypes
 import warnings
 
 import numpy as np
 from scipy import ndimage as ndi
 
 from tobac_flow_amd import _lib
-from tobac_flow_amd.utils.label_utils import find_overlapping_labels, flat_label
+from tobac_flow_amd.utils.label_utils import find_overlapping_labels
 
 
-def _overlap_edges(flat, warped, sizes, overlap, absolute_overlap):
-    """Directed edges a -> b (b seen in `warped` under the pixels of a) that satisfy the reference's
-    criterion; returned as (a, b) arrays sorted by (a, b)."""
-    t = _lib.torch()
-    a = flat.reshape(-1).to(t.int64)
-    b = warped.reshape(-1).to(t.int64)
-    both = (a > 0) & (b != 0)
-    a, b = a[both], b[both]
-    neg = b < 0                      # np.bincount(np.maximum(hit, 0)): negative warped labels count as 0 and are dropped
-    a, b = a[~neg], b[~neg]
-    nlab = int(sizes.numel())
-    key, cnt = t.unique(a * nlab + b, return_counts=True)
-    ea, eb = key // nlab, key % nlab
-    ok = (cnt > absolute_overlap) & (cnt.to(t.float64) >= overlap * t.minimum(sizes[ea], sizes[eb]).to(t.float64))
-    return ea[ok].cpu().numpy(), eb[ok].cpu().numpy()
+def _structure_bytes(structure):
+    s = np.asarray(structure)
+    if s.shape != (3, 3, 3):
+        raise ValueError("structure must be a (3, 3, 3) array")
+    s = np.ascontiguousarray(s != 0, np.uint8)
+    if int(s[0].sum()) != 1 or int(s[2].sum()) != 1:
+        # label.py:129-131 unpacks Flow.convolve's stack into exactly two arrays
+        raise ValueError("structure must have exactly one element in each of its first and last planes "
+                         f"(got {int(s[0].sum())} and {int(s[2].sum())}): the reference unpacks two warped label stacks")
+    return s
 
 
-def _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, present_mask, on_device=False):
-    t = _lib.torch()
-    label_struct = structure * np.array([1, 0, 1])[:, np.newaxis, np.newaxis]
-    flat_dev = _lib.to_dev(flat_labels, t.int32)
-    back_labels, forward_labels = flow.convolve(flat_dev, method="nearest", dtype=dtype, structure=label_struct,
-                                                fill_value=0)
-    n = int(flat_dev.max().item()) + 1
-    sizes = t.bincount(flat_dev.reshape(-1).to(t.int64), minlength=n)
-    edges = [_overlap_edges(flat_dev, w, sizes, overlap, absolute_overlap) for w in (forward_labels, back_labels)]
-    # adjacency in the reference's visiting order: forward-warp neighbours (ascending), then backward-warp ones
-    order = []
-    for ea, eb in edges:
-        idx = np.searchsorted(ea, np.arange(n + 1))
-        order.append((idx, eb))
-    sizes_np = sizes.cpu().numpy()
-    processed = np.zeros(n, dtype=bool)
-    group_of = np.zeros(n, dtype=np.int64)
-    n_groups = 0
-    for label in range(1, n):
-        if processed[label]:
+def _call_with_run_retry(fn, size_fn, shape, tag):
+    """The library sizes its pair-count scratch for a number of label runs; on TF_ENOMEM it reports the number it
+    needs (in the object-count slot) and the call is repeated once with that."""
+    T, H, W = shape
+    n_obj = ctypes.c_int(0)
+    guess = max(T * H * W // 16, 65536)
+    for attempt in range(2):
+        ws = _lib.workspace(size_fn(T, H, W, guess), tag)
+        rc = fn(ws, n_obj)
+        if rc == -2 and attempt == 0 and n_obj.value > guess:
+            guess = int(n_obj.value) + 1024
             continue
-        n_groups += 1
-        stack = [label]
-        processed[label] = True
-        i = 0
-        while i < len(stack):
-            cur = stack[i]
-            if sizes_np[cur] > 0:
-                for idx, eb in order:
-                    for new in eb[idx[cur]:idx[cur + 1]]:
-                        if not processed[new]:
-                            processed[new] = True
-                            stack.append(new)
-            i += 1
-        group_of[stack] = n_groups
-    group_of[sizes_np == 0] = 0          # labels without pixels are never written (label.py:166-170)
-    lut = t.from_numpy(group_of.astype(np.int64)).to(flat_dev.device)
-    new_dev = lut[flat_dev.to(t.int64)]
-    if on_device:
-        if not bool(((new_dev != 0) == present_mask).all()):
-            warnings.warn("Not all regions present in labeled array", RuntimeWarning)
-        return new_dev.to(t.int32)
-    new_labels = new_dev.cpu().numpy().astype(dtype)
-    if not np.all((new_labels != 0) == present_mask):
-        warnings.warn("Not all regions present in labeled array", RuntimeWarning)
-    return new_labels
+        break
+    _lib.check(rc, tag)
+    return n_obj.value
+
+
+def link_overlap_dev(flow, flat_dev, structure, overlap, absolute_overlap):
+    """tf_flow_link_overlap on a device int32 tensor of per-step labels; returns the device int32 object labels."""
+    t = _lib.torch()
+    L = _lib.lib()
+    st = _structure_bytes(structure)
+    fw, bw = flow._dev_flows()
+    T, H, W = flat_dev.shape
+    out = _lib.empty((T, H, W), t.int32)
+    _call_with_run_retry(
+        lambda ws, n_obj: L.tf_flow_link_overlap(_lib.ptr(flat_dev), _lib.ptr(fw), _lib.ptr(bw), T, H, W,
+                                                 st.ctypes.data_as(_lib._P), float(overlap), int(absolute_overlap),
+                                                 _lib.ptr(out), ctypes.byref(n_obj), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream_ptr()),
+        L.tf_flow_link_workspace_bytes, (T, H, W), "tf_flow_link_overlap")
+    return out
+
+
+def flow_label_dev(flow, mask_dev, structure, overlap, absolute_overlap):
+    """tf_flow_label on a device uint8 mask; returns the device int32 object labels."""
+    t = _lib.torch()
+    L = _lib.lib()
+    st = _structure_bytes(structure)
+    fw, bw = flow._dev_flows()
+    T, H, W = mask_dev.shape
+    out = _lib.empty((T, H, W), t.int32)
+    _call_with_run_retry(
+        lambda ws, n_obj: L.tf_flow_label(_lib.ptr(mask_dev), _lib.ptr(fw), _lib.ptr(bw), T, H, W,
+                                          st.ctypes.data_as(_lib._P), float(overlap), int(absolute_overlap),
+                                          _lib.ptr(out), ctypes.byref(n_obj), _lib.ptr(ws), ws.numel(),
+                                          _lib.stream_ptr()),
+        L.tf_flow_label_workspace_bytes, (T, H, W), "tf_flow_label")
+    return out
+
+
+def _finish(new_dev, present_dev, dtype, on_device):
+    if not bool(((new_dev != 0) == present_dev).all()):
+        warnings.warn("Not all regions present in labeled array", RuntimeWarning)      # label.py:172-174
+    return new_dev if on_device else new_dev.cpu().numpy().astype(dtype)
 
 
 def flow_label(flow, mask, structure=ndi.generate_binary_structure(3, 1), dtype=np.int32, overlap: float = 0.0,
@@ -93,14 +97,12 @@ def flow_label(flow, mask, structure=ndi.generate_binary_structure(3, 1), dtype=
         raise NotImplementedError("subsegment_shrink != 0 (label.py:13-80, scikit-image watershed) is outside the "
                                   "MI355X hot path; production uses subsegment_shrink=0")
     t = _lib.torch()
-    from tobac_flow_amd import ndimage_dev as nd
     on_device = isinstance(mask, t.Tensor)
-    m = _lib.to_dev(mask) != 0
-    # per-frame connected components on the GPU (tf_label: SciPy's numbering, tests/test_gpu_detection.py)
-    flat_labels = nd.flat_label(m, structure)
-    if on_device:
-        return _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, m, on_device=True)
-    return _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, np.asarray(mask) != 0)
+    m = (_lib.to_dev(mask) != 0)
+    if tuple(m.shape) != tuple(flow.shape):
+        raise AssertionError("Data input must have the same shape as the Flow object")
+    new_dev = flow_label_dev(flow, m.to(t.uint8).contiguous(), structure, overlap, absolute_overlap)
+    return _finish(new_dev, m, dtype, on_device)
 
 
 def find_neighbour_labels(label, label_stack, bins, args, processed_labels, forward_labels, back_labels,
@@ -120,8 +122,13 @@ def find_neighbour_labels(label, label_stack, bins, args, processed_labels, forw
 def flow_link_overlap(flow, flat_labels, structure=ndi.generate_binary_structure(3, 1), dtype=np.int32,
                       overlap: float = 0.0, absolute_overlap: int = 0):
     """Link existing per-step labels into contiguous objects (reference: label.py:249-321)."""
-    flat_labels = np.asarray(flat_labels)
-    return _link(flow, flat_labels, structure, dtype, overlap, absolute_overlap, flat_labels.astype(bool))
+    t = _lib.torch()
+    on_device = isinstance(flat_labels, t.Tensor)
+    flat_dev = _lib.to_dev(flat_labels, t.int32)
+    if tuple(flat_dev.shape) != tuple(flow.shape):
+        raise AssertionError("Data input must have the same shape as the Flow object")
+    new_dev = link_overlap_dev(flow, flat_dev, structure, overlap, absolute_overlap)
+    return _finish(new_dev, flat_dev != 0, dtype, on_device)
 
 
-__all__ = ("flow_label", "find_neighbour_labels", "flow_link_overlap")
+__all__ = ("flow_label", "find_neighbour_labels", "flow_link_overlap", "flow_label_dev", "link_overlap_dev")
