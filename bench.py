@@ -8,7 +8,7 @@ marker-controlled watershed) on 5424 x 5424 GOES-16 full-disk-sized frames, one 
   fresh rank processes itself (one per GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line.
 
 A step is one pass of the hot path over one window of `--frames` synthetic frames resident in HBM:
-create_flow(Farneback, smoothing_passes=1, interp_method="cubic")  ->  Flow.sobel(uphill, cubic,
+create_flow(Farneback, vr_steps=1, smoothing_passes=1, interp_method="cubic")  ->  Flow.sobel(uphill, cubic,
 float64)  ->  combined edge field  ->  Flow.watershed(conn 1) with the detect_anvils marker recipe.
 Frame windows are independent units: every rank processes its own window of ONE synthetic sequence (weak scaling;
 consecutive windows share `--overlap` frames, bit for bit) and the label IDs are stitched at the end of each step by
@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=12, help="frames per window (per GPU, per step)")
+    ap.add_argument("--vr-steps", type=int, default=1,
+                    help="create_flow(vr_steps=...): 1 = the setting of the reference's drop-in scripts "
+                         "(scripts/dcc_detect_goes.py:164-166), 0 = no variational refinement")
     ap.add_argument("--overlap", type=int, default=4,
                     help="frames consecutive windows (ranks) share; the stitch compares all but the first and last of them")
     ap.add_argument("--height", type=int, default=5424)
@@ -211,7 +214,7 @@ def main():
     ws_stats = []                                            # tf_watershed stats of every step (warmup included)
 
     def step():
-        flow = tf.create_flow(bt, model="Farneback", smoothing_passes=1, interp_method="cubic")
+        flow = tf.create_flow(bt, model="Farneback", vr_steps=a.vr_steps, smoothing_passes=1, interp_method="cubic")
         # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
         e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
@@ -265,7 +268,7 @@ def main():
                                        "(BASELINE config F frame size; 144-frame stack = 12 such windows)"
                                        if (H, W) == (5424, 5424) else
                                        f"REDUCED rehearsal window (not the benchmark configuration): {T}x{H}x{W} float32 frames per GPU per step"),
-                          "stages": "create_flow(Farneback, vr_steps=0, smoothing_passes=1, cubic) + Flow.sobel(uphill, cubic, f64) "
+                          "stages": f"create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.sobel(uphill, cubic, f64) "
                                     "+ edge field + Flow.watershed(connectivity 1, detect_anvils markers)",
                           "sharding": f"one time window per GPU cut from one sequence, consecutive windows share {a.overlap} frames; "
                                       "label IDs stitched by the reference's overlap rule (>= 5 px and >= 0.5, linking.py:49-161) "

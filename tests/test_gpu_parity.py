@@ -549,7 +549,7 @@ def test_calculate_flow_2_pairs_two_stacks(tf):
     assert np.array_equal(fwd[T - 1], -bwd[T - 1]) and np.array_equal(bwd[0], -fwd[0])
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (7, 64), (65, 17), (96, 128), (333, 517)])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (7, 64), (65, 17), (96, 128), (129, 257), (333, 517)])
 def test_variational_refinement_bit_exact_vs_oracle(tf, shape):
     """tf_varref (cv2.VariationalRefinement, flow.py:359, 513-519) against the oracle's C restatement: every float
     expression is evaluated in the same order, so the refined flow is IDENTICAL -- tile seams, odd sizes and images
@@ -571,6 +571,12 @@ def test_variational_refinement_bit_exact_vs_oracle(tf, shape):
     vr.fixedPointIterations, vr.sorIterations, vr.alpha, vr.omega = 2, 3, 5.0, 1.2
     assert np.array_equal(vr.calc(i0, i1, flow.copy()),
                           np_ops.variational_refinement(i0, i1, flow, 2, 3, alpha=5.0, omega=1.2))
+    # more sweeps than the fused SOR kernel's halo covers: one launch per half sweep, same arithmetic
+    vr.fixedPointIterations, vr.sorIterations = 2, 7
+    assert np.array_equal(vr.calc(i0, i1, flow.copy()),
+                          np_ops.variational_refinement(i0, i1, flow, 2, 7, alpha=5.0, omega=1.2))
+    vr.sorIterations = 0
+    assert np.array_equal(vr.calc(i0, i1, flow.copy()), flow + np.float32(0))
 
 
 def test_vr_steps_refine_once_per_direction_like_the_reference(tf):

@@ -100,6 +100,9 @@ def lib():
             raise ImportError(
                 f"{_SO} not found: build it with `make -C tobac_flow_amd/csrc` (or __graft_entry__.build()). "
                 "tobac_flow_amd has no CPU fallback.")
+        # torch first: it brings its own HIP runtime (libamdhip64), and the library must bind to THAT instance -- loaded the
+        # other way round the process ends up with two runtimes and the library's sees no device (hipErrorNoDevice)
+        torch()
         L = ctypes.CDLL(_SO)
         for name, (res, args) in _PROTOS.items():
             f = getattr(L, name)

@@ -21,6 +21,7 @@
 // HBM layout (planar, per flow direction): D1 = float4 {Ix, Iy, Ixz, Iyz}, D2 = float4 {Ixx, Ixy, Iyy, Iz},
 // S = float4 {A11, A22, b1, b2}, A12 float, wt float, W float2 (the input flow), dW float2.
 #include "tf_common.h"
+#include <stdlib.h>
 
 struct VrP { float alpha2, delta2, gamma2, omega, zeta2, eps2; };
 
@@ -180,6 +181,102 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
     dW[j] = d;
 }
 
+// ---- all sorIterations red-black sweeps of one fixed-point iteration in ONE pass over HBM -------------------------
+// A half sweep only reads the four neighbours of the other colour, so 2 * sorIterations half sweeps of a tile need a
+// halo of 2 * sorIterations pixels and nothing else.  One 512-thread workgroup owns a 128 x 64 tile + VRT_HALO: every
+// thread keeps the system (A11, A22, b1, b2, A12) and the weight of ITS pixel pairs in registers for the whole kernel;
+// only dW and the weights of the left / upper neighbours live in LDS (12 B / px, 149 KB), in OpenCV's own red-black
+// split: the pixels of one colour of a row are contiguous, so a wave's neighbour reads are unit-stride.  The outermost
+// ring is never updated and invalid values creep inwards one pixel per half sweep -- they stop short of the tile.
+// Same expressions in the same order as k_vr_sor: bit-identical results (tests compare the two paths).
+#define VRT_W 128
+#define VRT_H 64
+#define VRT_HALO 10
+#define VRT_RW (VRT_W + 2 * VRT_HALO)
+#define VRT_RH (VRT_H + 2 * VRT_HALO)
+#define VRT_PW (VRT_RW / 2)
+#define VRT_NPAIR (VRT_PW * VRT_RH)
+#define VRT_THREADS 512
+#define VRT_K ((VRT_NPAIR + VRT_THREADS - 1) / VRT_THREADS)
+#define VRT_LDS_BYTES (2 * VRT_RH * VRT_PW * 12)
+
+__global__ void __launch_bounds__(VRT_THREADS, 2)
+k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
+              int n_half, float omega, const float2 *__restrict__ dW_in, float2 *__restrict__ dW_out)
+{
+    extern __shared__ __align__(16) unsigned char vr_lds[];
+    float2 *l_dw = (float2 *)vr_lds;                                   // [2][VRT_RH][VRT_PW]
+    float *l_wt = (float *)(vr_lds + 2 * VRT_RH * VRT_PW * 8);         // [2][VRT_RH][VRT_PW]
+    const int x0 = blockIdx.x * VRT_W - VRT_HALO, y0 = blockIdx.y * VRT_H - VRT_HALO;
+    const int par0 = (x0 + y0) & 1;                                    // image colour of local (0, 0)
+    float a11[VRT_K][2], a22[VRT_K][2], b1[VRT_K][2], b2[VRT_K][2], a12[VRT_K][2], wp[VRT_K][2];
+#pragma unroll
+    for (int k = 0; k < VRT_K; k++) {
+        const int q = threadIdx.x + k * VRT_THREADS;
+        const int r = q / VRT_PW, cp = q - r * VRT_PW;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = 2 * cp + e, x = x0 + c, y = y0 + r;
+            const bool in = q < VRT_NPAIR && x >= 0 && y >= 0 && x < W && y < H;
+            const int64_t p = in ? (int64_t)y * W + x : 0;
+            const float4 sv = in ? S[p] : make_float4(1.f, 1.f, 0.f, 0.f);
+            a11[k][e] = sv.x; a22[k][e] = sv.y; b1[k][e] = sv.z; b2[k][e] = sv.w;
+            a12[k][e] = in ? A12[p] : 0.f;
+            wp[k][e] = in ? wt[p] : 0.f;
+            const float2 d = in ? dW_in[p] : make_float2(0.f, 0.f);
+            if (q < VRT_NPAIR) {
+                const int lp = (r + c) & 1;
+                l_dw[(lp * VRT_RH + r) * VRT_PW + cp] = d;
+                l_wt[(lp * VRT_RH + r) * VRT_PW + cp] = wp[k][e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int s = 0; s < n_half; s++) {
+        const int colour = s & 1;
+#pragma unroll
+        for (int k = 0; k < VRT_K; k++) {
+            const int q = threadIdx.x + k * VRT_THREADS;
+            const int r = q / VRT_PW, cp = q - r * VRT_PW;
+            const int e = (par0 + r + colour) & 1;                     // which pixel of the pair has this colour
+            const int c = 2 * cp + e, x = x0 + c, y = y0 + r;
+            const bool act = q < VRT_NPAIR && r > 0 && r < VRT_RH - 1 && c > 0 && c < VRT_RW - 1 && x >= 0 && y >= 0 && x < W && y < H;
+            if (act) {
+                const int lp = (r + c) & 1, op = lp ^ 1;
+                const int row = (op * VRT_RH + r) * VRT_PW;
+                const float2 dl = l_dw[row + cp - (1 - e)], dr = l_dw[row + cp + e];
+                const float2 du_ = l_dw[row - VRT_PW + cp], dd = l_dw[row + VRT_PW + cp];
+                const float wl = l_wt[row + cp - (1 - e)], wu = l_wt[row - VRT_PW + cp];
+                // value selects (a select between two array ELEMENTS would be a select of addresses and push the
+                // arrays into scratch)
+                const float w0 = wp[k][0], w1 = wp[k][1], p0 = a11[k][0], p1 = a11[k][1], q0 = a22[k][0], q1 = a22[k][1];
+                const float r0 = b1[k][0], r1 = b1[k][1], t0 = b2[k][0], t1 = b2[k][1], c0 = a12[k][0], c1 = a12[k][1];
+                const float w = e ? w1 : w0, a = e ? c1 : c0;
+                const float4 sv = make_float4(e ? p1 : p0, e ? q1 : q0, e ? r1 : r0, e ? t1 : t0);
+                float2 d = l_dw[(lp * VRT_RH + r) * VRT_PW + cp];
+                const float sigmaU = wl * dl.x + w * dr.x + wu * du_.x + w * dd.x;
+                const float sigmaV = wl * dl.y + w * dr.y + wu * du_.y + w * dd.y;
+                d.x += omega * ((sigmaU + sv.z - d.y * a) / sv.x - d.x);
+                d.y += omega * ((sigmaV + sv.w - d.x * a) / sv.y - d.y);
+                l_dw[(lp * VRT_RH + r) * VRT_PW + cp] = d;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < VRT_K; k++) {
+        const int q = threadIdx.x + k * VRT_THREADS;
+        const int r = q / VRT_PW, cp = q - r * VRT_PW;
+        if (q >= VRT_NPAIR || r < VRT_HALO || r >= VRT_HALO + VRT_H) continue;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int c = 2 * cp + e, x = x0 + c, y = y0 + r;
+            if (c < VRT_HALO || c >= VRT_HALO + VRT_W || x >= W || y >= H) continue;
+            dW_out[(int64_t)y * W + x] = l_dw[(((r + c) & 1) * VRT_RH + r) * VRT_PW + cp];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_vr_finish(const float2 *__restrict__ Wf, const float2 *__restrict__ dW, int64_t n, float2 *__restrict__ out)
 {
@@ -199,8 +296,8 @@ extern "C" size_t tf_varref_workspace_bytes(int64_t H, int64_t W)
 {
     if (H <= 0 || W <= 0) return 0;
     const size_t n = (size_t)H * W;
-    // D1, D2, S (float4), A12, wt (float), W copy, dW (float2)
-    return 3 * tf_align_up(n * 16, 256) + 2 * tf_align_up(n * 4, 256) + 2 * tf_align_up(n * 8, 256) + 4096;
+    // D1, D2, S (float4), A12, wt (float), W copy, dW and its ping-pong partner (float2)
+    return 3 * tf_align_up(n * 16, 256) + 2 * tf_align_up(n * 4, 256) + 3 * tf_align_up(n * 8, 256) + 4096;
 }
 
 extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
@@ -216,7 +313,7 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
     TfArena ar(ws, ws_bytes);
     float4 *D1 = ar.take<float4>(n), *D2 = ar.take<float4>(n), *S = ar.take<float4>(n);
     float *A12 = ar.take<float>(n), *wt = ar.take<float>(n);
-    float2 *Wf = ar.take<float2>(n), *dW = ar.take<float2>(n);
+    float2 *Wf = ar.take<float2>(n), *dW = ar.take<float2>(n), *dW2 = ar.take<float2>(n);
     if (!ar.ok()) { tf_set_error("tf_varref: workspace too small"); return TF_ENOMEM; }
     VrP P;
     P.alpha2 = params->alpha / 4; P.delta2 = params->delta / 2; P.gamma2 = params->gamma / 2; P.omega = params->omega;
@@ -231,6 +328,17 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
     }
     TF_CHECK_LAUNCH();
     const dim3 g1((iW + 63) / 64, (iH + 3) / 4), g2(((iW + 1) / 2 + 63) / 64, (iH + 3) / 4);
+    // the fused SOR kernel covers up to VRT_HALO half sweeps; TF_VR_SOR_SWEEPS=1 selects the one-launch-per-half-sweep
+    // form (same results, kept as the reference for the fused one and for larger sorIterations)
+    static const bool force_sweeps = getenv("TF_VR_SOR_SWEEPS") != nullptr;
+    const bool tiled = !force_sweeps && 2 * params->sor_iterations <= VRT_HALO;
+    if (tiled) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile, hipFuncAttributeMaxDynamicSharedMemorySize, VRT_LDS_BYTES));
+            attr_set = true;
+        }
+    }
     for (int it = 0; it < params->fixed_point_iterations; it++) {
         {
             TfProfScope ps(TFK_VR_SYSTEM, (16.0 + 4.0 + 32.0 + 16.0 + 4.0 + 20.0) * (double)n, s);
@@ -239,7 +347,14 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
                                (const float2 *)dW, (const float *)wt, iH, iW, P, S, A12);
         }
         TF_CHECK_LAUNCH();
-        {
+        if (tiled && params->sor_iterations > 0) {
+            // algorithmic bytes: system 20 + weight 4 + dW 8 read, dW 8 written, once per fixed-point iteration
+            TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + 8.0 + 8.0) * (double)n, s);
+            hipLaunchKernelGGL(k_vr_sor_tile, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
+                               VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
+                               2 * params->sor_iterations, P.omega, (const float2 *)dW, dW2);
+            float2 *t = dW; dW = dW2; dW2 = t;
+        } else {
             TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + 8.0 + 8.0) * (double)n * params->sor_iterations, s);
             for (int k = 0; k < params->sor_iterations; k++) {
                 hipLaunchKernelGGL(k_vr_sor, g2, dim3(256), 0, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW, 0, P.omega, dW);
