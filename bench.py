@@ -27,20 +27,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def _fullres_traffic():
-    """HBM bytes of the dominant kernel's full-resolution launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes (profiles/round1_pmc_traffic_fullres_pair_v10.json).  `traffic` itself stays null: the counter passes crash
-    on the whole benchmark on this stack, and a per-launch figure for its mix of pyramid levels cannot be measured."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic_fullres_pair_v10.json")
+# library profile name -> kernel symbol prefix in the rocprofv3 counter files
+_KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<4, 0>", "vr_sor": "k_vr_sor_tile", "vr_system": "k_vr_system",
+                  "sobel": "void k_sobel27<2, double, 2, true>", "fb_polyexp": "k_fb_polyexp"}
+_TRAFFIC_FILE = "profiles/round2_pmc_traffic_bench.json"
+
+
+def _traffic(profile_name):
+    """HBM bytes per launch of one kernel from the committed rocprofv3 counter passes over THIS benchmark
+    (`rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline` and the same with
+    WRITE_SIZE: separate passes, FETCH_SIZE doubled for wide reads as MI355X_MICROARCH.md prescribes; summarised by
+    tools/pmc_traffic_json.py).  The benchmark cannot run the profiler on itself, so the figure belongs to the build
+    the file was recorded with; None if the file or the kernel is missing."""
     try:
-        with open(path) as fh:
-            t = json.load(fh)
-    except (OSError, ValueError):
+        with open(os.path.join(ROOT, _TRAFFIC_FILE)) as fh:
+            k = json.load(fh)["kernels"][_KERNEL_SYMBOL[profile_name]]
+        return {"bytes_per_launch": k["fetch_bytes_corrected_per_launch"] + k["write_bytes_per_launch"],
+                "fetch_bytes_raw": k["fetch_bytes_raw_per_launch"], "fetch_bytes_corrected": k["fetch_bytes_corrected_per_launch"],
+                "write_bytes": k["write_bytes_per_launch"], "launches_profiled": k["launches"], "source": _TRAFFIC_FILE}
+    except (OSError, ValueError, KeyError, TypeError):
         return None
-    return {"launch": t["launch"], "fetch_bytes_raw": t["fetch_bytes_raw"],
-            "fetch_bytes_corrected": t["fetch_bytes_wide_read_corrected"], "write_bytes": t["write_bytes"],
-            "algorithmic_bytes": t["algorithmic_bytes"], "launch_us": t["launch_us_same_box"],
-            "source": "profiles/round1_pmc_traffic_fullres_pair_v10.json"}
 
 
 def cpu_baseline(seed):
@@ -250,14 +256,25 @@ def main():
         if dom:
             name, (calls, ms, by) = dom
             achieved = by / (ms * 1e-3) / 1e9
+            tr = _traffic(name)
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": calls,
-                    "avg_launch_us": round(ms * 1e3 / calls, 2),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr["bytes_per_launch"] if tr else None,
+                    "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2),
+                    "algorithmic_bytes_per_launch": round(by / calls, 1),
                     "share_of_step": round(ms / (dt * 1e3), 4),
-                    "traffic_fullres_pair": _fullres_traffic(),
+                    "traffic_detail": tr,
                     "all_kernels": {k: {"ms_per_step": round(v[1] / a.steps, 3),
                                         "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[2] > 0 else None}
                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+            if tr:                                       # what the kernel really moves, at the measured launch time
+                roof["traffic_GBps"] = round(tr["bytes_per_launch"] / (ms * 1e-3 / calls) / 1e9, 1)
+                roof["traffic_frac_of_peak"] = round(roof["traffic_GBps"] / HBM_PEAK_GBS, 4)
+            if name == "fb_iteration_fused":
+                # SURVEY.md 8(d) prices an iteration at 56 B per level pixel per DIRECTION; the fused launch serves both
+                # directions of a pair and reads the two expansions R0, R1 once: 40 + 2 x 16 = 72 B per level pixel per
+                # PAIR is what it must move at least.  Both fractions are reported.
+                roof["achieved_compulsory"] = round(achieved * 72.0 / 112.0, 1)
+                roof["frac_compulsory"] = round(achieved * 72.0 / 112.0 / HBM_PEAK_GBS, 4)
         out = {"metric": "Mpix/s end-to-end flow+sobel+watershed, 5424^2 frames" if (H, W) == (5424, 5424)
                else f"Mpix/s end-to-end flow+sobel+watershed, {H}x{W} frames (rehearsal size)", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
                "unit": "Mpix/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist is not None else 1,

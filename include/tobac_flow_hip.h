@@ -171,7 +171,8 @@ int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int64_t W, con
 /* ---- a14/a15: semi-Lagrangian marker-controlled watershed -------------------------------------
  * replaces tobac_flow/watershed.py:17-168 (wrapper) and tobac_flow/_watershed.pyx:222-344
  * (watershed_raveled, the reference's only native kernel; compactness = 0, wsl = False).
- *   field    (T, H, W) float32            image values (watershed.py:64-65 coercion is the caller's)
+ *   field    (T, H, W) float32            image values (watershed.py:64-65 coercion is the caller's); a NaN at a
+ *            floodable pixel (or at a seed next to one) is TF_EINVAL: the reference's heap order is undefined for NaN
  *   markers  (T, H, W) int32, non-zero = seed (negative allowed)
  *   mask     (T, H, W) int8 or NULL (= all ones)
  *   fwd, bwd (T, H, W, 2) float; rounded half-to-even to integer pixel offsets (watershed.py:121-141)

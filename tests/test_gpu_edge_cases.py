@@ -288,3 +288,25 @@ def test_stitch_window_list_on_gpu_equals_host_result():
     dev = [x.cpu().numpy() for x in stitch_window_list([torch.from_numpy(w).cuda() for w in wins], overlap=4)]
     for h, d in zip(host, dev):
         assert np.array_equal(h, d)
+
+
+def test_watershed_refuses_a_nan_field_where_it_matters(tf):
+    """`smaller()` of the reference heap (_watershed.pyx:161-164) is not an order on NaN: with NaN keys its pop order
+    depends on the heap's array state and has no closed form -- the library refuses (ValueError) instead of returning
+    labels that look plausible.  A NaN strictly inside a seed region (never compared) is harmless."""
+    rng = np.random.default_rng(3)
+    shape = (2, 20, 24)
+    field = rand_field(rng, shape)
+    markers = np.zeros(shape, np.int32)
+    markers[:, 2:8, 2:8] = 1
+    markers[:, 14:18, 15:20] = 2
+    z = np.zeros(shape + (2,), np.float32)
+    ok = tf.watershed(z, z, field, markers)
+    inside = field.copy()
+    inside[0, 4, 4] = np.nan                                   # interior of seed 1: all neighbours are seeds
+    assert np.array_equal(tf.watershed(z, z, inside, markers), ok)
+    for where in ((1, 10, 12), (0, 2, 2)):                     # a floodable pixel; a seed pixel that touches floodable ones
+        bad = field.copy()
+        bad[where] = np.nan
+        with pytest.raises(ValueError, match="NaN"):
+            tf.watershed(z, z, bad, markers)

@@ -139,7 +139,7 @@ k_ws_cid(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, cons
 __global__ void __launch_bounds__(256)
 k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, const float *__restrict__ bwd,
              const int *__restrict__ cid, WsGeom g, u64 *__restrict__ pix, unsigned *__restrict__ val,
-             int *__restrict__ nbr, u64 *__restrict__ K2, u64 *__restrict__ M1)
+             int *__restrict__ nbr, u64 *__restrict__ K2, u64 *__restrict__ M1, int *__restrict__ nan_flag)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     const int64_t t = blockIdx.z;
@@ -151,7 +151,9 @@ k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, con
     const int64_t id = marker ? -2 - c : c;
     const float2 fw = ((const float2 *)fwd)[p], bw = ((const float2 *)bwd)[p];
     const int fx = ws_round_flow(fw.x), fy = ws_round_flow(fw.y), bx = ws_round_flow(bw.x), by = ws_round_flow(bw.y);
-    const unsigned v = ws_ordkey(field[p]);
+    const float fv = field[p];
+    if (fv != fv) *nan_flag = 1;                 // (every writer stores the same value)
+    const unsigned v = ws_ordkey(fv);
     pix[id] = (u64)p | (marker ? WS_MARKER_BIT : 0ull);
     val[id] = v;
     for (int i = 0; i < g.n_nbr; i++) {
@@ -638,11 +640,24 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         Q.q[0] = ar.take<int>(2 * R + 64); Q.q[1] = ar.take<int>(2 * R + 64); Q.inq = ar.take<int>(R);
         Q.cnt = d_flags; Q.h_cnt = h_cnt; Q.processed = &st[7];
         if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
+        int *d_nan = d_flags + WS_BATCH + 4;
+        TF_CHECK_HIP(hipMemsetAsync(d_nan, 0, sizeof(int), s));
         {
             TfProfScope ps(TFK_WS_SETUP, 0.0, s);
-            hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1);
+            hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1, d_nan);
         }
         TF_CHECK_LAUNCH();
+        {   // the reference's `smaller()` (_watershed.pyx:161-164) is not an order on NaN: its heap then pops in an order
+            // that depends on the array state, and no closed form exists.  Refuse instead of returning something else.
+            int h_nan = 0;
+            TF_CHECK_HIP(hipMemcpyAsync(&h_nan, d_nan, sizeof(int), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            if (h_nan) {
+                tf_set_error("tf_watershed: the field is NaN at a floodable pixel or at a seed next to one; the pop order of the "
+                             "reference's heap is undefined for NaN keys (detection.get_combined_edge_field maps NaN to +inf)");
+                return TF_EINVAL;
+            }
+        }
         const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
         const int64_t max_sweeps = 4096 + 512 * (T + H + W);
         int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0]);
