@@ -2,8 +2,8 @@
 
 The only first-party native component of the reference is
 /root/reference/tobac_flow/_watershed.pyx.  This recipe compiles it
-*from where it lies* -- nothing from the reference is copied into the repository; the
-generated C file and the extension module land in oracle/_ref/, which is git-ignored.
+*from where it lies* -- nothing from the reference is copied into the repository; only the
+compiled extension module stays in oracle/_ref/ (git-ignored); the generated C file is deleted.
 
 Usage:  python oracle/build_ref.py [python-executable]
         (default interpreter: the one running this script)
@@ -45,6 +45,9 @@ def build(python=sys.executable, quiet=True):
     cmd = ["gcc", "-O2", "-fPIC", "-shared", "-w", "-I" + inc[0], "-I" + inc[1],
            "-DNPY_NO_DEPRECATED_API=0", cfile, "-o", so]
     subprocess.check_call(cmd)
+    # the generated C file quotes the .pyx line by line in its comments: it is an intermediate, not a deliverable, and
+    # must not travel with the tree (the compiled module is all the checker needs)
+    os.remove(cfile)
     return so
 
 

@@ -1,4 +1,5 @@
 """Edge cases through the C ABI: degenerate shapes, empty / saturated inputs, extreme flows, NaN / inf."""
+import os
 import warnings
 
 import numpy as np
@@ -310,3 +311,25 @@ def test_watershed_refuses_a_nan_field_where_it_matters(tf):
         bad[where] = np.nan
         with pytest.raises(ValueError, match="NaN"):
             tf.watershed(z, z, bad, markers)
+
+
+def test_development_switches_do_not_change_results(tf, tmp_path):
+    """Library switches that select an alternative kernel for the same arithmetic (development switches) must
+    give bit-identical flows: the generic polynomial-expansion kernel instead of the register-blocked polyN = 5 one, the
+    one-launch-per-half-sweep SOR instead of the fused tile kernel, the two-pass blur instead of the fused 3 x 3 one.
+    The switches are read once per process, so the alternative runs in a child process."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(21)
+    a = ndi.gaussian_filter(rng.normal(size=(3, 150, 210)), (0, 2.5, 2.5)).astype(np.float32) * 30 + 250
+    np.save(tmp_path / "in.npy", a)
+    fw, bw = tf.calculate_flow(a, "Farneback", vr_steps=1)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import tobac_flow_amd.flow as tf; "
+            "a = np.load(%r); f, b = tf.calculate_flow(a, 'Farneback', vr_steps=1); np.save(%r, np.stack([f, b]))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for var in ("TF_FB_POLYEXP_GENERIC", "TF_VR_SOR_SWEEPS", "TF_FB_BLUR_TWOPASS"):
+        out = tmp_path / f"{var}.npy"
+        env = dict(os.environ, **{var: "1"})
+        subprocess.check_call([sys.executable, "-c", code % (root, str(tmp_path / "in.npy"), str(out))], env=env)
+        alt = np.load(out)
+        assert np.array_equal(alt[0], fw, equal_nan=True) and np.array_equal(alt[1], bw, equal_nan=True), var

@@ -702,3 +702,29 @@ def test_farneback_and_remap_against_opencv_when_it_is_installed(tf):
     for name in ("nearest", "linear", "cubic"):
         assert res[f"remap_{name}_nan_mask_equal"]
         assert res[f"remap_{name}_max_abs_diff"] <= (0 if name == "nearest" else 1e-3)
+
+
+@pytest.mark.parametrize("kw", [dict(win_size=9), dict(win_size=15, num_iters=3), dict(poly_n=7, poly_sigma=1.5),
+                                dict(num_levels=2, pyr_scale=0.6, win_size=13)])
+def test_farneback_non_default_parameters_match_oracle(tf, kw):
+    """Parameters other than OpenCV's defaults take other kernels: window sizes != 13 the unfused pair
+    k_fb_update_matrices + k_fb_blur_solve, polyN != 5 the generic expansion kernel, other pyramid scales the generic
+    resize -- each against the oracle's restatement with the same parameters."""
+    import ctypes
+    from oracle import _lib as ol
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow
+    rng = np.random.default_rng(17)
+    a = ndi.gaussian_filter(rng.normal(size=(141, 203)), 2.5)
+    a = ((a - a.min()) / np.ptp(a) * 255).astype(np.uint8)
+    b = np.roll(a, (1, -2), (0, 1))
+    p = dict(num_levels=5, pyr_scale=0.5, win_size=13, num_iters=10, poly_n=5, poly_sigma=1.1)
+    p.update(kw)
+    got = FarnebackFlow(**p).calc(a, b, None)
+    L = ol.lib()
+    L.oracle_farneback.restype = ctypes.c_int
+    want = np.zeros(a.shape + (2,), np.float32)
+    L.oracle_farneback(ol.ptr(a, ctypes.c_uint8), ol.ptr(b, ctypes.c_uint8), a.shape[0], a.shape[1], ol.ptr(want, ctypes.c_float),
+                       p["num_levels"], ctypes.c_double(p["pyr_scale"]), p["win_size"], p["num_iters"], p["poly_n"],
+                       ctypes.c_double(p["poly_sigma"]))
+    assert np.abs(got - want).max() <= 1e-4, np.abs(got - want).max()
+    assert np.abs(np.median(got[20:-20, 20:-20].reshape(-1, 2), 0) - np.array([-2, 1])).max() < 0.2

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "csrc", "libtobac_flow_hip.so")
+# TF_LIB_PATH: development switch (A/B runs of two builds of the library)
+_SO = os.environ.get("TF_LIB_PATH") or os.path.join(_HERE, "csrc", "libtobac_flow_hip.so")
 
 INTERP = {"nearest": 0, "linear": 1, "cubic": 2}
 TF_F32, TF_F64, TF_I32 = 0, 1, 2

@@ -171,6 +171,11 @@ k_convolve(const typename StackTraits<TS>::In *__restrict__ data, const float *_
 //    border take the generic per-tap path;
 //  * Sobel weights are compile-time constants: zero-weight products are skipped (adding 0 is exact),
 //    unit weights need no multiply.
+// Measured and NOT adopted (round 2, 12 x 5424^2, fused edge-field variant, 9.9 ms as it stands): staging the two
+// warped-frame regions and the same-step tile of a workgroup in LDS (64 x 4 pixels per workgroup: 18.3 ms; 64 x 16:
+// 12.3 ms; the same structure with the LDS path switched off: 10.7 ms).  The patch loads hit L1 / L2 and are not what
+// bounds the kernel: per pixel it issues ~560 unfused FP32 operations for the two bicubic planes (the reference's
+// 16-term row-major sums admit no sharing between taps) plus ~190 FP64 ones at half rate, a VALU floor of ~5 ms.
 template <int METHOD>
 __device__ __forceinline__ void sobel_plane_taps(const float *__restrict__ img, int H, int W, int x, int y,
                                                  float flx, float fly, float cval, float (&tap)[9])
@@ -234,9 +239,11 @@ __device__ __forceinline__ void sobel_accumulate(TS v, TS c, int wx, int wy, int
     const double dd = (double)d;
     if (DIR == TF_FUNC_SOBEL && dd != dd) return;            // nansum skips NaN products
     // (inf * 0 is NaN in the reference and is skipped there too; inf * w stays in the sum)
-    if (wx) gx += dd * (double)wx;
-    if (wy) gy += dd * (double)wy;
-    if (wt) gt += dd * (double)wt;
+    // The Sobel weights are +-1, +-2, +-4: dd * w is exact in double, so one fused multiply-add returns exactly the
+    // value of the reference's multiply followed by its add (a product that carries no rounding cannot be "contracted")
+    if (wx) gx = (wx == 1 || wx == -1) ? gx + (wx > 0 ? dd : -dd) : __fma_rn(dd, (double)wx, gx);
+    if (wy) gy = (wy == 1 || wy == -1) ? gy + (wy > 0 ? dd : -dd) : __fma_rn(dd, (double)wy, gy);
+    if (wt) gt = (wt == 1 || wt == -1) ? gt + (wt > 0 ? dd : -dd) : __fma_rn(dd, (double)wt, gt);
 }
 
 // EDGE: the tail of detection.py:638-642 (get_combined_edge_field) is applied to the float64 magnitude before it is

@@ -9,13 +9,18 @@
 //   flow init (zeros | upsampled previous level * 2), UpdateMatrices, then numIters x
 //   [13x13 box filter of M in double -> per-pixel 2x2 solve -> flow ; UpdateMatrices].
 //
-// MI355X design notes
-//   * both directions share the Gaussian pyramid and the polynomial expansion of the two images;
-//   * R and M are PLANAR (5 planes) so that every stencil/gather load is lane-contiguous;
-//   * the box filter + solve runs on LDS tiles (64 x 16 outputs, 6-pixel halo), one channel at
-//     a time, column sums then row sums in double -- the clamped-window form of OpenCV's
-//     replicate-border running sums; nothing wider than the 5 float planes of M touches HBM;
-//   * all of these are HBM/L2-bound stencils: no MFMA.
+// MI355X design notes (what the file does today; history and measurements: DESIGN.md section 4)
+//   * both directions of a pair share the Gaussian pyramid and the polynomial expansion of the two images, and a
+//     BATCH of pairs goes through every launch (blockIdx.z) so that the coarse levels fill the chip;
+//   * the blur is evaluated only at the pixels the resize samples (k_fb_blur_rows_sampled / _cols_resize; fused 3 x 3
+//     forms for the two finest levels);
+//   * the polynomial expansion R is stored as float4 {y, x, yy, xx} + a float plane {xy}: a bilinear gather is five wide
+//     loads per corner pair instead of twenty scalar ones (k_fb_polyexp / k_fb_polyexp5, LDS tiles);
+//   * ONE kernel per iteration (k_fb_iter): UpdateMatrices -> 13 x 13 box sums in double -> 2 x 2 solve; each thread walks
+//     down a column with the last 13 rows of M in a register ring, column sums parked in a padded LDS row, four window
+//     sums per thread in the horizontal phase.  The 5-channel M of OpenCV never exists in HBM.  The unfused pair
+//     k_fb_update_matrices + k_fb_blur_solve (LDS tiles, one channel at a time) serves window sizes other than 13;
+//   * all of these are HBM / L2- or latency-bound stencils: no MFMA.
 #include "tf_common.h"
 #include <math.h>
 #include <float.h>
@@ -289,6 +294,8 @@ struct FbPoly { int n; float g[FB_MAX_POLY_N + 1], xg[FB_MAX_POLY_N + 1], xxg[FB
 // (float4 {y, x, yy, xx} + float {xy}).  HBM traffic = 4 B read + 20 B written per level pixel.
 #define FBP_W 64
 #define FBP_H 16
+// development switch: TF_FB_POLYEXP_GENERIC=1 routes polyN = 5 through the generic kernel too (same results)
+static bool fb_polyexp_generic() { static const bool v = getenv("TF_FB_POLYEXP_GENERIC") != nullptr; return v; }
 #define FBP_MAXN FB_MAX_POLY_N
 __global__ void __launch_bounds__(256)
 k_fb_polyexp(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restrict__ R, int64_t plane,
@@ -339,6 +346,90 @@ k_fb_polyexp(const float *__restrict__ I, int H, int W, FbPoly pp, float *__rest
             b3 += (b[k] + b[-k]) * g0;
             b6 += (b[k] - b[-k]) * pp.xg[k];
             b5 += (c[k] + c[-k]) * g0;
+        }
+        const int64_t o = (int64_t)y * W + x;
+        ((float4 *)R)[o] = make_float4((float)(b3 * pp.ig11), (float)(b2 * pp.ig11),
+                                       (float)(b1 * pp.ig03 + b5 * pp.ig33), (float)(b1 * pp.ig03 + b4 * pp.ig33));
+        R[4 * plane + o] = (float)(b6 * pp.ig55);
+    }
+}
+
+// The same kernel for polyN = 5 (the default), register-blocked: a work item of the vertical pass owns one tile column
+// for FOUR output rows (14 tile values feed 4 x 11 taps), a thread of the horizontal pass owns FOUR consecutive output
+// columns of one row (14 values of each moment, fetched as three 16-byte and one 8-byte LDS reads from rows padded to
+// a multiple of four floats).  LDS reads per output drop from 11 + 33 to 3.5 + 10.5; every output is still formed by the
+// expressions of k_fb_polyexp in the same order (bit-identical, tests compare the two).
+#define FBP5_TS (FBP_W + 2 * 5 + 2)      /* row stride of the moment tiles: 76 floats, 16-byte aligned rows */
+__global__ void __launch_bounds__(256)
+k_fb_polyexp5(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restrict__ R, int64_t plane,
+              int64_t bs_I, int64_t bs_R)
+{
+    constexpr int n = 5, tw = FBP_W + 2 * n, th = FBP_H + 2 * n;
+    __shared__ float tI[th * tw];
+    __shared__ __attribute__((aligned(16))) float tT[3][FBP_H * FBP5_TS];
+    I += (int64_t)blockIdx.z * bs_I; R += (int64_t)blockIdx.z * bs_R;
+    const int bx = blockIdx.x * FBP_W, by = blockIdx.y * FBP_H;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int i = tid; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        tI[i] = I[(int64_t)tf_clampi(by + ty - n, 0, H - 1) * W + tf_clampi(bx + tx - n, 0, W - 1)];
+    }
+    __syncthreads();
+    float g[n + 1], xg[n + 1], xxg[n + 1];
+#pragma unroll
+    for (int k = 0; k <= n; k++) { g[k] = pp.g[k]; xg[k] = pp.xg[k]; xxg[k] = pp.xxg[k]; }
+    for (int i = tid; i < tw * (FBP_H / 4); i += 256) {
+        const int rg = i / tw, tx = i - rg * tw;
+        float v[14];
+#pragma unroll
+        for (int j = 0; j < 14; j++) v[j] = tI[(4 * rg + j) * tw + tx];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float r0 = v[r + n] * g[0], r1 = 0.f, r2 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= n; k++) {
+                const float s0 = v[r + n - k], s1 = v[r + n + k];
+                const float p = s0 + s1;
+                r0 = r0 + g[k] * p;
+                r1 = r1 + xg[k] * (s1 - s0);
+                r2 = r2 + xxg[k] * p;
+            }
+            const int o = (4 * rg + r) * FBP5_TS + tx;
+            tT[0][o] = r0; tT[1][o] = r1; tT[2][o] = r2;
+        }
+    }
+    __syncthreads();
+    const int oy = tid >> 4, x4 = (tid & 15) * 4, y = by + oy;
+    if (y >= H || bx + x4 >= W) return;
+    float a[14], b[14], c[14];
+    {
+        const float *pa = tT[0] + oy * FBP5_TS + x4, *pb = tT[1] + oy * FBP5_TS + x4, *pc = tT[2] + oy * FBP5_TS + x4;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const float4 va = ((const float4 *)pa)[q], vb = ((const float4 *)pb)[q], vc = ((const float4 *)pc)[q];
+            a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
+            b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
+            c[4 * q] = vc.x; c[4 * q + 1] = vc.y; c[4 * q + 2] = vc.z; c[4 * q + 3] = vc.w;
+        }
+        const float2 ea = ((const float2 *)pa)[6], eb = ((const float2 *)pb)[6], ec = ((const float2 *)pc)[6];
+        a[12] = ea.x; a[13] = ea.y; b[12] = eb.x; b[13] = eb.y; c[12] = ec.x; c[13] = ec.y;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int x = bx + x4 + e;
+        if (x >= W) break;
+        const int m = e + n;                      // centre of this output inside the 14-value windows
+        float g0 = g[0];
+        double b1 = a[m] * g0, b2 = 0, b3 = b[m] * g0, b4 = 0, b5 = c[m] * g0, b6 = 0;
+#pragma unroll
+        for (int k = 1; k <= n; k++) {
+            const double tg = a[m + k] + a[m - k];
+            g0 = g[k];
+            b1 += tg * g0; b4 += tg * xxg[k];
+            b2 += (a[m + k] - a[m - k]) * xg[k];
+            b3 += (b[m + k] + b[m - k]) * g0;
+            b6 += (b[m + k] - b[m - k]) * xg[k];
+            b5 += (c[m + k] + c[m - k]) * g0;
         }
         const int64_t o = (int64_t)y * W + x;
         ((float4 *)R)[o] = make_float4((float)(b3 * pp.ig11), (float)(b2 * pp.ig11),
@@ -890,7 +981,7 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
             }
             {
                 TfProfScope ps(TFK_FB_POLYEXP, 24.0 * plane * B, s);   // fused-ideal: 4 r + 20 w per level pixel
-                hipLaunchKernelGGL(k_fb_polyexp, dim3((w + FBP_W - 1) / FBP_W, (h + FBP_H - 1) / FBP_H, B), block, 0, s,
+                hipLaunchKernelGGL(pp.n == 5 && !fb_polyexp_generic() ? k_fb_polyexp5 : k_fb_polyexp, dim3((w + FBP_W - 1) / FBP_W, (h + FBP_H - 1) / FBP_H, B), block, 0, s,
                                    Ik, h, w, pp, R[i], plane, bs_Ik, bs_R);
             }
         }

@@ -17,6 +17,7 @@ ap.add_argument("--strided", type=int, default=0)
 ap.add_argument("--size", type=int, default=5424)
 ap.add_argument("--torch-only", type=int, default=0, help="control: this many plain torch kernels, no library call")
 ap.add_argument("--repeat", type=int, default=1)
+ap.add_argument("--vr", type=int, default=0, help="also run one variational refinement of the first pair")
 a = ap.parse_args()
 H = a.size
 g = torch.Generator(device="cuda")
@@ -47,5 +48,8 @@ else:
 m = FarnebackFlow(num_levels=a.levels)
 for _ in range(a.repeat):
     m.calc_batch_dev(prev, nxt, fwd, bwd)
+if a.vr:
+    import tobac_flow_amd.flow as tf
+    tf.vr_model.calc_dev(prev[0], nxt[0], fwd[0].contiguous())
 torch.cuda.synchronize()
 print("done", float(fwd[0, H // 2, H // 2, 0]), flush=True)
