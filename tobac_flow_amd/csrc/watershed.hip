@@ -192,6 +192,12 @@ k_ws_init_labelset(const u64 *__restrict__ pix, const int32_t *__restrict__ mark
 }
 
 // ---- frontier queues ---------------------------------------------------------------------------
+// Two modes.  WITHOUT in-queue flags (inq == nullptr, the default): a pixel is appended whenever a relaxation STRICTLY
+// lowers its key -- no lost update by construction (the append follows the atomic that lowered the key), and a pixel
+// lowered twice in one sweep simply sits in the queue twice (the second visit finds nothing to do).  That removes
+// ~4 of the ~10 returning atomics a processed pixel costs, which is what bounds the sweeps.  The queue length then has
+// no a-priori bound: if a sweep overflows its queue the host re-seeds the phase with a full scan (every finite key is
+// pushed again; the fixpoint is the same).  WITH flags (TF_WS_DEDUPE=1, the round-1 scheme):
 // A sweep processes the queue of pixels whose key changed (qin) and appends every pixel whose key it
 // lowers to qout.  inq[n] = 1 while n sits in a queue and has not been processed since: the flag is
 // cleared BEFORE the pixel's key is read, so a later decrease always re-queues it (no lost update); a
@@ -255,7 +261,7 @@ __device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, int w, boo
         if (s0 == 0 && act) {
             // relaxed L2 atomics only: the key is loaded after the exchange has returned (the flag is cleared BEFORE
             // the key is read, so a later decrease re-queues the pixel); the id loads above are already in flight
-            const int dep = ws_after(atomicExch(&inq[p], 0));
+            const int dep = inq ? ws_after(atomicExch(&inq[p], 0)) : 0;
             kp = ws_load(&c.K2[p] + dep);
         }
         const u64 lp = kp >> 32;
@@ -280,7 +286,7 @@ __device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, int w, boo
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) {
             was_q[j] = 1;
-            if (n[j] >= 0 && cand[j] < old[j]) was_q[j] = atomicExch(&inq[n[j]], 1);
+            if (n[j] >= 0 && cand[j] < old[j]) was_q[j] = inq ? atomicExch(&inq[n[j]], 1) : 0;
         }
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) ws_stage(st, w, was_q[j] == 0, n[j], qout, cnt_out, qcap);
@@ -347,7 +353,7 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
         if (s0 == 0 && act0) {
             // the in-queue flag is cleared BEFORE p's own keys are read (the loads take the exchange's
             // return value as an address term), so a later decrease re-queues p: no lost update
-            const int dep = ws_after(atomicExch(&inq[p], 0));
+            const int dep = inq ? ws_after(atomicExch(&inq[p], 0)) : 0;
             kp = c.K2[p];                        // final since phase A
             own = ws_load(&dst[p] + dep);
             if (root) { own_lo = ws_load_i(&c.Llo[p] + dep); own_hi = ws_load_i(&c.Lhi[p] + dep); }
@@ -391,7 +397,7 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
         for (int j = 0; j < WS_NB; j++) {
             was_q[j] = 1;
             const bool improved = offered[j] < old[j] || (root && (own_lo < olo[j] || own_hi > ohi[j]));
-            if (improved) was_q[j] = atomicExch(&inq[n[j]], 1);
+            if (improved) was_q[j] = inq ? atomicExch(&inq[n[j]], 1) : 0;
         }
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) ws_stage(st, w, was_q[j] == 0, n[j], qout, cnt_out, qcap);
@@ -554,15 +560,19 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
 {
     const unsigned nbR = (unsigned)((c.R + 255) / 256);
     const unsigned nb = nbR < 2048u ? nbR : 2048u;
-    TF_CHECK_HIP(hipMemsetAsync(Q.cnt, 0, (WS_BATCH + 1) * sizeof(int), s));
-    TF_CHECK_HIP(hipMemsetAsync(Q.inq, 0, (size_t)c.R * sizeof(int), s));
-    // development switch: TF_WS_LOCAL_ROUNDS=<n> (0 = one front step per launch, the round-1 behaviour; same labels)
+    // development switches (same labels either way): TF_WS_LOCAL_ROUNDS=<n> (0 = one front step per launch),
+    // TF_WS_DEDUPE=1 (in-queue flags: every pixel at most once per queue, the round-1 scheme)
     static const int rounds = getenv("TF_WS_LOCAL_ROUNDS") ? atoi(getenv("TF_WS_LOCAL_ROUNDS")) : 4;
+    static const bool dedupe = getenv("TF_WS_DEDUPE") != nullptr;
+    int *inq = dedupe ? Q.inq : nullptr;
+    TF_CHECK_HIP(hipMemsetAsync(Q.cnt, 0, (WS_BATCH + 1) * sizeof(int), s));
+    if (dedupe) TF_CHECK_HIP(hipMemsetAsync(Q.inq, 0, (size_t)c.R * sizeof(int), s));
     int64_t sweeps = 0;
     int parity = 0;
-    bool first = true;
+    bool first = true;                // the next launch scans every relevant pixel instead of reading a queue
     unsigned grid_hint = nb;          // sized from the frontier seen at the end of the previous batch
     for (;;) {
+        const bool scan_batch = first;
         // one timing scope per batch of launches, not per launch: ~1000 event pairs per call cost more than the
         // small sweeps themselves (measured: 8.5 ms per 12x5424^2 step); the scope therefore includes dispatch gaps
         {
@@ -571,9 +581,9 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
                 const int *qin = first ? nullptr : Q.q[parity];
                 const unsigned blocks = first ? nbR : grid_hint;
                 if (phase_k == 0)
-                    hipLaunchKernelGGL(k_ws_sweep_a, dim3(blocks), dim3(256), 0, s, c, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, Q.inq, Q.qcap, rounds);
+                    hipLaunchKernelGGL(k_ws_sweep_a, dim3(blocks), dim3(256), 0, s, c, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, inq, Q.qcap, rounds);
                 else
-                    hipLaunchKernelGGL(k_ws_sweep_chain, dim3(blocks), dim3(256), 0, s, c, phase_k, depth, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, Q.inq, Q.qcap, rounds);
+                    hipLaunchKernelGGL(k_ws_sweep_chain, dim3(blocks), dim3(256), 0, s, c, phase_k, depth, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, inq, Q.qcap, rounds);
                 parity ^= 1;
                 first = false;
             }
@@ -581,17 +591,18 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
         TF_CHECK_LAUNCH();
         TF_CHECK_HIP(hipMemcpyAsync(Q.h_cnt, Q.cnt, (WS_BATCH + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
         TF_CHECK_HIP(hipStreamSynchronize(s));
-        bool done = false;
-        // slot b holds the size of the queue consumed by sweep b (slot 0 of the first batch is unused:
-        // that sweep scans everything)
+        bool done = false, overflow = false;
+        // slot b holds the size of the queue consumed by sweep b (slot 0 of a batch that starts with a full scan is
+        // unused)
         static const bool trace = getenv("TF_WS_TRACE") != nullptr;      // development aid: frontier size per sweep
         if (trace) {
             fprintf(stderr, "ws_trace phase %d sweeps %lld:", phase_k, (long long)sweeps);
             for (int b = 0; b <= WS_BATCH; b++) fprintf(stderr, " %d", Q.h_cnt[b]);
             fprintf(stderr, "\n");
         }
-        for (int b = (sweeps == 0 ? 1 : 0); b <= WS_BATCH; b++) {
-            if (Q.h_cnt[b] > Q.qcap) { tf_set_error("tf_watershed: frontier queue overflow"); return TF_EHIP; }
+        for (int b = (scan_batch ? 1 : 0); b <= WS_BATCH; b++) overflow = overflow || Q.h_cnt[b] > Q.qcap;
+        if (overflow && dedupe) { tf_set_error("tf_watershed: frontier queue overflow"); return TF_EHIP; }
+        for (int b = (scan_batch ? 1 : 0); b <= WS_BATCH && !overflow; b++) {
             if (Q.h_cnt[b] == 0) { done = true; break; }
             if (b < WS_BATCH) *Q.processed += Q.h_cnt[b];
         }
@@ -605,6 +616,13 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
         }
         if (done) break;
         if (sweeps > max_sweeps) { tf_set_error("tf_watershed: phase %d did not converge in %lld sweeps", phase_k, (long long)sweeps); return TF_ENOCONV; }
+        if (overflow) {
+            // a queue was cut off: appended pixels were dropped.  Every key is still a valid upper bound (relaxations only
+            // lower keys), so a scan of ALL relevant pixels re-seeds the fronts and the phase carries on to the same fixpoint
+            first = true;
+            TF_CHECK_HIP(hipMemsetAsync(Q.cnt, 0, (WS_BATCH + 1) * sizeof(int), s));
+            continue;
+        }
         // carry the last count into slot 0, clear the rest
         TF_CHECK_HIP(hipMemcpyAsync(Q.cnt, Q.cnt + WS_BATCH, sizeof(int), hipMemcpyDeviceToDevice, s));
         TF_CHECK_HIP(hipMemsetAsync(Q.cnt + 1, 0, WS_BATCH * sizeof(int), s));
