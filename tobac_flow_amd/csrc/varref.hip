@@ -196,11 +196,11 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 #define VRT_RH (VRT_H + 2 * VRT_HALO)
 #define VRT_PW (VRT_RW / 2)
 #define VRT_NPAIR (VRT_PW * VRT_RH)
-#define VRT_THREADS 512
+#define VRT_THREADS 1024
 #define VRT_K ((VRT_NPAIR + VRT_THREADS - 1) / VRT_THREADS)
 #define VRT_LDS_BYTES (2 * VRT_RH * VRT_PW * 12)
 
-__global__ void __launch_bounds__(VRT_THREADS, 2)
+__global__ void __launch_bounds__(VRT_THREADS)
 k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
               int n_half, float omega, const float2 *__restrict__ dW_in, float2 *__restrict__ dW_out)
 {
