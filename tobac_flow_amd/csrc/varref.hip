@@ -189,6 +189,10 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 // split: the pixels of one colour of a row are contiguous, so a wave's neighbour reads are unit-stride.  The outermost
 // ring is never updated and invalid values creep inwards one pixel per half sweep -- they stop short of the tile.
 // Same expressions in the same order as k_vr_sor: bit-identical results (tests compare the two paths).
+// Measured alternatives (12 x 5424^2, ms per step for all 110 launches): 512 threads / 13 pixel pairs per thread /
+// 256 VGPRs: 93.2 (kept); 1024 threads / 7 pairs / 128 VGPRs with a small spill: 95.9.  One workgroup per CU either
+// way (149 KB of LDS): the tile load is not overlapped with the sweeps, and ten block-wide barriers per launch keep half
+// of the wave cycles waiting (profiles/round2_pmc_sq_summary.txt).
 #define VRT_W 128
 #define VRT_H 64
 #define VRT_HALO 10
@@ -196,11 +200,11 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 #define VRT_RH (VRT_H + 2 * VRT_HALO)
 #define VRT_PW (VRT_RW / 2)
 #define VRT_NPAIR (VRT_PW * VRT_RH)
-#define VRT_THREADS 1024
+#define VRT_THREADS 512
 #define VRT_K ((VRT_NPAIR + VRT_THREADS - 1) / VRT_THREADS)
 #define VRT_LDS_BYTES (2 * VRT_RH * VRT_PW * 12)
 
-__global__ void __launch_bounds__(VRT_THREADS)
+__global__ void __launch_bounds__(VRT_THREADS, 2)
 k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
               int n_half, float omega, const float2 *__restrict__ dW_in, float2 *__restrict__ dW_out)
 {
