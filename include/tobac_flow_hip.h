@@ -39,6 +39,7 @@ extern "C" {
 #define TF_INTERP_NEAREST 0
 #define TF_INTERP_LINEAR 1
 #define TF_INTERP_CUBIC 2
+#define TF_INTERP_LANCZOS 3   /* cv2.INTER_LANCZOS4: 8 x 8 taps (convolve.py:47-54 "lanczos") */
 
 /* element types of `data` / `out` arguments */
 #define TF_F32 0

@@ -24,15 +24,13 @@ import scipy.ndimage as ndi
 
 from . import _lib
 
-_METHODS = {"nearest": 0, "linear": 1, "cubic": 2}
+_METHODS = {"nearest": 0, "linear": 1, "cubic": 2, "lanczos": 3}
 
 
 def remap(img, locs, method, fill_value):
     """cv2.remap(img, locs(rows, cols, 2) f32, None, method, None, BORDER_CONSTANT, fill_value)."""
     if method not in ("nearest", "linear", "cubic", "lanczos"):
         raise ValueError("method must be one of ['nearest', 'linear', 'cubic', 'lanczos']")
-    if method == "lanczos":
-        raise NotImplementedError("lanczos is not restated in the oracle")
     L = _lib.lib()
     locs = np.ascontiguousarray(locs, np.float32)
     rows, cols = locs.shape[:2]

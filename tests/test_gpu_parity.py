@@ -728,3 +728,30 @@ def test_farneback_non_default_parameters_match_oracle(tf, kw):
                        ctypes.c_double(p["poly_sigma"]))
     assert np.abs(got - want).max() <= 1e-4, np.abs(got - want).max()
     assert np.abs(np.median(got[20:-20, 20:-20].reshape(-1, 2), 0) - np.array([-2, 1])).max() < 0.2
+
+
+def test_lanczos_interpolation_matches_oracle_everywhere_it_is_accepted(tf):
+    """method="lanczos" (cv2.INTER_LANCZOS4, convolve.py:47-54 / flow_utils.py:22-34): single-image warp, the smoothing
+    step, the generic convolve (raw stack and nanmean) and the 27-tap Sobel, bit for bit against the oracle; borders,
+    far-out flows and NaN samples included."""
+    from oracle import np_ops
+    rng = np.random.default_rng(23)
+    shape = (3, 41, 57)
+    data = rand_field(rng, shape, nan_frac=0.005)
+    fwd, bwd = rand_flow(rng, shape, 2.5), rand_flow(rng, shape, 2.5)
+    fwd[0, 5, 5] = (60.0, -70.0)                                   # far outside
+    _eq(tf.warp_flow(data[0], fwd[0], method="lanczos"), np_ops.warp_flow_single(data[0], fwd[0], "lanczos"))
+    gf, gb = tf.smooth_flow_step(fwd[1], bwd[1], "lanczos")
+    wf, wb = np_ops.smooth_flow_step(fwd[1], bwd[1], "lanczos")
+    _eq(gf, wf)
+    _eq(gb, wb)
+    fl = tf.Flow(fwd, bwd)
+    s = ndi.generate_binary_structure(3, 1)
+    _eq(fl.convolve(data, structure=s, method="lanczos"), np_ops.convolve(data, fwd, bwd, s, "lanczos", np.float32, np.nan, None))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = np_ops.convolve(data, fwd, bwd, s, "lanczos", np.float32, np.nan, lambda x: np.nanmean(x, 0))
+    _eq(fl.convolve(data, structure=s, method="lanczos", func=lambda x: np.nanmean(x, 0)), want)
+    for direction in (None, "uphill"):
+        _eq(fl.sobel(data, method="lanczos", direction=direction), np_ops.sobel(data, fwd, bwd, "lanczos", None, np.nan, direction))

@@ -402,7 +402,8 @@ def test_small_utilities_known_answers():
     assert get_datetime_from_coord(coord) == times
     assert np.array_equal(get_time_diff_from_coord(coord), [5.0, 7.5, 7.5, 5.0])
     assert select_interp_mode("nearest") == 0 and select_interp_mode("linear") == 1 and select_interp_mode("cubic") == 2
-    for bad, err in [("lanczos", NotImplementedError), ("spline", ValueError)]:
+    assert select_interp_mode("lanczos") == 3
+    for bad, err in [("spline", ValueError)]:
         with pytest.raises(err):
             select_interp_mode(bad)
     assert select_border_mode("constant") == "constant"

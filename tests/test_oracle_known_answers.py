@@ -322,3 +322,33 @@ def test_variational_refinement_sor_solves_the_system_it_assembles():
     r2 = A22 * dW[..., 1] + A12 * dW[..., 0] - lap(dW[..., 1]) - (b2 + lap(v))
     scale = np.abs(b1 + lap(u)).max() + np.abs(b2 + lap(v)).max()
     assert diag.min() > 0 and max(np.abs(r1).max(), np.abs(r2).max()) < 2e-3 * scale
+
+
+def test_remap_lanczos4_identities():
+    """cv2.INTER_LANCZOS4 as restated in oracle/c/remap.c (parity unpinned): integer shifts are exact (the table entry
+    for a zero fraction is a delta), constants are reproduced to float rounding (weights normalised to unit sum), the
+    half-pixel kernel is symmetric, and a smooth image is interpolated several times better than by the bilinear kernel."""
+    from oracle import np_ops
+    rng = np.random.default_rng(9)
+    img = rng.normal(size=(40, 52)).astype(np.float32)
+    yy, xx = np.mgrid[0:40, 0:52].astype(np.float32)
+    inner = (slice(8, -8), slice(8, -8))
+    for dy, dx in ((0, 0), (3, -2), (-5, 4)):
+        out = np_ops.remap(img, np.stack([xx + dx, yy + dy], -1), "lanczos", np.nan)
+        assert np.array_equal(out[inner], np.roll(img, (-dy, -dx), (0, 1))[inner])
+    const = np.full((40, 52), 7.25, np.float32)
+    out = np_ops.remap(const, np.stack([xx + 0.37, yy - 0.81], -1), "lanczos", np.nan)
+    assert np.abs(out[inner] - 7.25).max() < 1e-5
+    half = np_ops.remap(img, np.stack([xx + 0.5, yy], -1), "lanczos", np.nan)
+    mirror = np_ops.remap(img[:, ::-1].copy(), np.stack([xx + 0.5, yy], -1), "lanczos", np.nan)[:, ::-1]
+    assert np.allclose(half[inner][:, :-1], mirror[inner][:, 1:], atol=2e-6)         # symmetric half-pixel kernel
+    smooth = np.sin(xx / 5.0) * np.cos(yy / 7.0)
+    truth = np.sin((xx + 0.4375) / 5.0) * np.cos((yy + 0.28125) / 7.0)            # shifts on the 1/32 grid
+    locs = np.stack([xx + 0.4375, yy + 0.28125], -1)
+    e_lan = np.abs(np_ops.remap(smooth, locs, "lanczos", np.nan) - truth)[inner].max()
+    e_lin = np.abs(np_ops.remap(smooth, locs, "linear", np.nan) - truth)[inner].max()
+    assert e_lan < 0.5 * e_lin
+    # border: a patch that straddles the image takes cval + sum (S - cval) w; NaN poisons it, far outside is cval
+    out = np_ops.remap(img, np.stack([xx + 0.5, yy], -1), "lanczos", np.nan)
+    assert np.isnan(out[:, -4:]).all() and np.isfinite(out[8:-8, 8:-8]).all()
+    assert np.isnan(np_ops.remap(img, np.stack([xx + 100, yy], -1), "lanczos", np.nan)).all()

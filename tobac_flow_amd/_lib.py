@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TF_LIB_PATH: development switch (A/B runs of two builds of the library)
 _SO = os.environ.get("TF_LIB_PATH") or os.path.join(_HERE, "csrc", "libtobac_flow_hip.so")
 
-INTERP = {"nearest": 0, "linear": 1, "cubic": 2}
+INTERP = {"nearest": 0, "linear": 1, "cubic": 2, "lanczos": 3}
 TF_F32, TF_F64, TF_I32 = 0, 1, 2
 FUNC_STACK, FUNC_SOBEL, FUNC_SOBEL_UPHILL, FUNC_SOBEL_DOWNHILL, FUNC_NANMEAN, FUNC_DIFF, FUNC_ANY, FUNC_NANMAX = range(8)
 

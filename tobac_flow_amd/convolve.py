@@ -41,8 +41,6 @@ def _func_code(func):
 def _check_method(method, structure):
     if method not in _METHODS:
         raise ValueError(f"method must be one of {list(_METHODS)}")
-    if method == "lanczos" and (np.any(structure[0]) or np.any(structure[2])):
-        raise NotImplementedError("interpolation 'lanczos' has no HIP kernel (nearest / linear / cubic do)")
 
 
 def _np_dtype(dtype):

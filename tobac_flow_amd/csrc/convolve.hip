@@ -12,9 +12,41 @@
 // reference is never materialised: each tap is reduced as soon as it is gathered.  HBM traffic
 // per pixel is the algorithmic 4 (field, each frame reused by 3 outputs through L2/MALL) + 16
 // (two flow vectors) + 4 or 8 (output) bytes.
+#define TF_LANCZOS_TABLE_DEFINED
+#include <hip/hip_runtime.h>
+__constant__ float c_tf_lanczos[32][8];
 #include "remap_dev.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <math.h>
+#include <float.h>
+
+// interpolateLanczos4 (imgwarp.cpp) at the 32 fractional positions of the remap table, uploaded on first use
+static int ensure_lanczos_table()
+{
+    static bool done = false;
+    if (done) return TF_OK;
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    float tab[32][8];
+    for (int k = 0; k < 32; k++) {
+        const float x = (float)k * (1.f / 32.f);
+        float *c = tab[k];
+        if (x < FLT_EPSILON) { for (int i = 0; i < 8; i++) c[i] = 0; c[3] = 1; continue; }
+        float sum = 0;
+        const double y0 = -(x + 3) * M_PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+        for (int i = 0; i < 8; i++) {
+            const double y = -(x + 3 - i) * M_PI * 0.25;
+            c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+            sum += c[i];
+        }
+        sum = 1.f / sum;
+        for (int i = 0; i < 8; i++) c[i] *= sum;
+    }
+    TF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tf_lanczos), tab, sizeof(tab)));
+    done = true;
+    return TF_OK;
+}
 
 struct ConvTaps {
     int nb, ns, nf;        // taps taken from t-1 (backward flow), t, t+1 (forward flow)
@@ -180,10 +212,10 @@ template <int METHOD>
 __device__ __forceinline__ void sobel_plane_taps(const float *__restrict__ img, int H, int W, int x, int y,
                                                  float flx, float fly, float cval, float (&tap)[9])
 {
-    if (METHOD == TF_INTERP_NEAREST) {
+    if (METHOD == TF_INTERP_NEAREST || METHOD == TF_INTERP_LANCZOS) {      // (a 10 x 10 patch does not fit the registers)
 #pragma unroll
         for (int k = 0; k < 9; k++)
-            tap[k] = tf_remap_nearest<float>(img, H, W, tf_loc(flx, k % 3 - 1, x), tf_loc(fly, k / 3 - 1, y), cval);
+            tap[k] = tf_remap<METHOD>(img, H, W, tf_loc(flx, k % 3 - 1, x), tf_loc(fly, k / 3 - 1, y), cval);
         return;
     }
     int fx[3], fy[3];
@@ -363,6 +395,7 @@ static int launch_convolve(const void *data, int64_t T, int H, int W, const floa
     if constexpr (!std::is_same<TS, int32_t>::value) {
         if (is_sobel && !getenv("TF_SOBEL_GENERIC")) {
             if (interp == TF_INTERP_NEAREST) launch_sobel27<TF_INTERP_NEAREST, TS>(func, grid, block, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
+            else if (interp == TF_INTERP_LANCZOS) launch_sobel27<TF_INTERP_LANCZOS, TS>(func, grid, block, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
             else if (interp == TF_INTERP_LINEAR) launch_sobel27<TF_INTERP_LINEAR, TS>(func, grid, block, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
             else launch_sobel27<TF_INTERP_CUBIC, TS>(func, grid, block, s, d, fwd, bwd, T, H, W, fill, out, out_type, t0);
             TF_CHECK_LAUNCH();
@@ -374,6 +407,8 @@ static int launch_convolve(const void *data, int64_t T, int H, int W, const floa
         hipLaunchKernelGGL((k_convolve<TF_INTERP_NEAREST, TS>), grid, block, 0, s, d, fwd, bwd, T, H, W, tp, fill, func, out, out_type, t0); break;
     case TF_INTERP_LINEAR:
         hipLaunchKernelGGL((k_convolve<TF_INTERP_LINEAR, TS>), grid, block, 0, s, d, fwd, bwd, T, H, W, tp, fill, func, out, out_type, t0); break;
+    case TF_INTERP_LANCZOS:
+        hipLaunchKernelGGL((k_convolve<TF_INTERP_LANCZOS, TS>), grid, block, 0, s, d, fwd, bwd, T, H, W, tp, fill, func, out, out_type, t0); break;
     default:
         hipLaunchKernelGGL((k_convolve<TF_INTERP_CUBIC, TS>), grid, block, 0, s, d, fwd, bwd, T, H, W, tp, fill, func, out, out_type, t0); break;
     }
@@ -388,7 +423,8 @@ extern "C" int tf_convolve(const void *data, int data_type, int64_t T, int64_t H
 {
     TF_REQUIRE(data && fwd && bwd && structure_host && out, "tf_convolve: null pointer");
     TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_convolve: bad shape");
-    TF_REQUIRE(interp >= TF_INTERP_NEAREST && interp <= TF_INTERP_CUBIC, "tf_convolve: bad interp");
+    TF_REQUIRE(interp >= TF_INTERP_NEAREST && interp <= TF_INTERP_LANCZOS, "tf_convolve: bad interp");
+    if (interp == TF_INTERP_LANCZOS) { const int rc = ensure_lanczos_table(); if (rc) return rc; }
     TF_REQUIRE(func >= TF_FUNC_STACK && func <= TF_FUNC_NANMAX, "tf_convolve: bad func");
     TF_REQUIRE(data_type == TF_F32 || data_type == TF_I32, "tf_convolve: data_type must be f32 or i32");
     TF_REQUIRE(out_type >= TF_F32 && out_type <= TF_I32, "tf_convolve: bad out_type");
@@ -455,6 +491,33 @@ __device__ __forceinline__ float2 sample_flow2(const float *__restrict__ f2, int
         float2 v2 = (okx0 && oky1) ? at(sy + 1, sx) : cval, v3 = (okx1 && oky1) ? at(sy + 1, sx + 1) : cval;
         return f2_add(f2_add(f2_add(f2_mul(v0, w0), f2_mul(v1, w1)), f2_mul(v2, w2)), f2_mul(v3, w3));
     }
+    if (METHOD == TF_INTERP_LANCZOS) {
+        const int bx = sx - 3, by = sy - 3;
+        const float *wx = c_tf_lanczos[fx & 31], *wy = c_tf_lanczos[fy & 31];
+        int w1lim = W - 7 > 0 ? W - 7 : 0, h1lim = H - 7 > 0 ? H - 7 : 0;
+        if ((unsigned)bx < (unsigned)w1lim && (unsigned)by < (unsigned)h1lim) {
+            float2 sum = make_float2(0.f, 0.f);
+            for (int r = 0; r < 8; r++) {
+                const float wr = wy[r];
+                float2 row = f2_mul(at(by + r, bx), wr * wx[0]);
+#pragma unroll
+                for (int j = 1; j < 8; j++) row = f2_add(row, f2_mul(at(by + r, bx + j), wr * wx[j]));
+                sum = f2_add(sum, row);
+            }
+            return sum;
+        }
+        if (bx >= W || bx + 8 <= 0 || by >= H || by + 8 <= 0) return cval;
+        float2 sum = f2_mul(cval, 1.f);
+        for (int i = 0; i < 8; i++) {
+            int yi = by + i;
+            if (yi < 0 || yi >= H) continue;
+            for (int j = 0; j < 8; j++) {
+                int xj = bx + j;
+                if (xj >= 0 && xj < W) sum = f2_add(sum, f2_mul(f2_sub(at(yi, xj), cval), wy[i] * wx[j]));
+            }
+        }
+        return sum;
+    }
     float cx[4], cy[4];
     tf_cubic_coeffs((float)(fx & 31) * (1.f / 32.f), cx);
     tf_cubic_coeffs((float)(fy & 31) * (1.f / 32.f), cy);
@@ -513,11 +576,13 @@ extern "C" int tf_warp_flow(const float *img, const float *flow, int64_t H, int6
 {
     TF_REQUIRE(img && flow && out, "tf_warp_flow: null pointer");
     TF_REQUIRE(H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_warp_flow: bad shape");
-    TF_REQUIRE(interp >= 0 && interp <= 2, "tf_warp_flow: bad interp");
+    TF_REQUIRE(interp >= 0 && interp <= 3, "tf_warp_flow: bad interp");
+    if (interp == TF_INTERP_LANCZOS) { const int rc = ensure_lanczos_table(); if (rc) return rc; }
     dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
     if (interp == 0) hipLaunchKernelGGL(k_warp<0>, grid, block, 0, s, img, flow, (int)H, (int)W, out);
     else if (interp == 1) hipLaunchKernelGGL(k_warp<1>, grid, block, 0, s, img, flow, (int)H, (int)W, out);
+    else if (interp == 3) hipLaunchKernelGGL(k_warp<3>, grid, block, 0, s, img, flow, (int)H, (int)W, out);
     else hipLaunchKernelGGL(k_warp<2>, grid, block, 0, s, img, flow, (int)H, (int)W, out);
     TF_CHECK_LAUNCH();
     return TF_OK;
@@ -529,12 +594,14 @@ extern "C" int tf_smooth_flow_step(const float *fwd, const float *bwd, int64_t H
     TF_REQUIRE(fwd && bwd && fwd_out && bwd_out, "tf_smooth_flow_step: null pointer");
     TF_REQUIRE(fwd_out != fwd && fwd_out != bwd && bwd_out != fwd && bwd_out != bwd, "tf_smooth_flow_step: outputs alias inputs");
     TF_REQUIRE(H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_smooth_flow_step: bad shape");
-    TF_REQUIRE(interp >= 0 && interp <= 2, "tf_smooth_flow_step: bad interp");
+    TF_REQUIRE(interp >= 0 && interp <= 3, "tf_smooth_flow_step: bad interp");
+    if (interp == TF_INTERP_LANCZOS) { const int rc = ensure_lanczos_table(); if (rc) return rc; }
     dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
     TfProfScope ps(TFK_SMOOTH, 48.0 * (double)H * W, s);
     if (interp == 0) hipLaunchKernelGGL(k_smooth<0>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
     else if (interp == 1) hipLaunchKernelGGL(k_smooth<1>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
+    else if (interp == 3) hipLaunchKernelGGL(k_smooth<3>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
     else hipLaunchKernelGGL(k_smooth<2>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
     TF_CHECK_LAUNCH();
     return TF_OK;
@@ -587,7 +654,8 @@ extern "C" int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int
 {
     TF_REQUIRE(field && fwd && bwd && out, "tf_sobel_edge_field: null pointer");
     TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_sobel_edge_field: bad shape");
-    TF_REQUIRE(interp >= TF_INTERP_NEAREST && interp <= TF_INTERP_CUBIC, "tf_sobel_edge_field: bad interp");
+    TF_REQUIRE(interp >= TF_INTERP_NEAREST && interp <= TF_INTERP_LANCZOS, "tf_sobel_edge_field: bad interp");
+    if (interp == TF_INTERP_LANCZOS) { const int rc = ensure_lanczos_table(); if (rc) return rc; }
     TF_REQUIRE(out_type == TF_F32 || out_type == TF_F64, "tf_sobel_edge_field: out_type must be f32 or f64");
     hipStream_t s = (hipStream_t)stream;
     const double fill = NAN;                                  // Flow.sobel's default fill_value
@@ -598,6 +666,8 @@ extern "C" int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int
         hipLaunchKernelGGL((k_sobel27<TF_INTERP_NEAREST, double, TF_FUNC_SOBEL_UPHILL, true>), grid, block, 0, s, field, fwd, bwd, T, (int)H, (int)W, fill, out, out_type, (int64_t)0);
     else if (interp == TF_INTERP_LINEAR)
         hipLaunchKernelGGL((k_sobel27<TF_INTERP_LINEAR, double, TF_FUNC_SOBEL_UPHILL, true>), grid, block, 0, s, field, fwd, bwd, T, (int)H, (int)W, fill, out, out_type, (int64_t)0);
+    else if (interp == TF_INTERP_LANCZOS)
+        hipLaunchKernelGGL((k_sobel27<TF_INTERP_LANCZOS, double, TF_FUNC_SOBEL_UPHILL, true>), grid, block, 0, s, field, fwd, bwd, T, (int)H, (int)W, fill, out, out_type, (int64_t)0);
     else
         hipLaunchKernelGGL((k_sobel27<TF_INTERP_CUBIC, double, TF_FUNC_SOBEL_UPHILL, true>), grid, block, 0, s, field, fwd, bwd, T, (int)H, (int)W, fill, out, out_type, (int64_t)0);
     TF_CHECK_LAUNCH();

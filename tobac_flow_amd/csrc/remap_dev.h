@@ -86,10 +86,47 @@ __device__ __forceinline__ float tf_remap_cubic(const float *__restrict__ img, i
     return sum;
 }
 
+// cv2.INTER_LANCZOS4 (imgwarp.cpp remapLanczos4): 8 x 8 taps around (sx - 3, sy - 3), 1-D weights from a 32-entry
+// table (interpolateLanczos4 at f = k / 32, built on the host with the C library's sin / cos exactly as OpenCV builds
+// it, uploaded once), 2-D weight = wy * wx in float; the sum goes ROW BY ROW: sum += (S0 w0 + S1 w1 + ... + S7 w7).
+// Border (BORDER_CONSTANT): fully outside -> cval; straddling -> cval + SUM (S - cval) w over the inside taps.
+#ifndef TF_LANCZOS_TABLE_DEFINED
+extern __constant__ float c_tf_lanczos[32][8];
+#endif
+
+__device__ __forceinline__ float tf_remap_lanczos(const float *__restrict__ img, int h, int w, float mx, float my, float cval) {
+    int fx = tf_cvround(mx * 32.f), fy = tf_cvround(my * 32.f);
+    int sx = tf_sat_short(fx >> 5) - 3, sy = tf_sat_short(fy >> 5) - 3;
+    const float *wx = c_tf_lanczos[fx & 31], *wy = c_tf_lanczos[fy & 31];
+    int w1lim = w - 7 > 0 ? w - 7 : 0, h1lim = h - 7 > 0 ? h - 7 : 0;
+    if ((unsigned)sx < (unsigned)w1lim && (unsigned)sy < (unsigned)h1lim) {
+        const float *S = img + (int64_t)sy * w + sx;
+        float sum = 0.f;
+        for (int r = 0; r < 8; r++, S += w) {
+            const float wr = wy[r];
+            sum += S[0] * (wr * wx[0]) + S[1] * (wr * wx[1]) + S[2] * (wr * wx[2]) + S[3] * (wr * wx[3])
+                 + S[4] * (wr * wx[4]) + S[5] * (wr * wx[5]) + S[6] * (wr * wx[6]) + S[7] * (wr * wx[7]);
+        }
+        return sum;
+    }
+    if (sx >= w || sx + 8 <= 0 || sy >= h || sy + 8 <= 0) return cval;
+    float sum = cval * 1.f;
+    for (int i = 0; i < 8; i++) {
+        int yi = sy + i;
+        if (yi < 0 || yi >= h) continue;
+        for (int j = 0; j < 8; j++) {
+            int xj = sx + j;
+            if (xj >= 0 && xj < w) sum += (img[(int64_t)yi * w + xj] - cval) * (wy[i] * wx[j]);
+        }
+    }
+    return sum;
+}
+
 template <int METHOD>
 __device__ __forceinline__ float tf_remap(const float *__restrict__ img, int h, int w, float mx, float my, float cval) {
     if (METHOD == TF_INTERP_NEAREST) return tf_remap_nearest<float>(img, h, w, mx, my, cval);
     if (METHOD == TF_INTERP_LINEAR) return tf_remap_linear(img, h, w, mx, my, cval);
+    if (METHOD == TF_INTERP_LANCZOS) return tf_remap_lanczos(img, h, w, mx, my, cval);
     return tf_remap_cubic(img, h, w, mx, my, cval);
 }
 
@@ -110,6 +147,21 @@ __device__ __forceinline__ float tf_remap_const(int h, int w, float mx, float my
         float ax = (float)(fx & 31) * (1.f / 32.f), ay = (float)(fy & 31) * (1.f / 32.f);
         float w0 = (1.f - ay) * (1.f - ax), w1 = (1.f - ay) * ax, w2 = ay * (1.f - ax), w3 = ay * ax;
         return fill * w0 + fill * w1 + fill * w2 + fill * w3;      // inside and border taps all read `fill`
+    }
+    if (METHOD == TF_INTERP_LANCZOS) {
+        int bx = sx - 3, by = sy - 3;
+        int w1lim = w - 7 > 0 ? w - 7 : 0, h1lim = h - 7 > 0 ? h - 7 : 0;
+        if ((unsigned)bx < (unsigned)w1lim && (unsigned)by < (unsigned)h1lim) {
+            const float *wx = c_tf_lanczos[fx & 31], *wy = c_tf_lanczos[fy & 31];
+            float sum = 0.f;
+            for (int r = 0; r < 8; r++) {
+                const float wr = wy[r];
+                sum += fill * (wr * wx[0]) + fill * (wr * wx[1]) + fill * (wr * wx[2]) + fill * (wr * wx[3])
+                     + fill * (wr * wx[4]) + fill * (wr * wx[5]) + fill * (wr * wx[6]) + fill * (wr * wx[7]);
+            }
+            return sum;
+        }
+        return fill;       // fully outside -> cval; straddling -> cval + sum (fill - cval) * w = fill
     }
     int bx = sx - 1, by = sy - 1;
     int w1lim = w - 3 > 0 ? w - 3 : 0, h1lim = h - 3 > 0 ? h - 3 : 0;

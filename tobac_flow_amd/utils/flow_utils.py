@@ -20,8 +20,6 @@ def select_border_mode(mode: str):
 def select_interp_mode(mode: str):
     if mode not in interp_modes:
         raise ValueError("Invalid border mode")
-    if mode == "lanczos":
-        raise NotImplementedError("interpolation 'lanczos' has no HIP kernel (nearest / linear / cubic do)")
     return _lib.INTERP[mode]
 
 
