@@ -241,6 +241,24 @@ int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *m
                      int32_t *labels, uint8_t *ambiguous, void *ws, size_t ws_bytes,
                      int64_t *stats_host, void *stream);
 
+/* tf_watershed_raveled: the reference's only native seam, argument for argument --
+ *   tobac_flow/_watershed.pyx:222-233  watershed_raveled(image, marker_locations, structure, forward_offset,
+ *   backward_offset, forward_offset_locations, backward_offset_locations, mask, strides, compactness, output, wsl)
+ * as tobac_flow/watershed.py:151-164 calls it (flat, padded, C-contiguous arrays; `output` mutated in place).
+ *   image, forward_offset, backward_offset, mask, output, marker_locations: DEVICE arrays (n elements; marker_locations
+ *   n_markers int64, strictly ascending = np.flatnonzero order); structure / *_offset_locations / strides: HOST arrays
+ *   of n_structure (n_strides) entries.  compactness must be 0 and wsl 0 (the reference's call path); neighbour indices
+ *   are range-checked in addition to the mask test.  Exactness contract, return codes and stats as tf_watershed_ex2
+ *   (chain depth starts at min(3, max_depth)). */
+size_t tf_watershed_raveled_workspace_bytes(int64_t n, int n_structure, int max_depth, int64_t max_relevant);
+int tf_watershed_raveled(const float *image, int64_t n, const int64_t *marker_locations, int64_t n_markers,
+                         const int64_t *structure_host, int n_structure,
+                         const int32_t *forward_offset, const int32_t *backward_offset,
+                         const int32_t *forward_offset_locations_host, const int32_t *backward_offset_locations_host,
+                         const int8_t *mask, const int32_t *strides_host, int n_strides, double compactness,
+                         int32_t *output, int wsl, int max_depth, void *ws, size_t ws_bytes,
+                         int64_t *stats_host, void *stream);
+
 /* ---- section 8f-2: scipy.ndimage glue of the detection recipes (bit-exact with SciPy) ---------------------
  * tf_binary_morph: scipy.ndimage.binary_erosion (op 0) / binary_dilation (op 1) of a (T, H, W) uint8 volume with a
  *   3x3x3 structuring element (27 host bytes, C order), `iterations` >= 1, `border_value` 0/1

@@ -755,3 +755,57 @@ def test_lanczos_interpolation_matches_oracle_everywhere_it_is_accepted(tf):
     _eq(fl.convolve(data, structure=s, method="lanczos", func=lambda x: np.nanmean(x, 0)), want)
     for direction in (None, "uphill"):
         _eq(fl.sobel(data, method="lanczos", direction=direction), np_ops.sobel(data, fwd, bwd, "lanczos", None, np.nan, direction))
+
+
+@pytest.mark.parametrize("name", EXACT_VS_REFERENCE + ["C_quant4_c1", "E_const_plateau_c1"])
+def test_watershed_raveled_twin_takes_the_references_own_arguments(tf, golden_ws, name):
+    """tobac_flow_amd._watershed.watershed_raveled = the reference's native seam (_watershed.pyx:222-233), same twelve
+    arguments, `output` mutated in place: fed with exactly what watershed.py:59-149 prepares (oracle/ws_oracle.prepare:
+    padding, raveled neighbourhood, raveled int32 flow offsets) it returns the reference's golden labels -- and, on the
+    tie-heavy goldens, the idealised-order labels with a warning."""
+    import warnings
+    from oracle import ws_oracle
+    from tobac_flow_amd._watershed import watershed_raveled
+    from tobac_flow_amd.watershed import WatershedAmbiguityWarning
+    c = golden_ws[name]
+    conn = int(c["conn"])
+    p = ws_oracle.prepare(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn)
+    out = p["out"].ravel().copy()
+    args = (np.ascontiguousarray(p["field"].ravel()), p["markers"].astype(np.intp), p["nbr"].astype(np.intp), p["fwd_off"],
+            p["bwd_off"], p["fwd_loc"], p["bwd_loc"], p["mask"], p["strides"].astype(np.int32), 0.0, out, False)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert watershed_raveled(*args) is None
+    pd = p["pad"]
+    o = out.reshape(p["out"].shape)
+    got = o[pd[0]:o.shape[0] - pd[0], pd[1]:o.shape[1] - pd[1], pd[2]:o.shape[2] - pd[2]]
+    tie_heavy = name in ("C_quant4_c1", "E_const_plateau_c1")
+    want = ws_oracle.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn, tie_mode=1) if tie_heavy else c["labels"]
+    assert np.array_equal(got, want)
+    assert any(issubclass(w.category, WatershedAmbiguityWarning) for w in rec) == tie_heavy
+    assert not o[:pd[0]].any() and not o[:, :pd[1]].any() and not o[:, :, :pd[2]].any()          # the padding ring stays 0
+
+
+def test_watershed_raveled_argument_checks(tf):
+    from tobac_flow_amd._watershed import watershed_raveled
+    img = np.zeros(27, np.float32)
+    out = np.zeros(27, np.int32)
+    out[13] = 1
+    i32, z8 = np.zeros(27, np.int32), np.ones(27, np.int8)
+    ok = [img, np.array([13], np.intp), np.array([-1, 1], np.intp), i32, i32, np.zeros(2, np.int32), np.zeros(2, np.int32), z8,
+          np.array([9, 3, 1], np.int32), 0.0, out, False]
+    assert watershed_raveled(*ok) is None and out.tolist() == [1] * 27               # a 1-D chain floods end to end
+    for k, bad in ((0, img.astype(np.float64)), (10, out.astype(np.int64)), (7, z8.astype(bool)), (3, i32.reshape(3, 9))):
+        args = list(ok)
+        args[k] = bad
+        with pytest.raises(ValueError):
+            watershed_raveled(*args)
+    for k, bad in ((9, 0.5), (11, True)):                                            # compact watershed / watershed lines
+        args = list(ok)
+        args[k] = bad
+        with pytest.raises(ValueError):
+            watershed_raveled(*args)
+    args = list(ok)
+    args[1] = np.array([13, 5], np.intp)                                             # not np.flatnonzero order
+    with pytest.raises(ValueError):
+        watershed_raveled(*args)

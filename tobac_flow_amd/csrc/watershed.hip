@@ -166,6 +166,93 @@ k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, con
     M1[id] = WS_INF;
 }
 
+// ---- the reference's own raveled form (tf_watershed_raveled) -------------------------------------------------------
+// neighbour i of flat index p:  p + structure[i] + fwd_loc[i] * fwd_off[p] + bwd_loc[i] * bwd_off[p]
+// (_watershed.pyx:310-313).  The reference relies on a zero-masked padding ring to stay inside the arrays; here every
+// neighbour index is range-checked as well.
+struct WsRavel {
+    int64_t n; int n_nbr;
+    int64_t structure[WS_MAX_NBR]; int32_t floc[WS_MAX_NBR], bloc[WS_MAX_NBR];
+    const int32_t *foff, *boff;
+};
+__device__ __forceinline__ int64_t wsr_neighbour(const WsRavel &g, int64_t p, int fo, int bo, int i) {
+    const int64_t n = p + g.structure[i] + (int64_t)g.floc[i] * fo + (int64_t)g.bloc[i] * bo;
+    return (n >= 0 && n < g.n) ? n : -1;
+}
+
+// seeds are the entries of marker_locations (ascending = np.flatnonzero order, checked): flag them
+__global__ void __launch_bounds__(256)
+k_wsr_seeds(const int64_t *__restrict__ locs, int64_t n_locs, int64_t n, uint8_t *__restrict__ seed, int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_locs) return;
+    const int64_t p = locs[i];
+    if (p < 0 || p >= n || (i > 0 && locs[i - 1] >= p)) { *bad = 1; return; }
+    seed[p] = 1;
+}
+
+// cls: 2 seed; 1 floodable (mask set, output 0); 0 anything else (masked out, or pre-labelled without being a seed)
+__global__ void __launch_bounds__(256)
+k_wsr_classify(const uint8_t *__restrict__ seed, const int32_t *__restrict__ output, const int8_t *__restrict__ mask, int64_t n,
+               uint8_t *__restrict__ cls, int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool sd = seed[i] != 0;
+    if (sd && output[i] == 0) *bad = 2;          // "output must already contain nonzero entries at all the seed locations"
+    cls[i] = sd ? 2 : ((mask[i] != 0 && output[i] == 0) ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(256)
+k_wsr_relevant(const uint8_t *__restrict__ cls, WsRavel g, uint8_t *__restrict__ flag)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.n) return;
+    const uint8_t c = cls[p];
+    uint8_t f = c == 1;
+    if (c == 2) {
+        const int fo = g.foff[p], bo = g.boff[p];
+        for (int i = 0; i < g.n_nbr && !f; i++) { const int64_t n = wsr_neighbour(g, p, fo, bo, i); f |= n >= 0 && cls[n] == 1; }
+    }
+    flag[p] = f;
+}
+
+__global__ void __launch_bounds__(256)
+k_wsr_compact(const float *__restrict__ image, const int *__restrict__ cid, WsRavel g, u64 *__restrict__ pix,
+              unsigned *__restrict__ val, int *__restrict__ nbr, u64 *__restrict__ K2, u64 *__restrict__ M1, int *__restrict__ nan_flag)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= g.n) return;
+    const int c = cid[p];
+    if (c == -1) return;
+    const bool marker = c < 0;
+    const int64_t id = marker ? -2 - c : c;
+    const int fo = g.foff[p], bo = g.boff[p];
+    const float fv = image[p];
+    if (fv != fv) *nan_flag = 1;
+    const unsigned v = ws_ordkey(fv);
+    pix[id] = (u64)p | (marker ? WS_MARKER_BIT : 0ull);
+    val[id] = v;
+    for (int i = 0; i < g.n_nbr; i++) {
+        const int64_t n = wsr_neighbour(g, p, fo, bo, i);
+        int cn = -1;
+        if (n >= 0) { cn = cid[n]; if (cn < 0) cn = -1; }
+        nbr[id * g.n_nbr + i] = cn;
+    }
+    K2[id] = marker ? ((u64)v << 32) : WS_INF;
+    M1[id] = WS_INF;
+}
+
+// in place: output[i] = label of its root seed for every flooded pixel (seeds and everything else untouched)
+__global__ void __launch_bounds__(256)
+k_wsr_labels(const int *__restrict__ cid, const u64 *__restrict__ Rt, int32_t *output, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cid[i];
+    if (c >= 0 && output[i] == 0) { const u64 r = Rt[c]; if (r != WS_INF) output[i] = output[r]; }
+}
+
 // chain arrays of a marker: C_k = 0 for every k; root = raster index
 __global__ void __launch_bounds__(256)
 k_ws_init_level(const u64 *__restrict__ pix, u64 *__restrict__ dst, int64_t R, int is_root)
@@ -633,22 +720,28 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
 
 // One call = classification / compaction, phase A, then root phases at increasing chain depth until the exactness
 // check finds no origin whose chains were cut off (or depth_max is reached).
+// `rv` != nullptr: the raveled form (tf_watershed_raveled): `field` = image, `markers` = `labels` = output (in place),
+// seeds = rv_locs; T, H, W, fwd, bwd, nbr_host unused.
 static int ws_run(const float *field, const int32_t *markers, const int8_t *mask,
                   const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                   const int8_t *nbr_host, int n_nbr, int depth0, int depth_max, int flags, int32_t *labels,
-                  uint8_t *amb_out, void *ws, size_t ws_bytes, int64_t *st, void *stream)
+                  uint8_t *amb_out, void *ws, size_t ws_bytes, int64_t *st, void *stream,
+                  const WsRavel *rv = nullptr, const int64_t *rv_locs = nullptr, int64_t rv_n_locs = 0)
 {
     TF_REQUIRE((flags & ~TF_WS_SKIP_FAST_PATH) == 0, "tf_watershed: unknown flag");
-    TF_REQUIRE(field && markers && fwd && bwd && nbr_host && labels && ws, "tf_watershed: null pointer");
-    TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15) && T < 65536, "tf_watershed: bad shape");
+    TF_REQUIRE(field && markers && labels && ws, "tf_watershed: null pointer");
+    if (!rv) {
+        TF_REQUIRE(fwd && bwd && nbr_host, "tf_watershed: null pointer");
+        TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15) && T < 65536, "tf_watershed: bad shape");
+    }
     TF_REQUIRE(n_nbr > 0 && n_nbr <= WS_MAX_NBR, "tf_watershed: bad neighbour count");
     TF_REQUIRE(depth0 >= 1 && depth0 <= depth_max && depth_max <= WS_MAX_DEPTH, "tf_watershed: bad chain_depth");
-    const int64_t N = T * H * W;
-    TF_REQUIRE(N <= 0x7fffffffll, "tf_watershed: more than 2^31 - 1 voxels per call (use time windows)");
+    const int64_t N = rv ? rv->n : T * H * W;
+    TF_REQUIRE(N > 0 && N <= 0x7fffffffll, "tf_watershed: more than 2^31 - 1 voxels per call (use time windows)");
     if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(1, n_nbr, depth_max)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
     hipStream_t s = (hipStream_t)stream;
     WsGeom g; g.T = T; g.H = (int)H; g.W = (int)W; g.plane = H * W; g.n_nbr = n_nbr;
-    for (int i = 0; i < n_nbr; i++) {
+    for (int i = 0; i < n_nbr && !rv; i++) {
         g.dt[i] = nbr_host[i * 3]; g.dy[i] = nbr_host[i * 3 + 1]; g.dx[i] = nbr_host[i * 3 + 2];
         TF_REQUIRE(abs(g.dt[i]) <= 1 && abs(g.dy[i]) <= 1 && abs(g.dx[i]) <= 1, "tf_watershed: neighbour offset out of range");
     }
@@ -662,13 +755,30 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     unsigned long long *d_cnt = ar.take<unsigned long long>(4);
     if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
 
-    dim3 block(64, 4, 1), grid((g.W + 63) / 64, (g.H + 3) / 4, (unsigned)T);
+    dim3 block(64, 4, 1), grid(rv ? 1 : (g.W + 63) / 64, rv ? 1 : (g.H + 3) / 4, rv ? 1 : (unsigned)T);
     const unsigned nb1 = (unsigned)((N + 255) / 256);
     int64_t R = 0;
     {
         TfProfScope ps(TFK_WS_SETUP, 29.0 * (double)N, s);
-        hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
-        hipLaunchKernelGGL(k_ws_relevant, grid, block, 0, s, cls, fwd, bwd, g, flag);
+        if (rv) {
+            // `flag` doubles as the seed bitmap until the relevance pass overwrites it (cls is final by then)
+            int *d_bad = d_flags + WS_BATCH + 5;
+            TF_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+            TF_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)N, s));
+            if (rv_n_locs > 0)
+                hipLaunchKernelGGL(k_wsr_seeds, dim3((unsigned)((rv_n_locs + 255) / 256)), dim3(256), 0, s, rv_locs, rv_n_locs, N, flag, d_bad);
+            hipLaunchKernelGGL(k_wsr_classify, dim3(nb1), dim3(256), 0, s, (const uint8_t *)flag, markers, mask, N, cls, d_bad);
+            TF_CHECK_LAUNCH();
+            int h_bad = 0;
+            TF_CHECK_HIP(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            TF_REQUIRE(h_bad != 1, "tf_watershed_raveled: marker_locations must be strictly ascending indices into the arrays (np.flatnonzero order)");
+            TF_REQUIRE(h_bad != 2, "tf_watershed_raveled: output must be non-zero at every marker location (_watershed.pyx:241-244)");
+            hipLaunchKernelGGL(k_wsr_relevant, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, *rv, flag);
+        } else {
+            hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
+            hipLaunchKernelGGL(k_ws_relevant, grid, block, 0, s, cls, fwd, bwd, g, flag);
+        }
         TF_CHECK_LAUNCH();
         size_t tb = scan_bytes;
         WsFlagIter it(flag, WsU8ToInt());
@@ -708,7 +818,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         TF_CHECK_HIP(hipMemsetAsync(d_nan, 0, sizeof(int), s));
         {
             TfProfScope ps(TFK_WS_SETUP, 0.0, s);
-            hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1, d_nan);
+            if (rv) hipLaunchKernelGGL(k_wsr_compact, dim3(nb1), dim3(256), 0, s, field, (const int *)cid, *rv, pix, val, nbr, c.K2, c.M1, d_nan);
+            else hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1, d_nan);
         }
         TF_CHECK_LAUNCH();
         {   // the reference's `smaller()` (_watershed.pyx:161-164) is not an order on NaN: its heap then pops in an order
@@ -766,8 +877,9 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     st[8] = depth; st[9] = (int64_t)h_amb[0]; st[10] = (int64_t)h_amb[1]; st[11] = (int64_t)h_amb[2];
     {
         TfProfScope ps(TFK_WS_LABELS, 12.0 * (double)N, s);
-        hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, c.Llo, c.Lhi, org, labels,
-                           R > 0 ? amb_out : nullptr, N);
+        if (rv) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)cid, (const u64 *)c.Rt, labels, N); }
+        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, c.Llo, c.Lhi, org, labels,
+                                R > 0 ? amb_out : nullptr, N);
     }
     TF_CHECK_LAUNCH();
     if (R == 0 && amb_out) TF_CHECK_HIP(hipMemsetAsync(amb_out, 0, (size_t)N, s));
@@ -813,4 +925,39 @@ extern "C" int tf_watershed(const float *field, const int32_t *markers, const in
 {
     return tf_watershed_ex(field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, chain_depth, 0, labels,
                            ws, ws_bytes, stats_host, stream);
+}
+
+// The reference's only native seam, argument for argument (tobac_flow/_watershed.pyx:222-233), on the GPU.
+extern "C" size_t tf_watershed_raveled_workspace_bytes(int64_t n, int n_structure, int max_depth, int64_t max_relevant)
+{
+    if (n <= 0 || n > 0x7fffffffll || max_depth < 1 || max_depth > WS_MAX_DEPTH || n_structure < 1 || n_structure > WS_MAX_NBR) return 0;
+    if (max_relevant <= 0 || max_relevant > n) max_relevant = n;
+    return ws_full_bytes(n) + ws_compact_bytes(max_relevant, n_structure, max_depth);
+}
+
+extern "C" int tf_watershed_raveled(const float *image, int64_t n, const int64_t *marker_locations, int64_t n_markers,
+                                    const int64_t *structure_host, int n_structure,
+                                    const int32_t *forward_offset, const int32_t *backward_offset,
+                                    const int32_t *forward_offset_locations_host, const int32_t *backward_offset_locations_host,
+                                    const int8_t *mask, const int32_t *strides_host, int n_strides, double compactness,
+                                    int32_t *output, int wsl, int max_depth, void *ws, size_t ws_bytes,
+                                    int64_t *stats_host, void *stream)
+{
+    TF_REQUIRE(image && structure_host && forward_offset && backward_offset && forward_offset_locations_host &&
+               backward_offset_locations_host && mask && output && ws && (marker_locations || n_markers == 0),
+               "tf_watershed_raveled: null pointer");
+    (void)strides_host; (void)n_strides;         // only used by the compact-watershed branch of the reference
+    TF_REQUIRE(compactness == 0.0 && !wsl, "tf_watershed_raveled: compactness > 0 and watershed lines are the dead branches of the "
+               "reference's call path (watershed.py:151-164 passes 0 and False) and are not built");
+    TF_REQUIRE(n_structure > 0 && n_structure <= WS_MAX_NBR, "tf_watershed_raveled: bad neighbour count");
+    WsRavel rv; rv.n = n; rv.n_nbr = n_structure; rv.foff = forward_offset; rv.boff = backward_offset;
+    for (int i = 0; i < n_structure; i++) {
+        rv.structure[i] = structure_host[i]; rv.floc[i] = forward_offset_locations_host[i]; rv.bloc[i] = backward_offset_locations_host[i];
+    }
+    int64_t st[TF_WS_NSTATS];
+    const int d0 = max_depth < 3 ? max_depth : 3;
+    const int rc = ws_run(image, output, mask, nullptr, nullptr, 0, 0, 0, nullptr, n_structure, d0, max_depth, 0, output,
+                          nullptr, ws, ws_bytes, st, stream, &rv, marker_locations, n_markers);
+    if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = st[i];
+    return rc;
 }
