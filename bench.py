@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--height", type=int, default=5424)
     ap.add_argument("--width", type=int, default=5424)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed vr_steps=0 comparison steps after the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -219,8 +220,9 @@ def main():
     nbr = neighbour_offsets(1)
     ws_stats = []                                            # tf_watershed stats of every step (warmup included)
 
-    def step():
-        flow = tf.create_flow(bt, model="Farneback", vr_steps=a.vr_steps, smoothing_passes=1, interp_method="cubic")
+    def step(vr_steps=None):
+        flow = tf.create_flow(bt, model="Farneback", vr_steps=a.vr_steps if vr_steps is None else vr_steps,
+                              smoothing_passes=1, interp_method="cubic")
         # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
         e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
@@ -246,6 +248,16 @@ def main():
     dt = time.perf_counter() - t0
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
+    # for comparison with round 1 (which had no refinement): two extra steps with vr_steps = 0, outside the timed region
+    ms_no_vr = None
+    if a.vr_steps > 0 and not a.no_extra:
+        step(0)
+        barrier()
+        t1 = time.perf_counter()
+        step(0)
+        step(0)
+        barrier()
+        ms_no_vr = (time.perf_counter() - t1) / 2 * 1e3
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=bt.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -299,6 +311,10 @@ def main():
                             "marker_tie_points": timed[-1][10], "ties_left_by_depth_cut_off": timed[-1][11],
                             "timed_steps_probing": sum(1 for t_ in timed if t_[5] >= 0),
                             "timed_steps_skipping_root_phase": sum(1 for t_ in timed if t_[5] < 0)}
+        if ms_no_vr is not None:
+            out["without_refinement"] = {"ms_per_step": round(ms_no_vr, 2), "value": round(world * T * H * W / ms_no_vr / 1e3, 2),
+                                         "note": "same step with create_flow(vr_steps=0), 2 steps after the timed region: the "
+                                                 "schedule round 1 measured (the refinement did not exist then)"}
         if not a.no_cpu_baseline and world == 1:             # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(20240601)
             out["cv2_parity"] = cv2_parity()
