@@ -49,7 +49,7 @@ def _traffic(profile_name):
         return None
 
 
-def cpu_baseline(seed):
+def cpu_baseline(seed, vr_steps=1):
     """The oracle (CPU restatement of the reference's cv2/numpy/Cython path, kind = "port") timed on the host cores of
     this box on a bounded sample of the same workload: a 5 x 1536 x 1536 stack.  The order-independent stages run on a
     thread pool (Farneback: one task per frame pair and direction; Sobel: one task per frame -- the C restatements and
@@ -81,7 +81,10 @@ def cpu_baseline(seed):
     with warnings.catch_warnings(), ThreadPoolExecutor(threads) as pool:
         warnings.simplefilter("ignore")
         p8 = [np_ops.to_8bit(np_ops.linear_norm(bt[i:i + 2].copy()), 0, 1) for i in range(T - 1)]
-        raw = list(pool.map(fb, [(p[0], p[1]) for p in p8] + [(p[1], p[0]) for p in p8]))
+        pairs = [(p[0], p[1]) for p in p8] + [(p[1], p[0]) for p in p8]
+        raw = list(pool.map(fb, pairs))
+        if vr_steps > 0:                                     # flow.py:513-519: one refinement per direction
+            raw = list(pool.map(lambda k: np_ops.variational_refinement(pairs[k][0], pairs[k][1], raw[k]), range(len(pairs))))
         sm = list(pool.map(lambda i: np_ops.smooth_flow_step(raw[i], raw[T - 1 + i], "cubic"), range(T - 1)))
         for i, (f, b) in enumerate(sm):
             fw[i], bw[i + 1] = f, b
@@ -104,7 +107,7 @@ def cpu_baseline(seed):
     dt = time.perf_counter() - t0
     return {"value": round(T * H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": threads, "kind": "port",
             "sample": f"{T}x{H}x{W} synthetic stack, same stage sequence, oracle (C/numpy restatement of the "
-                      f"cv2+scipy+Cython path): flow {t_flow:.1f} s and Sobel {t_sobel:.1f} s on {threads} threads, flood "
+                      f"cv2+scipy+Cython path{', with the refinement' if vr_steps > 0 else ''}): flow {t_flow:.1f} s and Sobel {t_sobel:.1f} s on {threads} threads, flood "
                       f"{dt - t_flow - t_sobel:.1f} s on one (sequential heap), {dt:.1f} s in all; host has {os.cpu_count()} cores"}
 
 
@@ -316,7 +319,7 @@ def main():
                                          "note": "same step with create_flow(vr_steps=0), 2 steps after the timed region: the "
                                                  "schedule round 1 measured (the refinement did not exist then)"}
         if not a.no_cpu_baseline and world == 1:             # reported baseline: rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(20240601)
+            out["cpu_baseline"] = cpu_baseline(20240601, a.vr_steps)
             out["cv2_parity"] = cv2_parity()
         print(json.dumps(out))
     if dist is not None:
