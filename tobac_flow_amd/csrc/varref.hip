@@ -183,26 +183,30 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 
 // ---- all sorIterations red-black sweeps of one fixed-point iteration in ONE pass over HBM -------------------------
 // A half sweep only reads the four neighbours of the other colour, so 2 * sorIterations half sweeps of a tile need a
-// halo of 2 * sorIterations pixels and nothing else.  One 512-thread workgroup owns a 128 x 64 tile + VRT_HALO: every
-// thread keeps the system (A11, A22, b1, b2, A12) and the weight of ITS pixel pairs in registers for the whole kernel;
-// only dW and the weights of the left / upper neighbours live in LDS (12 B / px, 149 KB), in OpenCV's own red-black
-// split: the pixels of one colour of a row are contiguous, so a wave's neighbour reads are unit-stride.  The outermost
-// ring is never updated and invalid values creep inwards one pixel per half sweep -- they stop short of the tile.
+// halo of 2 * sorIterations pixels and nothing else.  One 512-thread workgroup owns a 108 x 84 tile + VRT_HALO = a
+// 128 x 104 region: wave w owns the rows w, w + 8, ... (13 of them), lane l the pixel pair (2l, 2l + 1) of each.  Every
+// thread keeps the system (A11, A22, b1, b2, A12) and the weight of ITS pixels in registers for the whole kernel, sorted
+// by COLOUR (which pixel of a pair is red depends on the row parity = the wave parity, a per-wave constant); only dW and
+// the weights of the left / upper neighbours live in LDS (12 B / px, 156 KB), in OpenCV's own red-black split: the
+// pixels of one colour of a row are contiguous, so a wave's neighbour reads are unit-stride, all LDS addresses are one
+// per-wave base + compile-time offsets, and row activity is a scalar branch.  The outermost ring is never updated and
+// invalid values creep inwards one pixel per half sweep -- they stop short of the tile; half sweep s therefore skips the
+// rows closer than s to the region's edge (their values can no longer reach the tile).
 // Same expressions in the same order as k_vr_sor: bit-identical results (tests compare the two paths).
-// Measured alternatives (12 x 5424^2, ms per step for all 110 launches): 512 threads / 13 pixel pairs per thread /
-// 256 VGPRs: 93.2 (kept); 1024 threads / 7 pairs / 128 VGPRs with a small spill: 95.9.  One workgroup per CU either
-// way (149 KB of LDS): the tile load is not overlapped with the sweeps, and ten block-wide barriers per launch keep half
-// of the wave cycles waiting (profiles/round2_pmc_sq_summary.txt).
-#define VRT_W 128
-#define VRT_H 64
+// Measured alternatives (12 x 5424^2, ms per step for all 110 launches): 128 x 64 tile, thread -> pair q = t + 512 k
+// (row and pair parity vary inside a wave: per-pixel index arithmetic, activity predicates and value selects between the
+// two pixels of a pair), 256 VGPRs: 93.2; the same with 1024 threads / 7 pairs / 128 VGPRs and a small spill: 95.9.
+#define VRT_W 108
+#define VRT_H 84
 #define VRT_HALO 10
 #define VRT_RW (VRT_W + 2 * VRT_HALO)
 #define VRT_RH (VRT_H + 2 * VRT_HALO)
 #define VRT_PW (VRT_RW / 2)
-#define VRT_NPAIR (VRT_PW * VRT_RH)
 #define VRT_THREADS 512
-#define VRT_K ((VRT_NPAIR + VRT_THREADS - 1) / VRT_THREADS)
+#define VRT_WAVES (VRT_THREADS / 64)
+#define VRT_K (VRT_RH / VRT_WAVES)
 #define VRT_LDS_BYTES (2 * VRT_RH * VRT_PW * 12)
+static_assert(VRT_PW == 64 && VRT_RH % VRT_WAVES == 0, "one wave per region row, whole rows per wave");
 
 __global__ void __launch_bounds__(VRT_THREADS, 2)
 k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
@@ -212,71 +216,73 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
     float2 *l_dw = (float2 *)vr_lds;                                   // [2][VRT_RH][VRT_PW]
     float *l_wt = (float *)(vr_lds + 2 * VRT_RH * VRT_PW * 8);         // [2][VRT_RH][VRT_PW]
     const int x0 = blockIdx.x * VRT_W - VRT_HALO, y0 = blockIdx.y * VRT_H - VRT_HALO;
-    const int par0 = (x0 + y0) & 1;                                    // image colour of local (0, 0)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cp = threadIdx.x & 63;
+    // [ci]: image colour (0 red, 1 black).  A pixel of image colour ci has local parity lp = (r + c) & 1 = ci ^ par0 and
+    // sits in column 2 cp + e with e = (lp + r) & 1; r = wv + 8 k has the parity of wv
+    const int par0 = (x0 + y0) & 1;
+    int e_[2], own_[2];
+    bool colact[2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ci++) {
+        const int lp = ci ^ par0;
+        e_[ci] = (lp + wv) & 1;
+        own_[ci] = (lp * VRT_RH + wv) * VRT_PW + cp;                   // + k * VRT_WAVES * VRT_PW
+        const int c = 2 * cp + e_[ci], x = x0 + c;
+        colact[ci] = c > 0 && c < VRT_RW - 1 && x >= 0 && x < W;
+    }
     float a11[VRT_K][2], a22[VRT_K][2], b1[VRT_K][2], b2[VRT_K][2], a12[VRT_K][2], wp[VRT_K][2];
 #pragma unroll
     for (int k = 0; k < VRT_K; k++) {
-        const int q = threadIdx.x + k * VRT_THREADS;
-        const int r = q / VRT_PW, cp = q - r * VRT_PW;
+        const int r = wv + k * VRT_WAVES, y = y0 + r;
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int c = 2 * cp + e, x = x0 + c, y = y0 + r;
-            const bool in = q < VRT_NPAIR && x >= 0 && y >= 0 && x < W && y < H;
+        for (int ci = 0; ci < 2; ci++) {
+            const int x = x0 + 2 * cp + e_[ci];
+            const bool in = x >= 0 && y >= 0 && x < W && y < H;
             const int64_t p = in ? (int64_t)y * W + x : 0;
             const float4 sv = in ? S[p] : make_float4(1.f, 1.f, 0.f, 0.f);
-            a11[k][e] = sv.x; a22[k][e] = sv.y; b1[k][e] = sv.z; b2[k][e] = sv.w;
-            a12[k][e] = in ? A12[p] : 0.f;
-            wp[k][e] = in ? wt[p] : 0.f;
-            const float2 d = in ? dW_in[p] : make_float2(0.f, 0.f);
-            if (q < VRT_NPAIR) {
-                const int lp = (r + c) & 1;
-                l_dw[(lp * VRT_RH + r) * VRT_PW + cp] = d;
-                l_wt[(lp * VRT_RH + r) * VRT_PW + cp] = wp[k][e];
-            }
+            a11[k][ci] = sv.x; a22[k][ci] = sv.y; b1[k][ci] = sv.z; b2[k][ci] = sv.w;
+            a12[k][ci] = in ? A12[p] : 0.f;
+            wp[k][ci] = in ? wt[p] : 0.f;
+            l_dw[own_[ci] + k * VRT_WAVES * VRT_PW] = in ? dW_in[p] : make_float2(0.f, 0.f);
+            l_wt[own_[ci] + k * VRT_WAVES * VRT_PW] = wp[k][ci];
         }
     }
     __syncthreads();
-    for (int s = 0; s < n_half; s++) {
-        const int colour = s & 1;
+    for (int s = 0; s < n_half; s += 2) {
 #pragma unroll
-        for (int k = 0; k < VRT_K; k++) {
-            const int q = threadIdx.x + k * VRT_THREADS;
-            const int r = q / VRT_PW, cp = q - r * VRT_PW;
-            const int e = (par0 + r + colour) & 1;                     // which pixel of the pair has this colour
-            const int c = 2 * cp + e, x = x0 + c, y = y0 + r;
-            const bool act = q < VRT_NPAIR && r > 0 && r < VRT_RH - 1 && c > 0 && c < VRT_RW - 1 && x >= 0 && y >= 0 && x < W && y < H;
-            if (act) {
-                const int lp = (r + c) & 1, op = lp ^ 1;
-                const int row = (op * VRT_RH + r) * VRT_PW;
-                const float2 dl = l_dw[row + cp - (1 - e)], dr = l_dw[row + cp + e];
-                const float2 du_ = l_dw[row - VRT_PW + cp], dd = l_dw[row + VRT_PW + cp];
-                const float wl = l_wt[row + cp - (1 - e)], wu = l_wt[row - VRT_PW + cp];
-                // value selects (a select between two array ELEMENTS would be a select of addresses and push the
-                // arrays into scratch)
-                const float w0 = wp[k][0], w1 = wp[k][1], p0 = a11[k][0], p1 = a11[k][1], q0 = a22[k][0], q1 = a22[k][1];
-                const float r0 = b1[k][0], r1 = b1[k][1], t0 = b2[k][0], t1 = b2[k][1], c0 = a12[k][0], c1 = a12[k][1];
-                const float w = e ? w1 : w0, a = e ? c1 : c0;
-                const float4 sv = make_float4(e ? p1 : p0, e ? q1 : q0, e ? r1 : r0, e ? t1 : t0);
-                float2 d = l_dw[(lp * VRT_RH + r) * VRT_PW + cp];
-                const float sigmaU = wl * dl.x + w * dr.x + wu * du_.x + w * dd.x;
-                const float sigmaV = wl * dl.y + w * dr.y + wu * du_.y + w * dd.y;
-                d.x += omega * ((sigmaU + sv.z - d.y * a) / sv.x - d.x);
-                d.y += omega * ((sigmaV + sv.w - d.x * a) / sv.y - d.y);
-                l_dw[(lp * VRT_RH + r) * VRT_PW + cp] = d;
+        for (int ci = 0; ci < 2; ci++) {
+            // neighbours live in the other colour's plane: left = pair cp - (1 - e), right = pair cp + e, up / down = cp
+            const int opb = own_[ci ^ 1], lft = opb - (1 - e_[ci]), rgt = opb + e_[ci];
+            const int reach = s + ci + 1;                              // 1-based index of this half sweep
+#pragma unroll
+            for (int k = 0; k < VRT_K; k++) {
+                const int r = wv + k * VRT_WAVES, y = y0 + r, o = k * VRT_WAVES * VRT_PW;
+                if (r < reach || r > VRT_RH - 1 - reach || y < 0 || y >= H) continue;      // wave-uniform
+                if (colact[ci]) {
+                    const float2 dl = l_dw[lft + o], dr = l_dw[rgt + o];
+                    const float2 du_ = l_dw[opb + o - VRT_PW], dd = l_dw[opb + o + VRT_PW];
+                    const float wl = l_wt[lft + o], wu = l_wt[opb + o - VRT_PW];
+                    const float w = wp[k][ci];
+                    float2 d = l_dw[own_[ci] + o];
+                    const float sigmaU = wl * dl.x + w * dr.x + wu * du_.x + w * dd.x;
+                    const float sigmaV = wl * dl.y + w * dr.y + wu * du_.y + w * dd.y;
+                    d.x += omega * ((sigmaU + b1[k][ci] - d.y * a12[k][ci]) / a11[k][ci] - d.x);
+                    d.y += omega * ((sigmaV + b2[k][ci] - d.x * a12[k][ci]) / a22[k][ci] - d.y);
+                    l_dw[own_[ci] + o] = d;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int k = 0; k < VRT_K; k++) {
-        const int q = threadIdx.x + k * VRT_THREADS;
-        const int r = q / VRT_PW, cp = q - r * VRT_PW;
-        if (q >= VRT_NPAIR || r < VRT_HALO || r >= VRT_HALO + VRT_H) continue;
+        const int r = wv + k * VRT_WAVES, y = y0 + r;
+        if (r < VRT_HALO || r >= VRT_HALO + VRT_H || y >= H) continue;
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int c = 2 * cp + e, x = x0 + c, y = y0 + r;
-            if (c < VRT_HALO || c >= VRT_HALO + VRT_W || x >= W || y >= H) continue;
-            dW_out[(int64_t)y * W + x] = l_dw[(((r + c) & 1) * VRT_RH + r) * VRT_PW + cp];
+        for (int ci = 0; ci < 2; ci++) {
+            const int c = 2 * cp + e_[ci], x = x0 + c;
+            if (c < VRT_HALO || c >= VRT_HALO + VRT_W || x >= W) continue;
+            dW_out[(int64_t)y * W + x] = l_dw[own_[ci] + k * VRT_WAVES * VRT_PW];
         }
     }
 }
