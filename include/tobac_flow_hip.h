@@ -343,6 +343,11 @@ int tf_profile_kernel_count(void);
 const char *tf_profile_kernel_name(int id);
 int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
 
+/* SURVEY.md 8(b) "ownership": the library never retains a caller's pointer past return and owns no device memory (all
+ * scratch is the caller's workspace); its only pooled resource is the HIP events of the timing facility above.
+ * tf_shutdown() switches timing off and destroys them.  Idempotent; the library remains usable afterwards. */
+int tf_shutdown(void);
+
 #ifdef __cplusplus
 }
 #endif

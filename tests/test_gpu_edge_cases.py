@@ -333,3 +333,22 @@ def test_development_switches_do_not_change_results(tf, tmp_path):
         subprocess.check_call([sys.executable, "-c", code % (root, str(tmp_path / "in.npy"), str(out))], env=env)
         alt = np.load(out)
         assert np.array_equal(alt[0], fw, equal_nan=True) and np.array_equal(alt[1], bw, equal_nan=True), var
+
+
+def test_shutdown_releases_the_timing_pool_and_leaves_the_library_usable(tf):
+    """tf_shutdown (SURVEY 8(b) ownership row): timing off, pooled events destroyed, idempotent, library still works."""
+    from tobac_flow_amd import _lib
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 255, (40, 50)).astype(np.uint8)
+    b = rng.integers(0, 255, (40, 50)).astype(np.uint8)
+    flow0 = rng.normal(size=(40, 50, 2)).astype(np.float32)
+    vr = tf.VariationalRefinement.create()
+    _lib.profile_enable(True)
+    want = vr.calc(a, b, flow0.copy())
+    assert _lib.profile_collect()                     # something was timed
+    vr.calc(a, b, flow0.copy())                       # leaves recorded, uncollected events behind
+    L = _lib.lib()
+    assert L.tf_shutdown() == 0 and L.tf_shutdown() == 0
+    got = vr.calc(a, b, flow0.copy())
+    assert np.array_equal(got, want)
+    assert _lib.profile_collect() == {}               # timing is off after shutdown, nothing left over

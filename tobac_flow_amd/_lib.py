@@ -87,6 +87,7 @@ _PROTOS = {
     "tf_profile_kernel_count": (_c.c_int, []),
     "tf_profile_kernel_name": (_c.c_char_p, [_c.c_int]),
     "tf_profile_collect": (_c.c_int, [_P, _P, _P]),
+    "tf_shutdown": (_c.c_int, []),
 }
 
 EXPORTS = tuple(_PROTOS)

@@ -60,3 +60,14 @@ extern "C" int tf_profile_collect(int64_t *calls, double *ms, double *bytes) {
     g_recs.clear();
     return TF_OK;
 }
+
+// The library keeps no device memory of its own (every workspace is the caller's); the only pooled resource is the HIP
+// events of the timing facility.  tf_shutdown() turns timing off and destroys them; the library stays usable.
+extern "C" int tf_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_tf_prof_on = false;
+    for (auto &r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : g_free) (void)hipEventDestroy(e);
+    g_recs.clear(); g_free.clear();
+    return TF_OK;
+}
