@@ -95,7 +95,8 @@ k_vr_weights(const float2 *__restrict__ Wf, const float2 *__restrict__ dW, int H
     if (x >= W || y >= H) return;
     const int64_t j = (int64_t)y * W + x;
     const int64_t jr = x + 1 < W ? j + 1 : j, jd = y + 1 < H ? j + W : j;
-    const float2 w0 = Wf[j], d0 = dW[j], wr = Wf[jr], dr = dW[jr], wd = Wf[jd], dd = dW[jd];
+    const float2 z = make_float2(0.f, 0.f);                            // dW == nullptr: the first iteration's dW = 0
+    const float2 w0 = Wf[j], d0 = dW ? dW[j] : z, wr = Wf[jr], dr = dW ? dW[jr] : z, wd = Wf[jd], dd = dW ? dW[jd] : z;
     const float cu = w0.x + d0.x, cv = w0.y + d0.y;
     const float ux = (wr.x + dr.x) - cu, vx = (wr.y + dr.y) - cv, uy = (wd.x + dd.x) - cu, vy = (wd.y + dd.y) - cv;
     wt[j] = P.alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + P.eps2);
@@ -111,7 +112,7 @@ k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const 
     const int64_t j = (int64_t)y * W + x;
     const float4 d1 = D1[j], d2 = D2[j];
     const float Ix = d1.x, Iy = d1.y, Ixz = d1.z, Iyz = d1.w, Ixx = d2.x, Ixy = d2.y, Iyy = d2.z, Iz = d2.w;
-    const float2 d = dW[j];
+    const float2 d = dW ? dW[j] : make_float2(0.f, 0.f);
     const float du = d.x, dv = d.y;
     // ComputeDataTerm
     float derivNorm = Ix * Ix + Iy * Iy + P.zeta2;
@@ -193,6 +194,9 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 // invalid values creep inwards one pixel per half sweep -- they stop short of the tile; half sweep s therefore skips the
 // rows closer than s to the region's edge (their values can no longer reach the tile).
 // Same expressions in the same order as k_vr_sor: bit-identical results (tests compare the two paths).
+// dW_in == nullptr stands for dW = 0 (first fixed-point iteration); Wadd != nullptr (last iteration) makes the kernel
+// store W + dW, the refined flow, instead of dW -- dW_out may then be the flow array itself (this kernel never reads W
+// except at the pixel a thread is about to write).
 // Measured alternatives (12 x 5424^2, ms per step for all 110 launches): 128 x 64 tile, thread -> pair q = t + 512 k
 // (row and pair parity vary inside a wave: per-pixel index arithmetic, activity predicates and value selects between the
 // two pixels of a pair), 256 VGPRs: 93.2; the same with 1024 threads / 7 pairs / 128 VGPRs and a small spill: 95.9.
@@ -210,7 +214,7 @@ static_assert(VRT_PW == 64 && VRT_RH % VRT_WAVES == 0, "one wave per region row,
 
 __global__ void __launch_bounds__(VRT_THREADS, 2)
 k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
-              int n_half, float omega, const float2 *__restrict__ dW_in, float2 *__restrict__ dW_out)
+              int n_half, float omega, const float2 *__restrict__ dW_in, const float2 *Wadd, float2 *dW_out)
 {
     extern __shared__ __align__(16) unsigned char vr_lds[];
     float2 *l_dw = (float2 *)vr_lds;                                   // [2][VRT_RH][VRT_PW]
@@ -243,7 +247,7 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
             a11[k][ci] = sv.x; a22[k][ci] = sv.y; b1[k][ci] = sv.z; b2[k][ci] = sv.w;
             a12[k][ci] = in ? A12[p] : 0.f;
             wp[k][ci] = in ? wt[p] : 0.f;
-            l_dw[own_[ci] + k * VRT_WAVES * VRT_PW] = in ? dW_in[p] : make_float2(0.f, 0.f);
+            l_dw[own_[ci] + k * VRT_WAVES * VRT_PW] = (in && dW_in) ? dW_in[p] : make_float2(0.f, 0.f);
             l_wt[own_[ci] + k * VRT_WAVES * VRT_PW] = wp[k][ci];
         }
     }
@@ -282,13 +286,16 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
         for (int ci = 0; ci < 2; ci++) {
             const int c = 2 * cp + e_[ci], x = x0 + c;
             if (c < VRT_HALO || c >= VRT_HALO + VRT_W || x >= W) continue;
-            dW_out[(int64_t)y * W + x] = l_dw[own_[ci] + k * VRT_WAVES * VRT_PW];
+            const int64_t p = (int64_t)y * W + x;
+            float2 d = l_dw[own_[ci] + k * VRT_WAVES * VRT_PW];
+            if (Wadd) { const float2 w = Wadd[p]; d = make_float2(w.x + d.x, w.y + d.y); }   // last iteration: the refined flow
+            dW_out[p] = d;
         }
     }
 }
 
 __global__ void __launch_bounds__(256)
-k_vr_finish(const float2 *__restrict__ Wf, const float2 *__restrict__ dW, int64_t n, float2 *__restrict__ out)
+k_vr_finish(const float2 *Wf, const float2 *__restrict__ dW, int64_t n, float2 *out)     // out may be Wf
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -306,8 +313,8 @@ extern "C" size_t tf_varref_workspace_bytes(int64_t H, int64_t W)
 {
     if (H <= 0 || W <= 0) return 0;
     const size_t n = (size_t)H * W;
-    // D1, D2, S (float4), A12, wt (float), W copy, dW and its ping-pong partner (float2)
-    return 3 * tf_align_up(n * 16, 256) + 2 * tf_align_up(n * 4, 256) + 3 * tf_align_up(n * 8, 256) + 4096;
+    // D1, D2, S (float4), A12, wt (float), dW and its ping-pong partner (float2)
+    return 3 * tf_align_up(n * 16, 256) + 2 * tf_align_up(n * 4, 256) + 2 * tf_align_up(n * 8, 256) + 4096;
 }
 
 extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
@@ -323,18 +330,18 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
     TfArena ar(ws, ws_bytes);
     float4 *D1 = ar.take<float4>(n), *D2 = ar.take<float4>(n), *S = ar.take<float4>(n);
     float *A12 = ar.take<float>(n), *wt = ar.take<float>(n);
-    float2 *Wf = ar.take<float2>(n), *dW = ar.take<float2>(n), *dW2 = ar.take<float2>(n);
+    float2 *dW = ar.take<float2>(n), *dW2 = ar.take<float2>(n);
     if (!ar.ok()) { tf_set_error("tf_varref: workspace too small"); return TF_ENOMEM; }
     VrP P;
     P.alpha2 = params->alpha / 4; P.delta2 = params->delta / 2; P.gamma2 = params->gamma / 2; P.omega = params->omega;
     P.zeta2 = 0.1f * 0.1f; P.eps2 = 0.001f * 0.001f;
-    TF_CHECK_HIP(hipMemcpyAsync(Wf, flow, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-    TF_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)n * 8, s));
+    // W is the caller's flow array itself: it is only read until the last kernel replaces it by W + dW
+    const float2 *Wf = (const float2 *)flow;
     const int iH = (int)H, iW = (int)W;
     {
         TfProfScope ps(TFK_VR_PREPARE, (1.0 + 1.0 + 8.0 + 32.0) * (double)n, s);
         hipLaunchKernelGGL(k_vr_prepare, dim3((iW + VR_TW - 1) / VR_TW, (iH + VR_TH - 1) / VR_TH), dim3(256), 0, s,
-                           I0, I1, (const float2 *)Wf, iH, iW, D1, D2);
+                           I0, I1, Wf, iH, iW, D1, D2);
     }
     TF_CHECK_LAUNCH();
     const dim3 g1((iW + 63) / 64, (iH + 3) / 4), g2(((iW + 1) / 2 + 63) / 64, (iH + 3) / 4);
@@ -349,21 +356,31 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
             attr_set = true;
         }
     }
+    const bool tile_path = tiled && params->sor_iterations > 0;
+    // dW = 0 at the start: the tiled path passes "no dW" to the first iteration's kernels, the sweep path needs the array
+    const float2 *dW_cur = nullptr;
+    if (!tile_path) { TF_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)n * 8, s)); dW_cur = dW; }
+    bool flow_done = false;
     for (int it = 0; it < params->fixed_point_iterations; it++) {
         {
-            TfProfScope ps(TFK_VR_SYSTEM, (16.0 + 4.0 + 32.0 + 16.0 + 4.0 + 20.0) * (double)n, s);
-            hipLaunchKernelGGL(k_vr_weights, g1, dim3(256), 0, s, (const float2 *)Wf, (const float2 *)dW, iH, iW, P, wt);
-            hipLaunchKernelGGL(k_vr_system, g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, (const float2 *)Wf,
-                               (const float2 *)dW, (const float *)wt, iH, iW, P, S, A12);
+            // algorithmic bytes: weights W 8 + dW 8 r, 4 w; system D1 + D2 32, W 8, dW 8, weight 4 r, S 16 + A12 4 w
+            TfProfScope ps(TFK_VR_SYSTEM, (16.0 + 4.0 + 32.0 + 16.0 + 4.0 + 20.0 - (dW_cur ? 0.0 : 16.0)) * (double)n, s);
+            hipLaunchKernelGGL(k_vr_weights, g1, dim3(256), 0, s, Wf, dW_cur, iH, iW, P, wt);
+            hipLaunchKernelGGL(k_vr_system, g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
+                               dW_cur, (const float *)wt, iH, iW, P, S, A12);
         }
         TF_CHECK_LAUNCH();
-        if (tiled && params->sor_iterations > 0) {
-            // algorithmic bytes: system 20 + weight 4 + dW 8 read, dW 8 written, once per fixed-point iteration
-            TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + 8.0 + 8.0) * (double)n, s);
+        if (tile_path) {
+            // algorithmic bytes: system 20 + weight 4 + dW 8 read, dW 8 written, once per fixed-point iteration (no dW
+            // to read in the first; W 8 more to read in the last, which writes the refined flow)
+            const bool last = it == params->fixed_point_iterations - 1;
+            TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + (dW_cur ? 8.0 : 0.0) + (last ? 8.0 : 0.0) + 8.0) * (double)n, s);
+            float2 *dst = last ? (float2 *)flow : (dW_cur == dW ? dW2 : dW);
             hipLaunchKernelGGL(k_vr_sor_tile, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
                                VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
-                               2 * params->sor_iterations, P.omega, (const float2 *)dW, dW2);
-            float2 *t = dW; dW = dW2; dW2 = t;
+                               2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);
+            dW_cur = dst;
+            flow_done = last;
         } else {
             TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + 8.0 + 8.0) * (double)n * params->sor_iterations, s);
             for (int k = 0; k < params->sor_iterations; k++) {
@@ -373,7 +390,11 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
         }
         TF_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_vr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float2 *)Wf, (const float2 *)dW, n, (float2 *)flow);
-    TF_CHECK_LAUNCH();
+    if (!flow_done) {
+        // no tiled last iteration (sweep path, or no iterations at all): flow = W + dW, with dW = 0 if nothing ran
+        if (!dW_cur) { TF_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)n * 8, s)); dW_cur = dW; }
+        hipLaunchKernelGGL(k_vr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wf, dW_cur, n, (float2 *)flow);
+        TF_CHECK_LAUNCH();
+    }
     return TF_OK;
 }
