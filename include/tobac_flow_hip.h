@@ -333,6 +333,17 @@ int tf_window_overlap_pairs(const int32_t *left, const int32_t *right, int64_t n
                             int32_t *pairs_host, int64_t max_pairs, int64_t *n_pairs_host,
                             void *ws, size_t ws_bytes, void *stream);
 
+/* tf_slice_labels: tobac_flow/utils/label_utils.py:312-349 (`slice_labels`, the `*_step_label` variables of the output
+ *   files, tobac_flow/dataset.py:189-229): one id per (label, time step) of an int32 (T, hw) label volume -- the pieces of
+ *   a label inside one step stay together -- numbered densely from 1 in ascending (step, label) order; 0 (and anything
+ *   negative) stays 0.  (As in the reference, a volume in which NO voxel is 0 loses its smallest shifted id to 0: the
+ *   dense LUT is np.arange over the ids that occur.)  *n_step_labels_host = the largest id written.  The workspace holds two int32 per shifted id (sum over
+ *   steps of the step's largest label, `id_capacity`); if it is too small the call returns TF_ENOMEM with
+ *   *n_step_labels_host = the capacity to size a retry with.  Synchronises the stream. */
+size_t tf_slice_labels_workspace_bytes(int64_t T, int64_t id_capacity);
+int tf_slice_labels(const int32_t *labels, int64_t T, int64_t hw, int32_t *out, int64_t *n_step_labels_host,
+                    void *ws, size_t ws_bytes, void *stream);
+
 /* ---- measurement aid (bench.py's roofline figure) ---------------------------------------------
  * tf_profile_enable(1): every kernel launch of the library is bracketed by HIP events on its own
  * stream and tagged with its ALGORITHMIC byte count.  tf_profile_collect() synchronises

@@ -352,3 +352,35 @@ def test_remap_lanczos4_identities():
     out = np_ops.remap(img, np.stack([xx + 0.5, yy], -1), "lanczos", np.nan)
     assert np.isnan(out[:, -4:]).all() and np.isfinite(out[8:-8, 8:-8]).all()
     assert np.isnan(np_ops.remap(img, np.stack([xx + 100, yy], -1), "lanczos", np.nan)).all()
+
+
+def test_label_contract_oracle_known_answers():
+    """oracle/np_dataset.py on a case small enough to work out by hand (the reference holds no fixture for dataset.py)."""
+    from oracle import np_dataset as D
+    core = np.zeros((2, 4, 4), np.int32); core[0, 1, 1] = 1; core[1, 1, 1] = 1; core[1, 3, 3] = 2
+    thick = np.zeros_like(core); thick[:, 0:3, 0:3] = 5
+    thin = thick.copy(); thin[1, 3, 2:4] = 6
+    ds = {"core_label": core, "thick_anvil_label": thick, "thin_anvil_label": thin, "coords": {}}
+    D.add_label_coords(ds)
+    D.link_cores_and_anvils(ds, atol=1)
+    # core 1 lies in anvil 5 (2 px), core 2 over background only -> no anvil
+    assert ds["core_anvil_index"].tolist() == [5, 0] and ds["anvil_core_count"].tolist() == [1, 0]
+    D.add_step_labels(ds)
+    D.add_label_coords(ds)
+    # step ids ascend by (step, label): core 1 @ t0 -> 1, core 1 @ t1 -> 2, core 2 @ t1 -> 3
+    assert ds["core_step_label"][0, 1, 1] == 1 and ds["core_step_label"][1, 1, 1] == 2 and ds["core_step_label"][1, 3, 3] == 3
+    assert ds["coords"]["core_step"].tolist() == [1, 2, 3] and ds["coords"]["anvil"].tolist() == [5, 6]
+    D.link_step_labels(ds)
+    assert ds["core_step_core_index"].tolist() == [1, 1, 2]
+    assert ds["thick_anvil_step_anvil_index"].tolist() == [5, 5] and ds["thin_anvil_step_anvil_index"].tolist() == [5, 5, 6]
+    D.flag_edge_labels(ds)
+    assert ds["core_edge_label_flag"].tolist() == [False, True]          # core 2 sits in the corner
+    assert ds["core_start_label_flag"].tolist() == [True, False] and ds["core_end_label_flag"].tolist() == [True, True]
+    assert ds["thin_anvil_edge_label_flag"].tolist() == [True, True]
+    # atol above the overlap: no link
+    ds2 = {"core_label": core, "thick_anvil_label": thick.copy(), "thin_anvil_label": thin.copy(), "coords": {}}
+    D.add_label_coords(ds2); D.link_cores_and_anvils(ds2, atol=3)
+    assert ds2["core_anvil_index"].tolist() == [0, 0]
+    # slice_labels: a step without labels leaves no gap in the numbering
+    lab = np.zeros((3, 2, 2), np.int32); lab[0, 0, 0] = 7; lab[2, 1, 1] = 2; lab[2, 0, 1] = 7
+    assert D.slice_labels(lab)[[0, 2, 2], [0, 1, 0], [0, 1, 1]].tolist() == [1, 2, 3]

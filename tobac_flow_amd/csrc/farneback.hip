@@ -88,19 +88,36 @@ template <typename TIn>
 __global__ void __launch_bounds__(256)
 k_fb_blur3_fused(const TIn *__restrict__ src, int H, int W, const FbKernel kk, float *__restrict__ dst, int64_t bs_src, int64_t bs_dst)
 {
+    // a thread owns FOUR consecutive pixels of a row: 3 x 6 source pixels feed them (18 loads instead of 36), one
+    // 16-byte store when the row start allows it
     src += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || y >= H) return;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= W || y >= H) return;
     const float *k = kk.k;
-    const int xl = fb_reflect101(x - 1, W), xr = fb_reflect101(x + 1, W);
     const int yu = fb_reflect101(y - 1, H), yd = fb_reflect101(y + 1, H);
     const TIn *S0 = src + (int64_t)y * W, *Su = src + (int64_t)yu * W, *Sd = src + (int64_t)yd * W;
-    const float r0 = (float)S0[x] * k[1] + ((float)S0[xl] + (float)S0[xr]) * k[0];
-    const float ru = (float)Su[x] * k[1] + ((float)Su[xl] + (float)Su[xr]) * k[0];
-    const float rd = (float)Sd[x] * k[1] + ((float)Sd[xl] + (float)Sd[xr]) * k[0];
-    float s = k[1] * r0;
-    s += k[2] * (rd + ru);                                    // k_fb_blur_cols: k[r + 1] * (tmp[y + 1] + tmp[y - 1])
-    dst[(int64_t)y * W + x] = s;
+    int xs[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) xs[j] = fb_reflect101(min(x0 - 1 + j, W), W);      // columns x0 - 1 .. x0 + 4 (past-the-end ones unused)
+    float v0[6], vu[6], vd[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { v0[j] = (float)S0[xs[j]]; vu[j] = (float)Su[xs[j]]; vd[j] = (float)Sd[xs[j]]; }
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float r0 = v0[e + 1] * k[1] + (v0[e] + v0[e + 2]) * k[0];
+        const float ru = vu[e + 1] * k[1] + (vu[e] + vu[e + 2]) * k[0];
+        const float rd = vd[e + 1] * k[1] + (vd[e] + vd[e + 2]) * k[0];
+        float s = k[1] * r0;
+        s += k[2] * (rd + ru);                                // k_fb_blur_cols: k[r + 1] * (tmp[y + 1] + tmp[y - 1])
+        o[e] = s;
+    }
+    float *D = dst + (int64_t)y * W + x0;
+    if (x0 + 3 < W && (((uintptr_t)D) & 15) == 0) *(float4 *)D = make_float4(o[0], o[1], o[2], o[3]);
+    else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) if (x0 + e < W) D[e] = o[e];
+    }
 }
 
 // 3 x 3 Gaussian blur followed by the exact-2x INTER_AREA resize (pyramid level 1), in one pass: a thread of the
@@ -164,6 +181,32 @@ k_fb_resize_linear(const float *__restrict__ src, int sh, int sw, int cn, float 
     }
 }
 
+// the same for a two-channel image (the flow upsample between pyramid levels): one 8-byte access per tap and per
+// output instead of two 4-byte ones; per channel the expressions of k_fb_resize_linear
+__global__ void __launch_bounds__(256)
+k_fb_resize_linear2(const float2 *__restrict__ src, int sh, int sw, float2 *__restrict__ dst, int dh, int dw,
+                    double scale_x, double scale_y, float post, int64_t bs_src, int64_t bs_dst)
+{
+    src += (int64_t)blockIdx.z * bs_src; dst += (int64_t)blockIdx.z * bs_dst;
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = tf_cvfloor(fx); fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = tf_cvfloor(fy); fy -= sy;
+    const int sy0 = tf_clampi(sy, 0, sh - 1), sy1 = tf_clampi(sy + 1, 0, sh - 1);
+    const int sx1 = sx + 1 < sw ? sx + 1 : sx;
+    const float ax0 = 1.f - fx, ax1 = fx, ay0 = 1.f - fy, ay1 = fy;
+    const float2 a = src[(int64_t)sy0 * sw + sx], b = src[(int64_t)sy0 * sw + sx1];
+    const float2 c = src[(int64_t)sy1 * sw + sx], d = src[(int64_t)sy1 * sw + sx1];
+    const float r0x = a.x * ax0 + b.x * ax1, r1x = c.x * ax0 + d.x * ax1;
+    const float r0y = a.y * ax0 + b.y * ax1, r1y = c.y * ax0 + d.y * ax1;
+    const float vx = r0x * ay0 + r1x * ay1, vy = r0y * ay0 + r1y * ay1;
+    dst[(int64_t)dy * dw + dx] = post == 1.f ? make_float2(vx, vy) : make_float2(vx * post, vy * post);
+}
+
 // exact 2x decimation: OpenCV switches INTER_LINEAR to the INTER_AREA fast path
 __global__ void __launch_bounds__(256)
 k_fb_resize_area2(const float *__restrict__ src, int sw, float *__restrict__ dst, int dh, int dw, int64_t bs_src, int64_t bs_dst)
@@ -217,7 +260,17 @@ k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKern
         float s0 = k[0] * prev, s1;
         float cur = (float)P[1];
         s1 = k[0] * cur;
-        for (int i = 1; i < ksize; i++) {
+        // four pixels per trip: the loads of a trip are independent of its accumulations (which keep their order)
+        int i = 1;
+        for (; i + 3 < ksize; i += 4) {
+            const float n0 = (float)P[i + 1], n1 = (float)P[i + 2], n2 = (float)P[i + 3], n3 = (float)P[i + 4];
+            s0 += k[i] * cur;     s1 += k[i] * n0;
+            s0 += k[i + 1] * n0;  s1 += k[i + 1] * n1;
+            s0 += k[i + 2] * n1;  s1 += k[i + 2] * n2;
+            s0 += k[i + 3] * n2;  s1 += k[i + 3] * n3;
+            cur = n3;
+        }
+        for (; i < ksize; i++) {
             const float nxt = (float)P[i + 1];
             s0 += k[i] * cur;
             s1 += k[i] * nxt;
@@ -958,7 +1011,7 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 {
                     if (hk.ksize == 3 && !two_pass) {
                         TfProfScope ps(TFK_FB_BLUR, 5.0 * n * B, s);  // u8 r + f32 w
-                        hipLaunchKernelGGL(k_fb_blur3_fused<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, blur, img_stride, bs_n);
+                        hipLaunchKernelGGL(k_fb_blur3_fused<uint8_t>, dim3((W + 255) / 256, (H + 3) / 4, B), block, 0, s, img[i], H, W, hk, blur, img_stride, bs_n);
                     } else {
                         TfProfScope ps(TFK_FB_BLUR, 13.0 * n * B, s); // u8 r + f32 w, then f32 r + f32 w
                         hipLaunchKernelGGL(k_fb_blur_rows<uint8_t>, gfull, block, 0, s, img[i], H, W, hk, tmp, img_stride, bs_tmp);
@@ -1002,8 +1055,12 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 const int src = cur[d], dst = 1 - cur[d];
                 TfProfScope ps(TFK_FB_RESIZE, (8.0 * pw * ph + 8.0 * plane) * B, s);
                 const double sx = 1. / ((double)w / pw), sy = 1. / ((double)h / ph);
-                hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, slot[d][src], ph, pw, 2, slot[d][dst], h, w, sx, sy,
-                                   (float)(1. / p->pyr_scale), slot_bs[d][src], slot_bs[d][dst]);
+                if (slot_bs[d][src] % 2 == 0 && slot_bs[d][dst] % 2 == 0)
+                    hipLaunchKernelGGL(k_fb_resize_linear2, glev, block, 0, s, (const float2 *)slot[d][src], ph, pw, (float2 *)slot[d][dst],
+                                       h, w, sx, sy, (float)(1. / p->pyr_scale), slot_bs[d][src] / 2, slot_bs[d][dst] / 2);
+                else                                          // odd caller stride: items are not 8-byte aligned
+                    hipLaunchKernelGGL(k_fb_resize_linear, glev, block, 0, s, slot[d][src], ph, pw, 2, slot[d][dst], h, w, sx, sy,
+                                       (float)(1. / p->pyr_scale), slot_bs[d][src], slot_bs[d][dst]);
                 cur[d] = dst;
             }
         }

@@ -460,3 +460,99 @@ extern "C" int tf_window_overlap_pairs(const int32_t *left, const int32_t *right
     if (out > max_pairs) { tf_set_error("tf_window_overlap_pairs: %lld pairs, room for %lld", (long long)out, (long long)max_pairs); return TF_ENOMEM; }
     return TF_OK;
 }
+
+// ---- slice_labels (utils/label_utils.py:312-349): one id per (label, time step) --------------------------------------
+// The reference shifts every step's labels by the running sum of the steps' largest labels, then renumbers the ids that
+// occur densely in ascending order (bincount -> LUT).  Here: per-step maxima (one atomicMax per wave), the T offsets on
+// the host, presence flags of the shifted ids, an exclusive scan as the LUT, one write pass.
+__global__ void __launch_bounds__(256)
+k_sl_step_max(const int32_t *__restrict__ labels, int64_t hw, int *__restrict__ step_max)
+{
+    const int32_t *L = labels + (int64_t)blockIdx.y * hw;
+    int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) m = max(m, L[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(step_max + blockIdx.y, m);
+}
+
+__global__ void __launch_bounds__(256)
+k_sl_mark(const int32_t *__restrict__ labels, int64_t hw, const int *__restrict__ offset, int *__restrict__ present)
+{
+    const int32_t *L = labels + (int64_t)blockIdx.y * hw;
+    const int off = offset[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = L[i];
+        // shifted id 0 is the background: it takes part in the dense renumbering when (and only when) it occurs
+        if (v > 0) { if (!present[off + v]) present[off + v] = 1; }
+        else if (v == 0 && !present[0]) present[0] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_sl_apply(const int32_t *__restrict__ labels, int64_t hw, const int *__restrict__ offset, const int *__restrict__ rank,
+           int32_t *__restrict__ out)
+{
+    const int64_t base = (int64_t)blockIdx.y * hw;
+    const int off = offset[blockIdx.y];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = labels[base + i];
+        // rank = number of present shifted ids below this one, the background id 0 included if any voxel is 0 -- in a
+        // volume WITHOUT background the reference's LUT (np.arange over the ids that occur) sends the smallest label to 0
+        out[base + i] = v > 0 ? rank[off + v] : 0;
+    }
+}
+
+static size_t sl_scan_bytes(int64_t n_ids)
+{
+    size_t b = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int *)nullptr, (int *)nullptr, (int)std::min<int64_t>(n_ids, INT32_MAX));
+    return b;
+}
+
+// id_capacity: the largest sum of per-step maxima the workspace is sized for (0 = unknown: size for T * 2^20)
+extern "C" size_t tf_slice_labels_workspace_bytes(int64_t T, int64_t id_capacity)
+{
+    if (T <= 0) return 0;
+    const int64_t ids = (id_capacity > 0 ? id_capacity : T * (int64_t)(1 << 20)) + 1;
+    return 2 * tf_align_up((size_t)T * 4, 256) + 2 * tf_align_up((size_t)ids * 4, 256) + tf_align_up(sl_scan_bytes(ids), 256) + 4096;
+}
+
+extern "C" int tf_slice_labels(const int32_t *labels, int64_t T, int64_t hw, int32_t *out, int64_t *n_step_labels_host,
+                               void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(labels && out && n_step_labels_host && ws, "tf_slice_labels: null pointer");
+    TF_REQUIRE(T > 0 && hw > 0 && T <= 65535, "tf_slice_labels: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    TfArena ar(ws, ws_bytes);
+    int *d_max = ar.take<int>(T), *d_off = ar.take<int>(T);
+    if (!ar.ok()) { tf_set_error("tf_slice_labels: workspace too small"); return TF_ENOMEM; }
+    TF_CHECK_HIP(hipMemsetAsync(d_max, 0, (size_t)T * 4, s));
+    const dim3 grid((unsigned)std::min<int64_t>((hw + 255) / 256, 1024), (unsigned)T);
+    hipLaunchKernelGGL(k_sl_step_max, grid, dim3(256), 0, s, labels, hw, d_max);
+    TF_CHECK_LAUNCH();
+    std::vector<int> h_max(T), h_off(T);
+    TF_CHECK_HIP(hipMemcpyAsync(h_max.data(), d_max, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    int64_t total = 0;
+    for (int64_t t = 0; t < T; t++) { h_off[t] = (int)total; total += h_max[t]; }
+    TF_REQUIRE(total < INT32_MAX, "tf_slice_labels: the shifted ids overflow int32 (as they would in the reference)");
+    *n_step_labels_host = total;                              // what a retry must be sized for, should the workspace be short
+    const int64_t ids = total + 1;
+    int *d_present = ar.take<int>(ids), *d_rank = ar.take<int>(ids);
+    size_t scan_bytes = sl_scan_bytes(ids);
+    void *d_scan = ar.take<unsigned char>(scan_bytes);
+    if (!ar.ok()) { tf_set_error("tf_slice_labels: workspace too small for %lld shifted ids", (long long)total); return TF_ENOMEM; }
+    TF_CHECK_HIP(hipMemcpyAsync(d_off, h_off.data(), (size_t)T * 4, hipMemcpyHostToDevice, s));
+    TF_CHECK_HIP(hipMemsetAsync(d_present, 0, (size_t)ids * 4, s));
+    hipLaunchKernelGGL(k_sl_mark, grid, dim3(256), 0, s, labels, hw, (const int *)d_off, d_present);
+    TF_CHECK_LAUNCH();
+    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, (const int *)d_present, d_rank, (int)ids, s));
+    hipLaunchKernelGGL(k_sl_apply, grid, dim3(256), 0, s, labels, hw, (const int *)d_off, (const int *)d_rank, out);
+    TF_CHECK_LAUNCH();
+    int last_rank = 0, last_present = 0;
+    TF_CHECK_HIP(hipMemcpyAsync(&last_rank, d_rank + total, 4, hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipMemcpyAsync(&last_present, d_present + total, 4, hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));                    // h_off must outlive the copy; the count is returned on the host
+    *n_step_labels_host = (int64_t)last_rank + last_present - 1;       // ids that occur, minus the one that maps to 0
+    return TF_OK;
+}

@@ -131,4 +131,73 @@ def flow_link_overlap(flow, flat_labels, structure=ndi.generate_binary_structure
     return _finish(new_dev, flat_dev != 0, dtype, on_device)
 
 
-__all__ = ("flow_label", "find_neighbour_labels", "flow_link_overlap", "flow_label_dev", "link_overlap_dev")
+def pair_counts(a, b, include_b_zero=False):
+    """Every distinct pair (a[i], b[i]) with a[i] > 0 and b[i] > 0 (b[i] >= 0 with include_b_zero) of two int32 label
+    volumes and how often it occurs, sorted by (a, b): host int64 arrays (ids_a, ids_b, counts).  tf_pair_counts --
+    the per-label np.bincount / np.unique of the reference (label_utils.py:352-376, linking.py:33-47, dataset.py:292-297)
+    as one run-length / sort / reduce-by-key pass on the GPU."""
+    t = _lib.torch()
+    L = _lib.lib()
+    a_dev, b_dev = _lib.to_dev(a, t.int32).contiguous(), _lib.to_dev(b, t.int32).contiguous()
+    if a_dev.shape != b_dev.shape:
+        raise ValueError("label volumes must have the same shape")
+    n = a_dev.numel()
+    if n == 0:
+        z = np.zeros(0, np.int64)
+        return z, z.copy(), z.copy()
+    runs = cap = max(n // 16, 65536)
+    n_out = ctypes.c_int64(0)
+    for _ in range(3):
+        ws = _lib.workspace(L.tf_pair_counts_workspace_bytes(n, runs), "pair_counts")
+        oa, ob, oc = _lib.empty((cap,), t.int32), _lib.empty((cap,), t.int32), _lib.empty((cap,), t.int64)
+        rc = L.tf_pair_counts(_lib.ptr(a_dev), _lib.ptr(b_dev), n, 1 if include_b_zero else 0, _lib.ptr(oa), _lib.ptr(ob),
+                              _lib.ptr(oc), cap, ctypes.byref(n_out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        if rc == -2 and n_out.value > 0:                      # needs room for that many runs / pairs
+            runs = cap = int(n_out.value) + 1024
+            continue
+        break
+    _lib.check(rc, "tf_pair_counts")
+    k = int(n_out.value)
+    return (oa[:k].cpu().numpy().astype(np.int64), ob[:k].cpu().numpy().astype(np.int64), oc[:k].cpu().numpy())
+
+
+def label_sizes(labels, n_labels=None):
+    """np.bincount(labels.ravel(), minlength=n_labels + 1) of a non-negative int32 volume (tf_label_sizes); ids above
+    n_labels are not counted."""
+    t = _lib.torch()
+    L = _lib.lib()
+    lab = _lib.to_dev(labels, t.int32).contiguous()
+    if n_labels is None:
+        n_labels = int(lab.max()) if lab.numel() else 0
+    out = _lib.empty((int(n_labels) + 1,), t.int64)
+    if lab.numel() == 0:
+        return np.zeros(int(n_labels) + 1, np.int64)
+    _lib.check(L.tf_label_sizes(_lib.ptr(lab), lab.numel(), int(n_labels), _lib.ptr(out), _lib.stream_ptr()), "tf_label_sizes")
+    return out.cpu().numpy()
+
+
+def slice_labels_dev(labels):
+    """utils.label_utils.slice_labels on the GPU (tf_slice_labels): (device int32 step labels, number of step labels)."""
+    t = _lib.torch()
+    L = _lib.lib()
+    lab = _lib.to_dev(labels, t.int32).contiguous()
+    T = lab.shape[0]
+    hw = lab.numel() // max(T, 1)
+    out = _lib.empty(tuple(lab.shape), t.int32)
+    if lab.numel() == 0:
+        return out, 0
+    n_ids = ctypes.c_int64(0)
+    cap = 1 << 22
+    for _ in range(2):
+        ws = _lib.workspace(L.tf_slice_labels_workspace_bytes(T, cap), "slice_labels")
+        rc = L.tf_slice_labels(_lib.ptr(lab), T, hw, _lib.ptr(out), ctypes.byref(n_ids), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        if rc == -2 and n_ids.value > cap:
+            cap = int(n_ids.value)
+            continue
+        break
+    _lib.check(rc, "tf_slice_labels")
+    return out, int(n_ids.value)
+
+
+__all__ = ("flow_label", "find_neighbour_labels", "flow_link_overlap", "flow_label_dev", "link_overlap_dev",
+           "pair_counts", "label_sizes", "slice_labels_dev")
