@@ -340,6 +340,14 @@ int tf_window_overlap_pairs(const int32_t *left, const int32_t *right, int64_t n
  *   dense LUT is np.arange over the ids that occur.)  *n_step_labels_host = the largest id written.  The workspace holds two int32 per shifted id (sum over
  *   steps of the step's largest label, `id_capacity`); if it is too small the call returns TF_ENOMEM with
  *   *n_step_labels_host = the capacity to size a retry with.  Synchronises the stream. */
+/* tf_label_stats: tobac_flow/analysis.py:293-376 (`weighted_statistics_on_labels`) and :204-245 (`get_stats_for_labels`,
+ *   weights == NULL: every weight 1) -- per label id 1 .. n_labels of an int32 volume of n voxels, over the voxels whose
+ *   `field` value is not NaN: out[(id - 1) * 6 + {0..5}] = { sum of all (non-NaN) weights of the label, sum of the weights
+ *   at valued voxels, weighted mean, weighted standard deviation about it (sqrt(sum w (x - mean)^2 / sum w)), max and min
+ *   of the values with weight > 0 } as doubles on the device (NaN where undefined).  Sums are accumulated in double. */
+size_t tf_label_stats_workspace_bytes(int64_t n_labels);
+int tf_label_stats(const int32_t *labels, const float *field, const float *weights, int64_t n, int64_t n_labels,
+                   double *out, void *ws, size_t ws_bytes, void *stream);
 size_t tf_slice_labels_workspace_bytes(int64_t T, int64_t id_capacity);
 int tf_slice_labels(const int32_t *labels, int64_t T, int64_t hw, int32_t *out, int64_t *n_step_labels_host,
                     void *ws, size_t ws_bytes, void *stream);

@@ -158,3 +158,35 @@ def flag_nan_adjacent_labels(ds, da):
         wh_nan = ndi.binary_dilation(np.isnan(da), structure=np.ones([3, 3, 3]))
         for k, dim in (("core", "core"), ("thick_anvil", "anvil"), ("thin_anvil", "anvil")):
             ds[k + "_nan_flag"] = _flags(ds["coords"][dim], np.unique(ds[k + "_label"][wh_nan]))
+
+
+# ---- per-label statistics: /root/reference/tobac_flow/analysis.py:204-245, 293-376, utils/legacy_utils.py:32-61 ----------
+def apply_weighted_func_to_labels(labels, field, weights, func, default=None):
+    if labels.shape != field.shape:
+        raise ValueError("Input labels and field do not have the same shape")
+    bins = np.cumsum(np.bincount(labels.ravel()))
+    args = np.argsort(labels.ravel())
+    return np.array([(func(field.ravel()[args[bins[i]:bins[i + 1]]], weights.ravel()[args[bins[i]:bins[i + 1]]])
+                      if bins[i + 1] > bins[i] else default) for i in range(bins.size - 1)])
+
+
+def weighted_statistics_on_labels(labels, da, weights):
+    def weighted_average(values, weights, ignore_nan=True):
+        if ignore_nan:
+            wh_nan = np.isnan(values)
+            values = values[~wh_nan]
+            weights = weights[~wh_nan]
+        if np.nansum(weights) == 0:
+            return np.nan
+        return np.average(values, weights=weights)
+
+    weighted_std = lambda x, w: weighted_average((x - weighted_average(x, w)) ** 2, w) ** 0.5
+    weighted_stats = lambda x, w: ([weighted_average(x, w), weighted_std(x, w), np.nanmax(x[w > 0]), np.nanmin(x[w > 0])]
+                                   if np.nansum(w) > 0 else [np.nan, np.nan, np.nan, np.nan])
+    stats_array = apply_weighted_func_to_labels(labels, da, weights, weighted_stats, default=[np.nan] * 4)
+    return tuple(stats_array[..., k] for k in range(4))
+
+
+def get_stats_for_labels(labels, da):
+    idx = range(1, int(labels.max()) + 1)
+    return tuple(ndi.labeled_comprehension(da, labels, idx, f, np.float64, np.nan) for f in (np.nanmean, np.nanstd, np.nanmax, np.nanmin))

@@ -131,3 +131,39 @@ def test_pair_counts_wrapper_matches_numpy():
         keys, want = np.unique(np.stack([a[keep], b[keep]], 1), axis=0, return_counts=True)
         assert np.array_equal(np.stack([ia, ib], 1), keys) and np.array_equal(cnt, want)
     assert np.array_equal(label_sizes(a), np.bincount(a.ravel()))
+
+
+def test_label_statistics_match_numpy_within_float32_summation_error():
+    """tf_label_stats accumulates in double; the reference sums float32 data in float32 (np.average / np.nanmean): the
+    tolerance is that of the reference's own sums, 2e-5 relative (+ 1e-6 absolute near zero); max / min are exact."""
+    import warnings
+    from tobac_flow_amd.analysis import get_stats_for_labels, weighted_statistics_on_labels
+    rng = np.random.default_rng(11)
+    core, thick, thin = _volumes(11)
+    labels = thin
+    x = (250 + 30 * rng.normal(size=labels.shape)).astype(np.float32)
+    x[rng.random(labels.shape) < 0.05] = np.nan
+    w = rng.random(labels.shape).astype(np.float32)
+    w[rng.random(labels.shape) < 0.3] = 0
+    biggest = np.argmax(np.bincount(labels.ravel())[1:]) + 1
+    w[labels == 1] = 0                                           # a label without any weight -> NaN x 4
+    x[labels == 2] = np.nan                                      # a label without any value
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_w = np_dataset.weighted_statistics_on_labels(labels, x, w)
+        want_u = np_dataset.get_stats_for_labels(labels, x)
+    got_w = weighted_statistics_on_labels(labels, x, w)
+    got_u = get_stats_for_labels(labels, x)
+    for got, want in ((got_w, want_w), (got_u, want_u)):
+        for k in range(4):
+            g, v = np.asarray(got[k], np.float64), np.asarray(want[k], np.float64)
+            assert g.shape == v.shape and got[k].dtype == np.float32
+            assert np.array_equal(np.isnan(g), np.isnan(v)), k
+            ok = ~np.isnan(v)
+            if k >= 2:
+                assert np.array_equal(g[ok], v[ok].astype(np.float32)), k
+            else:
+                assert np.allclose(g[ok], v[ok], rtol=2e-5, atol=1e-6), (k, np.abs(g[ok] - v[ok]).max())
+    assert np.isnan(got_w[0][0]) and np.isnan(got_w[0][1]) and not np.isnan(got_w[0][biggest - 1])
+    with pytest.raises(ValueError):
+        get_stats_for_labels(labels, x[1:])

@@ -74,6 +74,8 @@ _PROTOS = {
     "tf_label": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _c.c_size_t, _P]),
     "tf_pair_counts_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     "tf_slice_labels_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    "tf_label_stats_workspace_bytes": (_c.c_size_t, [_c.c_int64]),
+    "tf_label_stats": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _c.c_size_t, _P]),
     "tf_slice_labels": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_size_t, _P]),
     "tf_pair_counts": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_int64, _P, _P, _c.c_size_t, _P]),
     "tf_label_sizes": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P]),

@@ -1,5 +1,7 @@
 """Label filters used by the detection recipes (host glue; mirrors the first three groups of
-/root/reference/tobac_flow/analysis.py:15-201; the dataset statistics below them are out of scope)."""
+/root/reference/tobac_flow/analysis.py:15-201) and the per-label statistics of analysis.py:204-245 / 293-376 as
+segmented reductions on the GPU (tf_label_stats).  The coverage / unique-count maps of analysis.py:248-290 and the
+xarray packaging (names, long_name, units attributes) are out of scope: xarray is not in this image."""
 import numpy as np
 from scipy import ndimage as ndi
 
@@ -87,3 +89,41 @@ def filter_labels_by_length_and_multimask_legacy(labels, masks, min_length):
     if type(masks) is not list:
         raise ValueError("masks input must be a list of masks to process")
     return _legacy_filter(labels, lambda n, where: n >= min_length and np.all([np.any(m.ravel()[where]) for m in masks]))
+
+
+def _label_stats(labels, field, weights, dtype):
+    """(mean, std, max, min) per label 1 .. labels.max() through tf_label_stats; NaN where a label carries no weight."""
+    import ctypes
+    from tobac_flow_amd import _lib
+    t = _lib.torch()
+    L = _lib.lib()
+    if tuple(np.shape(labels)) != tuple(np.shape(field)) or (weights is not None and tuple(np.shape(weights)) != tuple(np.shape(field))):
+        raise ValueError("Input labels and field do not have the same shape")          # legacy_utils.py:44-45
+    lab = _lib.to_dev(labels, t.int32).contiguous()
+    n_labels = int(lab.max()) if lab.numel() else 0
+    if dtype is None:
+        dtype = np.float32 if _lib.is_tensor(field) else np.asarray(field).dtype
+    if n_labels <= 0:
+        return tuple(np.zeros(0, dtype) for _ in range(4))
+    x = _lib.to_dev(field, t.float32).contiguous()
+    w = None if weights is None else _lib.to_dev(weights, t.float32).contiguous()
+    out = _lib.empty((n_labels, 6), t.float64)
+    ws = _lib.workspace(L.tf_label_stats_workspace_bytes(n_labels), "label_stats")
+    _lib.check(L.tf_label_stats(_lib.ptr(lab), _lib.ptr(x), _lib.ptr(w) if w is not None else ctypes.c_void_p(0), lab.numel(),
+                                n_labels, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "tf_label_stats")
+    o = out.cpu().numpy()
+    carries_weight = o[:, 0] > 0                                  # `if np.nansum(w) > 0 else [nan] * 4`
+    return tuple(np.where(carries_weight, o[:, k], np.nan).astype(dtype) for k in (2, 3, 4, 5))
+
+
+def get_stats_for_labels(labels, da, dim=None, dtype=None):
+    """np.nanmean / nanstd / nanmax / nanmin of `da` over every label 1 .. max: four arrays of length labels.max()
+    (reference: analysis.py:204-245, which wraps them as DataArrays named f"{dim}_{da.name}_mean" etc.).  Accumulated in
+    double on the GPU; the reference sums in the data's own precision."""
+    return _label_stats(labels, da, None, dtype)
+
+
+def weighted_statistics_on_labels(labels, da, weights, name=None, dim=None, dtype=None):
+    """Weighted mean, weighted standard deviation, and the max / min over the positively weighted values of `da` for every
+    label 1 .. max, NaN values ignored, NaN for labels without weight (reference: analysis.py:293-376)."""
+    return _label_stats(labels, da, weights, dtype)

@@ -556,3 +556,99 @@ extern "C" int tf_slice_labels(const int32_t *labels, int64_t T, int64_t hw, int
     *n_step_labels_host = (int64_t)last_rank + last_present - 1;       // ids that occur, minus the one that maps to 0
     return TF_OK;
 }
+
+// ---- per-label (weighted) statistics (analysis.py:204-245, 293-376) ----------------------------------------------------
+// weighted_statistics_on_labels / get_stats_for_labels evaluate, for every label, the weighted mean, the weighted
+// standard deviation about it, and the largest / smallest value where the weight is positive -- NaN values dropped.
+// Two passes over the volume, double accumulators, one atomic per RUN of equal labels in a thread's 16 consecutive
+// voxels (labels are spatially coherent): pass 1 sums w (all voxels / voxels with a value), w x, and the extrema;
+// pass 2 sums w (x - mean)^2.  acc layout per label id (0 .. n_labels): {sum w all, sum w valued, sum w x, sum w dev^2}
+// doubles + {max key, min key} as order-preserving 32-bit keys.
+__device__ __forceinline__ unsigned ls_key(float v) { const unsigned b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ls_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+template <int PASS>
+__global__ void __launch_bounds__(256)
+k_label_stats(const int32_t *__restrict__ labels, const float *__restrict__ field, const float *__restrict__ weights, int64_t n,
+              int64_t n_labels, double *__restrict__ acc, unsigned *__restrict__ ext)
+{
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i0 >= n) return;
+    int32_t cur = -1;
+    double s0 = 0, s1 = 0, s2 = 0, mean = 0; unsigned kmax = 0, kmin = 0xffffffffu;
+    auto flush = [&]() {
+        if (cur < 1 || cur > n_labels) return;
+        if (PASS == 1) {
+            if (s0 != 0) atomicAdd(&acc[4 * cur + 0], s0);
+            if (s1 != 0) atomicAdd(&acc[4 * cur + 1], s1);
+            if (s2 != 0) atomicAdd(&acc[4 * cur + 2], s2);
+            if (kmax != 0) atomicMax(&ext[2 * cur + 0], kmax);
+            if (kmin != 0xffffffffu) atomicMin(&ext[2 * cur + 1], kmin);
+        } else if (s2 != 0) atomicAdd(&acc[4 * cur + 3], s2);
+    };
+    for (int j = 0; j < 16 && i0 + j < n; j++) {
+        const int32_t l = labels[i0 + j];
+        if (l != cur) {
+            flush();
+            cur = l; s0 = s1 = s2 = 0; kmax = 0; kmin = 0xffffffffu;
+            if (PASS == 2 && l >= 1 && l <= n_labels) mean = acc[4 * l + 2] / acc[4 * l + 1];
+        }
+        if (l < 1 || l > n_labels) continue;
+        const float x = field[i0 + j], w = weights ? weights[i0 + j] : 1.f;
+        const bool has = !(x != x);
+        if (PASS == 1) {
+            if (!(w != w)) s0 += (double)w;                   // np.nansum(weights) over the whole region
+            if (has) {
+                s1 += (double)w; s2 += (double)w * (double)x;
+                if (w > 0.f) { const unsigned k = ls_key(x); kmax = max(kmax, k); kmin = min(kmin, k); }
+            }
+        } else if (has) { const double d = (double)x - mean; s2 += (double)w * (d * d); }
+    }
+    flush();
+}
+
+__global__ void __launch_bounds__(256)
+k_label_stats_finish(const double *__restrict__ acc, const unsigned *__restrict__ ext, int64_t n_labels, double *__restrict__ out)
+{
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (l > n_labels) return;
+    const double w_all = acc[4 * l], w_val = acc[4 * l + 1], nan = __longlong_as_double(0x7ff8000000000000ll);
+    double *o = out + 6 * (l - 1);
+    o[0] = w_all; o[1] = w_val;
+    o[2] = acc[4 * l + 2] / w_val;                            // 0 / 0 = NaN where nothing carries weight
+    o[3] = sqrt(acc[4 * l + 3] / w_val);
+    o[4] = ext[2 * l] ? (double)ls_unkey(ext[2 * l]) : nan;
+    o[5] = ext[2 * l + 1] != 0xffffffffu ? (double)ls_unkey(ext[2 * l + 1]) : nan;
+}
+
+extern "C" size_t tf_label_stats_workspace_bytes(int64_t n_labels)
+{
+    if (n_labels < 0) return 0;
+    return tf_align_up((size_t)(n_labels + 1) * 32, 256) + tf_align_up((size_t)(n_labels + 1) * 8, 256) + 1024;
+}
+
+extern "C" int tf_label_stats(const int32_t *labels, const float *field, const float *weights, int64_t n, int64_t n_labels,
+                              double *out, void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(labels && field && ws && n > 0 && n_labels >= 0, "tf_label_stats: bad arguments");
+    if (n_labels == 0) return TF_OK;
+    TF_REQUIRE(out, "tf_label_stats: null output");
+    hipStream_t s = (hipStream_t)stream;
+    TfArena ar(ws, ws_bytes);
+    double *acc = ar.take<double>(4 * (n_labels + 1));
+    unsigned *ext = ar.take<unsigned>(2 * (n_labels + 1));
+    if (!ar.ok()) { tf_set_error("tf_label_stats: workspace too small"); return TF_ENOMEM; }
+    TF_CHECK_HIP(hipMemsetAsync(acc, 0, (size_t)(n_labels + 1) * 32, s));
+    TF_CHECK_HIP(hipMemsetAsync(ext, 0, (size_t)(n_labels + 1) * 8, s));
+    {
+        // min keys start at all-ones: every second 32-bit word
+        TF_CHECK_HIP(hipMemset2DAsync((char *)ext + 4, 8, 0xff, 4, (size_t)(n_labels + 1), s));
+    }
+    const dim3 grid((unsigned)((n + 4095) / 4096));
+    hipLaunchKernelGGL(k_label_stats<1>, grid, dim3(256), 0, s, labels, field, weights, n, n_labels, acc, ext);
+    hipLaunchKernelGGL(k_label_stats<2>, grid, dim3(256), 0, s, labels, field, weights, n, n_labels, acc, ext);
+    hipLaunchKernelGGL(k_label_stats_finish, dim3((unsigned)((n_labels + 255) / 256)), dim3(256), 0, s, (const double *)acc,
+                       (const unsigned *)ext, n_labels, out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
