@@ -554,8 +554,8 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 }
 
 // ---- fused iteration: UpdateMatrices -> 13x13 box sums (double) -> 2x2 solve -----------------------
-// One launch = one Farnebaeck iteration of BOTH directions for a batch of frame pairs.  A 256-thread
-// workgroup owns a strip of FBI_OW = 244 output columns (+ 6 halo columns each side) and `hs` rows.
+// One launch = one Farnebaeck iteration of BOTH directions for a batch of frame pairs.  A workgroup of FBI_T = 128
+// threads owns a strip of FBI_OW = 116 output columns (+ 6 halo columns each side) and `hs` rows.
 // Thread j walks DOWN its column: at every row it evaluates M = UpdateMatrices(R0, R1, flow_old) in
 // registers, keeps the last 13 rows of M in a register ring and the running 13-row column sums in
 // double; the five column sums go to an LDS row, from which the 244 interior threads add 13 neighbours,
@@ -567,11 +567,17 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 // at 3 waves / SIMD, not by bytes.
 #define FBI_M 6
 #define FBI_WIN (2 * FBI_M + 1)
-#define FBI_OW (256 - 2 * FBI_M)
+#ifndef FBI_T
+#define FBI_T 128                   // threads = evaluated columns per workgroup
+#endif
+#define FBI_OW (FBI_T - 2 * FBI_M)
 #define FBI_HS 512                  // tallest strip; halved until the grid has >= 1536 workgroups
 // R[img] / fin[q] / fout[q] are the pointers of batch item 0; item b adds b * the matching stride
 struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2]; };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
+#ifndef FBI_NB
+#define FBI_NB 4                    // rows whose gathers are in flight together
+#endif
 
 // Addressing: per-thread 64-bit byte offsets from per-item base pointers.  (A variant with wave-uniform bases + 32-bit
 // offsets, the global_load "saddr + voffset" form, saves 7 % of the VALU instructions and runs 12 % SLOWER at 5424^2:
@@ -599,17 +605,18 @@ __device__ __forceinline__ float2 fb_iter_flow_at(const FbIterCtx &c, int s)
 }
 
 // issue every load of one M evaluation (same arithmetic as fb_matrix_at, branch-free)
+template <int ABL = 0>
 __device__ __forceinline__ void fb_taps_load(const FbIterCtx &c, int s, float2 fl, FbTaps &t)
 {
     typedef fb_off_t off_t;
     const int y = tf_clampi(s, 0, c.H - 1);
-    const off_t o = (off_t)y * (off_t)c.W + (off_t)c.xc;
+    const off_t o = ABL == 2 ? (off_t)c.xc : (off_t)y * (off_t)c.W + (off_t)c.xc;      // ABL 2: every gather from row 0
     t.dx = fl.x; t.dy = fl.y;
     const float fx = c.xc + t.dx, fy = y + t.dy;
     const int x1 = tf_cvfloor(fx), y1 = tf_cvfloor(fy);
     const bool inb = (unsigned)x1 < (unsigned)(c.W - 1) && (unsigned)y1 < (unsigned)(c.H - 1);
     // out of the image: the patch at element 0 is read instead (always valid, see the base pointers) and discarded
-    const off_t q = inb ? (off_t)y1 * (off_t)c.W + (off_t)x1 : (off_t)0;
+    const off_t q = ABL == 2 ? (off_t)(inb ? x1 : 0) : (inb ? (off_t)y1 * (off_t)c.W + (off_t)x1 : (off_t)0);
     const off_t q16 = q * 16, q4 = q * 4;
     t.q0 = fb_ld<float4>(c.R0, o * 16);
     t.q04 = fb_ld<float>(c.R0e, o * 4);
@@ -661,7 +668,7 @@ __device__ __forceinline__ void fb_taps_eval(const FbIterCtx &c, int s, const Fb
 
 // LDS row of column sums: column i lives at i + i/4 (one pad per four) so that both access patterns are
 // conflict-free: the vertical phase writes consecutive i, the horizontal phase reads i = 4 q + k (stride 5).
-#define FBI_VS 320
+#define FBI_VS (FBI_T + FBI_T / 4)
 #define FBI_Q (FBI_OW / 4)          // 61 quads of 4 outputs per strip row
 
 // horizontal phase for one (row g, quad q): 16 column sums per channel -> four 13-wide window sums ->
@@ -707,7 +714,8 @@ __device__ __forceinline__ void fb_iter_quad(const FbIterCtx &c, int yo, int g, 
 //      park them in LDS,
 //   2. fetch the flow of the next group's GN rows,
 //   3. one barrier, then the horizontal phase: thread t takes (row t / 61, quad t % 61).
-// ABL 1 (development aid, env TF_FBI_ABLATE=1): synthetic M instead of the gathers.
+// ABL 1 (development aid, env TF_FBI_ABLATE=1): synthetic M instead of the gathers; ABL 2: the gathers read row 0 only
+// (same instructions, cache-resident data).
 template <int K0, int G, int GN, int NB, int ABL>
 __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
                                               float2 (&fl)[FBI_G], double *vrow)
@@ -718,7 +726,7 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float 
         float m[NB][5];
 #pragma unroll
         for (int r = 0; r < NB; r++)
-            if (g0 + r < G && ABL != 1) fb_taps_load(c, s0 + g0 + r, fl[g0 + r], t[r]);
+            if (g0 + r < G && ABL != 1) fb_taps_load<ABL>(c, s0 + g0 + r, fl[g0 + r], t[r]);
 #pragma unroll
         for (int r = 0; r < NB; r++)
             if (g0 + r < G) {
@@ -738,16 +746,27 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float 
     }
     __syncthreads();
     if (c.j < G * FBI_Q) fb_iter_quad(c, s0 + c.tg - FBI_M, c.tg, c.tq, vrow);
-    if (G * FBI_Q > 256 && c.j < G * FBI_Q - 256) fb_iter_quad(c, s0 + 4 - FBI_M, 4, c.j + 256 - 4 * FBI_Q, vrow);
+    if (G * FBI_Q > FBI_T && c.j < G * FBI_Q - FBI_T) {
+        const int item = c.j + FBI_T, tg = item / FBI_Q;
+        fb_iter_quad(c, s0 + tg - FBI_M, tg, item - tg * FBI_Q, vrow);
+    }
     __syncthreads();
 }
 
+// Workgroup width (round 2): 128 threads = two waves.  The occupancy is two waves per SIMD whatever the width, i.e. FOUR
+// independent barrier domains per CU instead of the two of 256-thread workgroups: the phases of a workgroup (gathers,
+// matrix arithmetic, LDS column sums, window sums + solve) run one after the other, so what overlaps them is the number
+// of workgroups in different phases.  12 x 5424^2 step: 132.4 ms (256 threads, 5 % halo columns) -> 115.4 ms (128
+// threads, 10 %) -> 126.2 ms (64 threads, 23 %).  The rows-in-flight count FBI_NB no longer matters (2 / 4 / 5: 116.3 /
+// 116.1 / 116.3 ms): with every gather redirected to a cache-resident row (TF_FBI_ABLATE=2) the 256-thread kernel
+// took 117.9 instead of 132.5 ms and without gathers and matrix arithmetic (TF_FBI_ABLATE=1) 51.7 ms -- the kernel is
+// bound by the SUM of its VALU (about 55 ms at full issue rate), L1 (22 ms) and LDS (22 ms) work, not by HBM latency.
 // Occupancy is two waves per SIMD by construction (65 ring registers + the 72 of the horizontal phase; 64 KB of LDS):
 // the launch bound says so, which lets the compiler schedule for the 256-register budget (5 % faster than the
 // default bound).  Forcing three waves spills the ring (+70 %); row groups 4 + 4 + 4 + 1 with 51 KB of LDS cost
 // 2 % for the extra barrier pair and gain nothing while the registers hold the kernel at two waves.
 template <int NB, int ABL>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(FBI_T, 2)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
 {
     __shared__ double vrow[FBI_G * 5 * FBI_VS];
@@ -1069,7 +1088,7 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
             // strip height: tall strips amortise the 12-row halo, short ones keep all CUs busy on coarse levels
             static const int hs_max = getenv("TF_FBI_HS") ? atoi(getenv("TF_FBI_HS")) : FBI_HS;
             int hs = hs_max;
-            while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd * B < 1536) hs >>= 1;
+            while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd * B < 1536 * (256 / FBI_T)) hs >>= 1;
             const int nx = (w + FBI_OW - 1) / FBI_OW;
             const dim3 gi(((nx + 7) / 8) * 8 * nd, (h + hs - 1) / hs, B);
             FbIterArgs ia;
@@ -1084,8 +1103,9 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 {
                     TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd * B, s);
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
-                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<4, 1>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
-                    else hipLaunchKernelGGL((k_fb_iter<4, 0>), gi, dim3(256), 0, s, ia, h, w, plane, hs);
+                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1>), gi, dim3(FBI_T), 0, s, ia, h, w, plane, hs);
+                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2>), gi, dim3(FBI_T), 0, s, ia, h, w, plane, hs);
+                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0>), gi, dim3(FBI_T), 0, s, ia, h, w, plane, hs);
                 }
                 for (int q = 0; q < nd; q++) cur[dirs[q]] = 1 - cur[dirs[q]];
             }
