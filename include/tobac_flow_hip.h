@@ -367,6 +367,11 @@ int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
  * tf_shutdown() switches timing off and destroys them.  Idempotent; the library remains usable afterwards. */
 int tf_shutdown(void);
 
+/* development aid (tests): compares, on `count` pseudo-random operand pairs drawn from the range it is used in, the
+ * shared-reciprocal division of the refinement's system kernel with the hardware's correctly rounded division;
+ * *mismatches_host must come back 0.  Allocates and frees 8 bytes of device memory. */
+int tf_selftest_shared_divide(int64_t count, uint64_t seed, uint64_t *mismatches_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -327,7 +327,7 @@ def test_development_switches_do_not_change_results(tf, tmp_path):
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import tobac_flow_amd.flow as tf; "
             "a = np.load(%r); f, b = tf.calculate_flow(a, 'Farneback', vr_steps=1); np.save(%r, np.stack([f, b]))")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for var in ("TF_FB_POLYEXP_GENERIC", "TF_VR_SOR_SWEEPS", "TF_FB_BLUR_TWOPASS"):
+    for var in ("TF_FB_POLYEXP_GENERIC", "TF_VR_SOR_SWEEPS", "TF_VR_WEIGHTS_PASS", "TF_FB_BLUR_TWOPASS"):
         out = tmp_path / f"{var}.npy"
         env = dict(os.environ, **{var: "1"})
         subprocess.check_call([sys.executable, "-c", code % (root, str(tmp_path / "in.npy"), str(out))], env=env)

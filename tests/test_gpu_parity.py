@@ -809,3 +809,15 @@ def test_watershed_raveled_argument_checks(tf):
     args[1] = np.array([13, 5], np.intp)                                             # not np.flatnonzero order
     with pytest.raises(ValueError):
         watershed_raveled(*args)
+
+
+def test_shared_reciprocal_division_equals_the_hardware_division():
+    """k_vr_system divides fifteen products of derivative values by three denominators through one refined reciprocal
+    each; in the operands' range that is the IEEE division bit for bit (varref.hip, vr_div_shared)."""
+    import ctypes
+    from tobac_flow_amd import _lib
+    L = _lib.lib()
+    for seed in (1, 2, 3):
+        bad = ctypes.c_uint64(123)
+        _lib.check(L.tf_selftest_shared_divide(1 << 26, seed, ctypes.byref(bad), _lib.stream_ptr()), "selftest")
+        assert bad.value == 0

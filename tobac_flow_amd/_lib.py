@@ -92,6 +92,7 @@ _PROTOS = {
     "tf_profile_kernel_name": (_c.c_char_p, [_c.c_int]),
     "tf_profile_collect": (_c.c_int, [_P, _P, _P]),
     "tf_shutdown": (_c.c_int, []),
+    "tf_selftest_shared_divide": (_c.c_int, [_c.c_int64, _c.c_uint64, _P, _P]),
 }
 
 EXPORTS = tuple(_PROTOS)

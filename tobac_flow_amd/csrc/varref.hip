@@ -10,8 +10,9 @@
 //                  image, Iz, and all first / second central differences (Sobel ksize 1, replicated border) on ONE LDS
 //                  tile with a 2-pixel halo: the eight derivative planes are written once (32 B / px), nothing else
 //                  touches HBM
-//   k_vr_weights   smoothness weights of the current flow W + dW (forward differences, replicated border)
-//   k_vr_system    the 2x2 system of every pixel: data term (robust colour- and gradient-constancy weights) plus the
+//   k_vr_system    smoothness weights of the current flow W + dW (forward differences, replicated border; each
+//                  weight shared with the right / lower neighbour through a lane shuffle / LDS) and
+//                  the 2x2 system of every pixel: data term (robust colour- and gradient-constancy weights) plus the
 //                  smoothness contributions of its four edges, accumulated in OpenCV's pass order (red before black,
 //                  horizontal before vertical -- the order at a pixel depends on its colour)
 //   k_vr_sor       one half sweep (one colour) of red-black SOR on dW
@@ -88,6 +89,67 @@ k_vr_prepare(const uint8_t *__restrict__ I0, const uint8_t *__restrict__ I1, con
     }
 }
 
+// ---- correctly rounded division with the reciprocal work shared between numerators -----------------------------------
+// `n / d` in IEEE arithmetic costs the GPU eleven instructions: two range scalings, v_rcp, one Newton step on the
+// reciprocal, q = n r, two residual corrections (the last one the final, correctly rounding FMA) and a fix-up for
+// special values.  The reciprocal and its Newton step depend on d alone; the scalings and the fix-up do nothing when n
+// is 0 or 2^-100 < |n| < 2^96 |d| and the quotient is a normal number.  vr_div_shared performs exactly the remaining
+// five operations and the fix-up (which also gives -0 / d its sign), so its result is the hardware division's bit for bit in that range.  It is used only where the
+// range is guaranteed: the derivative planes of k_vr_prepare are exact multiples of 2^-11 of magnitude <= 1020 (sums
+// and differences of uint8 values and of bilinear samples with 1/32-quantised weights, all exact in float), so a
+// product of two of them is 0 or lies in [2^-22, 2^20], and the denominators lie in [zeta^2, 2^22].
+// tf_selftest_shared_divide compares the two forms on random operands of that range (tests/test_gpu_parity.py).
+struct VrRcp { float d, r; };
+__device__ __forceinline__ VrRcp vr_rcp_refined(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __fmaf_rn(-d, r, 1.f);
+    r = __fmaf_rn(e, r, r);
+    VrRcp k; k.d = d; k.r = r;
+    return k;
+}
+__device__ __forceinline__ float vr_div_shared(float n, VrRcp k)
+{
+#ifdef VR_PLAIN_DIVIDE                 /* A/B build: the hardware division */
+    return n / k.d;
+#endif
+    float q = n * k.r;
+    float e = __fmaf_rn(-k.d, q, n);
+    q = __fmaf_rn(e, k.r, q);
+    e = __fmaf_rn(-k.d, q, n);
+    return __builtin_amdgcn_div_fixupf(__fmaf_rn(e, k.r, q), k.d, n);     // the fix-up keeps the sign of a zero numerator
+}
+
+__global__ void __launch_bounds__(256)
+k_vr_selftest_divide(unsigned long long seed, int64_t count, unsigned long long *__restrict__ mismatches)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    // splitmix64 -> operands shaped like the kernel's: products of two multiples of 2^-11 over a sum of squares + zeta^2
+    auto next = [](unsigned long long &z) { z += 0x9e3779b97f4a7c15ull; unsigned long long x = z; x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+                                            x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; return x ^ (x >> 31); };
+    unsigned long long st = seed + 0x632be59bd9b4e019ull * (unsigned long long)i;
+    float v[4];
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long r = next(st);
+        const int mag = (int)(r % 2088961u) - 1044480;                   // -1020 * 1024 .. 1020 * 1024, in units of 2^-11... / 2
+        const int shift = (int)((r >> 40) % 12);                          // small values as often as large ones
+        v[k] = (float)(mag >> shift) * (1.f / 2048.f);
+    }
+    const float d = v[0] * v[0] + v[1] * v[1] + 0.1f * 0.1f, n = v[2] * v[3];
+    const float fast = vr_div_shared(n, vr_rcp_refined(d)), ieee = n / d;
+    if (__float_as_uint(fast) != __float_as_uint(ieee)) atomicAdd(mismatches, 1ull);
+}
+
+// smoothness weight from the current flow at a pixel (c0), its right (cr) and its lower (cd) neighbour
+__device__ __forceinline__ float vr_weight(float2 c0, float2 cr, float2 cd, const VrP &P)
+{
+    const float ux = cr.x - c0.x, vx = cr.y - c0.y, uy = cd.x - c0.x, vy = cd.y - c0.y;
+    return P.alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + P.eps2);
+}
+
+__device__ __forceinline__ float2 vr_add2(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+
 __global__ void __launch_bounds__(256)
 k_vr_weights(const float2 *__restrict__ Wf, const float2 *__restrict__ dW, int H, int W, VrP P, float *__restrict__ wt)
 {
@@ -97,47 +159,87 @@ k_vr_weights(const float2 *__restrict__ Wf, const float2 *__restrict__ dW, int H
     const int64_t jr = x + 1 < W ? j + 1 : j, jd = y + 1 < H ? j + W : j;
     const float2 z = make_float2(0.f, 0.f);                            // dW == nullptr: the first iteration's dW = 0
     const float2 w0 = Wf[j], d0 = dW ? dW[j] : z, wr = Wf[jr], dr = dW ? dW[jr] : z, wd = Wf[jd], dd = dW ? dW[jd] : z;
-    const float cu = w0.x + d0.x, cv = w0.y + d0.y;
-    const float ux = (wr.x + dr.x) - cu, vx = (wr.y + dr.y) - cv, uy = (wd.x + dd.x) - cu, vy = (wd.y + dd.y) - cv;
-    wt[j] = P.alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + P.eps2);
+    wt[j] = vr_weight(vr_add2(w0, d0), vr_add2(wr, dr), vr_add2(wd, dd), P);
 }
 
+// WEIGHTS = true: the smoothness weights are formed here instead of in a k_vr_weights pass (same expression, so the same
+// bits): every thread computes the weight of ITS pixel (written to `wt` for the SOR kernel), the left neighbour's weight
+// comes from the neighbouring lane (lane 0 computes it itself), the upper neighbour's from the wave above through LDS
+// (the first wave of the 64 x 4 block computes the row above itself): 1.27 weights per pixel instead of a pass of
+// 16 B read + 4 B written and a 4 B read here.
+template <bool WEIGHTS>
 __global__ void __launch_bounds__(256)
 k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const float2 *__restrict__ Wf,
-            const float2 *__restrict__ dW, const float *__restrict__ wt, int H, int W, VrP P,
-            float4 *__restrict__ S, float *__restrict__ A12o)
+            const float2 *__restrict__ dW, const float *wt_in, int H, int W, VrP P,
+            float4 *__restrict__ S, float *__restrict__ A12o, float *wt_out)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
-    const int64_t j = (int64_t)y * W + x;
+    __shared__ float s_w[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wv;
+    const bool in = x < W && y < H;
+    if (!WEIGHTS && !in) return;
+    const int64_t j = in ? (int64_t)y * W + x : 0;
+    const float2 z2 = make_float2(0.f, 0.f);
+    const float2 d = dW ? dW[j] : z2;
+    const bool has_r = x + 1 < W, has_l = x > 0, has_d = y + 1 < H, has_u = y > 0;
+    const float2 w0 = Wf[j];
+    const float2 wr = (in && has_r) ? Wf[j + 1] : w0, wlf = (in && has_l) ? Wf[j - 1] : w0;
+    const float2 wd = (in && has_d) ? Wf[j + W] : w0, wuf = (in && has_u) ? Wf[j - W] : w0;
+    float wp, wl, wu;
+    if (WEIGHTS) {
+        const float2 cO = vr_add2(w0, d);
+        const float2 cR = (in && has_r) ? vr_add2(wr, dW ? dW[j + 1] : z2) : cO;
+        const float2 cD = (in && has_d) ? vr_add2(wd, dW ? dW[j + W] : z2) : cO;
+        wp = vr_weight(cO, cR, cD, P);
+        if (in) wt_out[j] = wp;
+        s_w[wv][lane] = wp;
+        wl = __shfl_up(wp, 1);
+        if (lane == 0 && in && has_l) {
+            // weight of (x - 1, y): its right neighbour is this pixel, its lower one (x - 1, y + 1) or itself
+            const float2 cL = vr_add2(wlf, dW ? dW[j - 1] : z2);
+            const float2 cDL = has_d ? vr_add2(Wf[j + W - 1], dW ? dW[j + W - 1] : z2) : cL;
+            wl = vr_weight(cL, cO, cDL, P);
+        }
+        float wu0 = 0.f;
+        if (wv == 0 && in && has_u) {
+            // weight of (x, y - 1): its lower neighbour is this pixel, its right one (x + 1, y - 1) or itself
+            const float2 cU = vr_add2(wuf, dW ? dW[j - W] : z2);
+            const float2 cUR = has_r ? vr_add2(Wf[j - W + 1], dW ? dW[j - W + 1] : z2) : cU;
+            wu0 = vr_weight(cU, cUR, cO, P);
+        }
+        __syncthreads();
+        wu = wv == 0 ? wu0 : s_w[wv > 0 ? wv - 1 : 0][lane];
+        if (!in) return;
+        wl = has_l ? wl : 0.f; wu = has_u ? wu : 0.f;
+    } else {
+        wp = wt_in[j]; wl = has_l ? wt_in[j - 1] : 0.f; wu = has_u ? wt_in[j - W] : 0.f;
+    }
     const float4 d1 = D1[j], d2 = D2[j];
     const float Ix = d1.x, Iy = d1.y, Ixz = d1.z, Iyz = d1.w, Ixx = d2.x, Ixy = d2.y, Iyy = d2.z, Iz = d2.w;
-    const float2 d = dW ? dW[j] : make_float2(0.f, 0.f);
     const float du = d.x, dv = d.y;
-    // ComputeDataTerm
+    // ComputeDataTerm.  The fifteen quotients whose numerator is a product of two derivative values share the
+    // reciprocal work of their three denominators (vr_div_shared: bit-identical to `/` in their range, see there)
     float derivNorm = Ix * Ix + Iy * Iy + P.zeta2;
+    const VrRcp k1 = vr_rcp_refined(derivNorm);
     const float Ik1z = Iz + Ix * du + Iy * dv;
     float weight = P.delta2 / sqrtf(Ik1z * Ik1z / derivNorm + P.eps2);
-    float A11 = weight * (Ix * Ix / derivNorm) + P.zeta2;
-    float A12 = weight * (Ix * Iy / derivNorm);
-    float A22 = weight * (Iy * Iy / derivNorm) + P.zeta2;
-    float b1 = -weight * (Iz * Ix / derivNorm);
-    float b2 = -weight * (Iz * Iy / derivNorm);
+    float A11 = weight * vr_div_shared(Ix * Ix, k1) + P.zeta2;
+    float A12 = weight * vr_div_shared(Ix * Iy, k1);
+    float A22 = weight * vr_div_shared(Iy * Iy, k1) + P.zeta2;
+    float b1 = -weight * vr_div_shared(Iz * Ix, k1);
+    float b2 = -weight * vr_div_shared(Iz * Iy, k1);
     derivNorm = Ixx * Ixx + Ixy * Ixy + P.zeta2;
     const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + P.zeta2;
+    const VrRcp k2 = vr_rcp_refined(derivNorm), k3 = vr_rcp_refined(derivNorm2);
     const float Ik1zx = Ixz + Ixx * du + Ixy * dv;
     const float Ik1zy = Iyz + Ixy * du + Iyy * dv;
     weight = P.gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + P.eps2);
-    A11 += weight * (Ixx * Ixx / derivNorm + Ixy * Ixy / derivNorm2);
-    A12 += weight * (Ixx * Ixy / derivNorm + Ixy * Iyy / derivNorm2);
-    A22 += weight * (Ixy * Ixy / derivNorm + Iyy * Iyy / derivNorm2);
-    b1 += -weight * (Ixx * Ixz / derivNorm + Ixy * Iyz / derivNorm2);
-    b2 += -weight * (Ixy * Ixz / derivNorm + Iyy * Iyz / derivNorm2);
+    A11 += weight * (vr_div_shared(Ixx * Ixx, k2) + vr_div_shared(Ixy * Ixy, k3));
+    A12 += weight * (vr_div_shared(Ixx * Ixy, k2) + vr_div_shared(Ixy * Iyy, k3));
+    A22 += weight * (vr_div_shared(Ixy * Ixy, k2) + vr_div_shared(Iyy * Iyy, k3));
+    b1 += -weight * (vr_div_shared(Ixx * Ixz, k2) + vr_div_shared(Ixy * Iyz, k3));
+    b2 += -weight * (vr_div_shared(Ixy * Ixz, k2) + vr_div_shared(Iyy * Iyz, k3));
     // smoothness: each edge (p, right) / (p, down) carries the weight of its upper-left end
-    const bool has_r = x + 1 < W, has_l = x > 0, has_d = y + 1 < H, has_u = y > 0;
-    const float wp = wt[j], wl = has_l ? wt[j - 1] : 0.f, wu = has_u ? wt[j - W] : 0.f;
-    const float2 w0 = Wf[j];
-    const float2 wr = has_r ? Wf[j + 1] : w0, wlf = has_l ? Wf[j - 1] : w0, wd = has_d ? Wf[j + W] : w0, wuf = has_u ? Wf[j - W] : w0;
     // own edge terms as the horizontal / vertical passes form them at p, neighbour edge terms as they form them at the
     // left / upper neighbour
     const float own_ux = wp * (wr.x - w0.x), own_vx = wp * (wr.y - w0.y);
@@ -363,11 +465,16 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
     bool flow_done = false;
     for (int it = 0; it < params->fixed_point_iterations; it++) {
         {
-            // algorithmic bytes: weights W 8 + dW 8 r, 4 w; system D1 + D2 32, W 8, dW 8, weight 4 r, S 16 + A12 4 w
-            TfProfScope ps(TFK_VR_SYSTEM, (16.0 + 4.0 + 32.0 + 16.0 + 4.0 + 20.0 - (dW_cur ? 0.0 : 16.0)) * (double)n, s);
-            hipLaunchKernelGGL(k_vr_weights, g1, dim3(256), 0, s, Wf, dW_cur, iH, iW, P, wt);
-            hipLaunchKernelGGL(k_vr_system, g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
-                               dW_cur, (const float *)wt, iH, iW, P, S, A12);
+            // algorithmic bytes: D1 + D2 32, W 8, dW 8 read; S 16, A12 4, weight 4 written (no dW in the first iteration)
+            static const bool weights_pass = getenv("TF_VR_WEIGHTS_PASS") != nullptr;       // development aid: separate pass
+            TfProfScope ps(TFK_VR_SYSTEM, (32.0 + 8.0 + (dW_cur ? 8.0 : 0.0) + 16.0 + 4.0 + 4.0) * (double)n, s);
+            if (weights_pass) {
+                hipLaunchKernelGGL(k_vr_weights, g1, dim3(256), 0, s, Wf, dW_cur, iH, iW, P, wt);
+                hipLaunchKernelGGL(k_vr_system<false>, g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
+                                   dW_cur, (const float *)wt, iH, iW, P, S, A12, (float *)nullptr);
+            } else
+                hipLaunchKernelGGL(k_vr_system<true>, g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
+                                   dW_cur, (const float *)nullptr, iH, iW, P, S, A12, wt);
         }
         TF_CHECK_LAUNCH();
         if (tile_path) {
@@ -396,5 +503,24 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
         hipLaunchKernelGGL(k_vr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wf, dW_cur, n, (float2 *)flow);
         TF_CHECK_LAUNCH();
     }
+    return TF_OK;
+}
+
+// development aid: number of operand pairs (out of `count`, drawn from the range vr_div_shared is used in) for which the
+// shared-reciprocal division differs from the hardware's correctly rounded one.  Must be 0.
+extern "C" int tf_selftest_shared_divide(int64_t count, uint64_t seed, uint64_t *mismatches_host, void *stream)
+{
+    TF_REQUIRE(mismatches_host && count > 0, "tf_selftest_shared_divide: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *d_m = nullptr;
+    TF_CHECK_HIP(hipMalloc(&d_m, 8));
+    TF_CHECK_HIP(hipMemsetAsync(d_m, 0, 8, s));
+    hipLaunchKernelGGL(k_vr_selftest_divide, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, (unsigned long long)seed, count, d_m);
+    unsigned long long h = 0;
+    hipError_t e = hipMemcpyAsync(&h, d_m, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_m);
+    TF_CHECK_HIP(e);
+    *mismatches_host = h;
     return TF_OK;
 }
