@@ -299,6 +299,8 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 // dW_in == nullptr stands for dW = 0 (first fixed-point iteration); Wadd != nullptr (last iteration) makes the kernel
 // store W + dW, the refined flow, instead of dW -- dW_out may then be the flow array itself (this kernel never reads W
 // except at the pixel a thread is about to write).
+// Measured and not adopted: delaying the odd workgroups of the first round by half a tile's time, so that loads and sweeps
+// of different CUs overlap instead of running in lockstep: 5.63 / 5.70 / 5.74 / 5.63 ms per refinement for 0 / 5 / 10 / 20 us.
 // Measured alternatives (12 x 5424^2, ms per step for all 110 launches): 128 x 64 tile, thread -> pair q = t + 512 k
 // (row and pair parity vary inside a wave: per-pixel index arithmetic, activity predicates and value selects between the
 // two pixels of a pair), 256 VGPRs: 93.2; the same with 1024 threads / 7 pairs / 128 VGPRs and a small spill: 95.9.
@@ -337,21 +339,46 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
         colact[ci] = c > 0 && c < VRT_RW - 1 && x >= 0 && x < W;
     }
     float a11[VRT_K][2], a22[VRT_K][2], b1[VRT_K][2], b2[VRT_K][2], a12[VRT_K][2], wp[VRT_K][2];
+    // Load phase, ordered so that MANY loads are in flight per wave: an LDS store right behind its own load makes the
+    // compiler wait for everything issued before it (the first version ran 26 dependent round trips per thread).
+    // 1. dW of one colour at a time into temporaries, then into LDS; 2. all systems and weights straight into their
+    // registers; 3. the weights into LDS.
+#pragma unroll
+    for (int ci = 0; ci < 2; ci++) {
+        float2 t[VRT_K];
+        const int x = x0 + 2 * cp + e_[ci];
+#pragma unroll
+        for (int k = 0; k < VRT_K; k++) {
+            const int y = y0 + wv + k * VRT_WAVES;
+            const bool in = x >= 0 && y >= 0 && x < W && y < H;
+            t[k] = make_float2(0.f, 0.f);
+            if (dW_in) {                                       // uniform; nullptr = the first iteration's dW = 0
+                const float2 v = dW_in[in ? (int64_t)y * W + x : 0];
+                if (in) t[k] = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VRT_K; k++) l_dw[own_[ci] + k * VRT_WAVES * VRT_PW] = t[k];
+    }
 #pragma unroll
     for (int k = 0; k < VRT_K; k++) {
-        const int r = wv + k * VRT_WAVES, y = y0 + r;
+        const int y = y0 + wv + k * VRT_WAVES;
 #pragma unroll
         for (int ci = 0; ci < 2; ci++) {
             const int x = x0 + 2 * cp + e_[ci];
             const bool in = x >= 0 && y >= 0 && x < W && y < H;
             const int64_t p = in ? (int64_t)y * W + x : 0;
-            const float4 sv = in ? S[p] : make_float4(1.f, 1.f, 0.f, 0.f);
-            a11[k][ci] = sv.x; a22[k][ci] = sv.y; b1[k][ci] = sv.z; b2[k][ci] = sv.w;
-            a12[k][ci] = in ? A12[p] : 0.f;
-            wp[k][ci] = in ? wt[p] : 0.f;
-            l_dw[own_[ci] + k * VRT_WAVES * VRT_PW] = (in && dW_in) ? dW_in[p] : make_float2(0.f, 0.f);
-            l_wt[own_[ci] + k * VRT_WAVES * VRT_PW] = wp[k][ci];
+            const float4 sv = S[p];
+            const float av = A12[p], wv_ = wt[p];
+            a11[k][ci] = in ? sv.x : 1.f; a22[k][ci] = in ? sv.y : 1.f; b1[k][ci] = in ? sv.z : 0.f; b2[k][ci] = in ? sv.w : 0.f;
+            a12[k][ci] = in ? av : 0.f;
+            wp[k][ci] = in ? wv_ : 0.f;
         }
+    }
+#pragma unroll
+    for (int k = 0; k < VRT_K; k++) {
+#pragma unroll
+        for (int ci = 0; ci < 2; ci++) l_wt[own_[ci] + k * VRT_WAVES * VRT_PW] = wp[k][ci];
     }
     __syncthreads();
     for (int s = 0; s < n_half; s += 2) {
