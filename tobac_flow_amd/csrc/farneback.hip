@@ -423,9 +423,18 @@ k_fb_polyexp5(const float *__restrict__ I, int H, int W, FbPoly pp, float *__res
     I += (int64_t)blockIdx.z * bs_I; R += (int64_t)blockIdx.z * bs_R;
     const int bx = blockIdx.x * FBP_W, by = blockIdx.y * FBP_H;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int i = tid; i < tw * th; i += 256) {
-        const int ty = i / tw, tx = i - ty * tw;
-        tI[i] = I[(int64_t)tf_clampi(by + ty - n, 0, H - 1) * W + tf_clampi(bx + tx - n, 0, W - 1)];
+    {
+        // all loads of a thread first, the LDS stores afterwards: a store right behind its load makes every trip of the
+        // loop a full memory round trip (the rolled form ran eight of them back to back)
+        constexpr int NL = (tw * th + 255) / 256;
+        float v[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int i = tid + 256 * j, ty = i / tw, tx = i - ty * tw;
+            v[j] = I[(int64_t)tf_clampi(by + ty - n, 0, H - 1) * W + tf_clampi(bx + tx - n, 0, W - 1)];   // ty past the tile: clamped, unused
+        }
+#pragma unroll
+        for (int j = 0; j < NL; j++) { const int i = tid + 256 * j; if (i < tw * th) tI[i] = v[j]; }
     }
     __syncthreads();
     float g[n + 1], xg[n + 1], xxg[n + 1];

@@ -39,26 +39,43 @@ k_vr_prepare(const uint8_t *__restrict__ I0, const uint8_t *__restrict__ I1, con
 {
     __shared__ float s_avg[VR_LH][VR_LW], s_iz[VR_LH][VR_LW], s_ix[VR_LH][VR_LW], s_iy[VR_LH][VR_LW];
     const int x0 = blockIdx.x * VR_TW - 2, y0 = blockIdx.y * VR_TH - 2;
-    // warped / averaged image and Iz on the tile + 2 halo (in-image positions only; neighbours are clamped later)
-    for (int i = threadIdx.x; i < VR_LW * VR_LH; i += 256) {
-        const int ly = i / VR_LW, lx = i - ly * VR_LW;
-        const int x = x0 + lx, y = y0 + ly;
-        if (x < 0 || y < 0 || x >= W || y >= H) continue;
-        const int64_t p = (int64_t)y * W + x;
-        const float2 f = flow[p];
-        const float mx = (float)x + f.x, my = (float)y + f.y;
-        const int fx = tf_cvround(mx * 32.f), fy = tf_cvround(my * 32.f);
-        const int sx = tf_sat_short(fx >> 5), sy = tf_sat_short(fy >> 5);
-        const int ax = fx & 31, ay = fy & 31;
-        const float tx1 = (float)ax * (1.f / 32.f), tx0 = 1.f - tx1, ty1 = (float)ay * (1.f / 32.f), ty0 = 1.f - ty1;
-        const float w0 = ty0 * tx0, w1 = ty0 * tx1, w2 = ty1 * tx0, w3 = ty1 * tx1;
-        const int xa = vr_clampi(sx, W - 1), xb = vr_clampi(sx + 1, W - 1), ya = vr_clampi(sy, H - 1), yb = vr_clampi(sy + 1, H - 1);
-        const float v0 = (float)I1[(int64_t)ya * W + xa], v1 = (float)I1[(int64_t)ya * W + xb];
-        const float v2 = (float)I1[(int64_t)yb * W + xa], v3 = (float)I1[(int64_t)yb * W + xb];
-        const float warped = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
-        const float i0 = (float)I0[p];
-        s_avg[ly][lx] = (i0 + warped) * 0.5f;
-        s_iz[ly][lx] = warped - i0;
+    // warped / averaged image and Iz on the tile + 2 halo (in-image positions only; neighbours are clamped later).
+    // Three stages so that a thread's loads are in flight together: flow + I0 of all its positions, then the four I1
+    // taps of all of them (their addresses need the flow), then the arithmetic and the LDS stores.
+    {
+        constexpr int NL = (VR_LW * VR_LH + 255) / 256;
+        float2 f[NL]; float i0[NL]; bool ok[NL];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int i = threadIdx.x + 256 * j, ly = i / VR_LW, lx = i - ly * VR_LW;
+            const int x = x0 + lx, y = y0 + ly;
+            ok[j] = i < VR_LW * VR_LH && x >= 0 && y >= 0 && x < W && y < H;
+            const int64_t p = ok[j] ? (int64_t)y * W + x : 0;
+            f[j] = flow[p]; i0[j] = (float)I0[p];
+        }
+        float v[NL][4], wgt[NL][4];
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int i = threadIdx.x + 256 * j, ly = i / VR_LW, lx = i - ly * VR_LW;
+            const int x = x0 + lx, y = y0 + ly;
+            const float mx = (float)x + f[j].x, my = (float)y + f[j].y;
+            const int fx = tf_cvround(mx * 32.f), fy = tf_cvround(my * 32.f);
+            const int sx = tf_sat_short(fx >> 5), sy = tf_sat_short(fy >> 5);
+            const int ax = fx & 31, ay = fy & 31;
+            const float tx1 = (float)ax * (1.f / 32.f), tx0 = 1.f - tx1, ty1 = (float)ay * (1.f / 32.f), ty0 = 1.f - ty1;
+            wgt[j][0] = ty0 * tx0; wgt[j][1] = ty0 * tx1; wgt[j][2] = ty1 * tx0; wgt[j][3] = ty1 * tx1;
+            const int xa = vr_clampi(sx, W - 1), xb = vr_clampi(sx + 1, W - 1), ya = vr_clampi(sy, H - 1), yb = vr_clampi(sy + 1, H - 1);
+            v[j][0] = (float)I1[(int64_t)ya * W + xa]; v[j][1] = (float)I1[(int64_t)ya * W + xb];
+            v[j][2] = (float)I1[(int64_t)yb * W + xa]; v[j][3] = (float)I1[(int64_t)yb * W + xb];
+        }
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            if (!ok[j]) continue;
+            const int i = threadIdx.x + 256 * j, ly = i / VR_LW, lx = i - ly * VR_LW;
+            const float warped = v[j][0] * wgt[j][0] + v[j][1] * wgt[j][1] + v[j][2] * wgt[j][2] + v[j][3] * wgt[j][3];
+            s_avg[ly][lx] = (i0[j] + warped) * 0.5f;
+            s_iz[ly][lx] = warped - i0[j];
+        }
     }
     __syncthreads();
     // first differences of the averaged image on the tile + 1 halo (replicated border = clamped neighbour coordinates)
