@@ -262,6 +262,15 @@ k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKern
         s1 = k[0] * cur;
         // four pixels per trip: the loads of a trip are independent of its accumulations (which keep their order)
         int i = 1;
+        for (; i + 7 < ksize; i += 8) {                        // wide kernels (pyramid levels >= 3): eight per trip
+            float nn[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) nn[u] = (float)P[i + 1 + u];
+            s0 += k[i] * cur; s1 += k[i] * nn[0];
+#pragma unroll
+            for (int u = 1; u < 8; u++) { s0 += k[i + u] * nn[u - 1]; s1 += k[i + u] * nn[u]; }
+            cur = nn[7];
+        }
         for (; i + 3 < ksize; i += 4) {
             const float n0 = (float)P[i + 1], n1 = (float)P[i + 2], n2 = (float)P[i + 3], n3 = (float)P[i + 4];
             s0 += k[i] * cur;     s1 += k[i] * n0;
@@ -319,7 +328,15 @@ k_fb_blur_cols_resize(const float2 *__restrict__ rowf, FbResizeGeom g, const FbK
         const float2 c0 = rowf[(int64_t)y * w + dx];
         float s0 = k[r] * c0.x, s1 = k[r] * c0.y;
         if (y - r >= 0 && y + r < H) {
-            for (int i = 1; i <= r; i++) {
+            int i = 1;
+            for (; i + 3 <= r; i += 4) {                       // loads of a trip first, accumulation order unchanged
+                float2 p[4], m[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { p[u] = rowf[(int64_t)(y + i + u) * w + dx]; m[u] = rowf[(int64_t)(y - i - u) * w + dx]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { s0 += k[r + i + u] * (p[u].x + m[u].x); s1 += k[r + i + u] * (p[u].y + m[u].y); }
+            }
+            for (; i <= r; i++) {
                 const float2 p = rowf[(int64_t)(y + i) * w + dx], m = rowf[(int64_t)(y - i) * w + dx];
                 s0 += k[r + i] * (p.x + m.x); s1 += k[r + i] * (p.y + m.y);
             }
