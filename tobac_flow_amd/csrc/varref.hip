@@ -197,32 +197,37 @@ k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const 
     if (!WEIGHTS && !in) return;
     const int64_t j = in ? (int64_t)y * W + x : 0;
     const float2 z2 = make_float2(0.f, 0.f);
-    const float2 d = dW ? dW[j] : z2;
     const bool has_r = x + 1 < W, has_l = x > 0, has_d = y + 1 < H, has_u = y > 0;
-    const float2 w0 = Wf[j];
-    const float2 wr = (in && has_r) ? Wf[j + 1] : w0, wlf = (in && has_l) ? Wf[j - 1] : w0;
-    const float2 wd = (in && has_d) ? Wf[j + W] : w0, wuf = (in && has_u) ? Wf[j - W] : w0;
+    // EVERY load of the thread is issued here, before the first use: a missing neighbour reads the pixel itself (the
+    // value the replicated border stands for), so the loads are unconditional and in flight together, and the
+    // derivative planes arrive while the weights are being formed.  (Loads behind the weights' barrier, or behind
+    // per-neighbour branches, cost the kernel six dependent memory round trips.)
+    const int64_t jr = (in && has_r) ? j + 1 : j, jl = (in && has_l) ? j - 1 : j;
+    const int64_t jd = (in && has_d) ? j + W : j, ju = (in && has_u) ? j - W : j;
+    const int64_t jdl = (in && has_l && has_d) ? j + W - 1 : jl, jur = (in && has_u && has_r) ? j - W + 1 : ju;
+    const float4 d1 = D1[j], d2 = D2[j];
+    const float2 w0 = Wf[j], wr = Wf[jr], wlf = Wf[jl], wd = Wf[jd], wuf = Wf[ju];
+    float2 d = z2, dr = z2, dd = z2, dl = z2, ddl = z2, dup = z2, dur = z2, wdl = z2, wur = z2;
+    if (dW) { d = dW[j]; if (WEIGHTS) { dr = dW[jr]; dd = dW[jd]; dl = dW[jl]; ddl = dW[jdl]; } }
+    if (WEIGHTS) {
+        wdl = Wf[jdl];
+        if (wv == 0) { wur = Wf[jur]; if (dW) { dup = dW[ju]; dur = dW[jur]; } }
+    }
     float wp, wl, wu;
     if (WEIGHTS) {
         const float2 cO = vr_add2(w0, d);
-        const float2 cR = (in && has_r) ? vr_add2(wr, dW ? dW[j + 1] : z2) : cO;
-        const float2 cD = (in && has_d) ? vr_add2(wd, dW ? dW[j + W] : z2) : cO;
-        wp = vr_weight(cO, cR, cD, P);
+        wp = vr_weight(cO, vr_add2(wr, dr), vr_add2(wd, dd), P);      // missing neighbour = the pixel itself
         if (in) wt_out[j] = wp;
         s_w[wv][lane] = wp;
         wl = __shfl_up(wp, 1);
         if (lane == 0 && in && has_l) {
             // weight of (x - 1, y): its right neighbour is this pixel, its lower one (x - 1, y + 1) or itself
-            const float2 cL = vr_add2(wlf, dW ? dW[j - 1] : z2);
-            const float2 cDL = has_d ? vr_add2(Wf[j + W - 1], dW ? dW[j + W - 1] : z2) : cL;
-            wl = vr_weight(cL, cO, cDL, P);
+            wl = vr_weight(vr_add2(wlf, dl), cO, vr_add2(wdl, ddl), P);
         }
         float wu0 = 0.f;
         if (wv == 0 && in && has_u) {
             // weight of (x, y - 1): its lower neighbour is this pixel, its right one (x + 1, y - 1) or itself
-            const float2 cU = vr_add2(wuf, dW ? dW[j - W] : z2);
-            const float2 cUR = has_r ? vr_add2(Wf[j - W + 1], dW ? dW[j - W + 1] : z2) : cU;
-            wu0 = vr_weight(cU, cUR, cO, P);
+            wu0 = vr_weight(vr_add2(wuf, dup), vr_add2(wur, dur), cO, P);
         }
         __syncthreads();
         wu = wv == 0 ? wu0 : s_w[wv > 0 ? wv - 1 : 0][lane];
@@ -231,7 +236,6 @@ k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const 
     } else {
         wp = wt_in[j]; wl = has_l ? wt_in[j - 1] : 0.f; wu = has_u ? wt_in[j - W] : 0.f;
     }
-    const float4 d1 = D1[j], d2 = D2[j];
     const float Ix = d1.x, Iy = d1.y, Ixz = d1.z, Iyz = d1.w, Ixx = d2.x, Ixy = d2.y, Iyy = d2.z, Iz = d2.w;
     const float du = d.x, dv = d.y;
     // ComputeDataTerm.  The fifteen quotients whose numerator is a product of two derivative values share the
