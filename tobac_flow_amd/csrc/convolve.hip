@@ -208,6 +208,10 @@ k_convolve(const typename StackTraits<TS>::In *__restrict__ data, const float *_
 // 12.3 ms; the same structure with the LDS path switched off: 10.7 ms).  The patch loads hit L1 / L2 and are not what
 // bounds the kernel: per pixel it issues ~560 unfused FP32 operations for the two bicubic planes (the reference's
 // 16-term row-major sums admit no sharing between taps) plus ~190 FP64 ones at half rate, a VALU floor of ~5 ms.
+// Also measured: requesting everything a pixel reads before the arithmetic starts (both flows, the same-step
+// neighbourhood and BOTH warped patches: two dependent memory round trips instead of five) costs 166 VGPRs / three
+// waves per SIMD and runs in 11.1 ms; with only the first patch requested early (114 VGPRs, four waves) 10.0 ms;
+// as it stands (96 VGPRs, five waves) 9.9 ms: the kernel follows its occupancy, not its load latency.
 template <int METHOD>
 __device__ __forceinline__ void sobel_plane_taps(const float *__restrict__ img, int H, int W, int x, int y,
                                                  float flx, float fly, float cval, float (&tap)[9])
