@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s 
 
 
 # library profile name -> kernel symbol prefix in the rocprofv3 counter files
-_KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<4, 0>", "vr_sor": "k_vr_sor_tile", "vr_system": "k_vr_system",
+_KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<4, 0>", "vr_sor": "k_vr_sor_tile", "vr_system": "void k_vr_system<true>",
                   "sobel": "void k_sobel27<2, double, 2, true>", "fb_polyexp": "k_fb_polyexp"}
 _TRAFFIC_FILE = "profiles/round2_pmc_traffic_bench.json"
 
