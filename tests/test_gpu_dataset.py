@@ -167,3 +167,44 @@ def test_label_statistics_match_numpy_within_float32_summation_error():
     assert np.isnan(got_w[0][0]) and np.isnan(got_w[0][1]) and not np.isnan(got_w[0][biggest - 1])
     with pytest.raises(ValueError):
         get_stats_for_labels(labels, x[1:])
+
+
+def test_retry_paths_of_the_label_wrappers():
+    """pair_counts sizes its scratch for n / 16 runs and slice_labels_dev for 4 M shifted ids; both retry with what the
+    library reports when the data needs more."""
+    from tobac_flow_amd.label import pair_counts, slice_labels_dev
+    rng = np.random.default_rng(21)
+    a = rng.integers(0, 50, (8, 512, 512)).astype(np.int32)          # ~2 M runs >> n / 16
+    b = rng.integers(0, 7, a.shape).astype(np.int32)
+    ia, ib, cnt = pair_counts(a, b)
+    keep = (a > 0) & (b > 0)
+    want = np.zeros((50, 7), np.int64)
+    np.add.at(want, (a[keep], b[keep]), 1)
+    got = np.zeros_like(want)
+    got[ia, ib] = cnt
+    assert np.array_equal(got, want) and np.all(cnt > 0)
+    lab = np.zeros((4, 64, 64), np.int32)
+    lab[0, 3, 3] = 1_500_000; lab[1, 5, 5] = 2_000_000; lab[1, 9, 9] = 7; lab[3, 1, 1] = 1_900_000      # 5.4 M shifted ids
+    step, n = slice_labels_dev(lab)
+    assert n == 4 and np.array_equal(step.cpu().numpy(), np_dataset.slice_labels(lab))
+
+
+def test_label_contract_accepts_device_tensors():
+    """label volumes that already live on the GPU stay there (no host copies of the volumes), results are the same"""
+    import torch
+    from tobac_flow_amd import dataset as D
+    ds, ref = _pair(2)
+    for k in ("core_label", "thick_anvil_label", "thin_anvil_label"):
+        ds[k] = torch.as_tensor(ds[k]).cuda()
+    D.add_label_coords(ds); np_dataset.add_label_coords(ref)
+    D.link_cores_and_anvils(ds); np_dataset.link_cores_and_anvils(ref)
+    D.add_step_labels(ds); np_dataset.add_step_labels(ref)
+    D.add_label_coords(ds); np_dataset.add_label_coords(ref)
+    D.link_step_labels(ds); np_dataset.link_step_labels(ref)
+    D.flag_edge_labels(ds); np_dataset.flag_edge_labels(ref)
+    assert ds["core_step_label"].is_cuda and ds["thick_anvil_label"].is_cuda
+    for k in ("core_label", "thick_anvil_label", "thin_anvil_label", "core_step_label", "thin_anvil_step_label"):
+        assert np.array_equal(ds[k].cpu().numpy(), ref[k]), k
+    for k in ("core_anvil_index", "anvil_core_count", "core_step_core_index", "thin_anvil_step_anvil_index",
+              "core_edge_label_flag", "thin_anvil_end_label_flag"):
+        assert np.array_equal(ds[k], ref[k]), k
