@@ -1,0 +1,76 @@
+"""The drop-in script's sequence end to end on a synthetic scene (scripts/dcc_detect_goes.py:162-330): create_flow with
+refinement -> detect_cores -> get_anvil_markers -> detect_anvils (thick, thin) -> the output-file label contract and the
+per-label statistics.  Every stage has its own parity test; this one checks that the stages fit together (dtypes, label
+ranges, containers) and that the contract's variables are consistent with each other and with the oracle's restatement."""
+import warnings
+
+import numpy as np
+import pytest
+
+from helpers import blob_sequence
+from oracle import np_dataset
+from test_gpu_detection import FakeDataArray
+
+pytestmark = pytest.mark.gpu
+
+
+def test_detection_script_sequence_end_to_end():
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd import dataset as D
+    from tobac_flow_amd.analysis import weighted_statistics_on_labels
+    from tobac_flow_amd.detection import detect_anvils, detect_cores, get_anvil_markers
+    T, minutes = 8, 2
+    rng = np.random.default_rng(42)
+    bt0 = blob_sequence(rng, T, 96, 120, n_blobs=5, vmax=2.0, noise=0.5)
+    flow = tf.create_flow(bt0, model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    ramp = np.linspace(0.5, 1.4, T, dtype=np.float32)[:, None, None]
+    cold = np.clip(250.0 - bt0, 0, None)
+    bt = FakeDataArray((290.0 - ramp * cold).astype(np.float32), minutes=minutes)
+    # WVD - SWD crosses the thick-anvil thresholds (-5 / -12.5) and WVD + SWD the thin ones (0 / -7.5) around the cold blobs
+    wvd = FakeDataArray((0.8 * cold - 11).astype(np.float32), minutes=minutes)
+    swd = FakeDataArray(np.full(cold.shape, 3.0, np.float32), minutes=minutes)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        core = np.asarray(detect_cores(flow, bt, wvd, swd, use_wvd=False, min_length=3)).astype(np.int32)
+        wd, ws = np.asarray(wvd) - np.asarray(swd), np.asarray(wvd) + np.asarray(swd)
+        markers = np.asarray(get_anvil_markers(flow, wd, threshold=-5, overlap=0.5, absolute_overlap=4, min_length=3))
+        thick = np.asarray(detect_anvils(flow, wd, markers=markers, upper_threshold=-5, lower_threshold=-12.5,
+                                         erode_distance=2, min_length=3)).astype(np.int32)
+        thin = np.asarray(detect_anvils(flow, ws, markers=thick, upper_threshold=0, lower_threshold=-7.5,
+                                        erode_distance=2, min_length=3)).astype(np.int32)
+    assert core.max() >= 1 and thick.max() >= 1 and thin.max() >= 1
+    assert np.all(thin[thick > 0] == thick[thick > 0])               # the thin anvil grows from the thick one's labels
+
+    ds = D.LabelDataset(coords={"t": np.asarray(bt.t.values if hasattr(bt.t, "values") else bt.t)})
+    ref = {"coords": {"t": ds.coords["t"]}}
+    for name, v in (("core_label", core), ("thick_anvil_label", thick), ("thin_anvil_label", thin)):
+        ds.add(name, v.copy(), ("t", "y", "x")); ref[name] = v.copy()
+    for fn in ("add_label_coords", "link_cores_and_anvils", "add_step_labels", "add_label_coords", "link_step_labels",
+               "flag_edge_labels"):
+        getattr(D, fn)(ds); getattr(np_dataset, fn)(ref)
+    nan_field = np.asarray(wvd).copy(); nan_field[3, 40:43, 50:52] = np.nan
+    D.flag_nan_adjacent_labels(ds, nan_field); np_dataset.flag_nan_adjacent_labels(ref, nan_field)
+    for k, want in ref.items():
+        if k == "coords":
+            for c, v in want.items():
+                assert np.array_equal(ds.coords[c], v), c
+        else:
+            assert np.array_equal(np.asarray(ds[k]), want) and np.asarray(ds[k]).dtype == want.dtype, k
+    # the variables agree with each other
+    cores, anvils = ds.coords["core"], ds.coords["anvil"]
+    assert set(ds["core_anvil_index"]) <= set(anvils) | {0}
+    assert ds["anvil_core_count"].sum() == np.count_nonzero(ds["core_anvil_index"])
+    linked = ds["core_anvil_index"] > 0
+    for c, a in zip(cores[linked], ds["core_anvil_index"][linked]):
+        assert np.all(ds["thick_anvil_label"][ds["core_label"] == c] == a)      # cores were written into their anvil
+    step = ds["core_step_label"]
+    for k, parent in zip(ds.coords["core_step"], ds["core_step_core_index"]):
+        where = step == k
+        assert np.all(ds["core_label"][where] == parent) and len(np.unique(np.nonzero(where)[0])) == 1   # one step each
+    # per-label statistics of the brightness temperature over the cores
+    mean, std, mx, mn = weighted_statistics_on_labels(ds["core_label"], np.asarray(bt), np.ones(core.shape, np.float32))
+    assert mean.shape == (core.max(),)
+    for c in cores:
+        vals = np.asarray(bt)[ds["core_label"] == c].astype(np.float64)
+        assert abs(mean[c - 1] - vals.mean()) < 1e-3 and mx[c - 1] == vals.max().astype(np.float32) and mn[c - 1] == vals.min().astype(np.float32)
+        assert abs(std[c - 1] - vals.std()) < 1e-3
