@@ -315,6 +315,32 @@ def main():
                             "marker_tie_points": timed[-1][10], "ties_left_by_depth_cut_off": timed[-1][11],
                             "timed_steps_probing": sum(1 for t_ in timed if t_[5] >= 0),
                             "timed_steps_skipping_root_phase": sum(1 for t_ in timed if t_[5] < 0)}
+        # per-stage rates, and the measured device-to-device copy rate as the practical HBM ceiling
+        stage_of = {"to8bit_pair": "flow", "fb_gaussian_blur": "flow", "fb_resize": "flow", "fb_polyexp": "flow",
+                    "fb_update_matrices": "flow", "fb_blur_solve": "flow", "fb_iteration_fused": "flow", "smooth_flow": "flow",
+                    "vr_prepare": "refinement", "vr_system": "refinement", "vr_sor": "refinement",
+                    "convolve": "sobel", "sobel": "sobel", "ws_setup": "watershed", "ws_relax_sweep": "watershed", "ws_labels": "watershed"}
+        stage_ms = {}
+        for k, v in prof.items():
+            stage_ms[stage_of.get(k, "other")] = stage_ms.get(stage_of.get(k, "other"), 0.0) + v[1] / a.steps
+        out["stages"] = {k: {"kernel_ms_per_step": round(v, 2), "Mpix_per_s": round(T * H * W / v / 1e3, 1)}
+                         for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])}
+        if roof is not None:
+            n_copy = min(1 << 28, max(1 << 20, T * H * W))            # float32 elements: up to 1 GiB read + 1 GiB written
+            src = torch.empty(n_copy, dtype=torch.float32, device=bt.device).normal_()
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 10 * 2 * 4 * n_copy / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            roof["practical_peak"] = round(copy_gbps, 1)
+            roof["practical_peak_note"] = "device-to-device copy of 2 x %.2f GB measured in this run (read + written bytes)" % (4 * n_copy / 1e9)
+            roof["frac_practical"] = round(roof["achieved"] / copy_gbps, 4)
+            del src, dst
         if ms_no_vr is not None:
             out["without_refinement"] = {"ms_per_step": round(ms_no_vr, 2), "value": round(world * T * H * W / ms_no_vr / 1e3, 2),
                                          "note": "same step with create_flow(vr_steps=0), 2 steps after the timed region: the "
