@@ -1114,7 +1114,8 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
             // strip height: tall strips amortise the 12-row halo, short ones keep all CUs busy on coarse levels
             static const int hs_max = getenv("TF_FBI_HS") ? atoi(getenv("TF_FBI_HS")) : FBI_HS;
             int hs = hs_max;
-            while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd * B < 1536 * (256 / FBI_T)) hs >>= 1;
+            static const int64_t min_wg = getenv("TF_FBI_MIN_WG") ? atoll(getenv("TF_FBI_MIN_WG")) : 1536 * (256 / FBI_T);
+            while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd * B < min_wg) hs >>= 1;
             const int nx = (w + FBI_OW - 1) / FBI_OW;
             const dim3 gi(((nx + 7) / 8) * 8 * nd, (h + hs - 1) / hs, B);
             FbIterArgs ia;
