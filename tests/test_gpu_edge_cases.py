@@ -321,18 +321,21 @@ def test_development_switches_do_not_change_results(tf, tmp_path):
     import subprocess
     import sys
     rng = np.random.default_rng(21)
-    a = ndi.gaussian_filter(rng.normal(size=(3, 150, 210)), (0, 2.5, 2.5)).astype(np.float32) * 30 + 250
-    np.save(tmp_path / "in.npy", a)
-    fw, bw = tf.calculate_flow(a, "Farneback", vr_steps=1)
     code = ("import sys, numpy as np; sys.path.insert(0, %r); import tobac_flow_amd.flow as tf; "
             "a = np.load(%r); f, b = tf.calculate_flow(a, 'Farneback', vr_steps=1); np.save(%r, np.stack([f, b]))")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for var in ("TF_FB_POLYEXP_GENERIC", "TF_VR_SOR_SWEEPS", "TF_VR_WEIGHTS_PASS", "TF_FB_BLUR_TWOPASS"):
-        out = tmp_path / f"{var}.npy"
-        env = dict(os.environ, **{var: "1"})
-        subprocess.check_call([sys.executable, "-c", code % (root, str(tmp_path / "in.npy"), str(out))], env=env)
-        alt = np.load(out)
-        assert np.array_equal(alt[0], fw, equal_nan=True) and np.array_equal(alt[1], bw, equal_nan=True), var
+    # a width that is no multiple of four (byte staging with reflected borders) and one that is (word staging; deep
+    # pyramid: blur kernels up to 39 taps)
+    for tag, shape in (("a", (3, 150, 210)), ("b", (2, 272, 544))):
+        a = ndi.gaussian_filter(rng.normal(size=shape), (0, 2.5, 2.5)).astype(np.float32) * 30 + 250
+        np.save(tmp_path / f"in_{tag}.npy", a)
+        fw, bw = tf.calculate_flow(a, "Farneback", vr_steps=1)
+        for var in ("TF_FB_POLYEXP_GENERIC", "TF_VR_SOR_SWEEPS", "TF_VR_WEIGHTS_PASS", "TF_FB_BLUR_TWOPASS", "TF_FB_BLUR_NO_LDS"):
+            out = tmp_path / f"{var}_{tag}.npy"
+            env = dict(os.environ, **{var: "1"})
+            subprocess.check_call([sys.executable, "-c", code % (root, str(tmp_path / f"in_{tag}.npy"), str(out))], env=env)
+            alt = np.load(out)
+            assert np.array_equal(alt[0], fw, equal_nan=True) and np.array_equal(alt[1], bw, equal_nan=True), (var, tag)
 
 
 def test_shutdown_releases_the_timing_pool_and_leaves_the_library_usable(tf):

@@ -307,6 +307,87 @@ k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKern
     rowf[(int64_t)y * g.dw + dx] = out;
 }
 
+// The same pass with the source row segment of a workgroup staged in LDS (uint8 images, ksize > 5): 64 outputs x 4 rows
+// per 256-thread workgroup read `64 * stride + ksize` source bytes per row ONCE, as aligned 32-bit words issued together
+// (byte loads with the reflected border where the segment touches the image edge), instead of ksize + 1 byte loads per
+// output in a dependent loop.  The LDS row is padded by one word per `unit` bytes (unit = the largest power of two <=
+// stride) so that the lanes of a wave, which read bytes `stride` apart, fall into different banks.  Every output is the
+// left-to-right sum of k_fb_blur_rows_sampled, bit for bit.
+#define FBL_ROW_BYTES 4096            /* staged bytes per row the kernel accepts (before padding) */
+#define FBL_ROW_WORDS (FBL_ROW_BYTES / 4 + FBL_ROW_BYTES / 32 + 8)
+__global__ void __launch_bounds__(256)
+k_fb_blur_rows_sampled_lds(const uint8_t *__restrict__ src, FbResizeGeom g, const FbKernel kk, float2 *__restrict__ rowf,
+                           int64_t bs_src, int64_t bs_dst, int unit_shift)
+{
+    __shared__ unsigned s_row[4][FBL_ROW_WORDS];
+    src += (int64_t)blockIdx.z * bs_src; rowf += (int64_t)blockIdx.z * bs_dst;
+    const int lane = threadIdx.x, ry = threadIdx.y;
+    const int dx = blockIdx.x * 64 + lane, y0 = blockIdx.y * 4, y = y0 + ry;
+    const int ksize = kk.ksize, r = ksize >> 1, W = g.sw;
+    int sx; float fx;
+    fb_resize_coord(min(dx, g.dw - 1), g.scale_x, g.sw, sx, fx);
+    if (sx < 0) sx = 0;
+    if (sx >= g.sw - 1) sx = g.sw - 1;
+    const int sx1 = sx + 1 < g.sw ? sx + 1 : sx;
+    // segment of this workgroup: source columns [lo, hi] (before reflection), lo rounded down to a word
+    const int n_out = min(64, g.dw - blockIdx.x * 64);
+    const int lo = (__shfl(sx, 0) - r) & ~3, hi = __shfl(sx1, n_out - 1) + r;
+    const int span = hi - lo + 1;                                       // host guarantees span <= FBL_ROW_BYTES
+    const int n_words = (span + 3) >> 2;
+    const bool inside = lo >= 0 && lo + 4 * n_words <= W && ((W & 3) == 0) && ((bs_src & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
+    {
+        const int tid = ry * 64 + lane;
+        unsigned v[(4 * (FBL_ROW_BYTES / 4 + 1) + 255) / 256];
+#pragma unroll
+        for (int j = 0; j < (int)(sizeof(v) / sizeof(v[0])); j++) {
+            const int i = tid + 256 * j, row = i / n_words, wd = i - row * n_words;
+            const int yy = min(y0 + row, g.sh - 1);
+            v[j] = 0;
+            if (i < 4 * n_words) {
+                if (inside) v[j] = *(const unsigned *)(src + (int64_t)yy * W + lo + 4 * wd);
+                else {
+                    const uint8_t *S = src + (int64_t)yy * W;
+                    const int c = lo + 4 * wd;
+                    v[j] = (unsigned)S[fb_reflect101(c, W)] | ((unsigned)S[fb_reflect101(c + 1, W)] << 8) |
+                           ((unsigned)S[fb_reflect101(c + 2, W)] << 16) | ((unsigned)S[fb_reflect101(c + 3, W)] << 24);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (int)(sizeof(v) / sizeof(v[0])); j++) {
+            const int i = tid + 256 * j, row = i / n_words, wd = i - row * n_words;
+            if (i < 4 * n_words) s_row[row][wd + ((4 * wd) >> unit_shift)] = v[j];
+        }
+    }
+    __syncthreads();
+    if (dx >= g.dw || y >= g.sh) return;
+    const float *k = kk.k;
+    const uint8_t *L = (const uint8_t *)s_row[ry];
+    // byte a of the segment lives at a + 4 * (a >> unit_shift)
+    auto at = [&](int a) { return (float)L[a + ((a >> unit_shift) << 2)]; };
+    const int b0 = sx - r - lo, b1 = sx1 - r - lo;
+    float s0, s1;
+    if (b1 == b0 + 1) {
+        float cur = at(b0 + 1);
+        s0 = k[0] * at(b0); s1 = k[0] * cur;
+        int i = 1;
+        for (; i + 7 < ksize; i += 8) {
+            float nn[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) nn[u] = at(b0 + i + 1 + u);
+            s0 += k[i] * cur; s1 += k[i] * nn[0];
+#pragma unroll
+            for (int u = 1; u < 8; u++) { s0 += k[i + u] * nn[u - 1]; s1 += k[i + u] * nn[u]; }
+            cur = nn[7];
+        }
+        for (; i < ksize; i++) { const float nxt = at(b0 + i + 1); s0 += k[i] * cur; s1 += k[i] * nxt; cur = nxt; }
+    } else {
+        s0 = k[0] * at(b0); s1 = k[0] * at(b1);
+        for (int i = 1; i < ksize; i++) { s0 += k[i] * at(b0 + i); s1 += k[i] * at(b1 + i); }
+    }
+    rowf[(int64_t)y * g.dw + dx] = make_float2(s0, s1);
+}
+
 __global__ void __launch_bounds__(256)
 k_fb_blur_cols_resize(const float2 *__restrict__ rowf, FbResizeGeom g, const FbKernel kk, float *__restrict__ dst, int64_t bs_src, int64_t bs_dst)
 {
@@ -1072,8 +1153,18 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 // blur + resize fused on the sampled columns / rows (tmp holds rowf: H * w float2 <= n + 2H floats)
                 TfProfScope ps(TFK_FB_BLUR, (1.0 * n + 8.0 * (double)H * w * 2 + 4.0 * plane) * B, s);
                 FbResizeGeom rg; rg.sh = H; rg.sw = W; rg.dh = h; rg.dw = w; rg.scale_x = rsx; rg.scale_y = rsy;
-                hipLaunchKernelGGL(k_fb_blur_rows_sampled<uint8_t>, dim3((w + 63) / 64, (H + 3) / 4, B), block, 0, s, img[i], rg, hk,
-                                   (float2 *)tmp, img_stride, bs_tmp / 2);
+                // LDS-staged form when a workgroup's source segment fits (64 outputs * stride + ksize bytes per row)
+                static const bool no_lds = getenv("TF_FB_BLUR_NO_LDS") != nullptr;                 // development aid
+                const int64_t seg = (int64_t)(64 * rsx) + hk.ksize + 8;
+                if (!no_lds && hk.ksize > 5 && seg <= FBL_ROW_BYTES && W >= hk.ksize) {
+                    int unit_shift = 2;                                 // pad unit = largest power of two <= stride, >= 8 bytes;
+                    while ((2 << unit_shift) <= (int)rsx) unit_shift++; // unit 4 (shift 2) would pad every word: then no padding
+                    if (unit_shift < 3) unit_shift = 30;
+                    hipLaunchKernelGGL(k_fb_blur_rows_sampled_lds, dim3((w + 63) / 64, (H + 3) / 4, B), block, 0, s, img[i], rg, hk,
+                                       (float2 *)tmp, img_stride, bs_tmp / 2, unit_shift);
+                } else
+                    hipLaunchKernelGGL(k_fb_blur_rows_sampled<uint8_t>, dim3((w + 63) / 64, (H + 3) / 4, B), block, 0, s, img[i], rg, hk,
+                                       (float2 *)tmp, img_stride, bs_tmp / 2);
                 hipLaunchKernelGGL(k_fb_blur_cols_resize, glev, block, 0, s, (const float2 *)tmp, rg, hk, I, bs_tmp / 2, bs_n);
                 Ik = I;
             }
