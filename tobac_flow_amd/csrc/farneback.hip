@@ -1156,7 +1156,9 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 // LDS-staged form when a workgroup's source segment fits (64 outputs * stride + ksize bytes per row)
                 static const bool no_lds = getenv("TF_FB_BLUR_NO_LDS") != nullptr;                 // development aid
                 const int64_t seg = (int64_t)(64 * rsx) + hk.ksize + 8;
-                if (!no_lds && hk.ksize > 5 && seg <= FBL_ROW_BYTES && W >= hk.ksize) {
+                // (measured at 5424^2, 8 images: stride 32 / 16: 958 -> 282 / 554 -> 322 us; stride 8 / 4: 355 -> 415 / 380 -> 673 us --
+                // short kernels gain nothing from staging and pay for the barrier: LDS form from stride 12 on)
+                if (!no_lds && hk.ksize > 5 && rsx >= 12. && seg <= FBL_ROW_BYTES && W >= hk.ksize) {
                     int unit_shift = 2;                                 // pad unit = largest power of two <= stride, >= 8 bytes;
                     while ((2 << unit_shift) <= (int)rsx) unit_shift++; // unit 4 (shift 2) would pad every word: then no padding
                     if (unit_shift < 3) unit_shift = 30;
