@@ -208,8 +208,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     H, W = shape
     forward = _lib.empty((T, H, W, 2), t.float32)
     backward = _lib.empty((T, H, W, 2), t.float32)
-    forward.fill_(float("nan"))
-    backward.fill_(float("nan"))
+    # every frame is written below except the two mirrored ends, which tf_flow_finalize derives from their neighbours
+    # (NaN there if the stack has a single frame and there is nothing to mirror)
+    forward[T - 1].fill_(float("nan"))
+    backward[0].fill_(float("nan"))
     # Frame pairs are independent units: they are processed in batches of TF_FLOW_BATCH pairs per set of
     # kernel launches (tf_farneback_batch), which keeps the coarse pyramid levels busy on all CUs.
     linear = norm_name == "linear" and not normalisation_kwargs
