@@ -549,7 +549,7 @@ def test_calculate_flow_2_pairs_two_stacks(tf):
     assert np.array_equal(fwd[T - 1], -bwd[T - 1]) and np.array_equal(bwd[0], -fwd[0])
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (7, 64), (65, 17), (96, 128), (129, 257), (333, 517)])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (7, 64), (65, 17), (84, 108), (85, 109), (96, 128), (129, 257), (168, 216), (333, 517)])
 def test_variational_refinement_bit_exact_vs_oracle(tf, shape):
     """tf_varref (cv2.VariationalRefinement, flow.py:359, 513-519) against the oracle's C restatement: every float
     expression is evaluated in the same order, so the refined flow is IDENTICAL -- tile seams, odd sizes and images
