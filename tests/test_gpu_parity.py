@@ -821,3 +821,23 @@ def test_shared_reciprocal_division_equals_the_hardware_division():
         bad = ctypes.c_uint64(123)
         _lib.check(L.tf_selftest_shared_divide(1 << 26, seed, ctypes.byref(bad), _lib.stream_ptr()), "selftest")
         assert bad.value == 0
+
+
+def test_variational_refinement_random_shapes_and_parameters(tf):
+    """a sweep over shapes around the tile kernel's geometry (108 x 84 tiles, 128 x 104 regions, 10-pixel halo) with
+    random iteration counts and weights: identical to the oracle every time"""
+    from oracle import np_ops
+    rng = np.random.default_rng(2024)
+    shapes = [(int(rng.integers(1, 260)), int(rng.integers(1, 330))) for _ in range(10)] + [(83, 107), (94, 118), (104, 128), (105, 129)]
+    for H, W in shapes:
+        a = ndi.gaussian_filter(rng.normal(size=(H + 8, W + 8)), 1.5)
+        a = ((a - a.min()) / max(np.ptp(a), 1e-9) * 255)
+        i0, i1 = a[4:-4, 4:-4].astype(np.uint8), a[5:-3, 3:-5].astype(np.uint8)
+        flow = (rng.normal(size=(H, W, 2)) * 2).astype(np.float32)
+        fp, sor = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        alpha, delta, gamma, omega = float(rng.uniform(5, 30)), float(rng.uniform(1, 8)), float(rng.uniform(2, 15)), float(rng.uniform(1.0, 1.9))
+        vr = tf.VariationalRefinement.create()
+        vr.fixedPointIterations, vr.sorIterations, vr.alpha, vr.delta, vr.gamma, vr.omega = fp, sor, alpha, delta, gamma, omega
+        got = vr.calc(i0, i1, flow.copy())
+        want = np_ops.variational_refinement(i0, i1, flow, fp, sor, alpha=alpha, delta=delta, gamma=gamma, omega=omega)
+        assert np.array_equal(got, want), ((H, W), fp, sor, np.abs(got - want).max())
