@@ -218,3 +218,54 @@ def test_smooth_flow_config_c_matches_oracle():
     wf, wb = np_ops.smooth_flow_step(f, b, "cubic")
     assert np.array_equal(np.isnan(gf), np.isnan(wf)) and np.array_equal(np.nan_to_num(gf), np.nan_to_num(wf))
     assert np.array_equal(np.nan_to_num(gb), np.nan_to_num(wb))
+
+
+def test_watershed_beyond_2_to_31_voxels_equals_its_halves():
+    """SURVEY 8(e) "exact mode": one flood over a volume of more than 2^31 voxels (the whole of a long full-disk stack on
+    one GPU).  76 frames of 5424 x 5424 = 2.24e9 voxels with frame 38 masked out: nothing crosses a masked frame, so the
+    labels of frames 0..37 and 39..75 must be exactly those of flooding each half alone (1.12e9 voxels each, the size
+    range every other test covers)."""
+    import torch
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    T, H, W, cut = 76, 5424, 5424, 38
+    g = torch.Generator(device="cuda").manual_seed(7)
+    # a smooth field with plateaus (quantised) and sparse markers; smooth sub-pixel .. 2-pixel flows
+    base = torch.nn.functional.avg_pool2d(torch.randn((1, 1, H // 8 + 2, W // 8 + 2), device="cuda", generator=g), 3, 1, 1)
+    base = torch.nn.functional.interpolate(base, size=(H, W), mode="bilinear", align_corners=False)[0, 0]
+    field = torch.empty((T, H, W), dtype=torch.float32, device="cuda")
+    for t in range(T):
+        field[t] = torch.round((base + 0.02 * t) * 6) / 6
+    markers = torch.zeros((T, H, W), dtype=torch.int32, device="cuda")
+    ys = torch.arange(40, H, 211, device="cuda"); xs = torch.arange(20, W, 320, device="cuda")
+    ids = (torch.arange(ys.numel(), device="cuda")[:, None] * xs.numel() + torch.arange(xs.numel(), device="cuda")[None, :] + 1).to(torch.int32)
+    for t in (3, 20, 37, 41, 60, 74):
+        markers[t][ys[:, None], xs[None, :]] = ids + 100000 * t
+    # floodable: vertical stripes, a fifth of every frame (a detection volume floods ~5 % of its voxels; the compact
+    # arrays of the flood take ~130 B per floodable voxel)
+    mask = torch.zeros((T, H, W), dtype=torch.int8, device="cuda")
+    mask[:, :, (torch.arange(W, device="cuda") % 320) < 64] = 1
+    mask[cut] = 0
+    fwd = torch.empty((T, H, W, 2), dtype=torch.float32, device="cuda")
+    bwd = torch.empty((T, H, W, 2), dtype=torch.float32, device="cuda")
+    fl = torch.nn.functional.interpolate(torch.randn((1, 2, 12, 12), device="cuda", generator=g) * 1.2, size=(H, W), mode="bilinear")[0]
+    for t in range(T):
+        fwd[t] = fl.permute(1, 2, 0)
+        bwd[t] = -fl.permute(1, 2, 0)
+    del base, fl
+    nbr = neighbour_offsets(1)
+    st = {}
+    from tobac_flow_amd import _lib
+    try:
+        whole = watershed_dev(fwd, bwd, field, markers, mask, nbr, stats=st, on_ambiguous="ignore")
+        assert T * H * W > 2 ** 31 and st["sweeps"][6] > 10 ** 8          # relevant pixels: a real flood
+        assert int((whole[cut] != 0).sum()) == 0
+        for a, b in ((0, cut), (cut + 1, T)):
+            part = watershed_dev(fwd[a:b].contiguous(), bwd[a:b].contiguous(), field[a:b].contiguous(), markers[a:b].contiguous(),
+                                 mask[a:b].contiguous(), nbr, on_ambiguous="ignore")
+            assert torch.equal(part, whole[a:b]), (a, b, int((part != whole[a:b]).sum()))
+            assert int((part > 0).sum()) > 0.9 * int(mask[a:b].sum())       # the markers flooded (almost) everything floodable
+            del part
+    finally:
+        _lib.release_workspaces()                   # > 100 GB of scratch: give it back before the next test
+        del fwd, bwd, field, markers, mask
+        torch.cuda.empty_cache()

@@ -202,6 +202,7 @@ def workspace(nbytes, tag="default"):
     cur = _WS.get(tag)
     if cur is None or cur.numel() < nbytes or cur.device != device():
         _WS[tag] = None
+        cur = None                               # drop the old buffer BEFORE the new one is allocated (they can be > 100 GB)
         cur = t.empty(int(nbytes), dtype=t.uint8, device=device())
         _WS[tag] = cur
     return cur

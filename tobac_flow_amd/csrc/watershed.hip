@@ -611,12 +611,37 @@ k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, co
 struct WsU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
 typedef hipcub::TransformInputIterator<int, WsU8ToInt, const uint8_t *> WsFlagIter;
 
+// The flag scan runs in chunks of at most 2^30 voxels (the scan primitive counts its items in an int), each continuing
+// from the total of the chunks before it: volumes beyond 2^31 voxels -- config F's 144 full-disk frames as ONE exact
+// flood -- only need the RELEVANT pixel count to fit the int32 compact ids.
+#define WS_SCAN_CHUNK (1ll << 30)
 static size_t ws_scan_temp_bytes(int64_t n) {
     size_t bytes = 0;
     WsFlagIter it((const uint8_t *)nullptr, WsU8ToInt());
     // size query only (null temp storage): fills `bytes`
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, (int *)nullptr, (int)(n > 0x7fffffff ? 0x7fffffff : n));
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, bytes, it, (int *)nullptr, hipcub::Sum(), 0, (int)(n > WS_SCAN_CHUNK ? WS_SCAN_CHUNK : n));
     return bytes;
+}
+
+// scan[i] = number of flagged voxels before i; *total = number of flagged voxels.  Synchronises the stream.
+static int ws_scan_flags(const uint8_t *flag, int *scan, int64_t N, void *tmp, size_t tmp_bytes, hipStream_t s, int64_t *total)
+{
+    int64_t carry = 0;
+    for (int64_t off = 0; off < N; off += WS_SCAN_CHUNK) {
+        const int64_t n = N - off < WS_SCAN_CHUNK ? N - off : WS_SCAN_CHUNK;
+        size_t tb = tmp_bytes;
+        WsFlagIter it(flag + off, WsU8ToInt());
+        TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveScan(tmp, tb, it, scan + off, hipcub::Sum(), (int)carry, (int)n, s));
+        int last_scan = 0; uint8_t last_flag = 0;
+        TF_CHECK_HIP(hipMemcpyAsync(&last_scan, scan + off + n - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipMemcpyAsync(&last_flag, flag + off + n - 1, 1, hipMemcpyDeviceToHost, s));
+        TF_CHECK_HIP(hipStreamSynchronize(s));
+        carry = (int64_t)last_scan + last_flag;
+        // a chunk adds at most 2^30: the running total cannot wrap an int before this test sees it
+        TF_REQUIRE(carry <= 0x3fffff00ll, "tf_watershed: more than 2^30 relevant pixels in one call (use time windows)");
+    }
+    *total = carry;
+    return TF_OK;
 }
 
 static size_t ws_full_bytes(int64_t N) {
@@ -737,7 +762,9 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     TF_REQUIRE(n_nbr > 0 && n_nbr <= WS_MAX_NBR, "tf_watershed: bad neighbour count");
     TF_REQUIRE(depth0 >= 1 && depth0 <= depth_max && depth_max <= WS_MAX_DEPTH, "tf_watershed: bad chain_depth");
     const int64_t N = rv ? rv->n : T * H * W;
-    TF_REQUIRE(N > 0 && N <= 0x7fffffffll, "tf_watershed: more than 2^31 - 1 voxels per call (use time windows)");
+    // the raveled twin addresses voxels through int32 strides like the reference; the (T, H, W) entry points index in
+    // 64 bits and are bounded by memory (and by 2^30 RELEVANT pixels, checked after the scan)
+    TF_REQUIRE(N > 0 && (rv ? N <= 0x7fffffffll : N <= (1ll << 36)), "tf_watershed: too many voxels per call (use time windows)");
     if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(1, n_nbr, depth_max)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
     hipStream_t s = (hipStream_t)stream;
     WsGeom g; g.T = T; g.H = (int)H; g.W = (int)W; g.plane = H * W; g.n_nbr = n_nbr;
@@ -780,14 +807,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             hipLaunchKernelGGL(k_ws_relevant, grid, block, 0, s, cls, fwd, bwd, g, flag);
         }
         TF_CHECK_LAUNCH();
-        size_t tb = scan_bytes;
-        WsFlagIter it(flag, WsU8ToInt());
-        TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, it, scan, (int)N, s));
-        int last_scan = 0; uint8_t last_flag = 0;
-        TF_CHECK_HIP(hipMemcpyAsync(&last_scan, scan + N - 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        TF_CHECK_HIP(hipMemcpyAsync(&last_flag, flag + N - 1, 1, hipMemcpyDeviceToHost, s));
-        TF_CHECK_HIP(hipStreamSynchronize(s));
-        R = (int64_t)last_scan + last_flag;
+        const int rc_scan = ws_scan_flags(flag, scan, N, scan_tmp, scan_bytes, s, &R);
+        if (rc_scan) return rc_scan;
     }
     st[6] = R;
     if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(R > 0 ? R : 1, n_nbr, depth_max)) {

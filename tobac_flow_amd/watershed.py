@@ -120,8 +120,10 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
     # levels beyond chain_depth are rarely needed: the first call gets room for two more, a second one for all
     start, cap = chain_depth, min(max_chain_depth, chain_depth + 2)
     probed = None
+    ws = None
     while True:
         nbytes = L.tf_watershed_workspace_bytes(T, H, W, len(nbr), cap, guess)
+        ws = None                                # a retry must not hold the old buffer while the larger one is allocated
         ws = _lib.workspace(nbytes, "watershed")
         rc = L.tf_watershed_ex2(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
                                 T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), start, cap, flags, _lib.ptr(labels),
