@@ -188,6 +188,9 @@ int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int64_t W, con
  * markers that touch one).  tf_watershed_workspace_bytes(..., max_relevant) sizes the workspace for
  * at most that many (0 = worst case T*H*W).  If the volume has more, tf_watershed returns
  * TF_ENOMEM and stats_host[6] holds the exact count to size a retry with.
+ * Size limits: voxels are indexed in 64 bits (T < 65536, H, W < 32768, T*H*W <= 2^36) -- a whole long stack can be
+ * flooded exactly in one call if it fits the memory; the compact ids are int32: at most 2^30 relevant pixels
+ * (TF_EINVAL beyond).  tf_watershed_raveled keeps the reference's int32 strides: at most 2^31 - 1 voxels.
  * stats_host (optional, 8 x int64): [0] sweeps phase A, [1] sweeps root phase (fast path),
  * [2..4] sweeps of the chain phases when the fast path found a label conflict, [5] conflict flag,
  * [6] relevant pixel count.  This call synchronises the stream.
