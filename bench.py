@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--vr-steps", type=int, default=1,
                     help="create_flow(vr_steps=...): 1 = the setting of the reference's drop-in scripts "
                          "(scripts/dcc_detect_goes.py:164-166), 0 = no variational refinement")
+    ap.add_argument("--windows", type=int, default=3, help="distinct windows of the synthetic sequence the steps cycle through")
     ap.add_argument("--overlap", type=int, default=4,
                     help="frames consecutive windows (ranks) share; the stitch compares all but the first and last of them")
     ap.add_argument("--height", type=int, default=5424)
@@ -218,12 +219,20 @@ def main():
 
     T, H, W = a.frames, a.height, a.width
     # rank r holds frames r * (T - overlap) ... of ONE sequence: its last `overlap` frames are rank r + 1's first ones
-    bt = blob_stack(T, H, W, seed=20240601, t0=rank * (T - a.overlap))      # resident in HBM before the timed region
-    lin, markers = anvil_inputs(bt)
+    # `--windows` different windows of the sequence, visited in turn by the steps (a production run never sees the same
+    # window twice; with one window every data-dependent memo of the host layer would be perfectly warm)
+    inputs = []
+    for k in range(max(1, a.windows)):
+        bt_k = blob_stack(T, H, W, seed=20240601, t0=rank * (T - a.overlap) + 5 * k)      # resident in HBM before the timed region
+        inputs.append((bt_k,) + tuple(anvil_inputs(bt_k)))
+    bt = inputs[0][0]
+    step_no = [0]
     nbr = neighbour_offsets(1)
     ws_stats = []                                            # tf_watershed stats of every step (warmup included)
 
     def step(vr_steps=None):
+        bt, lin, markers = inputs[step_no[0] % len(inputs)]
+        step_no[0] += 1
         flow = tf.create_flow(bt, model="Farneback", vr_steps=a.vr_steps if vr_steps is None else vr_steps,
                               smoothing_passes=1, interp_method="cubic")
         # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
@@ -298,7 +307,7 @@ def main():
                "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": (f"GOES-16 ABI full-disk-sized window: {T}x{H}x{W} float32 frames per GPU per step "
-                                       "(BASELINE config F frame size; 144-frame stack = 12 such windows)"
+                                       "(BASELINE config F frame size; 144-frame stack = 12 such windows); the steps cycle through %d different windows" % len(inputs)
                                        if (H, W) == (5424, 5424) else
                                        f"REDUCED rehearsal window (not the benchmark configuration): {T}x{H}x{W} float32 frames per GPU per step"),
                           "stages": f"create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.sobel(uphill, cubic, f64) "
