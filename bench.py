@@ -2,17 +2,24 @@
 """bench.py -- end-to-end Mpix/s of the hot path (dense flow -> semi-Lagrangian Sobel edge field ->
 marker-controlled watershed) on 5424 x 5424 GOES-16 full-disk-sized frames, one process per GPU.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config F|V|F3|C|window]
   N > 1 under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...): the
   ranks come from RANK / LOCAL_RANK / WORLD_SIZE.  N > 1 WITHOUT a launcher: this process stays off the GPU, starts N
   fresh rank processes itself (one per GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line.
 
-A step is one pass of the hot path over one window of `--frames` synthetic frames resident in HBM:
-create_flow(Farneback, vr_steps=1, smoothing_passes=1, interp_method="cubic")  ->  Flow.sobel(uphill, cubic,
-float64)  ->  combined edge field  ->  Flow.watershed(conn 1) with the detect_anvils marker recipe.
-Frame windows are independent units: every rank processes its own window of ONE synthetic sequence (weak scaling;
-consecutive windows share `--overlap` frames, bit for bit) and the label IDs are stitched at the end of each step by
-the reference's overlap rule with one all-gather (tobac_flow_amd/parallel.py, linking.py:49-161).
+A step is one pass of the hot path over one STACK resident in HBM -- by default BASELINE.json's config F, 144 frames of
+5424 x 5424 -- processed the production way (scripts/dcc_detect_goes.py:153): twelve time windows sharing four frames,
+per window
+    seeds (linearise_field -> binary_erosion -> label: window-local component ids; -1 background seed)
+    create_flow(Farneback, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    Flow.sobel(uphill, cubic, float64) -> combined edge field
+    Flow.watershed(connectivity 1)
+and then the label ids of all windows stitched by the reference's overlap rule (linking.py:49-161), all inside the
+timed region.  `value` counts the DELIVERED frames (144 per step), not the 188 window frames computed.
+Under --gpus N every rank holds its own 144-frame segment of ONE synthetic sequence (weak scaling; consecutive segments
+share four frames bit for bit); the stitch then runs over all windows of all ranks with one neighbour message per rank
+boundary and all-gathers of the pair lists (tobac_flow_amd/parallel.py: stitch_rank_windows).
+--config window --frames 12 is the round-1/2 sub-report (one 12-frame window per step).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,7 +37,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s 
 # library profile name -> kernel symbol prefix in the rocprofv3 counter files
 _KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<4, 0>", "vr_sor": "k_vr_sor_tile", "vr_system": "void k_vr_system<true>",
                   "sobel": "void k_sobel27<2, double, 2, true>", "fb_polyexp": "k_fb_polyexp"}
-_TRAFFIC_FILE = "profiles/round2_pmc_traffic_bench.json"
+_TRAFFIC_FILE = "profiles/round3_pmc_traffic_bench.json"
+_TRAFFIC_WORKLOAD = ("F", 144, 5424, 5424, 1)      # (config, frames, height, width, vr_steps) the counter passes were recorded on
 
 
 def _traffic(profile_name):
@@ -101,7 +109,7 @@ def cpu_baseline(seed, vr_steps=1):
         edges = edges - lin
         t_sobel = time.perf_counter() - t0 - t_flow
         s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
-        markers = (lin >= 1) * ndi.binary_erosion(lin >= 1, structure=s).astype(np.int32)
+        markers = ndi.label(ndi.binary_erosion(lin >= 1, structure=s))[0].astype(np.int32)   # component-labelled seeds
         markers[ndi.binary_erosion(lin <= 0, structure=np.ones([3, 3, 3]), border_value=1)] = -1
         ws_oracle.watershed(fw, bw, edges, markers.astype(np.int32), None, 1)
     dt = time.perf_counter() - t0
@@ -166,22 +174,34 @@ def launch_ranks(a):
     return max(abs(c) for c in codes)
 
 
+CONFIGS = {     # BASELINE.json configs: frames, height, width, windows, channels
+    "F": (144, 5424, 5424, 12, 1),      # GOES-16 ABI full-disk C13, 144 frames, 1 x MI355X  (the metric's configuration)
+    "V": (288, 3712, 3712, 24, 1),      # SEVIRI full-disk, 288 frames
+    "F3": (288, 5424, 5424, 24, 3),     # full-disk, three channels (offsets 0 / -2 / -4 K) sharing ONE Flow
+    "C": (24, 1500, 2500, 2, 1),        # GOES-16 CONUS, 24 frames
+    "window": (12, 5424, 5424, 1, 1),   # one window per step (sub-report; --frames)
+}
+CHANNEL_OFFSETS = (0.0, -2.0, -4.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=12, help="frames per window (per GPU, per step)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="F", help="BASELINE.json configuration (default F = the metric's)")
+    ap.add_argument("--frames", type=int, default=None, help="frames of the stack per GPU per step (default: the config's)")
+    ap.add_argument("--n-windows", type=int, default=None, help="time windows the stack is processed in (default: the config's)")
     ap.add_argument("--vr-steps", type=int, default=1,
                     help="create_flow(vr_steps=...): 1 = the setting of the reference's drop-in scripts "
                          "(scripts/dcc_detect_goes.py:164-166), 0 = no variational refinement")
-    ap.add_argument("--windows", type=int, default=3, help="distinct windows of the synthetic sequence the steps cycle through")
     ap.add_argument("--overlap", type=int, default=4,
-                    help="frames consecutive windows (ranks) share; the stitch compares all but the first and last of them")
-    ap.add_argument("--height", type=int, default=5424)
-    ap.add_argument("--width", type=int, default=5424)
+                    help="frames consecutive windows (and ranks) share; the stitch compares all but the first and last of them")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--single-label-seeds", action="store_true",
+                    help="round-2 seeds (every positive seed = 1, detect_anvils(markers=None)) instead of component-labelled ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the untimed vr_steps=0 comparison steps after the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -213,35 +233,50 @@ def main():
     import tobac_flow_amd.flow as tf
     from tobac_flow_amd import _lib
     from tobac_flow_amd.detection import get_combined_edge_field
-    from tobac_flow_amd.parallel import stitch_labels
+    from tobac_flow_amd.parallel import stitch_rank_windows, window_bounds
     from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
-    from tools.synth import anvil_inputs, blob_stack
+    from tools.synth import anvil_seeds, blob_stack
 
-    T, H, W = a.frames, a.height, a.width
-    # rank r holds frames r * (T - overlap) ... of ONE sequence: its last `overlap` frames are rank r + 1's first ones
-    # `--windows` different windows of the sequence, visited in turn by the steps (a production run never sees the same
-    # window twice; with one window every data-dependent memo of the host layer would be perfectly warm)
-    inputs = []
-    for k in range(max(1, a.windows)):
-        bt_k = blob_stack(T, H, W, seed=20240601, t0=rank * (T - a.overlap) + 5 * k)      # resident in HBM before the timed region
-        inputs.append((bt_k,) + tuple(anvil_inputs(bt_k)))
-    bt = inputs[0][0]
-    step_no = [0]
+    cT, cH, cW, cN, C = CONFIGS[a.config]
+    T, H, W = a.frames or cT, a.height or cH, a.width or cW
+    n_windows = a.n_windows or (cN if T == cT else max(1, round(T / 12)))
+    full_size = (T, H, W, n_windows) == (cT, cH, cW, cN)
+    bounds = window_bounds(T, n_windows, a.overlap) if n_windows > 1 else [(0, T)]
+    # rank r holds frames r * (T - overlap) ... of ONE sequence: its last `overlap` frames are rank r + 1's first ones.
+    # Resident in HBM before the timed region: the brightness-temperature stack (generated in blocks of frames: torch's
+    # own kernels index in 32 bits, tools/synth.py).  Everything else -- seeds included -- is computed inside the step.
+    bt = torch.empty((T, H, W), dtype=torch.float32, device="cuda")
+    for f0 in range(0, T, 12):
+        f1 = min(f0 + 12, T)
+        bt[f0:f1] = blob_stack(f1 - f0, H, W, seed=20240601, t0=rank * (T - a.overlap) + f0)
     nbr = neighbour_offsets(1)
-    ws_stats = []                                            # tf_watershed stats of every step (warmup included)
+    ws_stats = []                                            # tf_watershed stats of every window of every step (warmup included)
+
+    def window(lo, hi, vr_steps):
+        """the hot path over frames lo .. hi - 1: one label volume per channel"""
+        w = bt[lo:hi]
+        flow = tf.create_flow(w, model="Farneback", vr_steps=vr_steps, smoothing_passes=1, interp_method="cubic")
+        fw, bw = flow._dev_flows()
+        out = []
+        for c in range(C):
+            lin, seeds = anvil_seeds(w + CHANNEL_OFFSETS[c] if c else w)
+            if a.single_label_seeds:
+                seeds = torch.clamp(seeds, max=1)
+            # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
+            e = get_combined_edge_field(flow, lin, dtype=np.float32)
+            st = {}
+            out.append(watershed_dev(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="ignore"))
+            ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
+        return out
 
     def step(vr_steps=None):
-        bt, lin, markers = inputs[step_no[0] % len(inputs)]
-        step_no[0] += 1
-        flow = tf.create_flow(bt, model="Farneback", vr_steps=a.vr_steps if vr_steps is None else vr_steps,
-                              smoothing_passes=1, interp_method="cubic")
-        # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
-        e = get_combined_edge_field(flow, lin, dtype=np.float32)
-        fw, bw = flow._dev_flows()
-        st = {}
-        labels = watershed_dev(fw, bw, e, markers, None, nbr, stats=st, on_ambiguous="ignore")
-        ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
-        return stitch_labels(labels, overlap=a.overlap) if world > 1 else labels
+        vr = a.vr_steps if vr_steps is None else vr_steps
+        per_channel = [[] for _ in range(C)]
+        for lo, hi in bounds:
+            for c, lab in enumerate(window(lo, hi, vr)):
+                per_channel[c].append(lab)
+        # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
+        return [stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins for wins in per_channel]
 
     def barrier():
         if dist is not None:
@@ -251,37 +286,33 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
+    n_warm = len(ws_stats)
     _lib.profile_enable(not a.no_kernel_events)
     _lib.profile_collect()
     t0 = time.perf_counter()
+    out_labels = None
     for _ in range(a.steps):
-        step()
+        out_labels = None                                    # the previous step's labels are released before the next step's exist
+        out_labels = step()
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
-    # for comparison with round 1 (which had no refinement): two extra steps with vr_steps = 0, outside the timed region
-    ms_no_vr = None
-    if a.vr_steps > 0 and not a.no_extra:
-        step(0)
-        barrier()
-        t1 = time.perf_counter()
-        step(0)
-        step(0)
-        barrier()
-        ms_no_vr = (time.perf_counter() - t1) / 2 * 1e3
+    n_objects = int(max(int(w.max()) for w in out_labels[0]))
+    del out_labels
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=bt.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
+        frames_computed = sum(hi - lo for lo, hi in bounds)
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
         roof = None
         if dom:
             name, (calls, ms, by) = dom
             achieved = by / (ms * 1e-3) / 1e9
             # the counter passes were recorded on the default workload: their per-launch bytes say nothing about another size
-            tr = _traffic(name) if (T, H, W, a.vr_steps) == (12, 5424, 5424, 1) else None
+            tr = _traffic(name) if (a.config, T, H, W, a.vr_steps) == _TRAFFIC_WORKLOAD and full_size else None
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr["bytes_per_launch"] if tr else None,
                     "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2),
@@ -300,30 +331,43 @@ def main():
                 # PAIR is what it must move at least.  Both fractions are reported.
                 roof["achieved_compulsory"] = round(achieved * 72.0 / 112.0, 1)
                 roof["frac_compulsory"] = round(achieved * 72.0 / 112.0 / HBM_PEAK_GBS, 4)
+        names = {"F": "BASELINE config F: GOES-16 ABI full-disk-sized stack", "V": "BASELINE config V: SEVIRI full-disk-sized stack",
+                 "F3": "BASELINE config F3: full-disk-sized stack, three channels sharing one Flow",
+                 "C": "BASELINE config C: GOES-16 CONUS-sized stack", "window": "sub-report: ONE window per step"}
+        what = (f"{names[a.config]}: {T}x{H}x{W} float32 frames per GPU per step" + (f" x {C} channels" if C > 1 else "") +
+                (f", processed as {n_windows} time windows sharing {a.overlap} frames ({frames_computed} window frames computed for {T} "
+                 f"delivered) + stitch of the label ids over all windows, all inside the timed region" if n_windows > 1 else ""))
+        if not full_size:
+            what = "REDUCED rehearsal of " + what
         out = {"metric": "Mpix/s end-to-end flow+sobel+watershed, 5424^2 frames" if (H, W) == (5424, 5424)
-               else f"Mpix/s end-to-end flow+sobel+watershed, {H}x{W} frames (rehearsal size)", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
+               else f"Mpix/s end-to-end flow+sobel+watershed, {H}x{W} frames", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
                "unit": "Mpix/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist is not None else 1,
                "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": (f"GOES-16 ABI full-disk-sized window: {T}x{H}x{W} float32 frames per GPU per step "
-                                       "(BASELINE config F frame size; 144-frame stack = 12 such windows); the steps cycle through %d different windows" % len(inputs)
-                                       if (H, W) == (5424, 5424) else
-                                       f"REDUCED rehearsal window (not the benchmark configuration): {T}x{H}x{W} float32 frames per GPU per step"),
-                          "stages": f"create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.sobel(uphill, cubic, f64) "
-                                    "+ edge field + Flow.watershed(connectivity 1, detect_anvils markers)",
-                          "sharding": f"one time window per GPU cut from one sequence, consecutive windows share {a.overlap} frames; "
-                                      "label IDs stitched by the reference's overlap rule (>= 5 px and >= 0.5, linking.py:49-161) "
-                                      "with one all-gather of pair lists"},
+               "config": {"workload": what,
+                          "frames_delivered_per_step": T, "window_frames_computed_per_step": frames_computed, "channels": C,
+                          "seeds": ("every positive seed = 1 (detect_anvils(markers=None))" if a.single_label_seeds else
+                                    "SURVEY 8(d): label(binary_erosion(field_lin >= 1)) per window on the device (component ids), "
+                                    "-1 where get_watershed_mask(field_lin); computed inside the timed region"),
+                          "stages": f"seeds + create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.sobel(uphill, cubic, f64) "
+                                    "+ edge field + Flow.watershed(connectivity 1)" + (" + stitch" if n_windows > 1 or world > 1 else ""),
+                          "sharding": f"one {T}-frame segment per GPU cut from one sequence, consecutive segments share {a.overlap} frames; "
+                                      "label IDs stitched over all windows of all ranks by the reference's overlap rule "
+                                      "(>= 5 px and >= 0.5, linking.py:49-161): one neighbour message per rank boundary + all-gathers of pair lists",
+                          "objects_after_stitch": n_objects},
+               "rate_over_computed_window_frames_Mpix_s": round(world * a.steps * frames_computed * H * W / dt / 1e6, 2),
                "roofline": roof}
-        # which watershed schedule the timed steps ran: stats[5] = 1 / 0 probe (speculative root phase + conflict test,
+        # which watershed schedule the timed windows ran: stats[5] = 1 / 0 probe (speculative root phase + conflict test,
         # conflict found / not found), -1 = root phase skipped on the conflict memo of watershed.py (identical labels)
-        timed = ws_stats[a.warmup:]
-        out["watershed"] = {"sweeps_per_phase_last_step": timed[-1][:5], "relevant_pixels": timed[-1][6],
-                            "chain_depth_used": timed[-1][8], "pixels_depending_on_equal_valued_marker_order": timed[-1][9],
-                            "marker_tie_points": timed[-1][10], "ties_left_by_depth_cut_off": timed[-1][11],
-                            "timed_steps_probing": sum(1 for t_ in timed if t_[5] >= 0),
-                            "timed_steps_skipping_root_phase": sum(1 for t_ in timed if t_[5] < 0)}
+        timed = np.array(ws_stats[n_warm:], np.int64)
+        out["watershed"] = {"floods_timed": int(len(timed)),
+                            "sweeps_per_phase_mean_per_flood": [round(float(v), 1) for v in timed[:, :5].mean(0)],
+                            "sweeps_per_phase_last_flood": timed[-1][:5].tolist(), "relevant_pixels_last_flood": int(timed[-1][6]),
+                            "chain_depth_used": int(timed[:, 8].max()), "chain_depth_used_min": int(timed[:, 8].min()),
+                            "pixels_depending_on_equal_valued_marker_order": int(timed[:, 9].sum() // a.steps),
+                            "marker_tie_points": int(timed[:, 10].sum() // a.steps), "ties_left_by_depth_cut_off": int(timed[:, 11].sum()),
+                            "floods_probing": int((timed[:, 5] >= 0).sum()), "floods_skipping_root_phase": int((timed[:, 5] < 0).sum())}
         # per-stage rates, and the measured device-to-device copy rate as the practical HBM ceiling
         stage_of = {"to8bit_pair": "flow", "fb_gaussian_blur": "flow", "fb_resize": "flow", "fb_polyexp": "flow",
                     "fb_update_matrices": "flow", "fb_blur_solve": "flow", "fb_iteration_fused": "flow", "smooth_flow": "flow",
@@ -332,10 +376,12 @@ def main():
         stage_ms = {}
         for k, v in prof.items():
             stage_ms[stage_of.get(k, "other")] = stage_ms.get(stage_of.get(k, "other"), 0.0) + v[1] / a.steps
-        out["stages"] = {k: {"kernel_ms_per_step": round(v, 2), "Mpix_per_s": round(T * H * W / v / 1e3, 1)}
+        out["stages"] = {k: {"kernel_ms_per_step": round(v, 2), "Mpix_per_s_over_computed_frames": round(frames_computed * H * W / v / 1e3, 1)}
                          for k, v in sorted(stage_ms.items(), key=lambda kv: -kv[1])}
+        out["stages"]["host_and_glue"] = {"ms_per_step": round(dt / a.steps * 1e3 - sum(stage_ms.values()), 2),
+                                          "note": "step time minus the library's kernel time: seeds' torch glue, stitch, launches, syncs"}
         if roof is not None:
-            n_copy = min(1 << 28, max(1 << 20, T * H * W))            # float32 elements: up to 1 GiB read + 1 GiB written
+            n_copy = 1 << 28                                                  # float32 elements: 1 GiB read + 1 GiB written
             src = torch.empty(n_copy, dtype=torch.float32, device=bt.device).normal_()
             dst = torch.empty_like(src)
             dst.copy_(src)
@@ -350,10 +396,6 @@ def main():
             roof["practical_peak_note"] = "device-to-device copy of 2 x %.2f GB measured in this run (read + written bytes)" % (4 * n_copy / 1e9)
             roof["frac_practical"] = round(roof["achieved"] / copy_gbps, 4)
             del src, dst
-        if ms_no_vr is not None:
-            out["without_refinement"] = {"ms_per_step": round(ms_no_vr, 2), "value": round(world * T * H * W / ms_no_vr / 1e3, 2),
-                                         "note": "same step with create_flow(vr_steps=0), 2 steps after the timed region: the "
-                                                 "schedule round 1 measured (the refinement did not exist then)"}
         if not a.no_cpu_baseline and world == 1:             # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(20240601, a.vr_steps)
             out["cv2_parity"] = cv2_parity()

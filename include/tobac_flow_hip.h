@@ -226,6 +226,18 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
  *   label conflicts (exact plateaus, as in detect_anvils), where the speculative root phase is wasted
  *   work.  With the flag stats_host[1] = 0 and stats_host[5] = -1 (speculative phase not run). */
 #define TF_WS_SKIP_FAST_PATH 1
+/* TF_WS_REFERENCE_ORDER (tf_watershed_ex2, tf_watershed_raveled_ex): when labels hang on the order of EQUAL-VALUED
+ *   MARKERS (the case otherwise reported as TF_WS_AMBIGUOUS), reproduce the order the reference's binary heap gives
+ *   them.  That order is a by-product of the heap's array mechanics (_watershed.pyx:67-152, 278-284) and depends on
+ *   every push and pop before it, so it cannot be derived from the tied markers alone: a first-party host routine of
+ *   this library replays the heap's push / pop / sift sequence over the compact flood graph the device has built --
+ *   keys only, no labels -- up to the largest marker value at which such a tie occurs, and returns each marker's pop
+ *   rank; the device then repeats its root phase with the pop rank in place of the raster index as the last component
+ *   of the chain comparison, and writes the labels.  The call returns TF_OK: the labels are the reference's bit for
+ *   bit.  Cost: sequential, O((seeds + flooded pixels below that value) log n) on one host core, plus the transfer of
+ *   the flood graph (28 B per relevant pixel) and of 8 B per seed; nothing extra when no such tie exists.
+ *   stats[13] = items the replay popped, [14] = seeds, [15] = microseconds the whole detour took (0 if not needed). */
+#define TF_WS_REFERENCE_ORDER 2
 int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
                     const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                     const int8_t *nbr_host, int n_nbr, int chain_depth, int flags, int32_t *labels,
@@ -260,6 +272,14 @@ int tf_watershed_raveled(const float *image, int64_t n, const int64_t *marker_lo
                          const int32_t *forward_offset_locations_host, const int32_t *backward_offset_locations_host,
                          const int8_t *mask, const int32_t *strides_host, int n_strides, double compactness,
                          int32_t *output, int wsl, int max_depth, void *ws, size_t ws_bytes,
+                         int64_t *stats_host, void *stream);
+/* the same with `flags` (TF_WS_REFERENCE_ORDER) */
+int tf_watershed_raveled_ex(const float *image, int64_t n, const int64_t *marker_locations, int64_t n_markers,
+                         const int64_t *structure_host, int n_structure,
+                         const int32_t *forward_offset, const int32_t *backward_offset,
+                         const int32_t *forward_offset_locations_host, const int32_t *backward_offset_locations_host,
+                         const int8_t *mask, const int32_t *strides_host, int n_strides, double compactness,
+                         int32_t *output, int wsl, int max_depth, int flags, void *ws, size_t ws_bytes,
                          int64_t *stats_host, void *stream);
 
 /* ---- section 8f-2: scipy.ndimage glue of the detection recipes (bit-exact with SciPy) ---------------------

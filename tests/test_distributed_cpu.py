@@ -27,7 +27,7 @@ def _worker(rank, world, port, volume, bounds, out_dir):
     a, b = bounds[rank]
     local = ndi.label(volume[a:b] > 0)[0].astype(np.int32)      # window-local IDs
     local[volume[a:b] < 0] = -1                                 # background seeds survive untouched
-    got = stitch_labels(torch.from_numpy(local), min_overlap=1)
+    got = stitch_labels(torch.from_numpy(local), min_overlap=1, overlap=1)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), got.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -133,3 +133,54 @@ def test_stitched_watershed_windows_equal_the_whole_volume_flood_away_from_the_s
         for w_id, g_id in pairs:                         # one stitched id per object of the whole-volume flood, everywhere
             assert mapping.setdefault(int(w_id), int(g_id)) == int(g_id), (r, w_id, g_id)
     assert len(set(mapping.values())) == len(mapping)    # ... and different objects keep different ids
+
+
+def _multi_window_worker(rank, world, port, windows_per_rank, overlap, out_dir):
+    """every rank holds SEVERAL consecutive windows of one sequence (bench.py config F under --gpus N)"""
+    import torch
+    import torch.distributed as dist
+    from tobac_flow_amd.parallel import stitch_rank_windows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = stitch_rank_windows([torch.from_numpy(w) for w in windows_per_rank[rank]], overlap=overlap)
+    for k, g in enumerate(got):
+        np.save(os.path.join(out_dir, f"r{rank}_w{k}.npy"), g.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("split", [(2, 2), (3, 1), (1, 2, 2)])
+def test_rank_window_lists_stitch_like_one_process(tmp_path, split):
+    """parallel.stitch_rank_windows over gloo (ranks holding 2+2, 3+1 and 1+2+2 windows of ONE sequence) returns exactly
+    what stitch_window_list returns for the concatenated window list in one process: same rule (linking.py:49-161), same
+    global numbering."""
+    import torch
+    import torch.multiprocessing as mp
+    from tobac_flow_amd.parallel import stitch_window_list, window_bounds
+    rng = np.random.default_rng(3)
+    overlap, n_windows = 4, sum(split)
+    T, H, W = 6 * n_windows + overlap, 32, 40
+    truth = ndi.label(ndi.gaussian_filter(rng.normal(size=(T, H, W)), (2.0, 1.5, 1.5)) > 0.03)[0].astype(np.int32)
+    truth[:, :2, :2] = -1
+    wins = []
+    for a, b in window_bounds(T, n_windows, overlap):
+        w = truth[a:b].copy()
+        ids = np.unique(w[w > 0])
+        perm = np.zeros(max(int(w.max()), 0) + 1, np.int32)
+        perm[ids] = rng.permutation(len(ids)) + 1               # window-local numbering
+        w[w > 0] = perm[w[w > 0]]
+        wins.append(w)
+    want = [x.numpy() for x in stitch_window_list([torch.from_numpy(w) for w in wins], overlap=overlap)]
+    per_rank, k = [], 0
+    for n in split:
+        per_rank.append(wins[k:k + n])
+        k += n
+    mp.spawn(_multi_window_worker, args=(len(split), _free_port(), per_rank, overlap, str(tmp_path)), nprocs=len(split), join=True)
+    k = 0
+    for r, n in enumerate(split):
+        for j in range(n):
+            assert np.array_equal(np.load(tmp_path / f"r{r}_w{j}.npy"), want[k]), (r, j)
+            k += 1
+    joined = sum(int(np.unique(w[w > 0]).size) for w in wins) - int(max(w.max() for w in want))
+    assert joined > 0                                           # the rule did link objects across boundaries

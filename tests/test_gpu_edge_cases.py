@@ -278,8 +278,8 @@ def test_stitch_window_list_on_gpu_equals_host_result():
         perm = np.zeros(w.max() + 1, np.int32)
         perm[ids] = rng.permutation(len(ids)) + 1
         wins.append(perm[w])
-    host = [x.numpy() for x in stitch_window_list([torch.from_numpy(w) for w in wins], min_overlap=1)]
-    dev = [x.cpu().numpy() for x in stitch_window_list([torch.from_numpy(w).cuda() for w in wins], min_overlap=1)]
+    host = [x.numpy() for x in stitch_window_list([torch.from_numpy(w) for w in wins], min_overlap=1, overlap=1)]
+    dev = [x.cpu().numpy() for x in stitch_window_list([torch.from_numpy(w).cuda() for w in wins], min_overlap=1, overlap=1)]
     for h, d in zip(host, dev):
         assert d.dtype == np.int32 and np.array_equal(h, d)
     # the reference's rule (>= 5 px, >= 0.5, outer common frames dropped) on windows that share four frames

@@ -1,0 +1,168 @@
+"""on_ambiguous="reference" / TF_WS_REFERENCE_ORDER: where labels hang on the order of EQUAL-VALUED MARKERS -- the one
+thing the reference decides by the array mechanics of its binary heap (_watershed.pyx:67-152, 278-284) -- the library
+replays those mechanics on the host for the pop ranks and the device flood uses them: the labels are then the
+reference's bit for bit ("What's missing" 1).  Checked against the reference's own golden outputs
+(tests/golden/watershed_ref.npz, produced by the reference's watershed.py + compiled _watershed.pyx) and against the C
+twin of that kernel (oracle/c/ws_heap.c, tie_mode 0 = the reference's semantics) on tie-heavy random volumes."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+ALL_GOLDENS = ["A_cont_c1", "B_cont_mask_c2", "B_cont_mask_c3", "C_quant4_c1", "C_quant32_c1", "D_anvil_like_c1",
+               "E_const_plateau_c1", "F_zero_flow_c1", "G_big_flow_c1"]
+
+
+@pytest.fixture(scope="module")
+def tf():
+    import tobac_flow_amd.flow as tf
+    return tf
+
+
+@pytest.mark.parametrize("name", ALL_GOLDENS)
+def test_every_reference_golden_is_reproduced_bit_for_bit(tf, golden_ws, name):
+    """All nine outputs of the reference itself -- the tie-heavy C_quant4 (21 px) and E_const_plateau (37 px) included,
+    which the default mode resolves by raster order and reports."""
+    c = golden_ws[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                           # reference order applied: nothing left to warn about
+        got = tf.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], mask=c.get("mask"), connectivity=int(c["conn"]),
+                           on_ambiguous="reference")
+    assert got.dtype == np.int32
+    assert np.array_equal(got, c["labels"]), f"{int((got != c['labels']).sum())} px differ from the reference"
+
+
+@pytest.mark.parametrize("name", ["C_quant4_c1", "E_const_plateau_c1"])
+def test_the_raveled_twin_in_reference_order(tf, golden_ws, name):
+    """the same through the reference's native seam (tf_watershed_raveled_ex, padded flat arrays as watershed.py:59-149
+    prepares them)"""
+    from oracle import ws_oracle
+    from tobac_flow_amd._watershed import watershed_raveled
+    c = golden_ws[name]
+    conn = int(c["conn"])
+    p = ws_oracle.prepare(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn)
+    out = p["out"].ravel().copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        watershed_raveled(np.ascontiguousarray(p["field"].ravel()), p["markers"].astype(np.intp), p["nbr"].astype(np.intp),
+                          p["fwd_off"], p["bwd_off"], p["fwd_loc"], p["bwd_loc"], p["mask"], p["strides"].astype(np.int32), 0.0,
+                          out, False, reference_order=True)
+    pd = p["pad"]
+    o = out.reshape(p["out"].shape)
+    assert np.array_equal(o[pd[0]:o.shape[0] - pd[0], pd[1]:o.shape[1] - pd[1], pd[2]:o.shape[2] - pd[2]], c["labels"])
+
+
+def _tie_heavy_case(seed):
+    """quantised fields (few distinct values, large exact plateaus), many seeds of several labels sharing those values,
+    non-zero flows, masks, all three connectivities"""
+    rng = np.random.default_rng(7000 + seed)
+    shape = (int(rng.integers(1, 6)), int(rng.integers(24, 64)), int(rng.integers(24, 72)))
+    levels = [1, 2, 3, 4, 8, 32][seed % 6]
+    smooth = ndi.gaussian_filter(rng.normal(size=shape), (0.5, 3, 3))
+    smooth = (smooth - smooth.min()) / (smooth.max() - smooth.min() + 1e-9)
+    field = (np.floor(smooth * levels) / max(levels, 1)).astype(np.float32)
+    if seed % 4 == 3:
+        field[rng.random(shape) < 0.01] = np.inf
+    markers = np.zeros(shape, np.int32)
+    n_seeds = int(rng.integers(6, 40))
+    for k in range(n_seeds):
+        t, y, x = (int(rng.integers(0, s)) for s in shape)
+        h, w = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        markers[t, y:y + h, x:x + w] = (k % 9) + 1 if seed % 2 else k + 1
+    if seed % 3 == 0:
+        markers[:, :2, :] = -1
+    mask = None if seed % 2 == 0 else ndi.gaussian_filter(rng.normal(size=shape), (0, 2, 2)) > -0.05
+    amp = [0.0, 1.5, 3.0][seed % 3]
+    fwd = (rng.normal(size=shape + (2,)) * amp).astype(np.float32)
+    bwd = (rng.normal(size=shape + (2,)) * amp).astype(np.float32)
+    return fwd, bwd, field, markers, mask, [1, 2, 3][(seed // 2) % 3]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_tie_heavy_random_volumes_equal_the_reference_kernel(tf, seed):
+    """against the C twin of the reference's kernel in the reference's own semantics (tie_mode 0, pinned by the goldens
+    and by the live compiled .pyx, tests/test_oracle_golden.py)"""
+    from oracle import ws_oracle
+    fwd, bwd, field, markers, mask, conn = _tie_heavy_case(seed)
+    want = ws_oracle.watershed(fwd, bwd, field, markers, mask, conn, tie_mode=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = tf.watershed(fwd, bwd, field, markers, mask=mask, connectivity=conn, on_ambiguous="reference")
+    assert np.array_equal(got, want), f"{int((got != want).sum())} px differ from the reference kernel"
+
+
+def test_reference_order_costs_nothing_when_no_tie_matters(tf, golden_ws):
+    """a clean input: no replay (stats), same labels"""
+    import torch
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    c = golden_ws["A_cont_c1"]
+    st = {}
+    lab = watershed_dev(_lib.to_dev(c["fwd"], torch.float32), _lib.to_dev(c["bwd"], torch.float32), _lib.to_dev(c["field"], torch.float32),
+                        _lib.to_dev(c["markers"], torch.int32), None, neighbour_offsets(int(c["conn"])), stats=st, on_ambiguous="reference")
+    assert st["reference_order"] == {"replayed_pops": 0, "seeds": 0, "microseconds": 0}
+    assert np.array_equal(lab.cpu().numpy(), c["labels"])
+    c = golden_ws["E_const_plateau_c1"]
+    lab = watershed_dev(_lib.to_dev(c["fwd"], torch.float32), _lib.to_dev(c["bwd"], torch.float32), _lib.to_dev(c["field"], torch.float32),
+                        _lib.to_dev(c["markers"], torch.int32), None, neighbour_offsets(int(c["conn"])), stats=st, on_ambiguous="reference")
+    assert st["reference_order"]["replayed_pops"] > 0 and st["reference_order"]["seeds"] == int((c["markers"] != 0).sum())
+    assert np.array_equal(lab.cpu().numpy(), c["labels"])
+
+
+def test_config_C_window_with_component_seeds_in_reference_order(tf):
+    """the 14 x 1500 x 2500 window of config C with component-labelled seeds -- 327 reported
+    voxels in the default mode, 21 of which the reference's heap orders the other way -- equals the reference kernel
+    (C twin, tie_mode 0) in every voxel; the cost of the replay is printed."""
+    import torch
+    from oracle import ws_oracle
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    from tools.synth import anvil_inputs, blob_stack
+    bt = blob_stack(14, 1500, 2500, seed=11, t0=0)
+    fl = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    lin, markers = anvil_inputs(bt)
+    comp = ndi.label(markers.cpu().numpy() > 0)[0].astype(np.int32)
+    comp[markers.cpu().numpy() < 0] = -1
+    e = get_combined_edge_field(fl, lin, dtype=np.float32)
+    fw, bw = fl._dev_flows()
+    st, st0 = {}, {}
+    seeds_dev = torch.from_numpy(comp).cuda()
+    base = watershed_dev(fw, bw, e, seeds_dev, None, neighbour_offsets(1), stats=st0, on_ambiguous="ignore")
+    lab = watershed_dev(fw, bw, e, seeds_dev, None, neighbour_offsets(1), stats=st, on_ambiguous="reference")
+    want = ws_oracle.watershed(fw.cpu().numpy(), bw.cpu().numpy(), e.cpu().numpy(), comp, None, 1, tie_mode=0)
+    got = lab.cpu().numpy()
+    print("config C window: default mode differs from the reference in", int((base.cpu().numpy() != want).sum()), "of",
+          st0["ambiguous_pixels"], "reported voxels; reference order:", st["reference_order"])
+    assert st0["ambiguous_pixels"] > 0                                # the case is present in this window
+    assert np.array_equal(got, want), f"{int((got != want).sum())} px differ from the reference kernel"
+
+
+def test_raveled_flood_along_a_path_of_several_thousand_pixels(tf):
+    """the raveled form knows no (T, H, W), its sweep limit has to come from the number of pixels: one seed at
+    the end of a snake-shaped mask whose flood path is ~7000 pixels long (used to stop with TF_ENOCONV at 4096 sweeps)."""
+    from tobac_flow_amd._watershed import watershed_raveled
+    H, W = 123, 121
+    mask2 = np.zeros((H, W), np.int8)
+    for r in range(1, H - 1, 2):                                       # corridors joined alternately at the right / left end
+        mask2[r, 1:W - 1] = 1
+        if r + 2 < H - 1:
+            mask2[r + 1, W - 2 if (r // 2) % 2 == 0 else 1] = 1
+    n = H * W
+    rng = np.random.default_rng(0)
+    img = rng.random(n).astype(np.float32)
+    out = np.zeros(n, np.int32)
+    start = 1 * W + 1
+    out[start] = 5
+    z = np.zeros(n, np.int32)
+    watershed_raveled(img, np.array([start], np.intp), np.array([-W, -1, 1, W], np.intp), z, z, np.zeros(4, np.int32),
+                      np.zeros(4, np.int32), mask2.ravel(), np.array([W, 1], np.int32), 0.0, out, False)
+    path = int(mask2.sum())
+    assert path > 5000
+    assert np.array_equal(out.reshape(H, W) == 5, mask2 == 1)

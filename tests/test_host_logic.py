@@ -445,7 +445,7 @@ def test_stitch_window_list_reassembles_a_labelling(n_windows):
         perm[ids] = rng.permutation(len(ids)) + 1              # what an independent per-window labelling would give
         w[w > 0] = perm[w[w > 0]]
         windows.append(torch.from_numpy(w))
-    out = [x.numpy() for x in stitch_window_list(windows, min_overlap=1)]
+    out = [x.numpy() for x in stitch_window_list(windows, min_overlap=1, overlap=1)]
     bounds = window_bounds(truth.shape[0], n_windows)
     for (a, b), w in zip(bounds, out):                          # shared frames agree between neighbours
         assert w.shape == truth[a:b].shape
@@ -503,7 +503,7 @@ def test_window_linking_rule_equals_the_reference_statement():
             assert np.array_equal(_overlap_pairs_host(a, b, atol, rtol), np.stack([x, y], 1)), (trial, atol, rtol)
     assert _overlap_pairs_host(np.zeros((1, 3, 3), int), np.ones((1, 3, 3), int), 5, 0.5).shape == (0, 2)
     # linking.py:55-56: of the common frames the first and the last are not compared
-    assert compare_frames(4) == slice(1, 3) and compare_frames(24) == slice(1, 23) and compare_frames(1) == slice(0, 1)
+    assert compare_frames(4) == slice(1, 3) and compare_frames(24) == slice(1, 23) and compare_frames(1) == slice(0, 0) and compare_frames(1, True) == slice(0, 1) and compare_frames(2, True) == slice(0, 2)
 
 
 def test_stitch_with_the_reference_rule_joins_only_well_overlapping_labels():
@@ -526,3 +526,22 @@ def test_stitch_with_the_reference_rule_joins_only_well_overlapping_labels():
     assert l[0, 2, 2] == r[0, 2, 2] and l[0, 2, 20] == r[0, 2, 20]
     assert l[0, 10, 2] != r[0, 10, 6] and l[0, 10, 30] != r[0, 10, 30]
     assert sorted(np.unique(np.concatenate([l[l > 0], r[r > 0]])).tolist()) == [1, 2, 3, 4, 5, 6]
+
+
+def test_short_overlaps_link_nothing_unless_opted_in():
+    """linking.py:55-56 compares the common frames [1:-1]: with one or two shared frames the reference links nothing.
+    stitch_window_list does the same by default; short_overlap_ok=True (or the round-1 `min_overlap` form) is the
+    explicit opt-in to linking on all shared frames."""
+    import torch
+    from tobac_flow_amd.parallel import stitch_window_list
+    left = np.zeros((4, 12, 12), np.int32)
+    right = np.zeros((4, 12, 12), np.int32)
+    left[:, 2:8, 2:8] = 1
+    right[:, 2:8, 2:8] = 1
+    for ov in (1, 2):
+        out = stitch_window_list([torch.from_numpy(left), torch.from_numpy(right)], overlap=ov)
+        assert int(out[0].max()) == 1 and int(out[1].max()) == 2            # two objects: not linked
+        out = stitch_window_list([torch.from_numpy(left), torch.from_numpy(right)], overlap=ov, short_overlap_ok=True)
+        assert int(out[0].max()) == 1 and int(out[1].max()) == 1            # opted in: one object
+    out = stitch_window_list([torch.from_numpy(left), torch.from_numpy(right)])          # default overlap = 4: [1:-1] compared
+    assert int(out[1].max()) == 1

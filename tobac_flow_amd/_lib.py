@@ -64,6 +64,8 @@ _PROTOS = {
     "tf_watershed_raveled_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int64]),
     "tf_watershed_raveled": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int,
                                         _c.c_double, _P, _c.c_int, _c.c_int, _P, _c.c_size_t, _P, _P]),
+    "tf_watershed_raveled_ex": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int,
+                                           _c.c_double, _P, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_size_t, _P, _P]),
     "tf_binary_morph": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P]),
     "tf_correlate1d_sym": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _P, _c.c_int, _P, _P]),
     "tf_grey_morph": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _P, _P]),

@@ -22,8 +22,10 @@ def _flat(a, dtype, name):
 
 
 def watershed_raveled(image, marker_locations, structure, forward_offset, backward_offset, forward_offset_locations,
-                      backward_offset_locations, mask, strides, compactness, output, wsl):
-    """Perform the watershed on a raveled image and neighbourhood (reference: _watershed.pyx:222-344)."""
+                      backward_offset_locations, mask, strides, compactness, output, wsl, reference_order=False):
+    """Perform the watershed on a raveled image and neighbourhood (reference: _watershed.pyx:222-344).
+    `reference_order=True` (not in the reference): equal-valued markers pop in the order the reference's heap gives them
+    (TF_WS_REFERENCE_ORDER, include/tobac_flow_hip.h) instead of marker_locations order + a warning."""
     t = _lib.torch()
     L = _lib.lib()
     image = _flat(image, np.float32, "image")
@@ -50,10 +52,11 @@ def watershed_raveled(image, marker_locations, structure, forward_offset, backwa
     guess = min(n, int(((d_out == 0) & (d_mask != 0)).sum().item() * 1.5) + 4096)
     for _ in range(2):
         ws = _lib.workspace(L.tf_watershed_raveled_workspace_bytes(n, structure.size, MAX_CHAIN_DEPTH, guess), "watershed")
-        rc = L.tf_watershed_raveled(_lib.ptr(d_img), n, _lib.ptr(d_loc), marker_locations.size, st64.ctypes.data_as(_lib._P),
+        rc = L.tf_watershed_raveled_ex(_lib.ptr(d_img), n, _lib.ptr(d_loc), marker_locations.size, st64.ctypes.data_as(_lib._P),
                                     structure.size, _lib.ptr(d_fo), _lib.ptr(d_bo), floc.ctypes.data_as(_lib._P),
                                     bloc.ctypes.data_as(_lib._P), _lib.ptr(d_mask), strides.ctypes.data_as(_lib._P), strides.size,
-                                    float(compactness), _lib.ptr(d_out), int(bool(wsl)), MAX_CHAIN_DEPTH, _lib.ptr(ws), ws.numel(),
+                                    float(compactness), _lib.ptr(d_out), int(bool(wsl)), MAX_CHAIN_DEPTH, 2 if reference_order else 0,
+                                    _lib.ptr(ws), ws.numel(),
                                     stats.ctypes.data_as(_lib._P), _lib.stream_ptr())
         if rc == -2 and stats[6] > guess:
             guess = int(stats[6])

@@ -245,23 +245,26 @@ k_wsr_compact(const float *__restrict__ image, const int *__restrict__ cid, WsRa
 
 // in place: output[i] = label of its root seed for every flooded pixel (seeds and everything else untouched)
 __global__ void __launch_bounds__(256)
-k_wsr_labels(const int *__restrict__ cid, const u64 *__restrict__ Rt, int32_t *output, int64_t n)
+k_wsr_labels(const int *__restrict__ cid, const u64 *__restrict__ Rt, const u64 *__restrict__ pix, int32_t *output, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = cid[i];
-    if (c >= 0 && output[i] == 0) { const u64 r = Rt[c]; if (r != WS_INF) output[i] = output[r]; }
+    if (c >= 0 && output[i] == 0) { const u64 r = Rt[c]; if (r != WS_INF) output[i] = output[pix[r & 0xFFFFFFFFull] & ~WS_MARKER_BIT]; }
 }
 
-// chain arrays of a marker: C_k = 0 for every k; root = raster index
+// chain arrays of a marker: C_k = 0 for every k; root key = (pop rank among equal keys << 32) | compact id.
+// rank == nullptr: rank = compact id, i.e. the markers' raster order (= the reference's marker_locations order);
+// otherwise the pop rank the reference's heap gives the marker (ws_reference_ranks below).
 __global__ void __launch_bounds__(256)
-k_ws_init_level(const u64 *__restrict__ pix, u64 *__restrict__ dst, int64_t R, int is_root)
+k_ws_init_level(const u64 *__restrict__ pix, u64 *__restrict__ dst, int64_t R, int is_root, const int *__restrict__ rank)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const u64 px = pix[i];
     const bool marker = (px & WS_MARKER_BIT) != 0ull;
-    dst[i] = marker ? (is_root ? (px & ~WS_MARKER_BIT) : 0ull) : WS_INF;
+    const u64 root = ((u64)(unsigned)(rank ? rank[i] : (int)i) << 32) | (u64)(unsigned)i;
+    dst[i] = marker ? (is_root ? root : 0ull) : WS_INF;
 }
 
 // root phase start: a marker's label set is its own label, everything else starts empty
@@ -589,7 +592,7 @@ k_ws_count_ambiguous(WsC c, const int *__restrict__ org, unsigned long long *__r
 // (TF_WS_AMB_DEPTH)
 __global__ void __launch_bounds__(256)
 k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, const u64 *__restrict__ Rt,
-            const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ org,
+            const u64 *__restrict__ pix, const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ org,
             int32_t *__restrict__ labels, uint8_t *__restrict__ amb, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -600,12 +603,45 @@ k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, co
     if (l == 0 && c >= 0) {
         const u64 r = Rt[c];
         if (r != WS_INF) {
-            l = markers[r];
+            l = markers[pix[r & 0xFFFFFFFFull] & ~WS_MARKER_BIT];      // root key = (rank << 32) | compact id of the marker
             if (amb) a = (uint8_t)((lo[c] != hi[c] ? 1 : 0) | ((org[c] & 3) << 1));
         }
     }
     labels[i] = l;
     if (amb) amb[i] = a;
+}
+
+// ---- reference order of equal-valued markers (TF_WS_REFERENCE_ORDER) ------------------------------------------------
+// flag[i] = 1 for every seed (cls 2): their exclusive scan numbers the seeds in raster order = marker_locations order
+__global__ void __launch_bounds__(256)
+k_ws_flag_seeds(const uint8_t *__restrict__ cls, int64_t n, uint8_t *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = cls[i] == 2;
+}
+// seeds number c0 .. c0 + cap - 1 (raster order): value key and compact id (-1: no floodable out-neighbour)
+__global__ void __launch_bounds__(256)
+k_ws_seed_list(const uint8_t *__restrict__ cls, const int *__restrict__ scan, const int *__restrict__ cid,
+               const float *__restrict__ field, int64_t n, int64_t c0, int64_t cap, unsigned *__restrict__ out_val,
+               int *__restrict__ out_cid)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || cls[i] != 2) return;
+    const int64_t k = (int64_t)scan[i] - c0;
+    if (k < 0 || k >= cap) return;
+    const int c = cid[i];
+    out_val[k] = ws_ordkey(field[i]);
+    out_cid[k] = c <= -2 ? -2 - c : -1;
+}
+// largest marker value (ordered key) below which the order of equal-valued markers decides a label: every origin
+// with complete chains ties down to markers of ONE value, the value of its own root
+__global__ void __launch_bounds__(256)
+k_ws_tie_value_max(WsC c, const int *__restrict__ org, unsigned *__restrict__ vmax)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.R || !(org[i] & 1)) return;
+    const u64 r = c.Rt[i];
+    if (r != WS_INF) atomicMax(vmax, c.val[r & 0xFFFFFFFFull]);
 }
 
 struct WsU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
@@ -653,7 +689,7 @@ static size_t ws_compact_bytes(int64_t R, int n_nbr, int depth) {
     return tf_align_up((size_t)R * 8, 256) + tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 4 * n_nbr, 256)
          + (size_t)(depth + 2) * tf_align_up((size_t)R * 8, 256)          // K2, M1, C_1..C_{d-1}, Rt
          + 2 * tf_align_up((size_t)R * 8 + 256, 256) + tf_align_up((size_t)R * 4, 256)           // two queues (2R ints), inq
-         + 3 * tf_align_up((size_t)R * 4, 256) + 4096;                                            // Llo, Lhi, org
+         + 4 * tf_align_up((size_t)R * 4, 256) + 4096;                                            // Llo, Lhi, org, rank
 }
 
 extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int n_nbr, int chain_depth, int64_t max_relevant)
@@ -743,6 +779,82 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
     return TF_OK;
 }
 
+// ---- the reference's pop order of equal-valued markers ------------------------------------------------------------
+// The reference pushes every marker with age 0 (_watershed.pyx:278-284), so markers of equal value compare equal
+// (`smaller`, :161-164) and pop in an order that is a by-product of its binary heap's array mechanics (:67-152): where
+// the sift-up / sift-down loops happen to leave them.  That order depends on EVERY push and pop before it -- a marker
+// of another value pushed in between, or a pixel flooded from a lower marker, moves tied items up and down the array
+// (two tied markers A, B and one smaller item X pushed between them pop X, B, A; without X: A, B) -- so it cannot be
+// derived from the tied markers alone: the mechanics have to be replayed with every item in place.  This routine is
+// that replay, on the host, over the compact flood graph the device has already built: the same push / pop / sift
+// rules, item for item, with the keys only (no labels are computed here -- the device flood does that, with the pop
+// rank returned here as the last component of its chain comparison).  It stops as soon as every marker whose rank can
+// matter has popped: at the first top item above `vmax`, the largest marker value at which the device found chains
+// that tie down to equal-valued markers of different labels.
+struct WsRefItem { unsigned v; int32_t age; int32_t id; };             // id: compact id, or -1 for a seed nobody floods from
+static inline bool ws_ref_smaller(const WsRefItem &a, const WsRefItem &b) { return a.v != b.v ? a.v < b.v : a.age < b.age; }
+
+static int64_t ws_reference_ranks(int64_t M, const unsigned *seed_val, const int *seed_cid, int64_t R, const unsigned *val,
+                                  const int *nbr, int n_nbr, unsigned vmax, int *rank)
+{
+    WsRefItem *h = (WsRefItem *)malloc((size_t)(M + R + 1) * sizeof(WsRefItem));     // every pixel is pushed at most once
+    uint8_t *state = (uint8_t *)calloc((size_t)(R > 0 ? R : 1), 1);                  // 1: already pushed / a marker
+    if (!h || !state) { free(h); free(state); return -1; }
+    int64_t items = 0;
+    auto push = [&](const WsRefItem &e) {                                              // _watershed.pyx:120-152
+        int64_t child = items;
+        h[child] = e;
+        items += 1;
+        while (child > 0) {
+            const int64_t parent = (child + 1) / 2 - 1;
+            if (ws_ref_smaller(h[child], h[parent])) { const WsRefItem t = h[parent]; h[parent] = h[child]; h[child] = t; child = parent; }
+            else break;
+        }
+    };
+    for (int64_t i = 0; i < M; i++) {                                                  // :278-284, marker_locations order
+        if (seed_cid[i] >= 0) state[seed_cid[i]] = 1;
+        push(WsRefItem{seed_val[i], 0, seed_cid[i]});
+    }
+    for (int64_t i = 0; i < R; i++) rank[i] = -1;
+    int64_t age = 1, popped = 0;
+    int n_ranked = 0;
+    while (items > 0) {
+        const WsRefItem e = h[0];
+        // all markers of value <= vmax pop before the first item that is above vmax or a flooded pixel AT vmax
+        if (e.v > vmax || (e.v == vmax && e.age != 0)) break;
+        items -= 1;                                                                    // :67-111
+        if (items > 0) {
+            h[0] = h[items];
+            int64_t i = 0, smallest = 0;
+            for (;;) {
+                const int64_t l = 2 * i + 1, r = 2 * i + 2;
+                if (l < items) {
+                    if (ws_ref_smaller(h[l], h[i])) smallest = l;
+                    if (r < items && ws_ref_smaller(h[r], h[smallest])) smallest = r;
+                } else break;
+                if (smallest == i) break;
+                const WsRefItem t = h[i]; h[i] = h[smallest]; h[smallest] = t;
+                i = smallest;
+            }
+        }
+        popped++;
+        if (e.id < 0) continue;
+        if (e.age == 0) rank[e.id] = n_ranked++;                                       // a marker: its pop rank
+        const int *np = nbr + (int64_t)e.id * n_nbr;
+        for (int k = 0; k < n_nbr; k++) {                                              // :308-341 (mask / already labelled: not pushed)
+            const int n = np[k];
+            if (n < 0 || state[n]) continue;
+            state[n] = 1;
+            age += 1;
+            push(WsRefItem{val[n], (int32_t)age, n});                                  // Py_ssize_t -> int32 store, :338
+        }
+    }
+    // markers that did not pop keep their raster order, after all that did (no label depends on their order)
+    for (int64_t i = 0; i < R; i++) if (rank[i] < 0) rank[i] = (int)(n_ranked + i);
+    free(h); free(state);
+    return popped;
+}
+
 // One call = classification / compaction, phase A, then root phases at increasing chain depth until the exactness
 // check finds no origin whose chains were cut off (or depth_max is reached).
 // `rv` != nullptr: the raveled form (tf_watershed_raveled): `field` = image, `markers` = `labels` = output (in place),
@@ -753,7 +865,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
                   uint8_t *amb_out, void *ws, size_t ws_bytes, int64_t *st, void *stream,
                   const WsRavel *rv = nullptr, const int64_t *rv_locs = nullptr, int64_t rv_n_locs = 0)
 {
-    TF_REQUIRE((flags & ~TF_WS_SKIP_FAST_PATH) == 0, "tf_watershed: unknown flag");
+    TF_REQUIRE((flags & ~(TF_WS_SKIP_FAST_PATH | TF_WS_REFERENCE_ORDER)) == 0, "tf_watershed: unknown flag");
     TF_REQUIRE(field && markers && labels && ws, "tf_watershed: null pointer");
     if (!rv) {
         TF_REQUIRE(fwd && bwd && nbr_host, "tf_watershed: null pointer");
@@ -822,6 +934,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     c.R = R; c.n_nbr = n_nbr;
     int *org = nullptr;
     int depth = 0;
+    bool reference_order_applied = false;
     unsigned long long h_amb[4] = {0, 0, 0, 0};
     if (R > 0) {
         u64 *pix = ar.take<u64>(R); unsigned *val = ar.take<unsigned>(R); int *nbr = ar.take<int>(R * n_nbr);
@@ -830,6 +943,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         for (int k = 1; k < depth_max; k++) c.C[k] = ar.take<u64>(R);
         c.Rt = ar.take<u64>(R);
         c.Llo = ar.take<int>(R); c.Lhi = ar.take<int>(R); org = ar.take<int>(R);
+        int *rank_dev = ar.take<int>(R);
         WsQueues Q;
         Q.qcap = (int)(2 * R < 0x7fffff00ll ? 2 * R : 0x7fffff00ll);
         Q.q[0] = ar.take<int>(2 * R + 64); Q.q[1] = ar.take<int>(2 * R + 64); Q.inq = ar.take<int>(R);
@@ -855,7 +969,10 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             }
         }
         const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
-        const int64_t max_sweeps = 4096 + 512 * (T + H + W);
+        // a front advances at least one pixel per sweep, so a phase needs at most "longest flood path" sweeps: bounded by
+        // T + H + W times a detour factor on a (T, H, W) grid; the raveled form knows no shape, there the only safe bound
+        // is the number of relevant pixels itself (a snake-shaped mask floods one pixel per sweep)
+        const int64_t max_sweeps = rv ? 4096 + 2 * R : 4096 + 512 * (T + H + W);
         int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0]);
         if (rc) return rc;
         // Speculative start: a root phase on K2 alone (depth 1).  If its exactness check finds no origin at all the
@@ -867,7 +984,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         int levels_done = 0;                        // C_1 .. C_levels_done are final
         for (;;) {
             for (int k = levels_done + 1; k < depth; k++) {
-                hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.C[k], R, 0);
+                hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.C[k], R, 0, (const int *)nullptr);
                 TF_CHECK_LAUNCH();
                 int64_t sw = 0;
                 rc = ws_run_phase(c, k, depth_max + 1, Q, s, max_sweeps, &sw);      // k < "depth": a chain level
@@ -875,7 +992,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
                 st[2 + (k < 3 ? k - 1 : 2)] += sw;
                 levels_done = k;
             }
-            hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1);
+            hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1, (const int *)nullptr);
             hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, markers, c.Llo, c.Lhi, R);
             TF_CHECK_LAUNCH();
             int64_t sw = 0;
@@ -894,12 +1011,76 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             if (h_amb[2] == 0 || depth >= depth_max) break;
             depth = depth < depth0 ? depth0 : depth + 1;
         }
+        if ((flags & TF_WS_REFERENCE_ORDER) && h_amb[1] > 0 && h_amb[2] == 0) {
+            // Labels hang on the order of equal-valued markers: get the reference's (ws_reference_ranks) and repeat the
+            // root phase with the pop rank in place of the raster index.  Chain levels, origins and label sets do not
+            // depend on that order, only the choice among tying candidates does.
+            hipEvent_t ev0, ev1;
+            TF_CHECK_HIP(hipEventCreate(&ev0)); TF_CHECK_HIP(hipEventCreate(&ev1));
+            TF_CHECK_HIP(hipEventRecord(ev0, s));
+            unsigned *d_vmax = (unsigned *)(d_cnt + 3);
+            TF_CHECK_HIP(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), s));
+            hipLaunchKernelGGL(k_ws_tie_value_max, dim3(nbr_blocks), dim3(256), 0, s, c, (const int *)org, d_vmax);
+            hipLaunchKernelGGL(k_ws_flag_seeds, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, N, flag);
+            TF_CHECK_LAUNCH();
+            unsigned h_vmax = 0;
+            TF_CHECK_HIP(hipMemcpyAsync(&h_vmax, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            int64_t M = 0;
+            const int rc_seeds = ws_scan_flags(flag, scan, N, scan_tmp, scan_bytes, s, &M);          // synchronises
+            if (rc_seeds) { tf_set_error("tf_watershed: TF_WS_REFERENCE_ORDER needs at most 2^30 seeds per call (use time windows)"); return rc_seeds; }
+            unsigned *h_seed_val = (unsigned *)malloc((size_t)(M > 0 ? M : 1) * sizeof(unsigned));
+            int *h_seed_cid = (int *)malloc((size_t)(M > 0 ? M : 1) * sizeof(int));
+            unsigned *h_val = (unsigned *)malloc((size_t)R * sizeof(unsigned));
+            int *h_nbr = (int *)malloc((size_t)R * n_nbr * sizeof(int));
+            int *h_rank = (int *)malloc((size_t)R * sizeof(int));
+            int rc2 = TF_OK;
+            int64_t popped = -1;
+            if (!h_seed_val || !h_seed_cid || !h_val || !h_nbr || !h_rank) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
+            // the seed list travels through the (now idle) frontier queues, 2R entries at a time
+            unsigned *stg_val = (unsigned *)Q.q[0]; int *stg_cid = Q.q[1];
+            const int64_t cap = 2 * R;
+            for (int64_t c0 = 0; c0 < M && rc2 == TF_OK; c0 += cap) {
+                const int64_t cnt = M - c0 < cap ? M - c0 : cap;
+                hipLaunchKernelGGL(k_ws_seed_list, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, (const int *)scan, (const int *)cid,
+                                   field, N, c0, cap, stg_val, stg_cid);
+                if (hipGetLastError() != hipSuccess ||
+                    hipMemcpyAsync(h_seed_val + c0, stg_val, (size_t)cnt * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipMemcpyAsync(h_seed_cid + c0, stg_cid, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess) { tf_set_error("tf_watershed: seed list transfer failed"); rc2 = TF_EHIP; }
+            }
+            if (rc2 == TF_OK &&
+                (hipMemcpyAsync(h_val, c.val, (size_t)R * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                 hipMemcpyAsync(h_nbr, c.nbr, (size_t)R * n_nbr * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                 hipStreamSynchronize(s) != hipSuccess)) { tf_set_error("tf_watershed: flood graph transfer failed"); rc2 = TF_EHIP; }
+            if (rc2 == TF_OK) {
+                popped = ws_reference_ranks(M, h_seed_val, h_seed_cid, R, h_val, h_nbr, n_nbr, h_vmax, h_rank);
+                if (popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
+            }
+            if (rc2 == TF_OK && (hipMemcpyAsync(rank_dev, h_rank, (size_t)R * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
+                                 hipStreamSynchronize(s) != hipSuccess)) { tf_set_error("tf_watershed: rank transfer failed"); rc2 = TF_EHIP; }
+            free(h_seed_val); free(h_seed_cid); free(h_val); free(h_nbr); free(h_rank);
+            if (rc2) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc2; }
+            hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1, (const int *)rank_dev);
+            hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, markers, c.Llo, c.Lhi, R);
+            TF_CHECK_LAUNCH();
+            int64_t sw = 0;
+            rc = ws_run_phase(c, depth, depth, Q, s, max_sweeps, &sw);
+            if (rc) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc; }
+            st[2 + (depth < 3 ? depth - 1 : 2)] += sw;
+            TF_CHECK_HIP(hipEventRecord(ev1, s));
+            TF_CHECK_HIP(hipEventSynchronize(ev1));
+            float ms = 0.f;
+            TF_CHECK_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+            (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+            st[13] = popped; st[14] = M; st[15] = (int64_t)(ms * 1000.0f);
+            reference_order_applied = true;
+        }
     }
     st[8] = depth; st[9] = (int64_t)h_amb[0]; st[10] = (int64_t)h_amb[1]; st[11] = (int64_t)h_amb[2];
     {
         TfProfScope ps(TFK_WS_LABELS, 12.0 * (double)N, s);
-        if (rv) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)cid, (const u64 *)c.Rt, labels, N); }
-        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, c.Llo, c.Lhi, org, labels,
+        if (rv) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)cid, (const u64 *)c.Rt, c.pix, labels, N); }
+        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, c.pix, c.Llo, c.Lhi, org, labels,
                                 R > 0 ? amb_out : nullptr, N);
     }
     TF_CHECK_LAUNCH();
@@ -911,7 +1092,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
                      (long long)st[11], depth);
         return TF_EDEPTH;
     }
-    return st[9] > 0 ? TF_WS_AMBIGUOUS : TF_OK;
+    // reference order applied: the labels ARE the reference's, whatever its heap did with the equal-valued markers
+    return (st[9] > 0 && !reference_order_applied) ? TF_WS_AMBIGUOUS : TF_OK;
 }
 
 extern "C" int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *mask,
@@ -956,14 +1138,15 @@ extern "C" size_t tf_watershed_raveled_workspace_bytes(int64_t n, int n_structur
     return ws_full_bytes(n) + ws_compact_bytes(max_relevant, n_structure, max_depth);
 }
 
-extern "C" int tf_watershed_raveled(const float *image, int64_t n, const int64_t *marker_locations, int64_t n_markers,
-                                    const int64_t *structure_host, int n_structure,
-                                    const int32_t *forward_offset, const int32_t *backward_offset,
-                                    const int32_t *forward_offset_locations_host, const int32_t *backward_offset_locations_host,
-                                    const int8_t *mask, const int32_t *strides_host, int n_strides, double compactness,
-                                    int32_t *output, int wsl, int max_depth, void *ws, size_t ws_bytes,
-                                    int64_t *stats_host, void *stream)
+extern "C" int tf_watershed_raveled_ex(const float *image, int64_t n, const int64_t *marker_locations, int64_t n_markers,
+                                       const int64_t *structure_host, int n_structure,
+                                       const int32_t *forward_offset, const int32_t *backward_offset,
+                                       const int32_t *forward_offset_locations_host, const int32_t *backward_offset_locations_host,
+                                       const int8_t *mask, const int32_t *strides_host, int n_strides, double compactness,
+                                       int32_t *output, int wsl, int max_depth, int flags, void *ws, size_t ws_bytes,
+                                       int64_t *stats_host, void *stream)
 {
+    TF_REQUIRE((flags & ~TF_WS_REFERENCE_ORDER) == 0, "tf_watershed_raveled_ex: unknown flag");
     TF_REQUIRE(image && structure_host && forward_offset && backward_offset && forward_offset_locations_host &&
                backward_offset_locations_host && mask && output && ws && (marker_locations || n_markers == 0),
                "tf_watershed_raveled: null pointer");
@@ -977,8 +1160,21 @@ extern "C" int tf_watershed_raveled(const float *image, int64_t n, const int64_t
     }
     int64_t st[TF_WS_NSTATS];
     const int d0 = max_depth < 3 ? max_depth : 3;
-    const int rc = ws_run(image, output, mask, nullptr, nullptr, 0, 0, 0, nullptr, n_structure, d0, max_depth, 0, output,
+    const int rc = ws_run(image, output, mask, nullptr, nullptr, 0, 0, 0, nullptr, n_structure, d0, max_depth, flags, output,
                           nullptr, ws, ws_bytes, st, stream, &rv, marker_locations, n_markers);
     if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = st[i];
     return rc;
+}
+
+extern "C" int tf_watershed_raveled(const float *image, int64_t n, const int64_t *marker_locations, int64_t n_markers,
+                                    const int64_t *structure_host, int n_structure,
+                                    const int32_t *forward_offset, const int32_t *backward_offset,
+                                    const int32_t *forward_offset_locations_host, const int32_t *backward_offset_locations_host,
+                                    const int8_t *mask, const int32_t *strides_host, int n_strides, double compactness,
+                                    int32_t *output, int wsl, int max_depth, void *ws, size_t ws_bytes,
+                                    int64_t *stats_host, void *stream)
+{
+    return tf_watershed_raveled_ex(image, n, marker_locations, n_markers, structure_host, n_structure, forward_offset,
+                                   backward_offset, forward_offset_locations_host, backward_offset_locations_host, mask,
+                                   strides_host, n_strides, compactness, output, wsl, max_depth, 0, ws, ws_bytes, stats_host, stream);
 }

@@ -58,11 +58,14 @@ def stitch_lut(counts, pairs_per_boundary):
     return [np.concatenate([[0], new[offs[r] + 1: offs[r + 1] + 1]]) for r in range(len(counts))]
 
 
-def compare_frames(overlap):
+def compare_frames(overlap, short_overlap_ok=False):
     """Which of the `overlap` common frames the linking looks at: all but the first and the last (linking.py:55-56).
-    The reference links nothing when two windows share fewer than three frames; here one or two shared frames are
-    all used (an extension: the rule is otherwise the same)."""
-    return slice(1, overlap - 1) if overlap > 2 else slice(0, overlap)
+    With fewer than three common frames the reference links NOTHING (its `[1:-1]` slice is empty): the same here
+    (an empty slice) unless the caller opts in with `short_overlap_ok=True` (extension: one or two shared frames are
+    then all used, the rule is otherwise the same)."""
+    if overlap > 2:
+        return slice(1, overlap - 1)
+    return slice(0, overlap) if short_overlap_ok else slice(0, 0)
 
 
 def _overlap_pairs_host(left, right, atol, rtol):
@@ -127,61 +130,98 @@ def boundary_pairs(left_last, right_first, base=None, min_overlap=1):
     return torch.from_numpy(overlap_pairs(left_last, right_first, atol=max(int(min_overlap), 1), rtol=0.0))
 
 
-def stitch_window_list(windows, min_overlap=None, overlap=1, atol=LINK_ATOL, rtol=LINK_RTOL):
+DEFAULT_OVERLAP = 4                    # frames consecutive windows share (scripts/dcc_detect_goes.py:153 n_pad_files; bench.py)
+
+
+def _rule(min_overlap, overlap, atol, rtol, short_overlap_ok):
+    """round-1 signature: `min_overlap` = absolute criterion only (atol = min_overlap, rtol = 0), which is also an
+    explicit opt-in to linking on one or two shared frames"""
+    if min_overlap is not None:
+        atol, rtol, short_overlap_ok = max(int(min_overlap), 1), 0.0, True
+    return atol, rtol, compare_frames(overlap, short_overlap_ok)
+
+
+def _local_pairs(windows, overlap, sel, atol, rtol):
+    pairs = []
+    for r in range(len(windows) - 1):
+        if windows[r].shape[1:] != windows[r + 1].shape[1:]:
+            raise ValueError("windows must share their spatial shape")
+        if windows[r].shape[0] < overlap or windows[r + 1].shape[0] < overlap:
+            raise ValueError("window shorter than the overlap")
+        left = windows[r][windows[r].shape[0] - overlap:][sel]
+        right = windows[r + 1][:overlap][sel]
+        pairs.append(overlap_pairs(left, right, atol, rtol))
+    return pairs
+
+
+def _count(w):
+    import torch
+    return int(torch.clamp(w.max(), min=0).item()) if w.numel() else 0
+
+
+def stitch_window_list(windows, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=LINK_ATOL, rtol=LINK_RTOL,
+                       short_overlap_ok=False):
     """Single-process form of stitch_labels: `windows` is a list of (T_w, H, W) int32 label tensors (CPU or GPU), the
     first `overlap` frames of window w + 1 being the last `overlap` frames of window w (e.g. a 144-frame stack processed
     as twelve windows on one GPU, window_bounds).  Returns the relabelled windows: positive ids made globally consistent
     (contiguous from 1 in order of first appearance), zero and negative ids kept.  Same rule and LUT logic as the
     distributed version.  `min_overlap` (round-1 signature) = absolute criterion only: atol = min_overlap, rtol = 0."""
-    import torch
     if len(windows) == 0:
         return []
-    if min_overlap is not None:
-        atol, rtol = max(int(min_overlap), 1), 0.0
-    counts = [int(torch.clamp(w.max(), min=0).item()) if w.numel() else 0 for w in windows]
-    sel = compare_frames(overlap)
-    pairs = []
-    for r in range(len(windows) - 1):
-        if windows[r].shape[1:] != windows[r + 1].shape[1:]:
-            raise ValueError("windows must share their spatial shape")
-        left = windows[r][windows[r].shape[0] - overlap:][sel]
-        right = windows[r + 1][:overlap][sel]
-        pairs.append(overlap_pairs(left, right, atol, rtol))
-    luts = stitch_lut(counts, pairs)
+    atol, rtol, sel = _rule(min_overlap, overlap, atol, rtol, short_overlap_ok)
+    luts = stitch_lut([_count(w) for w in windows], _local_pairs(windows, overlap, sel, atol, rtol))
     return [apply_global_lut(w, lut) for w, lut in zip(windows, luts)]
 
 
-def stitch_labels(labels, group=None, min_overlap=None, overlap=1, atol=LINK_ATOL, rtol=LINK_RTOL):
-    """Make the positive label IDs of per-rank windows globally consistent.
+def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=LINK_ATOL, rtol=LINK_RTOL,
+                        short_overlap_ok=False):
+    """Make the positive label IDs of ALL windows of ALL ranks globally consistent.
 
-    labels: (T_w, H, W) int32 torch tensor of this rank (negative and zero labels are kept).  The last `overlap`
-    frames of rank r and the first `overlap` frames of rank r+1 are the same time steps.  Communication:
-      1. all_gather of the per-rank label counts (one int64 each),
-      2. neighbour exchange: rank r+1 sends the label frames the linking compares (compare_frames) to rank r -- one
-         point-to-point message per boundary over a single xGMI link,
-      3. all_gather of the (id_left, id_right) pair lists found on each boundary, padded to the longest
-         list -- a few KB..MB; every rank then runs the same union-find and rewrites its own labels.
-    `min_overlap` (round-1 signature) = absolute criterion only: atol = min_overlap, rtol = 0."""
+    windows: this rank's list of (T_w, H, W) int32 label tensors, consecutive windows sharing `overlap` frames; the
+    last window of rank r and the first window of rank r + 1 share `overlap` frames too (one long sequence cut into
+    world x len(windows) windows, rank-major).  Every rank may hold a different number of windows (>= 1).
+    Communication:
+      1. all_gather of the per-rank window count, then of the per-window label counts (a few int64),
+      2. neighbour exchange: rank r + 1 sends the label frames the linking compares (compare_frames) of its FIRST
+         window to rank r -- one point-to-point message per rank boundary over a single xGMI link,
+      3. all_gather of the (boundary, id_left, id_right) triples found on each rank's boundaries (its internal ones and
+         the one to its right neighbour), padded to the longest list -- a few KB..MB; every rank then runs the same
+         union-find and rewrites its own windows (tf_apply_lut).
+    Without an initialised process group (or world size 1) this is stitch_window_list."""
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return labels
-    if min_overlap is not None:
-        atol, rtol = max(int(min_overlap), 1), 0.0
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    dev = labels.device
-    if dist.get_backend(group) == "gloo" and labels.is_cuda:
+        return stitch_window_list(windows, min_overlap, overlap, atol, rtol, short_overlap_ok)
+    if len(windows) == 0:
+        raise ValueError("every rank must hold at least one window")
+    dev = windows[0].device
+    if dist.get_backend(group) == "gloo" and windows[0].is_cuda:
         # gloo has no GPU collectives for these ops: stage the exchanged frames through the host
-        return stitch_labels(labels.cpu(), group, None, overlap, atol, rtol).to(dev)
-    if labels.shape[0] < overlap:
+        out = stitch_rank_windows([w.cpu() for w in windows], group, min_overlap, overlap, atol, rtol, short_overlap_ok)
+        return [w.to(dev) for w in out]
+    atol, rtol, sel = _rule(min_overlap, overlap, atol, rtol, short_overlap_ok)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if any(w.shape[0] < overlap for w in windows):
         raise ValueError("window shorter than the overlap")
-    count = torch.clamp(labels.max(), min=0).to(torch.int64).reshape(1)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, count, group=group)
-    counts = [int(c.item()) for c in counts]
-    # neighbour exchange of the compared frames
-    sel = compare_frames(overlap)
-    first = labels[:overlap][sel].contiguous()
+
+    def gather_i64(vec):
+        """all_gather of variable-length int64 vectors -> list of 1-D CPU tensors (length exchange, then padded payload)"""
+        vec = vec.to(dev).to(torch.int64).reshape(-1)
+        n = torch.tensor([vec.numel()], dtype=torch.int64, device=dev)
+        ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ns, n, group=group)
+        ns = [int(v.item()) for v in ns]
+        padded = torch.zeros(max(max(ns), 1), dtype=torch.int64, device=dev)
+        padded[:vec.numel()] = vec
+        got = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(got, padded, group=group)
+        return [g[:k].cpu() for g, k in zip(got, ns)]
+
+    counts = gather_i64(torch.tensor([_count(w) for w in windows], dtype=torch.int64))
+    n_win = [int(c.numel()) for c in counts]
+    first_window = np.concatenate([[0], np.cumsum(n_win)])             # global index of each rank's first window
+    # neighbour exchange of the compared frames of my first window
+    first = windows[0][:overlap][sel].contiguous()
     right_first = torch.empty_like(first)
     ops = []
     if rank > 0:
@@ -190,23 +230,35 @@ def stitch_labels(labels, group=None, min_overlap=None, overlap=1, atol=LINK_ATO
         ops.append(dist.P2POp(dist.irecv, right_first, rank + 1, group))
     for req in dist.batch_isend_irecv(ops) if ops else []:
         req.wait()
-    # pairs on my right boundary
-    if rank < world - 1:
-        mine = torch.from_numpy(overlap_pairs(labels[labels.shape[0] - overlap:][sel], right_first, atol, rtol)).to(dev)
-    else:
-        mine = torch.zeros((0, 2), dtype=torch.int64, device=dev)
-    n_mine = torch.tensor([mine.shape[0]], dtype=torch.int64, device=dev)
-    n_all = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(n_all, n_mine, group=group)
-    n_all = [int(v.item()) for v in n_all]
-    width = max(max(n_all), 1)
-    padded = torch.zeros((width, 2), dtype=torch.int64, device=dev)
-    padded[:mine.shape[0]] = mine
-    gathered = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(gathered, padded, group=group)
-    pairs = [gathered[r][:n_all[r]].cpu().numpy() for r in range(world - 1)]
-    lut = stitch_lut(counts, pairs)[rank]
-    return apply_global_lut(labels, lut)
+    mine = _local_pairs(windows, overlap, sel, atol, rtol)             # my internal boundaries ...
+    if rank < world - 1:                                               # ... and the one to my right neighbour
+        last = windows[-1]
+        mine.append(overlap_pairs(last[last.shape[0] - overlap:][sel], right_first, atol, rtol))
+    triples = [np.concatenate([np.full((len(p), 1), first_window[rank] + k, np.int64), np.asarray(p, np.int64).reshape(-1, 2)], 1)
+               for k, p in enumerate(mine)]
+    flat = np.concatenate(triples, 0).reshape(-1) if triples else np.zeros(0, np.int64)
+    gathered = gather_i64(torch.from_numpy(flat))
+    n_total = int(first_window[-1])
+    pairs = [[] for _ in range(n_total - 1)]
+    for g in gathered:
+        for b, x, y in g.numpy().reshape(-1, 3):
+            pairs[int(b)].append((int(x), int(y)))
+    pairs = [np.asarray(p, np.int64).reshape(-1, 2) for p in pairs]
+    all_counts = [int(v) for c in counts for v in c.tolist()]
+    luts = stitch_lut(all_counts, pairs)
+    return [apply_global_lut(w, luts[first_window[rank] + k]) for k, w in enumerate(windows)]
+
+
+def stitch_labels(labels, group=None, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=LINK_ATOL, rtol=LINK_RTOL,
+                  short_overlap_ok=False):
+    """One window per rank (stitch_rank_windows with a one-element list).  labels: (T_w, H, W) int32 torch tensor of
+    this rank (negative and zero labels are kept); the last `overlap` frames of rank r and the first `overlap` frames
+    of rank r + 1 are the same time steps.  `min_overlap` (round-1 signature) = absolute criterion only: atol =
+    min_overlap, rtol = 0."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return labels
+    return stitch_rank_windows([labels], group, min_overlap, overlap, atol, rtol, short_overlap_ok)[0]
 
 
 def apply_global_lut(labels, lut):

@@ -78,7 +78,7 @@ def neighbour_offsets(connectivity, ndim=3):
 _relevant_memo = {}      # (T, H, W, neighbours, depth) -> relevant pixels of the last successful call
 _conflict_memo = {}
 _REPROBE = 8
-TF_WS_SKIP_FAST_PATH = 1
+TF_WS_SKIP_FAST_PATH, TF_WS_REFERENCE_ORDER = 1, 2
 
 
 def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
@@ -90,10 +90,13 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
     own up to `max_chain_depth` and reports every pixel whose label still hangs on a last-resort tie-break.
       * ties between equal-valued markers (the reference resolves them by the internal state of its heap): labels
         follow the markers' raster order; `on_ambiguous` = "warn" (default) / "raise" / "ignore";
+        `on_ambiguous="reference"`: the library replays the reference heap's push / pop mechanics on the host
+        (TF_WS_REFERENCE_ORDER, include/tobac_flow_hip.h) to get the markers' pop ranks and floods with those: the
+        labels are then the reference's bit for bit, at the cost of a sequential pass (stats["reference_order"]);
       * ties left by the depth cut-off at `max_chain_depth`: WatershedDepthError (a warning with "ignore").
     return_ambiguous: also return the (T, H, W) uint8 report (AMB_* bits)."""
-    if on_ambiguous not in ("warn", "raise", "ignore"):
-        raise ValueError("on_ambiguous must be 'warn', 'raise' or 'ignore'")
+    if on_ambiguous not in ("warn", "raise", "ignore", "reference"):
+        raise ValueError("on_ambiguous must be 'warn', 'raise', 'ignore' or 'reference'")
     t = _lib.torch()
     L = _lib.lib()
     T, H, W = field.shape
@@ -117,6 +120,8 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
     memo = _conflict_memo.setdefault(key, [False, 0])          # [last probe conflicted, calls since that probe]
     skip = expect_conflict if expect_conflict is not None else (memo[0] and memo[1] < _REPROBE)
     flags = TF_WS_SKIP_FAST_PATH if (skip and chain_depth > 1) else 0
+    if on_ambiguous == "reference":
+        flags |= TF_WS_REFERENCE_ORDER
     # levels beyond chain_depth are rarely needed: the first call gets room for two more, a second one for all
     start, cap = chain_depth, min(max_chain_depth, chain_depth + 2)
     probed = None
@@ -134,7 +139,7 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
         if probed is None and rc in (0, TF_WS_AMBIGUOUS, TF_EDEPTH):
             probed = int(st[5])
         if rc == TF_EDEPTH and cap < max_chain_depth:
-            start, cap, flags = cap + 1, max_chain_depth, TF_WS_SKIP_FAST_PATH
+            start, cap, flags = cap + 1, max_chain_depth, TF_WS_SKIP_FAST_PATH | (flags & TF_WS_REFERENCE_ORDER)
             continue
         break
     if rc not in (TF_WS_AMBIGUOUS, TF_EDEPTH):
@@ -151,6 +156,7 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
         stats["ambiguous_pixels"] = int(st[9])
         stats["marker_tie_origins"] = int(st[10])
         stats["depth_origins"] = int(st[11])
+        stats["reference_order"] = {"replayed_pops": int(st[13]), "seeds": int(st[14]), "microseconds": int(st[15])}
     if rc == TF_EDEPTH:
         msg = (f"watershed: {int(st[11])} pixel(s) still tie at chain depth {int(st[8])} (the deepest allowed); "
                f"{int(st[9])} label(s) may differ from the reference")

@@ -50,10 +50,39 @@ def blob_stack(T, H, W, seed=20240601, device="cuda", nan_every=12, t0=0):
     return out
 
 
+_TORCH_INDEX_LIMIT = 2 ** 31 - 1       # torch's pooling / padding kernels index in 32 bits (a 4e9-voxel call faults the GPU)
+
+
 def anvil_inputs(bt, lower=270.0, upper=250.0):
     """linearised field, eroded markers (+1) and background seed (-1) as in detect_anvils with
-    markers=None (reference detection.py:545-561), computed with torch on the GPU."""
+    markers=None (reference detection.py:545-561), computed with torch on the GPU.
+    Volumes beyond 2^31 elements are processed in blocks of frames with a one-frame halo (the 3 x 3 x 3 erosion of the
+    background reaches one frame): torch's pooling kernels index in 32 bits, and a larger call does not raise, it
+    faults (gpurun_out/config_f_exact.log, round 2)."""
     import torch
+    T = bt.shape[0]
+    per_frame = int(bt[0].numel()) if T else 0
+    if per_frame * 3 > _TORCH_INDEX_LIMIT:
+        raise ValueError("anvil_inputs: a single frame of %d pixels is beyond what torch's 32-bit pooling kernels index" % per_frame)
+    block = max(1, _TORCH_INDEX_LIMIT // max(per_frame, 1) - 2)
+    if T <= block:
+        return _anvil_inputs_block(bt, lower, upper, True, True)
+    lin = torch.empty_like(bt)
+    markers = torch.empty(bt.shape, dtype=torch.int32, device=bt.device)
+    for a in range(0, T, block):
+        b = min(a + block, T)
+        lo, hi = max(a - 1, 0), min(b + 1, T)
+        l, m = _anvil_inputs_block(bt[lo:hi], lower, upper, lo == 0, hi == T)
+        lin[a:b], markers[a:b] = l[a - lo:b - lo], m[a - lo:b - lo]
+    return lin, markers
+
+
+def _anvil_inputs_block(bt, lower, upper, first, last):
+    """`first` / `last`: the block starts / ends the volume (border_value = 1 beyond it; interior block edges are halo
+    frames whose own result is discarded)"""
+    import torch
+    if bt.numel() + 2 * bt[0].numel() > _TORCH_INDEX_LIMIT:
+        raise ValueError("anvil_inputs: block beyond torch's 32-bit pooling kernels")
     F = torch.nn.functional
     lo, hi = min(lower, upper), max(lower, upper)
     lin = ((bt - lo) / (hi - lo)).clamp(0, 1)
@@ -73,3 +102,18 @@ def anvil_inputs(bt, lower=270.0, upper=250.0):
     bgm = (bge[0, 0] > 0.5) | nan
     markers[bgm] = -1
     return lin, markers
+
+
+def anvil_seeds(bt, lower=270.0, upper=250.0, erode_distance=1):
+    """SURVEY.md 8(d)'s marker recipe for one window, every step a library kernel (tobac_flow_amd/ndimage_dev.py):
+    field_lin = linearise_field(bt, lower, upper); markers = label(binary_erosion(field_lin >= 1)) -- window-local
+    component ids, as the drop-in scripts pass them (scripts/dcc_detect_goes.py:221-235) -- and -1 where
+    get_watershed_mask(field_lin, erode_distance) (detection.py:547-561).  Returns (field_lin f32, seeds i32)."""
+    import scipy.ndimage as ndi
+    import torch
+    from tobac_flow_amd import ndimage_dev as nd
+    from tobac_flow_amd.detection import get_watershed_mask
+    lin = nd.linearise_field(bt, lower, upper)
+    s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
+    comp = nd.label(nd.binary_erosion(lin >= 1, s))[0]
+    return lin, torch.where(get_watershed_mask(lin, erode_distance=erode_distance), torch.full_like(comp, -1), comp)
