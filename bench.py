@@ -8,14 +8,14 @@ marker-controlled watershed) on 5424 x 5424 GOES-16 full-disk-sized frames, one 
   fresh rank processes itself (one per GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line.
 
 A step is one pass of the hot path over one STACK resident in HBM -- by default BASELINE.json's config F, 144 frames of
-5424 x 5424 -- processed the production way (scripts/dcc_detect_goes.py:153): twelve time windows sharing four frames,
-per window
-    seeds (linearise_field -> binary_erosion -> label: window-local component ids; -1 background seed)
-    create_flow(Farneback, vr_steps=1, smoothing_passes=1, interp_method="cubic")
-    Flow.sobel(uphill, cubic, float64) -> combined edge field
-    Flow.watershed(connectivity 1)
+5424 x 5424 -- processed the production way (scripts/dcc_detect_goes.py:153): twelve time windows sharing four frames:
+    create_flow(Farneback, vr_steps=1, smoothing_passes=1, interp_method="cubic") over the stack's 143 frame pairs, once
+    per window:  Flow.window (= the Flow create_flow(window) would give, bit for bit: only the end frames differ)
+                 seeds (linearise_field -> binary_erosion -> label: window-local component ids; -1 background)
+                 Flow.sobel(uphill, cubic, float64) -> combined edge field
+                 Flow.watershed(connectivity 1)
 and then the label ids of all windows stitched by the reference's overlap rule (linking.py:49-161), all inside the
-timed region.  `value` counts the DELIVERED frames (144 per step), not the 188 window frames computed.
+timed region.  `value` counts the DELIVERED frames (144 per step), not the 188 window frames flooded.
 Under --gpus N every rank holds its own 144-frame segment of ONE synthetic sequence (weak scaling; consecutive segments
 share four frames bit for bit); the stitch then runs over all windows of all ranks with one neighbour message per rank
 boundary and all-gathers of the pair lists (tobac_flow_amd/parallel.py: stitch_rank_windows).
@@ -252,10 +252,12 @@ def main():
     nbr = neighbour_offsets(1)
     ws_stats = []                                            # tf_watershed stats of every window of every step (warmup included)
 
-    def window(lo, hi, vr_steps):
+    def window(flow_all, lo, hi):
         """the hot path over frames lo .. hi - 1: one label volume per channel"""
         w = bt[lo:hi]
-        flow = tf.create_flow(w, model="Farneback", vr_steps=vr_steps, smoothing_passes=1, interp_method="cubic")
+        # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame pair
+        # does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426)
+        flow = flow_all.window(lo, hi)
         fw, bw = flow._dev_flows()
         out = []
         for c in range(C):
@@ -272,9 +274,13 @@ def main():
     def step(vr_steps=None):
         vr = a.vr_steps if vr_steps is None else vr_steps
         per_channel = [[] for _ in range(C)]
+        # flow of all T - 1 frame pairs of the stack, ONCE (the frames two windows share are not computed twice), in batches
+        # sized by the library (tf_farneback_batch_hint)
+        flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic")
         for lo, hi in bounds:
-            for c, lab in enumerate(window(lo, hi, vr)):
+            for c, lab in enumerate(window(flow_all, lo, hi)):
                 per_channel[c].append(lab)
+        del flow_all
         # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
         return [stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins for wins in per_channel]
 
@@ -335,8 +341,9 @@ def main():
                  "F3": "BASELINE config F3: full-disk-sized stack, three channels sharing one Flow",
                  "C": "BASELINE config C: GOES-16 CONUS-sized stack", "window": "sub-report: ONE window per step"}
         what = (f"{names[a.config]}: {T}x{H}x{W} float32 frames per GPU per step" + (f" x {C} channels" if C > 1 else "") +
-                (f", processed as {n_windows} time windows sharing {a.overlap} frames ({frames_computed} window frames computed for {T} "
-                 f"delivered) + stitch of the label ids over all windows, all inside the timed region" if n_windows > 1 else ""))
+                (f", processed as {n_windows} time windows sharing {a.overlap} frames: flow of the {T - 1} frame pairs once for the stack, "
+                 f"then per window Sobel edge field + seeds + watershed ({frames_computed} window frames for {T} delivered) + stitch of "
+                 f"the label ids over all windows, all inside the timed region" if n_windows > 1 else ""))
         if not full_size:
             what = "REDUCED rehearsal of " + what
         out = {"metric": "Mpix/s end-to-end flow+sobel+watershed, 5424^2 frames" if (H, W) == (5424, 5424)
@@ -350,7 +357,7 @@ def main():
                           "seeds": ("every positive seed = 1 (detect_anvils(markers=None))" if a.single_label_seeds else
                                     "SURVEY 8(d): label(binary_erosion(field_lin >= 1)) per window on the device (component ids), "
                                     "-1 where get_watershed_mask(field_lin); computed inside the timed region"),
-                          "stages": f"seeds + create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.sobel(uphill, cubic, f64) "
+                          "stages": f"create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.window + seeds + Flow.sobel(uphill, cubic, f64) "
                                     "+ edge field + Flow.watershed(connectivity 1)" + (" + stitch" if n_windows > 1 or world > 1 else ""),
                           "sharding": f"one {T}-frame segment per GPU cut from one sequence, consecutive segments share {a.overlap} frames; "
                                       "label IDs stitched over all windows of all ranks by the reference's overlap rule "

@@ -97,6 +97,12 @@ int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H, int64
  * directly in forward_flow[i0 + b] and backward_flow[i0 + 1 + b].  Batching keeps the coarse pyramid
  * levels -- a few hundred workgroups per pair -- busy on all 256 CUs. */
 size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const tf_farneback_params *p);
+/* How many pairs to hand to tf_farneback_batch at a time.  OpenCV's box filter carries the float rounding of its running
+ * column sums down a whole column (optflowgf.cpp FarnebackUpdateFlow_Blur: `vsum[x] += srow1[x] - srow0[x]`), so the
+ * iteration kernel cannot split the rows of a column over workgroups: its parallelism is strips x directions x pairs,
+ * and a launch costs a whole number of "rounds" of resident workgroups.  Returns the batch size <= max_pairs whose
+ * workspace fits max_bytes (0 = no limit) and whose last round is fullest (21 pairs at 5424 x 5424, 16 at 3712 x 3712). */
+int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneback_params *p, int64_t max_pairs, size_t max_bytes);
 int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B, int64_t img_stride,
                        int64_t H, int64_t W, const tf_farneback_params *p,
                        float *flow_fwd, float *flow_bwd, int64_t flow_stride,

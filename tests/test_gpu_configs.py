@@ -86,7 +86,8 @@ def test_config_S_whole_pipeline_matches_the_oracle():
         assert got.shape == (16, 512, 512, 2) and got.dtype == np.float32
         assert np.array_equal(np.isnan(got), np.isnan(want))
         d = np.abs(np.nan_to_num(got) - np.nan_to_num(want))
-        assert np.percentile(d, 99.9) <= 1e-4 and d.max() <= 0.1, (np.percentile(d, 99.9), d.max())
+        print("config S composed flow vs oracle: 99.9th percentile %.3g, max %.3g" % (np.percentile(d, 99.9), d.max()))
+        assert d.max() <= 1e-4, (np.percentile(d, 99.9), d.max())
     raw_f, raw_b = tf.calculate_flow(bt, "Farneback")           # no refinement, no smoothing
     want_rf, want_rb = _oracle_flow(bt, 0, 0, "linear", max_value=np.inf)
     assert np.abs(raw_f - want_rf).max() <= 1e-4 and np.abs(raw_b - want_rb).max() <= 1e-4
@@ -113,11 +114,13 @@ def test_config_S_whole_pipeline_matches_the_oracle():
         warnings.simplefilter("ignore")
         labels = flow.watershed(edges, markers, connectivity=ndi.generate_binary_structure(3, 1))
         labels2, report = tf.watershed(fwd, bwd, edges, markers, connectivity=1, return_ambiguous=True)
+    ref_mode = flow.watershed(edges, markers, connectivity=ndi.generate_binary_structure(3, 1), on_ambiguous="reference")
     assert np.array_equal(labels, labels2)
     ideal = ws_oracle.watershed(fwd, bwd, edges, markers, None, 1, tie_mode=1)
-    ref = ws_oracle.watershed(fwd, bwd, edges, markers, None, 1)
-    assert np.array_equal(labels, ideal)
-    assert not ((labels != ref) & ((report & 1) == 0)).any()       # whatever differs from the reference order is reported
+    ref = ws_oracle.watershed(fwd, bwd, edges, markers, None, 1)     # tie_mode 0: the reference kernel's own semantics
+    assert np.array_equal(ref_mode, ref)                             # reference order: the reference's labels, every voxel
+    assert np.array_equal(labels, ideal)                             # default mode: raster order of equal-valued markers ...
+    assert not ((labels != ref) & ((report & 1) == 0)).any()         # ... and whatever differs from the reference is reported
     mask = field >= 0.5
     got_l = flow.label(mask, overlap=0.5, absolute_overlap=5)
     assert np.array_equal(got_l, np_label.flow_label(fwd, bwd, mask, overlap=0.5, absolute_overlap=5))
@@ -125,7 +128,7 @@ def test_config_S_whole_pipeline_matches_the_oracle():
 
 def test_config_C_24_frames_as_two_windows():
     """Config C: the 24-frame 1500 x 2500 stack, processed the production way: two 14-frame windows sharing four frames,
-    each flooded on the GPU (against the sequential oracle on the same window, bit for bit), stitched by the reference's
+    each flooded on the GPU in reference order (against the reference kernel's C twin on the same window, bit for bit), stitched by the reference's
     overlap rule; every object of the overlap keeps one id in both windows."""
     import torch
     import tobac_flow_amd.flow as tf
@@ -145,12 +148,10 @@ def test_config_C_24_frames_as_two_windows():
         comp = ndi.label(markers.cpu().numpy() > 0)[0].astype(np.int32)
         comp[markers.cpu().numpy() < 0] = -1
         e = get_combined_edge_field(fl, lin, dtype=np.float32)       # detection.py:620-642 (NaN -> +inf)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            lab = fl.watershed(e, torch.from_numpy(comp).cuda(), connectivity=1)
-        ideal = ws_oracle.watershed(fl.forward_flow.cpu().numpy(), fl.backward_flow.cpu().numpy(), e.cpu().numpy(), comp,
-                                    None, 1, tie_mode=1)
-        assert np.array_equal(lab.cpu().numpy(), ideal)
+        lab = fl.watershed(e, torch.from_numpy(comp).cuda(), connectivity=1, on_ambiguous="reference")
+        ref = ws_oracle.watershed(fl.forward_flow.cpu().numpy(), fl.backward_flow.cpu().numpy(), e.cpu().numpy(), comp,
+                                  None, 1, tie_mode=0)                # the reference kernel's own semantics
+        assert np.array_equal(lab.cpu().numpy(), ref)
         out.append(lab)
     left, right = stitch_window_list(out, overlap=overlap)
     l, r = left[-overlap:][1:-1].cpu().numpy(), right[:overlap][1:-1].cpu().numpy()      # the compared frames
@@ -181,12 +182,12 @@ def _windowed_detection(frames_of, T, n_windows, overlap, oracle):
         comp = torch.where(markers < 0, markers, nd.label(markers > 0)[0])
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            lab = fl.watershed(e, comp, connectivity=1)
+            lab = fl.watershed(e, comp, connectivity=1, on_ambiguous="reference" if oracle else "warn")
         if oracle:
             from oracle import ws_oracle
-            ideal = ws_oracle.watershed(fl.forward_flow.cpu().numpy(), fl.backward_flow.cpu().numpy(), e.cpu().numpy(),
-                                        comp.cpu().numpy(), None, 1, tie_mode=1)
-            assert np.array_equal(lab.cpu().numpy(), ideal)
+            ref = ws_oracle.watershed(fl.forward_flow.cpu().numpy(), fl.backward_flow.cpu().numpy(), e.cpu().numpy(),
+                                      comp.cpu().numpy(), None, 1, tie_mode=0)    # the reference kernel's own semantics
+            assert np.array_equal(lab.cpu().numpy(), ref)
         labs.append(lab)
         del fl, e, lin, markers, bt
     return labs

@@ -74,3 +74,27 @@ def test_detection_script_sequence_end_to_end():
         vals = np.asarray(bt)[ds["core_label"] == c].astype(np.float64)
         assert abs(mean[c - 1] - vals.mean()) < 1e-3 and mx[c - 1] == vals.max().astype(np.float32) and mn[c - 1] == vals.min().astype(np.float32)
         assert abs(std[c - 1] - vals.std()) < 1e-3
+
+
+def test_flow_window_equals_create_flow_on_the_slice():
+    """Flow.window(a, b) is the Flow create_flow(data[a:b]) returns, bit for bit, on the device and for numpy stacks:
+    the flow of a frame pair does not depend on the stack it is cut from; only the two end frames of a stack are
+    mirrored (flow.py:425-426).  bench.py computes the flow of a long stack once and floods overlapping windows of it."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tools.synth import blob_stack
+    bt = blob_stack(9, 150, 210, seed=3)
+    kw = dict(model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    whole = tf.create_flow(bt, **kw)
+    for a, b in ((0, 9), (0, 4), (3, 8), (5, 9), (4, 6), (7, 8)):
+        want = tf.create_flow(bt[a:b], **kw)
+        got = whole.window(a, b)
+        assert got.shape == want.shape
+        for g, w in ((got.forward_flow, want.forward_flow), (got.backward_flow, want.backward_flow)):
+            assert torch.equal(torch.nan_to_num(g, nan=-777.0), torch.nan_to_num(w, nan=-777.0)), (a, b)
+    whole_np = tf.create_flow(bt.cpu().numpy(), **kw)
+    got = whole_np.window(3, 8)
+    want = tf.create_flow(bt[3:8].cpu().numpy(), **kw)
+    assert isinstance(got.forward_flow, np.ndarray)
+    assert np.array_equal(got.forward_flow, want.forward_flow, equal_nan=True) and np.array_equal(got.backward_flow, want.backward_flow, equal_nan=True)
+    assert not np.shares_memory(got.forward_flow, whole_np.forward_flow)         # a window never aliases the stack it was cut from

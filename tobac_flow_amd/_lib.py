@@ -42,6 +42,7 @@ _PROTOS = {
     "tf_farneback_pair": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _P, _P, _P,
                                      _c.c_size_t, _P]),
     "tf_farneback_workspace_bytes_batch": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams)]),
+    "tf_farneback_batch_hint": (_c.c_int64, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int64, _c.c_size_t]),
     "tf_farneback_batch": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                       _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),
     "tf_varref_default_params": (None, [_c.POINTER(VarRefParams)]),
@@ -117,6 +118,8 @@ def lib():
         torch()
         L = ctypes.CDLL(_SO)
         for name, (res, args) in _PROTOS.items():
+            if os.environ.get("TF_LIB_PATH") and not hasattr(L, name):
+                continue                         # A/B runs against an older build of the library: entry points it lacks stay unbound
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args

@@ -662,23 +662,22 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 
 // ---- fused iteration: UpdateMatrices -> 13x13 box sums (double) -> 2x2 solve -----------------------
 // One launch = one Farnebaeck iteration of BOTH directions for a batch of frame pairs.  A workgroup of FBI_T = 128
-// threads owns a strip of FBI_OW = 116 output columns (+ 6 halo columns each side) and `hs` rows.
+// threads (two waves) owns a strip of FBI_OW = 116 output columns (+ 6 halo columns each side) over the WHOLE height.
 // Thread j walks DOWN its column: at every row it evaluates M = UpdateMatrices(R0, R1, flow_old) in
 // registers, keeps the last 13 rows of M in a register ring and the running 13-row column sums in
-// double; the five column sums go to an LDS row, from which the 244 interior threads add 13 neighbours,
-// solve the 2x2 system and write flow_new.  The 5-plane matrix M never exists in HBM: per level pixel
+// double (OpenCV's recurrence, float-rounded differences included); the five column sums go to an LDS row, from
+// which thread t takes (row t / 29, quad t % 29): four 13-wide window sums that share their ten middle terms, four
+// 2x2 solves, flow_new.  The 5-plane matrix M never exists in HBM: per level pixel
 // the kernel moves R0 (20 B) + R1 (20 B) + flow in (8 B) + flow out (8 B).
 // The per-row evaluation is BRANCH-FREE (out-of-image gathers read a valid dummy address and are
-// discarded by selects) so that the loads of two rows are in flight together, and the flow of the next
-// row group is fetched before the LDS phase of the current one: the kernel is bound by memory latency
-// at 3 waves / SIMD, not by bytes.
+// discarded by selects) so that the loads of FBI_NB rows are in flight together, and the flow of the next
+// row group is fetched before the LDS phase of the current one.  Occupancy: two waves per SIMD = four workgroups per CU.
 #define FBI_M 6
 #define FBI_WIN (2 * FBI_M + 1)
 #ifndef FBI_T
 #define FBI_T 128                   // threads = evaluated columns per workgroup
 #endif
 #define FBI_OW (FBI_T - 2 * FBI_M)
-#define FBI_HS 512                  // tallest strip; halved until the grid has >= 1536 workgroups
 // R[img] / fin[q] / fout[q] are the pointers of batch item 0; item b adds b * the matching stride
 struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2]; };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
@@ -872,22 +871,39 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float 
 // the launch bound says so, which lets the compiler schedule for the 256-register budget (5 % faster than the
 // default bound).  Forcing three waves spills the ring (+70 %); row groups 4 + 4 + 4 + 1 with 51 KB of LDS cost
 // 2 % for the extra barrier pair and gain nothing while the registers hold the kernel at two waves.
+// Workgroup = one CHAIN = (pair, strip of FBI_OW columns, direction), all rows.  Block ids that differ by 8 are the two
+// directions of a strip: they read the same two R images (each is the other's gather target), walk down in step, and
+// are placed on the SAME XCD (observed round-robin dispatch; this is for L2 reuse only, never for correctness): within
+// a group of 8 * nd consecutive ids, id % 8 picks the strip and id / 8 the direction.
+//
+// Why whole columns.  OpenCV's vertical running sum, term for term (FarnebackUpdateFlow_Blur; oracle/c/farneback.c:263-281):
+//   vsum  = M[0] * (m + 2)  [float product]  + M[1] + ... + M[m-1]          (rows clamped to H - 1)
+//   row y:  vsum += (double)( M[min(y + m, H - 1)] - M[max(y - m - 1, 0)] )   the difference ROUNDED TO FLOAT
+// The float rounding of every difference stays in vsum for all rows below it -- a drift that depends on the whole
+// column above a pixel, not on its 13-row window.  It is of the order of 1e-7 of the largest M in the column, which
+// in a low-texture spot below a textured one moves the solution by > 1e-4 (round 2: max 1.5e-4 at 5424^2 with
+// row strips that restarted the sum every <= 512 rows; now 7e-5, tests/test_gpu_fullsize.py).  So the rows of a chain
+// are processed in order by one workgroup, and the parallelism of a launch is strips x directions x PAIRS.
+// What was measured on the way (profiles/round3_fb_iter_notes.txt; 15 pairs at 5424^2, one launch):
+//   row strips of round 2 (15 840 independent workgroups)           10.7 ms
+//   whole columns, 1410 workgroups on 1024 resident slots            14.1 ms = exactly two rounds: a workgroup does not run
+//       faster when its CU is half empty, and the L2 / HBM counters equal those of the row-strip kernel
+//   chains cut into 8 segments handed over through memory, persistent workgroups on a ready queue (one queue, or one
+//       per XCD): balanced, but 14.1 - 14.4 ms: 16 - 21 % more HBM fetches and 60 - 90 % more L1 stall cycles eat the gain
+//   start delays that de-phase the workgroups: no effect
+// So the remedy is not in the kernel but in the batch: the host layer sizes a launch to a whole number of rounds
+// (tf_farneback_batch_hint: 21 pairs = 1974 chains = 96 % of two rounds at 5424^2), which a stack of frames allows.
 template <int NB, int ABL>
 __global__ void __launch_bounds__(FBI_T, 2)
-k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
+k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
 {
     __shared__ double vrow[FBI_G * 5 * FBI_VS];
-    // Work-item order.  Both directions of one strip read the same two R images (each is the other's gather
-    // target), so they are placed on the SAME XCD (block ids that differ by 8 share an XCD under the observed
-    // round-robin dispatch; this is for L2 reuse only, never for correctness): within a group of 8*nd
-    // consecutive block ids, id % 8 picks the strip and id / 8 the direction.
-    const int nstrips = a.nx;                                          // column strips per row-strip
-    const int gid = blockIdx.x;
+    const int gx = ((a.nx + 7) / 8) * 8 * a.nd;
+    const int b = blockIdx.x / gx, gid = blockIdx.x - b * gx;
     const int grp = gid / (8 * a.nd), rem = gid % (8 * a.nd);
     const int q = rem / 8;
     const int sx = grp * 8 + rem % 8;
-    if (sx >= nstrips) return;
-    const int b = blockIdx.z;
+    if (sx >= a.nx) return;
     const int d = a.dir[q];                                            // 0: prev -> next, 1: next -> prev
     FbIterCtx c;
     const float *R0 = a.R[d] + b * a.bs_R, *R1 = a.R[1 - d] + b * a.bs_R;
@@ -910,8 +926,8 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
     c.tg = c.j / FBI_Q; c.tq = c.j - c.tg * FBI_Q;
     c.x_strip = sx * FBI_OW;
     c.xc = tf_clampi(c.x_strip + c.j - FBI_M, 0, W - 1);              // column this thread evaluates M for (replicate border)
-    c.y0 = blockIdx.y * hs;
-    c.y1 = min(c.y0 + hs, H);                                         // output rows [y0, y1)
+    c.y0 = 0;
+    c.y1 = H;                                                         // output rows [0, H)
     {
         const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
         const int xb = W - 1 - c.xc;
@@ -922,15 +938,45 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane, int hs)
         c.xborder = (unsigned)(c.xc - 5) >= (unsigned)(W - 10);
     }
     float ring[FBI_WIN][5];
-#pragma unroll
-    for (int k = 0; k < FBI_WIN; k++) { ring[k][0] = ring[k][1] = ring[k][2] = ring[k][3] = ring[k][4] = 0.f; }
-    double S[5] = {0, 0, 0, 0, 0};
+    double S[5];
     float2 fl[FBI_G];
-    const int s_first = c.y0 - FBI_M, s_last = c.y1 - 1 + FBI_M;       // window rows needed (inclusive)
+    {
+        // rows 0 .. m-1 -> ring slots m+1 .. 2m; slots 0 .. m+1 hold row 0 (OpenCV's max(y - m - 1, 0) for the rows above the
+        // image); three rows at a time (their loads in flight together, few registers live next to the ring)
 #pragma unroll
-    for (int g = 0; g < FBI_G; g++) fl[g] = (ABL != 1) ? fb_iter_flow_at(c, s_first + g) : make_float2(0.f, 0.f);
+        for (int r0 = 0; r0 < FBI_M; r0 += 3) {
+            float2 f0[3];
+            FbTaps t[3];
+            float mm[3][5];
+#pragma unroll
+            for (int r = 0; r < 3; r++) f0[r] = (ABL != 1) ? fb_iter_flow_at(c, r0 + r) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 3; r++) if (ABL != 1) fb_taps_load<ABL>(c, r0 + r, f0[r], t[r]);
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int row = r0 + r;
+                if (ABL == 1) { mm[r][0] = (float)row; mm[r][1] = (float)c.xc; mm[r][2] = 1.f; mm[r][3] = 2.f; mm[r][4] = (float)(row + c.xc); }
+                else fb_taps_eval(c, row, t[r], mm[r]);
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    if (row == 0) {
+                        S[ch] = (double)(mm[r][ch] * (float)(FBI_M + 2));
+#pragma unroll
+                        for (int k = 0; k <= FBI_M + 1; k++) ring[k][ch] = mm[r][ch];       // rows -(m+1) .. 0
+                    } else {
+                        S[ch] += (double)mm[r][ch];
+                        ring[FBI_M + 1 + row][ch] = mm[r][ch];
+                    }
+                }
+            }
+        }
+    }
+    const int s_last = H - 1 + FBI_M;                                  // window rows needed (inclusive; clamped to H - 1)
+#pragma unroll
+    for (int g = 0; g < FBI_G; g++) fl[g] = (ABL != 1) ? fb_iter_flow_at(c, FBI_M + g) : make_float2(0.f, 0.f);
+    // row s enters ring slot (s - m) mod 13, which holds row s - 13 = (output row) - m - 1: OpenCV's srow0.
     // rows past s_last are evaluated (clamped, harmless) but never produce output
-    for (int base = s_first; base <= s_last; base += FBI_WIN) {
+    for (int base = FBI_M; base <= s_last; base += FBI_WIN) {
         fb_iter_group<0, 4, 4, NB, ABL>(c, base, ring, S, fl, vrow);
         fb_iter_group<4, 4, 5, NB, ABL>(c, base + 4, ring, S, fl, vrow);
         fb_iter_group<8, 5, 4, NB, ABL>(c, base + 8, ring, S, fl, vrow);
@@ -1065,6 +1111,30 @@ extern "C" size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64
 {
     if (B <= 0 || H <= 0 || W <= 0 || !p) return 0;
     return (size_t)B * fb_pair_floats(H, W) * sizeof(float) + 8192;
+}
+
+// Pairs per tf_farneback_batch call that fill the GPU best.  The iteration kernel runs one workgroup per (pair, strip,
+// direction) over all rows, four workgroups are resident per CU, and a workgroup does not speed up when its CU is
+// half empty: a launch costs ceil(chains / resident) rounds.  Returns the batch size <= max_pairs (and within
+// max_bytes of workspace, 0 = no limit) with the best fill of its last round, the larger one on ties within 2 %.
+extern "C" int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneback_params *p, int64_t max_pairs, size_t max_bytes)
+{
+    if (H <= 0 || W <= 0 || !p || max_pairs < 1) return 0;
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    const int64_t slots = 4ll * n_cu, per_pair = 2 * ((W + FBI_OW - 1) / FBI_OW);
+    const size_t per_pair_bytes = fb_pair_floats(H, W) * sizeof(float);
+    int64_t cap = max_pairs;
+    if (max_bytes > 0 && (int64_t)(max_bytes / per_pair_bytes) < cap) cap = (int64_t)(max_bytes / per_pair_bytes);
+    if (cap < 1) cap = 1;
+    if (cap > 1024) cap = 1024;
+    int64_t best = 1; double best_fill = 0;
+    for (int64_t B = 1; B <= cap; B++) {
+        const int64_t chains = B * per_pair, rounds = (chains + slots - 1) / slots;
+        const double fill = (double)chains / (double)(rounds * slots);
+        if (fill >= best_fill - 0.02) { if (fill > best_fill) best_fill = fill; best = B; }
+    }
+    return best;
 }
 
 extern "C" size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_params *p)
@@ -1204,13 +1274,9 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
         }
         TF_CHECK_LAUNCH();
         if (fused) {
-            // strip height: tall strips amortise the 12-row halo, short ones keep all CUs busy on coarse levels
-            static const int hs_max = getenv("TF_FBI_HS") ? atoi(getenv("TF_FBI_HS")) : FBI_HS;
-            int hs = hs_max;
-            static const int64_t min_wg = getenv("TF_FBI_MIN_WG") ? atoll(getenv("TF_FBI_MIN_WG")) : 1536 * (256 / FBI_T);
-            while (hs > 8 && (int64_t)((w + FBI_OW - 1) / FBI_OW) * ((h + hs - 1) / hs) * nd * B < min_wg) hs >>= 1;
+            // whole columns per workgroup (k_fb_iter): parallelism = strips x directions x pairs
             const int nx = (w + FBI_OW - 1) / FBI_OW;
-            const dim3 gi(((nx + 7) / 8) * 8 * nd, (h + hs - 1) / hs, B);
+            const dim3 gi((unsigned)(((nx + 7) / 8) * 8 * nd * B), 1, 1);
             FbIterArgs ia;
             ia.R[0] = R[0]; ia.R[1] = R[1]; ia.bs_R = bs_R; ia.nd = nd; ia.nx = nx;
             for (int it = 0; it < p->num_iters; it++) {
@@ -1223,9 +1289,9 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 {
                     TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd * B, s);
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
-                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1>), gi, dim3(FBI_T), 0, s, ia, h, w, plane, hs);
-                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2>), gi, dim3(FBI_T), 0, s, ia, h, w, plane, hs);
-                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0>), gi, dim3(FBI_T), 0, s, ia, h, w, plane, hs);
+                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1>), gi, dim3(FBI_T), 0, s, ia, h, w, plane);
+                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2>), gi, dim3(FBI_T), 0, s, ia, h, w, plane);
+                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0>), gi, dim3(FBI_T), 0, s, ia, h, w, plane);
                 }
                 for (int q = 0; q < nd; q++) cur[dirs[q]] = 1 - cur[dirs[q]];
             }

@@ -97,9 +97,42 @@ class Flow(AbstractFlow):
         return sobel(data, self.forward_flow, self.backward_flow, method=method, dtype=dtype,
                      fill_value=fill_value, direction=direction, _dev_flows=self._dev_flows())
 
-    def watershed(self, field, markers, mask=None, connectivity=1):
+    def window(self, start: int, stop: int) -> "Flow":
+        """The Flow object create_flow(data[start:stop]) would return, bit for bit, cut out of this one: the flow of a
+        frame pair does not depend on the stack it is part of, only the two END frames of a stack are special (their
+        missing neighbour is mirrored: forward[-1] = -backward[-1], backward[0] = -forward[0], flow.py:425-426).  A long
+        stack processed as overlapping time windows (scripts/dcc_detect_goes.py:153) therefore needs ONE flow
+        computation, not one per window: the frames two windows share are not computed twice.  (Not in the reference.)"""
+        T = self.shape[0]
+        start, stop, _ = slice(start, stop).indices(T)
+        if stop - start < 1:
+            raise ValueError("empty window")
+        t = _lib.torch()
+        on_device = isinstance(self.forward_flow, t.Tensor)
+        if on_device:
+            fw, bw = self.forward_flow[start:stop], self.backward_flow[start:stop]
+            if stop < T or start > 0:
+                fw, bw = fw.clone(), bw.clone()
+                if stop - start > 1:
+                    fw[-1] = -bw[-1]
+                    bw[0] = -fw[0]
+                else:
+                    fw[-1].fill_(float("nan"))
+                    bw[0].fill_(float("nan"))
+        else:
+            fw, bw = np.array(self.forward_flow[start:stop]), np.array(self.backward_flow[start:stop])
+            if stop - start > 1:
+                fw[-1] = -bw[-1]
+                bw[0] = -fw[0]
+            elif stop < T or start > 0:
+                fw[-1], bw[0] = np.nan, np.nan
+        return Flow(fw, bw)
+
+    def watershed(self, field, markers, mask=None, connectivity=1, **kwargs):
+        """reference: flow.py (Flow.watershed).  Extra keywords (`on_ambiguous`, `return_ambiguous`, `chain_depth`,
+        `max_chain_depth`: the exactness contract of tobac_flow_amd.watershed.watershed) are passed through."""
         return watershed(self.forward_flow, self.backward_flow, field, markers, mask=mask,
-                         connectivity=connectivity, _dev_flows=self._dev_flows())
+                         connectivity=connectivity, _dev_flows=self._dev_flows(), **kwargs)
 
     def label(self, data, structure=ndi.generate_binary_structure(3, 1), dtype: type = np.int32,
               overlap: float = 0, absolute_overlap: int = 1, subsegment_shrink: float = 0,
@@ -216,9 +249,24 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     # kernel launches (tf_farneback_batch), which keeps the coarse pyramid levels busy on all CUs.
     linear = norm_name == "linear" and not normalisation_kwargs
     interp = select_interp_mode(interp_method) if smoothing_passes > 0 else 1
-    chunk = max(1, int(os.environ.get("TF_FLOW_BATCH", "8")))
-    for i0 in range(0, T - 1, chunk):
-        B = min(chunk, T - 1 - i0)
+    # The fused iteration kernel walks whole columns (OpenCV's running column sums cannot be split over rows,
+    # csrc/farneback.hip), so its parallelism is strips x directions x PAIRS and a launch costs a whole number of rounds
+    # of resident workgroups: the library says which batch size fills its last round best (21 pairs at 5424^2), and the
+    # pairs of the stack are spread evenly over the batches.  TF_FLOW_BATCH overrides (development switch).
+    n_pairs = T - 1
+    if "TF_FLOW_BATCH" in os.environ:
+        chunk = max(1, int(os.environ["TF_FLOW_BATCH"]))
+    elif n_pairs > 0 and hasattr(of_model, "params"):
+        budget = int(float(os.environ.get("TF_FLOW_WORKSPACE_GB", "80")) * 1e9)
+        chunk = max(1, int(L.tf_farneback_batch_hint(H, W, ctypes.byref(of_model.params), n_pairs, budget)))
+    else:
+        chunk = 16
+    n_batches = max(1, -(-n_pairs // chunk))
+    starts = [round(k * n_pairs / n_batches) for k in range(n_batches + 1)]
+    for i0, i1 in zip(starts[:-1], starts[1:]):
+        B = i1 - i0
+        if B <= 0:
+            continue
         prev8 = _lib.empty((B, H, W), t.uint8)
         next8 = _lib.empty((B, H, W), t.uint8)
         for b in range(B):
