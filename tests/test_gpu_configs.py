@@ -7,7 +7,8 @@
       oracle can afford is compared with the oracle window by window
   F3  three channels (offsets 0 / -2 / -4 K) sharing ONE Flow: growth detection per channel, device-resident recipe against
       the SciPy-glue recipe, and detect_growth_markers_multichannel against the recipe assembled from oracle pieces
-  (V, SEVIRI 3712 x 3712, rides on tests/test_gpu_fullsize.py, whose fixtures run at both frame sizes.)
+  V   288 x 3712 x 3712 as twenty-four windows on one GPU (property checks + stitch, like F)
+  F3 at its stated size: 288 x 5424 x 5424, three channels sharing one Flow, twenty-four windows per channel
 """
 import os
 import sys
@@ -71,7 +72,7 @@ def test_config_S_whole_pipeline_matches_the_oracle():
     composed pipelines cannot agree to 1e-4 everywhere, by the algorithm itself: cv2's remap quantises sampling
     coordinates to 1/32 px, so a 1e-5 difference in a vector that sits on a bin edge moves the warped grey value by a
     finite step (up to gradient / 32) and the refined vector by ~1e-2 -- that happens at a handful of pixels and is
-    asserted as such (99.9 % of the vectors within 1e-4).
+    asserted as such (maximum <= 0.05 px, and at most 2e-5 of the components beyond 1e-4).
     Everything downstream is integer / bit-exact work and is compared bit for bit on the GPU's own flows."""
     import tobac_flow_amd.flow as tf
     from oracle import np_label, np_ops, ws_oracle
@@ -86,8 +87,13 @@ def test_config_S_whole_pipeline_matches_the_oracle():
         assert got.shape == (16, 512, 512, 2) and got.dtype == np.float32
         assert np.array_equal(np.isnan(got), np.isnan(want))
         d = np.abs(np.nan_to_num(got) - np.nan_to_num(want))
-        print("config S composed flow vs oracle: 99.9th percentile %.3g, max %.3g" % (np.percentile(d, 99.9), d.max()))
-        assert d.max() <= 1e-4, (np.percentile(d, 99.9), d.max())
+        n_off = int((d > 1e-4).sum())
+        print("config S composed flow vs oracle: 99.9th percentile %.3g, max %.3g, %d of %d components beyond 1e-4"
+              % (np.percentile(d, 99.9), d.max(), n_off, d.size))
+        # a MAX and a COUNT: the raw vectors differ by ~1e-7 (asserted below at <= 1e-4, and bit-exact stages on top of
+        # them), so a sampling coordinate crosses one of remap's 1/32-px bins at a few dozen of the 8 million vectors;
+        # there the refined vector moves by up to (grey-value step) / (local gradient), a few hundredths of a pixel
+        assert d.max() <= 0.05 and n_off <= 2e-5 * d.size, (np.percentile(d, 99.9), d.max(), n_off)
     raw_f, raw_b = tf.calculate_flow(bt, "Farneback")           # no refinement, no smoothing
     want_rf, want_rb = _oracle_flow(bt, 0, 0, "linear", max_value=np.inf)
     assert np.abs(raw_f - want_rf).max() <= 1e-4 and np.abs(raw_b - want_rb).max() <= 1e-4
@@ -223,17 +229,67 @@ def test_config_F_procedure_on_a_stack_the_oracle_can_afford():
     _check_stitched(stitch_window_list(labs, overlap=overlap), overlap)
 
 
+def _stack_detection_full_size(T, H, W, n_windows, overlap, offsets=(0.0,), seed=20240601):
+    """A BASELINE configuration at its stated size on ONE GPU, the way bench.py runs it: the flow of the T - 1 frame pairs
+    once for the stack (create_flow in library-sized batches), then per channel and per window Flow.window -> SURVEY 8(d)
+    seeds (component-labelled on the device) -> combined edge field -> watershed, and the stitch of the label ids over
+    all windows of the channel.  The channels (F3: offsets 0 / -2 / -4 K) share the ONE Flow and are processed one after
+    the other, so that only one channel's label volumes are resident.  Checked: _check_stitched per channel."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.parallel import stitch_window_list, window_bounds
+    from tools.synth import anvil_seeds, blob_stack
+    bounds = window_bounds(T, n_windows, overlap)
+    assert len(bounds) == n_windows and bounds[0][0] == 0 and bounds[-1][1] == T
+    bt = torch.empty((T, H, W), dtype=torch.float32, device="cuda")
+    for f0 in range(0, T, 12):
+        f1 = min(f0 + 12, T)
+        bt[f0:f1] = blob_stack(f1 - f0, H, W, seed=seed, t0=f0)
+    flow_all = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    _lib.release_workspaces()                                          # the flow scratch (tens of GB) is not needed any more
+    assert flow_all.shape == (T, H, W)
+    n_objects = []
+    for off in offsets:
+        labs = []
+        for a, b in bounds:
+            fl = flow_all.window(a, b)
+            lin, seeds = anvil_seeds(bt[a:b] + off if off else bt[a:b])
+            e = get_combined_edge_field(fl, lin, dtype=np.float32)   # detection.py:620-642 (NaN -> +inf)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                labs.append(fl.watershed(e, seeds, connectivity=1))
+            del fl, lin, seeds, e
+        out = stitch_window_list(labs, overlap=overlap)
+        del labs
+        _check_stitched(out, overlap)
+        n_objects.append(max(int(w.max()) for w in out))
+        del out
+    return n_objects
+
+
 def test_config_F_144_full_disk_frames_as_twelve_windows():
     """Config F itself on ONE GPU: 144 frames of 5424 x 5424 cut from one sequence, twelve overlapping windows through
     the whole hot path, label ids stitched over all of them (stitch_window_list: tf_window_overlap_pairs + union-find +
-    tf_apply_lut).  ~12 x 14 x 29.4 M voxels of labels stay resident (20 GB)."""
-    from tobac_flow_amd.parallel import stitch_window_list, window_bounds
-    from tools.synth import blob_stack
-    T, H, W, overlap = 144, 5424, 5424, 4
-    bounds = window_bounds(T, 12, overlap)
-    assert len(bounds) == 12 and bounds[0][0] == 0 and bounds[-1][1] == T
-    labs = _windowed_detection(lambda a, b: blob_stack(b - a, H, W, seed=20240601, t0=a), T, 12, overlap, oracle=False)
-    _check_stitched(stitch_window_list(labs, overlap=overlap), overlap)
+    tf_apply_lut).  ~12 x 16 x 29.4 M voxels of labels stay resident (22 GB), the stack's flow 68 GB."""
+    n = _stack_detection_full_size(144, 5424, 5424, 12, 4)
+    assert n[0] > 100
+
+
+def test_config_V_288_frames_as_24_windows():
+    """Config V at its stated size on ONE GPU: SEVIRI full-disk, 288 frames of 3712 x 3712 as twenty-four windows
+    (BASELINE.json shards them over 8 GPUs; the windows are the same, here one GPU visits them in turn)."""
+    n = _stack_detection_full_size(288, 3712, 3712, 24, 4)
+    assert n[0] > 100
+
+
+def test_config_F3_288_frames_three_channels():
+    """Config F3 at its stated size on ONE GPU: 288 full-disk frames, three channel stacks (offsets 0 / -2 / -4 K,
+    SURVEY.md 8d) as three independent detections sharing ONE Flow (136 GB of flow vectors resident), twenty-four
+    windows each.  A colder channel (more negative offset) has more seeded area, so its object count differs."""
+    n = _stack_detection_full_size(288, 5424, 5424, 24, 4, offsets=(0.0, -2.0, -4.0))
+    assert len(n) == 3 and all(v > 100 for v in n) and len(set(n)) > 1
 
 
 # ---- F3 -------------------------------------------------------------------------------------------------------------

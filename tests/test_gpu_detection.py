@@ -144,12 +144,13 @@ def test_get_combined_filters_runs_and_matches_any_reduction(scene):
 
 
 # ----------------------------------------------------------------------------- section 8f-2: ndimage glue on the GPU
+@pytest.mark.parametrize("width", [45, 48, 4, 260])          # 45: byte-per-thread kernel; multiples of 4: the word kernel (k_binary_morph4)
 @pytest.mark.parametrize("iterations,border", [(1, 0), (1, 1), (3, 0), (2, 1)])
-def test_binary_morphology_matches_scipy(iterations, border):
+def test_binary_morphology_matches_scipy(iterations, border, width):
     import torch
     from tobac_flow_amd import ndimage_dev as nd
     rng = np.random.default_rng(iterations * 10 + border)
-    x = ndi.gaussian_filter(rng.normal(size=(5, 37, 45)), (0.5, 1.5, 1.5)) > 0.0
+    x = ndi.gaussian_filter(rng.normal(size=(5, 37, width)), (0.5, 1.5, 1.5)) > 0.0
     cross = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
     skew = np.zeros((3, 3, 3), bool)
     skew[0, 0, 1] = skew[1, 1, 1] = skew[1, 1, 2] = skew[2, 2, 0] = True            # asymmetric: checks the reflection rule

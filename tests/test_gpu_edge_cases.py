@@ -182,7 +182,7 @@ def test_watershed_custom_structure_and_inf_field(tf):
 
 
 def test_watershed_ex_rejects_unknown_flags_and_chain_depth_one_ignores_the_hint(tf):
-    """C ABI: flags other than TF_WS_SKIP_FAST_PATH are TF_EINVAL; with chain_depth 1 there are no chain phases to
+    """C ABI: flags other than TF_WS_SKIP_FAST_PATH / TF_WS_REFERENCE_ORDER are TF_EINVAL; with chain_depth 1 there are no chain phases to
     skip to, so the hint is ignored and the root phase runs."""
     import torch
     from tobac_flow_amd import _lib
@@ -200,9 +200,10 @@ def test_watershed_ex_rejects_unknown_flags_and_chain_depth_one_ignores_the_hint
     st = np.zeros(8, np.int64)
     args = lambda flags: (_lib.ptr(f), _lib.ptr(m), None, _lib.ptr(fl), _lib.ptr(fl), T, H, W, nbr.ctypes.data_as(_lib._P),
                           len(nbr), 3, flags, _lib.ptr(out), _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), None)
-    assert L.tf_watershed_ex(*args(2)) == -1 and b"unknown flag" in L.tf_last_error()
+    assert L.tf_watershed_ex(*args(4)) == -1 and b"unknown flag" in L.tf_last_error()
     assert L.tf_watershed_ex(*args(0)) == 0
     probe = out.cpu().numpy().copy()
+    assert L.tf_watershed_ex(*args(2)) == 0 and np.array_equal(out.cpu().numpy(), probe)      # TF_WS_REFERENCE_ORDER: nothing to reorder here
     assert L.tf_watershed_ex(*args(1)) == 0 and st[5] == -1 and st[1] == 0
     assert np.array_equal(out.cpu().numpy(), probe)
     st1 = {}

@@ -33,6 +33,57 @@ k_binary_morph(const uint8_t *__restrict__ in, int64_t T, int H, int W, MorphTap
     out[t * plane + (int64_t)y * W + x] = r ? 1 : 0;
 }
 
+// Four pixels per thread (one 32-bit word of the uint8 volume; W % 4 == 0).  The taps are grouped by (dt, dy) row: a row
+// contributes its centre word and, for dx = -1 / +1, the word shifted by one byte with the neighbour word's edge byte
+// (or the border value at the volume's edge) -- three word loads per row instead of up to twelve byte loads.
+// Bytes are normalised to 0 / 1 first, so erosion = bitwise AND and dilation = bitwise OR over the taps.
+struct MorphRows { int n; int8_t dt[9], dy[9]; uint8_t dxmask[9]; };   // dxmask bit 0: dx = -1, bit 1: dx = 0, bit 2: dx = +1
+
+__device__ __forceinline__ uint32_t morph_norm(uint32_t w) {
+    w |= w >> 4; w |= w >> 2; w |= w >> 1;
+    return w & 0x01010101u;
+}
+
+__global__ void __launch_bounds__(256)
+k_binary_morph4(const uint32_t *__restrict__ in, int64_t T, int H, int W4, MorphRows rw, int op, int border,
+                uint32_t *__restrict__ out)
+{
+    const int x4 = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x4 >= W4 || y >= H) return;
+    const int64_t plane4 = (int64_t)H * W4;
+    const uint32_t bw = border ? 0x01010101u : 0u, bb = border ? 1u : 0u;
+    uint32_t r = op == 0 ? 0x01010101u : 0u;
+    const int s = op == 0 ? 1 : -1;                   // SciPy reflects the structure for the dilation
+    for (int i = 0; i < rw.n; i++) {
+        const int64_t tt = t + s * rw.dt[i];
+        const int yy = y + s * rw.dy[i];
+        uint32_t c = bw, l = bb, rt = bb;             // centre word; byte left of it; byte right of it
+        if (tt >= 0 && tt < T && yy >= 0 && yy < H) {
+            const uint32_t *row = in + tt * plane4 + (int64_t)yy * W4;
+            c = morph_norm(row[x4]);
+            if (rw.dxmask[i] & 5) {
+                if (x4 > 0) l = morph_norm(row[x4 - 1]) >> 24;
+                if (x4 + 1 < W4) rt = morph_norm(row[x4 + 1]) & 1u;
+            }
+        }
+        const uint32_t m = rw.dxmask[i];
+        // pixel p of the word sees in[x + s * dx]: dx = -1 (bit 0) is the left neighbour for the erosion, the right one for the dilation
+        const uint32_t left = (c << 8) | l, right = (c >> 8) | (rt << 24);
+        const uint32_t lo = s == 1 ? left : right, hi = s == 1 ? right : left;
+        if (op == 0) {
+            if (m & 1) r &= lo;
+            if (m & 2) r &= c;
+            if (m & 4) r &= hi;
+        } else {
+            if (m & 1) r |= lo;
+            if (m & 2) r |= c;
+            if (m & 4) r |= hi;
+        }
+    }
+    out[t * plane4 + (int64_t)y * W4 + x4] = r;
+}
+
 extern "C" int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
                                int op, int iterations, int border_value, uint8_t *out, uint8_t *tmp, void *stream)
 {
@@ -48,12 +99,22 @@ extern "C" int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t 
     TF_REQUIRE(tp.n > 0, "tf_binary_morph: empty structure");
     hipStream_t s = (hipStream_t)stream;
     dim3 block(64, 4), grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
+    MorphRows rw; rw.n = 0;
+    for (int p = 0; p < 3; p++) for (int r = 0; r < 3; r++) {
+        uint8_t m = 0;
+        for (int c = 0; c < 3; c++) if (structure_host[p * 9 + r * 3 + c]) m |= (uint8_t)(1 << c);
+        if (m) { rw.dt[rw.n] = (int8_t)(p - 1); rw.dy[rw.n] = (int8_t)(r - 1); rw.dxmask[rw.n] = m; rw.n++; }
+    }
+    // word form: rows of whole words, every buffer 4-byte aligned
+    const bool words = W % 4 == 0 && ((uintptr_t)in % 4 == 0) && ((uintptr_t)out % 4 == 0) && (!tmp || (uintptr_t)tmp % 4 == 0);
+    const dim3 grid4((unsigned)((W / 4 + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
     const uint8_t *src = in;
     for (int it = 0; it < iterations; it++) {
         // ping-pong so that the last iteration writes `out`
         uint8_t *dst = ((iterations - 1 - it) % 2 == 0) ? out : tmp;
         TfProfScope ps(TFK_CONVOLVE, 2.0 * (double)T * H * W, s);
-        hipLaunchKernelGGL(k_binary_morph, grid, block, 0, s, src, T, (int)H, (int)W, tp, op, border_value, dst);
+        if (words) hipLaunchKernelGGL(k_binary_morph4, grid4, block, 0, s, (const uint32_t *)src, T, (int)H, (int)(W / 4), rw, op, border_value, (uint32_t *)dst);
+        else hipLaunchKernelGGL(k_binary_morph, grid, block, 0, s, src, T, (int)H, (int)W, tp, op, border_value, dst);
         src = dst;
     }
     TF_CHECK_LAUNCH();
