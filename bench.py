@@ -31,7 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); the device-to-device copy timed in this run (roofline.practical_peak, ~5.0 TB/s read + written) is the practical ceiling
 
 
 # library profile name -> kernel symbol prefix in the rocprofv3 counter files

@@ -10,6 +10,9 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
+        if os.environ.get("ORACLE_LIB"):               # another build of the same sources (the sanitizer job: make -C oracle asan-test)
+            _LIB = ctypes.CDLL(os.environ["ORACLE_LIB"])
+            return _LIB
         so = os.path.join(_HERE, "_build", "liboracle.so")
         srcs = [os.path.join(_HERE, "c", f) for f in os.listdir(os.path.join(_HERE, "c"))]
         if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

@@ -356,3 +356,50 @@ def test_shutdown_releases_the_timing_pool_and_leaves_the_library_usable(tf):
     got = vr.calc(a, b, flow0.copy())
     assert np.array_equal(got, want)
     assert _lib.profile_collect() == {}               # timing is off after shutdown, nothing left over
+
+
+def test_two_host_threads_on_two_streams_do_not_disturb_each_other():
+    """Re-entrancy: two host threads, each with its own HIP stream, drive the library
+    at the same time on DIFFERENT inputs of the SAME shape -- the case in which process-global scratch buffers or memos
+    keyed by shape alone would be shared.  Workspaces and the watershed's scheduling memos are per stream: every result
+    equals the one the same call gives alone."""
+    import threading
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    from tools.synth import anvil_seeds, blob_stack
+    stacks = [blob_stack(5, 200, 260, seed=s) for s in (1, 2)]
+
+    def run(bt):
+        fl = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+        lin, seeds = anvil_seeds(bt)
+        e = get_combined_edge_field(fl, lin, dtype=np.float32)
+        fw, bw = fl._dev_flows()
+        lab = watershed_dev(fw, bw, e, seeds, None, neighbour_offsets(1), on_ambiguous="ignore")
+        return fw.clone(), e.clone(), lab.clone()
+
+    alone = [run(bt) for bt in stacks]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(4):
+                    results[k] = run(stacks[k])
+                stream.synchronize()
+        except Exception as exc:                                 # noqa: BLE001 -- reported below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for k in range(2):
+        for got, want in zip(results[k], alone[k]):
+            assert torch.equal(torch.nan_to_num(got.float(), nan=-7.0), torch.nan_to_num(want.float(), nan=-7.0)), k

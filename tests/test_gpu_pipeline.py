@@ -98,3 +98,24 @@ def test_flow_window_equals_create_flow_on_the_slice():
     assert isinstance(got.forward_flow, np.ndarray)
     assert np.array_equal(got.forward_flow, want.forward_flow, equal_nan=True) and np.array_equal(got.backward_flow, want.backward_flow, equal_nan=True)
     assert not np.shares_memory(got.forward_flow, whole_np.forward_flow)         # a window never aliases the stack it was cut from
+
+
+def test_flow_batches_and_stream_overlap_do_not_change_the_flow(monkeypatch):
+    """The flow of a stack does not depend on how its pairs are batched, nor on whether the refinement / smoothing of a
+    batch runs on the second stream while the next batch's Farneback is under way (flow.py: _calculate_flow_impl)."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tools.synth import blob_stack
+    bt = blob_stack(8, 180, 236, seed=9)
+    kw = dict(model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    monkeypatch.setenv("TF_FLOW_OVERLAP", "0")
+    monkeypatch.setenv("TF_FLOW_BATCH", "64")
+    want = tf.create_flow(bt, **kw)                                    # one batch, one stream
+    for batch, overlap in (("2", "1"), ("3", "1"), ("2", "0"), ("1", "1")):
+        monkeypatch.setenv("TF_FLOW_BATCH", batch)
+        monkeypatch.setenv("TF_FLOW_OVERLAP", overlap)
+        for _ in range(2):                                             # twice: the second run reuses the side stream and its buffers
+            got = tf.create_flow(bt, **kw)
+            torch.cuda.synchronize()
+            for g, w in ((got.forward_flow, want.forward_flow), (got.backward_flow, want.backward_flow)):
+                assert torch.equal(torch.nan_to_num(g, nan=-777.0), torch.nan_to_num(w, nan=-777.0)), (batch, overlap)

@@ -199,22 +199,29 @@ def empty(shape, dtype):
 
 
 _WS = {}
+_WS_LOCK = __import__("threading").Lock()
 
 
 def workspace(nbytes, tag="default"):
-    """Grow-only scratch buffer per tag (uint8 tensor)."""
+    """Grow-only scratch buffer (uint8 tensor) per (tag, device, STREAM): two host threads that drive the library on two
+    streams never share scratch memory (the library uses the buffer on the stream it is handed, so one buffer per stream
+    is exactly what keeps concurrent calls apart; calls on one stream are ordered by the stream)."""
     t = torch()
-    cur = _WS.get(tag)
-    if cur is None or cur.numel() < nbytes or cur.device != device():
-        _WS[tag] = None
-        cur = None                               # drop the old buffer BEFORE the new one is allocated (they can be > 100 GB)
-        cur = t.empty(int(nbytes), dtype=t.uint8, device=device())
-        _WS[tag] = cur
+    dev = device()
+    key = (tag, dev.index, t.cuda.current_stream().cuda_stream)
+    with _WS_LOCK:
+        cur = _WS.get(key)
+        if cur is None or cur.numel() < nbytes:
+            _WS[key] = None
+            cur = None                           # drop the old buffer BEFORE the new one is allocated (they can be > 100 GB)
+            cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
+            _WS[key] = cur
     return cur
 
 
 def release_workspaces():
-    _WS.clear()
+    with _WS_LOCK:
+        _WS.clear()
 
 
 def profile_enable(on=True):

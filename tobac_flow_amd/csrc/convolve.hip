@@ -24,8 +24,9 @@ __constant__ float c_tf_lanczos[32][8];
 // interpolateLanczos4 (imgwarp.cpp) at the 32 fractional positions of the remap table, uploaded on first use
 static int ensure_lanczos_table()
 {
-    static bool done = false;
-    if (done) return TF_OK;
+    static TfDeviceOnce once;                      // __constant__ memory is per device
+    TfDeviceOnce::Guard guard(once);
+    if (!guard.first) return TF_OK;
     static const double s45 = 0.70710678118654752440084436210485;
     static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
     float tab[32][8];
@@ -44,7 +45,7 @@ static int ensure_lanczos_table()
         for (int i = 0; i < 8; i++) c[i] *= sum;
     }
     TF_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tf_lanczos), tab, sizeof(tab)));
-    done = true;
+    guard.done();
     return TF_OK;
 }
 

@@ -47,6 +47,25 @@ struct TfArena {
     bool ok() const { return used <= size; }
 };
 
+// ---- once-per-DEVICE initialisation (constant tables, function attributes are per-device state) --------------------
+// tf_first_use_on_device(slot): true exactly once per (slot, current device), under a mutex: the caller performs its
+// initialisation inside `if (guard.first) { ... guard.done(); }` while the lock is held, so a second thread or a second
+// device never sees a half-initialised table (a process-global `static bool done` left the second device
+// with an all-zero Lanczos table).
+#include <mutex>
+#define TF_MAX_DEVICES 64
+struct TfDeviceOnce {
+    std::mutex mu; bool done_[TF_MAX_DEVICES] = {};
+    struct Guard {
+        TfDeviceOnce &o; std::unique_lock<std::mutex> lk; int dev; bool first;
+        explicit Guard(TfDeviceOnce &o_) : o(o_), lk(o_.mu), dev(0), first(false) {
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TF_MAX_DEVICES) dev = 0;
+            first = !o.done_[dev];
+        }
+        void done() { o.done_[dev] = true; }
+    };
+};
+
 // ---- device helpers ------------------------------------------------------------------------
 // cvRound(float): round half to even (the host reference uses cvtss2si under the default MXCSR)
 __device__ __forceinline__ int tf_cvround(float v) { return __float2int_rn(v); }

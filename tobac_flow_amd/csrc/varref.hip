@@ -500,10 +500,11 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
     static const bool force_sweeps = getenv("TF_VR_SOR_SWEEPS") != nullptr;
     const bool tiled = !force_sweeps && 2 * params->sor_iterations <= VRT_HALO;
     if (tiled) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static TfDeviceOnce once;                  // function attributes are per device
+        TfDeviceOnce::Guard guard(once);
+        if (guard.first) {
             TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile, hipFuncAttributeMaxDynamicSharedMemorySize, VRT_LDS_BYTES));
-            attr_set = true;
+            guard.done();
         }
     }
     const bool tile_path = tiled && params->sor_iterations > 0;

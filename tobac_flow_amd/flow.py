@@ -234,6 +234,18 @@ def _pair_flows_dev(prev8, next8, of_model, vr_steps, smoothing_steps, interp_me
     return fwd, bwd
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(main):
+    """one extra stream per (device, calling stream), created on first use"""
+    t = _lib.torch()
+    key = (main.device.index, main.cuda_stream)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = t.cuda.Stream(device=main.device)
+    return _SIDE_STREAMS[key]
+
+
 def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_passes, interp_method,
                          norm_name, norm_method, normalisation_kwargs, on_device, max_value=float("inf")):
     t = _lib.torch()
@@ -263,6 +275,15 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         chunk = 16
     n_batches = max(1, -(-n_pairs // chunk))
     starts = [round(k * n_pairs / n_batches) for k in range(n_batches + 1)]
+    # TF_FLOW_OVERLAP=1: a second stream for the per-pair stages after the Farneback batch.  Off by default: measured on
+    # config F (144 x 5424^2) it gains 1.5 % (5033 vs 5110 ms per step) -- every kernel involved fills the GPU by itself
+    # -- and the HIP-event kernel timing of bench.py cannot attribute time to kernels that run side by side.
+    main = t.cuda.current_stream()
+    side = None
+    if n_batches > 1 and (vr_steps > 0 or smoothing_passes > 0) and os.environ.get("TF_FLOW_OVERLAP", "0") == "1":
+        side = _side_stream(main)
+        forward.record_stream(side)
+        backward.record_stream(side)
     for i0, i1 in zip(starts[:-1], starts[1:]):
         B = i1 - i0
         if B <= 0:
@@ -279,20 +300,20 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                 prev8[b].copy_(_lib.to_dev(p8[0]))
                 next8[b].copy_(_lib.to_dev(p8[1]))
         if smoothing_passes == 0:
-            of_model.calc_batch_dev(prev8, next8, forward[i0:i0 + B], backward[i0 + 1:i0 + 1 + B])
-            if vr_steps > 0:                     # flow.py:513-519
-                for b in range(B):
-                    vr_model.calc_dev(prev8[b], next8[b], forward[i0 + b])
-                    vr_model.calc_dev(next8[b], prev8[b], backward[i0 + 1 + b])
+            f, bk = forward[i0:i0 + B], backward[i0 + 1:i0 + 1 + B]
         else:
             f = _lib.empty((B, H, W, 2), t.float32)
             bk = _lib.empty((B, H, W, 2), t.float32)
-            of_model.calc_batch_dev(prev8, next8, f, bk)
+        of_model.calc_batch_dev(prev8, next8, f, bk)
+        if vr_steps == 0 and smoothing_passes == 0:
+            continue
+
+        def refine_and_smooth(i0=i0, B=B, prev8=prev8, next8=next8, f=f, bk=bk):
             if vr_steps > 0:                     # flow.py:513-519, before the smoothing (flow.py:521-525)
                 for b in range(B):
                     vr_model.calc_dev(prev8[b], next8[b], f[b])
                     vr_model.calc_dev(next8[b], prev8[b], bk[b])
-            for b in range(B):
+            for b in range(B if smoothing_passes > 0 else 0):
                 fi, bi = f[b], bk[b]
                 for k in range(smoothing_passes):
                     last = k == smoothing_passes - 1
@@ -301,6 +322,21 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                     _lib.check(L.tf_smooth_flow_step(_lib.ptr(fi), _lib.ptr(bi), H, W, interp, _lib.ptr(fo), _lib.ptr(bo),
                                                      _lib.stream_ptr()), "tf_smooth_flow_step")
                     fi, bi = fo, bo
+
+        if side is None:
+            refine_and_smooth()
+        else:
+            # The refinement / smoothing of this batch runs on a second stream while the main stream goes on with the
+            # NEXT batch's pyramids and iterations: the iteration kernel leaves CUs idle (coarse levels, the last round of
+            # a launch), the refinement kernels fill them.  Same kernels on the same data -- the results do not change.
+            ready = main.record_event()
+            for x in (prev8, next8, f, bk):
+                x.record_stream(side)            # allocated on `main`, last used on `side`
+            with t.cuda.stream(side):
+                side.wait_event(ready)
+                refine_and_smooth()
+    if side is not None:
+        main.wait_stream(side)
     # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping
     _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
                "tf_flow_finalize")

@@ -75,8 +75,11 @@ def neighbour_offsets(connectivity, ndim=3):
 # the chain phases when it finds a label conflict.  Fields with exact plateaus (detect_anvils) conflict
 # every time, so for a volume shape whose last probe conflicted the speculative phase is skipped
 # (TF_WS_SKIP_FAST_PATH); every _REPROBE-th call probes again so that a change of data is noticed.
-_relevant_memo = {}      # (T, H, W, neighbours, depth) -> relevant pixels of the last successful call
+# Both memos are keyed by shape AND by the calling stream, and guarded by a lock: interleaved callers (two host threads,
+# two streams) each see the history of their own sequence of windows (process-global state keyed by shape).
+_relevant_memo = {}      # (T, H, W, neighbours, depth, stream) -> relevant pixels of the last successful call
 _conflict_memo = {}
+_MEMO_LOCK = __import__("threading").Lock()
 _REPROBE = 8
 TF_WS_SKIP_FAST_PATH, TF_WS_REFERENCE_ORDER = 1, 2
 
@@ -108,16 +111,18 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
     # the flood keys are compact over the relevant pixels: size the workspace from a cheap count of
     # the floodable pixels and retry once with the exact number if boundary markers exceed the slack
     st = np.zeros(16, np.int64)
-    key = (T, H, W, len(nbr), chain_depth)
+    key = (T, H, W, len(nbr), chain_depth, t.cuda.current_stream().cuda_stream)
     # ... unless the previous call of this shape has reported its exact count (stats[6]): consecutive windows of one
     # sequence differ little, the library checks the size anyway, and counting costs three passes and a host sync
-    if key in _relevant_memo:
-        guess = min(T * H * W, int(_relevant_memo[key] * 1.25) + 4096)
+    with _MEMO_LOCK:
+        known = _relevant_memo.get(key)
+        memo = list(_conflict_memo.get(key, (False, 0)))      # [last probe conflicted, calls since that probe]
+    if known is not None:
+        guess = min(T * H * W, int(known * 1.25) + 4096)
     else:
         floodable = (markers == 0) if mask is None else ((markers == 0) & (mask != 0))
         guess = min(T * H * W, int(floodable.sum().item() * 1.5) + 4096)
         del floodable
-    memo = _conflict_memo.setdefault(key, [False, 0])          # [last probe conflicted, calls since that probe]
     skip = expect_conflict if expect_conflict is not None else (memo[0] and memo[1] < _REPROBE)
     flags = TF_WS_SKIP_FAST_PATH if (skip and chain_depth > 1) else 0
     if on_ambiguous == "reference":
@@ -144,12 +149,14 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
         break
     if rc not in (TF_WS_AMBIGUOUS, TF_EDEPTH):
         _lib.check(rc, "tf_watershed")
-    if rc in (0, TF_WS_AMBIGUOUS, TF_EDEPTH):
-        _relevant_memo[key] = int(st[6])
     if probed is not None and probed >= 0:
         memo[0], memo[1] = bool(probed), 0                     # this call probed
     else:
         memo[1] += 1
+    with _MEMO_LOCK:
+        if rc in (0, TF_WS_AMBIGUOUS, TF_EDEPTH):
+            _relevant_memo[key] = int(st[6])
+        _conflict_memo[key] = memo
     if stats is not None:
         stats["sweeps"] = st[:8].tolist()
         stats["chain_depth"] = int(st[8])
