@@ -125,6 +125,15 @@ void tf_varref_default_params(tf_varref_params *p);
 size_t tf_varref_workspace_bytes(int64_t H, int64_t W);
 int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
               float *flow, void *ws, size_t ws_bytes, void *stream);
+/* tf_varref_ex = tf_varref + `flags`.
+ * TF_VR_FAST_DIVIDE (opt-in): the divisions and square roots of the system assembly and of the SOR updates use the
+ *   hardware reciprocal / reciprocal square root (1 ulp) and reciprocal-multiply (the SOR update divides by A11 / A22
+ *   ten times per fixed-point iteration: one reciprocal, ten products).  The result is no longer bit-identical to the
+ *   arithmetic of OpenCV's variational_refinement.cpp as restated in oracle/c/varref.c, but stays within the 1e-4 px the
+ *   flow is specified to (given the same input flow).  The default (flags = 0) evaluates every expression as written. */
+#define TF_VR_FAST_DIVIDE 1
+int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
+                 float *flow, int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- a6: forward/backward consistency smoothing ----------------------------------------------
  * replaces tobac_flow/flow.py:530-568 smooth_flow_step (4 x cv2.remap via

@@ -159,11 +159,18 @@ k_vr_selftest_divide(unsigned long long seed, int64_t count, unsigned long long 
 }
 
 // smoothness weight from the current flow at a pixel (c0), its right (cr) and its lower (cd) neighbour
+// FAST (TF_VR_FAST_DIVIDE, opt-in): hardware reciprocal square root / reciprocal (1 ulp) and reciprocal-multiply instead
+// of the correctly rounded `/` and sqrtf -- not bit-identical to OpenCV's arithmetic any more, within 1e-4 px of it
+// (tests/test_gpu_parity.py).  The default (FAST = false) evaluates every expression as written.
+template <bool FAST = false>
 __device__ __forceinline__ float vr_weight(float2 c0, float2 cr, float2 cd, const VrP &P)
 {
     const float ux = cr.x - c0.x, vx = cr.y - c0.y, uy = cd.x - c0.x, vy = cd.y - c0.y;
-    return P.alpha2 / sqrtf(ux * ux + vx * vx + uy * uy + vy * vy + P.eps2);
+    const float q = ux * ux + vx * vx + uy * uy + vy * vy + P.eps2;
+    return FAST ? P.alpha2 * __builtin_amdgcn_rsqf(q) : P.alpha2 / sqrtf(q);
 }
+template <bool FAST> __device__ __forceinline__ float vr_quot(float n, VrRcp k) { return FAST ? n * k.r : vr_div_shared(n, k); }
+template <bool FAST> __device__ __forceinline__ float vr_over_sqrt(float a, float q) { return FAST ? a * __builtin_amdgcn_rsqf(q) : a / sqrtf(q); }
 
 __device__ __forceinline__ float2 vr_add2(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
@@ -184,7 +191,7 @@ k_vr_weights(const float2 *__restrict__ Wf, const float2 *__restrict__ dW, int H
 // comes from the neighbouring lane (lane 0 computes it itself), the upper neighbour's from the wave above through LDS
 // (the first wave of the 64 x 4 block computes the row above itself): 1.27 weights per pixel instead of a pass of
 // 16 B read + 4 B written and a 4 B read here.
-template <bool WEIGHTS>
+template <bool WEIGHTS, bool FAST = false>
 __global__ void __launch_bounds__(256)
 k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const float2 *__restrict__ Wf,
             const float2 *__restrict__ dW, const float *wt_in, int H, int W, VrP P,
@@ -216,18 +223,18 @@ k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const 
     float wp, wl, wu;
     if (WEIGHTS) {
         const float2 cO = vr_add2(w0, d);
-        wp = vr_weight(cO, vr_add2(wr, dr), vr_add2(wd, dd), P);      // missing neighbour = the pixel itself
+        wp = vr_weight<FAST>(cO, vr_add2(wr, dr), vr_add2(wd, dd), P);      // missing neighbour = the pixel itself
         if (in) wt_out[j] = wp;
         s_w[wv][lane] = wp;
         wl = __shfl_up(wp, 1);
         if (lane == 0 && in && has_l) {
             // weight of (x - 1, y): its right neighbour is this pixel, its lower one (x - 1, y + 1) or itself
-            wl = vr_weight(vr_add2(wlf, dl), cO, vr_add2(wdl, ddl), P);
+            wl = vr_weight<FAST>(vr_add2(wlf, dl), cO, vr_add2(wdl, ddl), P);
         }
         float wu0 = 0.f;
         if (wv == 0 && in && has_u) {
             // weight of (x, y - 1): its lower neighbour is this pixel, its right one (x + 1, y - 1) or itself
-            wu0 = vr_weight(vr_add2(wuf, dup), vr_add2(wur, dur), cO, P);
+            wu0 = vr_weight<FAST>(vr_add2(wuf, dup), vr_add2(wur, dur), cO, P);
         }
         __syncthreads();
         wu = wv == 0 ? wu0 : s_w[wv > 0 ? wv - 1 : 0][lane];
@@ -243,23 +250,23 @@ k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const 
     float derivNorm = Ix * Ix + Iy * Iy + P.zeta2;
     const VrRcp k1 = vr_rcp_refined(derivNorm);
     const float Ik1z = Iz + Ix * du + Iy * dv;
-    float weight = P.delta2 / sqrtf(Ik1z * Ik1z / derivNorm + P.eps2);
-    float A11 = weight * vr_div_shared(Ix * Ix, k1) + P.zeta2;
-    float A12 = weight * vr_div_shared(Ix * Iy, k1);
-    float A22 = weight * vr_div_shared(Iy * Iy, k1) + P.zeta2;
-    float b1 = -weight * vr_div_shared(Iz * Ix, k1);
-    float b2 = -weight * vr_div_shared(Iz * Iy, k1);
+    float weight = vr_over_sqrt<FAST>(P.delta2, (FAST ? Ik1z * Ik1z * k1.r : Ik1z * Ik1z / derivNorm) + P.eps2);
+    float A11 = weight * vr_quot<FAST>(Ix * Ix, k1) + P.zeta2;
+    float A12 = weight * vr_quot<FAST>(Ix * Iy, k1);
+    float A22 = weight * vr_quot<FAST>(Iy * Iy, k1) + P.zeta2;
+    float b1 = -weight * vr_quot<FAST>(Iz * Ix, k1);
+    float b2 = -weight * vr_quot<FAST>(Iz * Iy, k1);
     derivNorm = Ixx * Ixx + Ixy * Ixy + P.zeta2;
     const float derivNorm2 = Iyy * Iyy + Ixy * Ixy + P.zeta2;
     const VrRcp k2 = vr_rcp_refined(derivNorm), k3 = vr_rcp_refined(derivNorm2);
     const float Ik1zx = Ixz + Ixx * du + Ixy * dv;
     const float Ik1zy = Iyz + Ixy * du + Iyy * dv;
-    weight = P.gamma2 / sqrtf(Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2 + P.eps2);
-    A11 += weight * (vr_div_shared(Ixx * Ixx, k2) + vr_div_shared(Ixy * Ixy, k3));
-    A12 += weight * (vr_div_shared(Ixx * Ixy, k2) + vr_div_shared(Ixy * Iyy, k3));
-    A22 += weight * (vr_div_shared(Ixy * Ixy, k2) + vr_div_shared(Iyy * Iyy, k3));
-    b1 += -weight * (vr_div_shared(Ixx * Ixz, k2) + vr_div_shared(Ixy * Iyz, k3));
-    b2 += -weight * (vr_div_shared(Ixy * Ixz, k2) + vr_div_shared(Iyy * Iyz, k3));
+    weight = vr_over_sqrt<FAST>(P.gamma2, (FAST ? Ik1zx * Ik1zx * k2.r + Ik1zy * Ik1zy * k3.r : Ik1zx * Ik1zx / derivNorm + Ik1zy * Ik1zy / derivNorm2) + P.eps2);
+    A11 += weight * (vr_quot<FAST>(Ixx * Ixx, k2) + vr_quot<FAST>(Ixy * Ixy, k3));
+    A12 += weight * (vr_quot<FAST>(Ixx * Ixy, k2) + vr_quot<FAST>(Ixy * Iyy, k3));
+    A22 += weight * (vr_quot<FAST>(Ixy * Ixy, k2) + vr_quot<FAST>(Iyy * Iyy, k3));
+    b1 += -weight * (vr_quot<FAST>(Ixx * Ixz, k2) + vr_quot<FAST>(Ixy * Iyz, k3));
+    b2 += -weight * (vr_quot<FAST>(Ixy * Ixz, k2) + vr_quot<FAST>(Iyy * Iyz, k3));
     // smoothness: each edge (p, right) / (p, down) carries the weight of its upper-left end
     // own edge terms as the horizontal / vertical passes form them at p, neighbour edge terms as they form them at the
     // left / upper neighbour
@@ -337,6 +344,7 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 #define VRT_LDS_BYTES (2 * VRT_RH * VRT_PW * 12)
 static_assert(VRT_PW == 64 && VRT_RH % VRT_WAVES == 0, "one wave per region row, whole rows per wave");
 
+template <bool FAST>
 __global__ void __launch_bounds__(VRT_THREADS, 2)
 k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
               int n_half, float omega, const float2 *__restrict__ dW_in, const float2 *Wadd, float2 *dW_out)
@@ -392,6 +400,7 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
             const float4 sv = S[p];
             const float av = A12[p], wv_ = wt[p];
             a11[k][ci] = in ? sv.x : 1.f; a22[k][ci] = in ? sv.y : 1.f; b1[k][ci] = in ? sv.z : 0.f; b2[k][ci] = in ? sv.w : 0.f;
+            if (FAST) { a11[k][ci] = __builtin_amdgcn_rcpf(a11[k][ci]); a22[k][ci] = __builtin_amdgcn_rcpf(a22[k][ci]); }   // divide once, multiply ten times
             a12[k][ci] = in ? av : 0.f;
             wp[k][ci] = in ? wv_ : 0.f;
         }
@@ -420,8 +429,13 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
                     float2 d = l_dw[own_[ci] + o];
                     const float sigmaU = wl * dl.x + w * dr.x + wu * du_.x + w * dd.x;
                     const float sigmaV = wl * dl.y + w * dr.y + wu * du_.y + w * dd.y;
-                    d.x += omega * ((sigmaU + b1[k][ci] - d.y * a12[k][ci]) / a11[k][ci] - d.x);
-                    d.y += omega * ((sigmaV + b2[k][ci] - d.x * a12[k][ci]) / a22[k][ci] - d.y);
+                    if (FAST) {
+                        d.x += omega * ((sigmaU + b1[k][ci] - d.y * a12[k][ci]) * a11[k][ci] - d.x);
+                        d.y += omega * ((sigmaV + b2[k][ci] - d.x * a12[k][ci]) * a22[k][ci] - d.y);
+                    } else {
+                        d.x += omega * ((sigmaU + b1[k][ci] - d.y * a12[k][ci]) / a11[k][ci] - d.x);
+                        d.y += omega * ((sigmaV + b2[k][ci] - d.x * a12[k][ci]) / a22[k][ci] - d.y);
+                    }
                     l_dw[own_[ci] + o] = d;
                 }
             }
@@ -467,9 +481,11 @@ extern "C" size_t tf_varref_workspace_bytes(int64_t H, int64_t W)
     return 3 * tf_align_up(n * 16, 256) + 2 * tf_align_up(n * 4, 256) + 2 * tf_align_up(n * 8, 256) + 4096;
 }
 
-extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
-                         float *flow, void *ws, size_t ws_bytes, void *stream)
+extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
+                            float *flow, int flags, void *ws, size_t ws_bytes, void *stream)
 {
+    TF_REQUIRE((flags & ~TF_VR_FAST_DIVIDE) == 0, "tf_varref_ex: unknown flag");
+    const bool fast = (flags & TF_VR_FAST_DIVIDE) != 0;
     TF_REQUIRE(I0 && I1 && flow && ws, "tf_varref: null pointer");
     TF_REQUIRE(H > 0 && W > 0 && H < 32768 && W < 32768, "tf_varref: bad shape");
     tf_varref_params dp;
@@ -503,7 +519,8 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
         static TfDeviceOnce once;                  // function attributes are per device
         TfDeviceOnce::Guard guard(once);
         if (guard.first) {
-            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile, hipFuncAttributeMaxDynamicSharedMemorySize, VRT_LDS_BYTES));
+            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, VRT_LDS_BYTES));
+            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, VRT_LDS_BYTES));
             guard.done();
         }
     }
@@ -515,14 +532,18 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
     for (int it = 0; it < params->fixed_point_iterations; it++) {
         {
             // algorithmic bytes: D1 + D2 32, W 8, dW 8 read; S 16, A12 4, weight 4 written (no dW in the first iteration)
-            static const bool weights_pass = getenv("TF_VR_WEIGHTS_PASS") != nullptr;       // development aid: separate pass
+            static const bool weights_pass_env = getenv("TF_VR_WEIGHTS_PASS") != nullptr;   // development aid: separate pass
+            const bool weights_pass = weights_pass_env && !fast;
             TfProfScope ps(TFK_VR_SYSTEM, (32.0 + 8.0 + (dW_cur ? 8.0 : 0.0) + 16.0 + 4.0 + 4.0) * (double)n, s);
             if (weights_pass) {
                 hipLaunchKernelGGL(k_vr_weights, g1, dim3(256), 0, s, Wf, dW_cur, iH, iW, P, wt);
-                hipLaunchKernelGGL(k_vr_system<false>, g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
+                hipLaunchKernelGGL((k_vr_system<false, false>), g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
                                    dW_cur, (const float *)wt, iH, iW, P, S, A12, (float *)nullptr);
-            } else
-                hipLaunchKernelGGL(k_vr_system<true>, g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
+            } else if (fast)
+                hipLaunchKernelGGL((k_vr_system<true, true>), g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
+                                   dW_cur, (const float *)nullptr, iH, iW, P, S, A12, wt);
+            else
+                hipLaunchKernelGGL((k_vr_system<true, false>), g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
                                    dW_cur, (const float *)nullptr, iH, iW, P, S, A12, wt);
         }
         TF_CHECK_LAUNCH();
@@ -532,9 +553,14 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
             const bool last = it == params->fixed_point_iterations - 1;
             TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + (dW_cur ? 8.0 : 0.0) + (last ? 8.0 : 0.0) + 8.0) * (double)n, s);
             float2 *dst = last ? (float2 *)flow : (dW_cur == dW ? dW2 : dW);
-            hipLaunchKernelGGL(k_vr_sor_tile, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
-                               VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
-                               2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);
+            if (fast)
+                hipLaunchKernelGGL(k_vr_sor_tile<true>, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
+                                   VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
+                                   2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);
+            else
+                hipLaunchKernelGGL(k_vr_sor_tile<false>, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
+                                   VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
+                                   2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);
             dW_cur = dst;
             flow_done = last;
         } else {
@@ -553,6 +579,12 @@ extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_
         TF_CHECK_LAUNCH();
     }
     return TF_OK;
+}
+
+extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
+                         float *flow, void *ws, size_t ws_bytes, void *stream)
+{
+    return tf_varref_ex(I0, I1, H, W, params, flow, 0, ws, ws_bytes, stream);
 }
 
 // development aid: number of operand pairs (out of `count`, drawn from the range vr_div_shared is used in) for which the

@@ -159,6 +159,9 @@ class VariationalRefinement:
         _lib.lib().tf_varref_default_params(ctypes.byref(p))
         self.fixedPointIterations, self.sorIterations = p.fixed_point_iterations, p.sor_iterations
         self.alpha, self.delta, self.gamma, self.omega = p.alpha, p.delta, p.gamma, p.omega
+        # not in OpenCV: True = hardware reciprocals instead of correctly rounded divisions / square roots
+        # (TF_VR_FAST_DIVIDE, include/tobac_flow_hip.h: within 1e-4 px of the default, ~25 % faster); default False
+        self.fastDivide = os.environ.get("TF_VR_FAST_DIVIDE", "0") == "1"
 
     @classmethod
     def create(cls):
@@ -176,8 +179,8 @@ class VariationalRefinement:
         assert flow.is_contiguous() and tuple(flow.shape) == (H, W, 2)
         ws = _lib.workspace(L.tf_varref_workspace_bytes(H, W), "varref")
         p = self._params()
-        _lib.check(L.tf_varref(_lib.ptr(i0), _lib.ptr(i1), H, W, ctypes.byref(p), _lib.ptr(flow), _lib.ptr(ws), ws.numel(),
-                               _lib.stream_ptr()), "tf_varref")
+        _lib.check(L.tf_varref_ex(_lib.ptr(i0), _lib.ptr(i1), H, W, ctypes.byref(p), _lib.ptr(flow), 1 if self.fastDivide else 0,
+                                  _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "tf_varref")
         return flow
 
     def calc(self, I0, I1, flow):
@@ -211,6 +214,11 @@ class _LazyVariationalRefinement:
         if _LazyVariationalRefinement._obj is None:
             _LazyVariationalRefinement._obj = VariationalRefinement()
         return getattr(_LazyVariationalRefinement._obj, name)
+
+    def __setattr__(self, name, value):                      # vr_model.fastDivide = True, vr_model.alpha = ... reach the object
+        if _LazyVariationalRefinement._obj is None:
+            _LazyVariationalRefinement._obj = VariationalRefinement()
+        setattr(_LazyVariationalRefinement._obj, name, value)
 
 
 vr_model = _LazyVariationalRefinement()
