@@ -54,6 +54,7 @@ struct WsC {               // compact arrays
     const u64 *pix; const unsigned *val; const int *nbr;
     u64 *K2, *M1, *C[WS_MAX_DEPTH], *Rt;
     int *Llo, *Lhi;        // smallest / largest label among the roots of all fully matching candidates (root phase)
+    const u64 *emask;      // per pixel p, bit i: out-edge i is a CANDIDATE edge (K2[p] == M1[nbr i]); bit 32 + i: nbr i is an entry
 };
 
 __device__ __forceinline__ unsigned ws_ordkey(float v) {
@@ -416,6 +417,37 @@ k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in,
     }
 }
 
+// After phase A the keys K2 and M1 are final, and with them which edges p -> n are candidate edges (K2[p] == M1[n]: p is
+// among the first in-neighbours of n to pop) and which pixels are entries (first pixel of a same-level run).  Every later
+// phase -- chain levels, root, the exactness check -- walks candidate edges only; they used to re-derive that per visit
+// from M1[n], K2[n] and val[n] of ALL neighbours (three scattered loads per edge, six edges per pixel at connectivity 1,
+// one or two of them candidates).  One pass stores the answer: 8 B per relevant pixel.
+__global__ void __launch_bounds__(256)
+k_ws_edge_masks(WsC c, u64 *__restrict__ emask)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= c.R) return;
+    const u64 kp = c.K2[p];
+    u64 m = 0ull;
+    if (kp != WS_INF) {
+        const int *np = c.nbr + p * c.n_nbr;
+        for (int i0 = 0; i0 < c.n_nbr; i0 += WS_NB) {
+            int n[WS_NB]; u64 m1[WS_NB], kn[WS_NB]; unsigned vn[WS_NB];
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) n[j] = i0 + j < c.n_nbr ? np[i0 + j] : -1;
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++) { const int q = n[j] >= 0 ? n[j] : 0; m1[j] = c.M1[q]; kn[j] = c.K2[q]; vn[j] = c.val[q]; }
+#pragma unroll
+            for (int j = 0; j < WS_NB; j++)
+                if (n[j] >= 0 && m1[j] == kp) {
+                    m |= 1ull << (i0 + j);
+                    if ((kn[j] >> 32) == (u64)vn[j] && (kn[j] & 0xFFFFFFFFull) == 1ull) m |= 1ull << (32 + i0 + j);
+                }
+        }
+    }
+    emask[p] = m;
+}
+
 // ---- phase k >= 1 (chain level k) and phase R (k == depth) ----------------------------------------
 // For edge p -> n with K2[p] == M1[n]:
 //   n is an ENTRY (first pixel of a same-level run, pushed from a lower level or by a level marker)
@@ -432,39 +464,38 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
 {
     const int *np = c.nbr + (int64_t)p * c.n_nbr;
     const bool root = k == depth;
-    u64 kp = WS_INF, own = WS_INF;
+    u64 kp = WS_INF, own = WS_INF, em = 0ull;
     int own_lo = 0x7fffffff, own_hi = (int)0x80000000;   // label set of p (root phase only)
     u64 cp[WS_MAX_DEPTH];                        // C_j[p], j < k: final since their own phases, read once per entry
-    bool act = false;
     for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
-        int n[WS_NB];
-#pragma unroll
-        for (int j = 0; j < WS_NB; j++) n[j] = (act0 && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
         if (s0 == 0 && act0) {
             // the in-queue flag is cleared BEFORE p's own keys are read (the loads take the exchange's
             // return value as an address term), so a later decrease re-queues p: no lost update
             const int dep = inq ? ws_after(atomicExch(&inq[p], 0)) : 0;
-            kp = c.K2[p];                        // final since phase A
+            em = c.emask[p];                     // final since phase A (0 for a pixel phase A never reached)
+            kp = c.K2[p];
             own = ws_load(&dst[p] + dep);
             if (root) { own_lo = ws_load_i(&c.Llo[p] + dep); own_hi = ws_load_i(&c.Lhi[p] + dep); }
             for (int j = 1; j < k; j++) cp[j] = c.C[j][p];
-            act = kp != WS_INF;
         }
-        u64 m1[WS_NB], kn[WS_NB], dn[WS_NB]; unsigned vn[WS_NB];
+        // candidate edges only: one or two of the six at connectivity 1
+        int n[WS_NB];
+#pragma unroll
+        for (int j = 0; j < WS_NB; j++) n[j] = (s0 + j < c.n_nbr && ((em >> (s0 + j)) & 1ull)) ? np[s0 + j] : -1;
+        u64 dn[WS_NB];
         int lon[WS_NB], hin[WS_NB];
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) {
-            const int q = n[j] >= 0 ? n[j] : 0;
-            m1[j] = c.M1[q]; kn[j] = c.K2[q]; vn[j] = c.val[q]; dn[j] = dst[q];
-            lon[j] = root ? c.Llo[q] : 0; hin[j] = root ? c.Lhi[q] : 0;
+            dn[j] = WS_INF; lon[j] = 0; hin[j] = 0;
+            if (n[j] >= 0) { dn[j] = dst[n[j]]; if (root) { lon[j] = c.Llo[n[j]]; hin[j] = c.Lhi[n[j]]; } }
         }
         u64 offered[WS_NB], old[WS_NB];
         int olo[WS_NB], ohi[WS_NB];              // raw atomic returns of the label-set relaxations
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) {
             offered[j] = WS_INF; old[j] = 0ull; olo[j] = (int)0x80000000; ohi[j] = 0x7fffffff;
-            if (act && n[j] >= 0 && m1[j] == kp) {
-                const bool entry = (kn[j] >> 32) == (u64)vn[j] && (kn[j] & 0xFFFFFFFFull) == 1ull;
+            if (n[j] >= 0) {
+                const bool entry = ((em >> (32 + s0 + j)) & 1ull) != 0ull;
                 bool match = true;
                 for (int l = 1; l < k && match; l++) {
                     const u64 offered_l = entry ? (l == 1 ? kp : cp[l - 1]) : cp[l];
@@ -549,11 +580,11 @@ k_ws_origins(WsC c, int depth, int *__restrict__ org)
     const int lo = c.Llo[p], hi = c.Lhi[p];
     u64 cp[WS_MAX_DEPTH];
     for (int j = 1; j < depth; j++) cp[j] = c.C[j][p];
+    const u64 em = c.emask[p];
     for (int i = 0; i < c.n_nbr; i++) {
+        if (!((em >> i) & 1ull)) continue;                   // candidate edges only
         const int n = c.nbr[p * c.n_nbr + i];
-        if (n < 0 || c.M1[n] != kp) continue;
-        const u64 kn = c.K2[n];
-        const bool entry = (kn >> 32) == (u64)c.val[n] && (kn & 0xFFFFFFFFull) == 1ull;
+        const bool entry = ((em >> (32 + i)) & 1ull) != 0ull;
         bool match = true;
         for (int l = 1; l < depth && match; l++) {
             const u64 offered_l = entry ? (l == 1 ? kp : cp[l - 1]) : cp[l];
@@ -689,7 +720,7 @@ static size_t ws_compact_bytes(int64_t R, int n_nbr, int depth) {
     return tf_align_up((size_t)R * 8, 256) + tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 4 * n_nbr, 256)
          + (size_t)(depth + 2) * tf_align_up((size_t)R * 8, 256)          // K2, M1, C_1..C_{d-1}, Rt
          + 2 * tf_align_up((size_t)R * 8 + 256, 256) + tf_align_up((size_t)R * 4, 256)           // two queues (2R ints), inq
-         + 4 * tf_align_up((size_t)R * 4, 256) + 4096;                                            // Llo, Lhi, org, rank
+         + 4 * tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 8, 256) + 4096;         // Llo, Lhi, org, rank; edge masks
 }
 
 extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int n_nbr, int chain_depth, int64_t max_relevant)
@@ -944,6 +975,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         c.Rt = ar.take<u64>(R);
         c.Llo = ar.take<int>(R); c.Lhi = ar.take<int>(R); org = ar.take<int>(R);
         int *rank_dev = ar.take<int>(R);
+        u64 *emask = ar.take<u64>(R);
+        c.emask = emask;
         WsQueues Q;
         Q.qcap = (int)(2 * R < 0x7fffff00ll ? 2 * R : 0x7fffff00ll);
         Q.q[0] = ar.take<int>(2 * R + 64); Q.q[1] = ar.take<int>(2 * R + 64); Q.inq = ar.take<int>(R);
@@ -975,6 +1008,11 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         const int64_t max_sweeps = rv ? 4096 + 2 * R : 4096 + 512 * (T + H + W);
         int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0]);
         if (rc) return rc;
+        {
+            TfProfScope ps(TFK_WS_SETUP, 0.0, s);
+            hipLaunchKernelGGL(k_ws_edge_masks, dim3(nbr_blocks), dim3(256), 0, s, c, emask);
+        }
+        TF_CHECK_LAUNCH();
         // Speculative start: a root phase on K2 alone (depth 1).  If its exactness check finds no origin at all the
         // labelling cannot depend on any tie-break and is final (tie-free fields).  The caller's hint skips it for
         // inputs known to contain exact plateaus: the labels are the same either way, only the work differs.
