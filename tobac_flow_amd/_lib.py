@@ -220,9 +220,14 @@ def workspace(nbytes, tag="default"):
     return cur
 
 
-def release_workspaces():
+def release_workspaces(tag=None):
+    """Hand the scratch buffers (all, or those of one tag) back to torch's caching allocator."""
     with _WS_LOCK:
-        _WS.clear()
+        if tag is None:
+            _WS.clear()
+        else:
+            for key in [k for k in _WS if k[0] == tag]:
+                del _WS[key]
 
 
 def profile_enable(on=True):

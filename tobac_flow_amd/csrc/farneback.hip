@@ -871,10 +871,7 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float 
 // the launch bound says so, which lets the compiler schedule for the 256-register budget (5 % faster than the
 // default bound).  Forcing three waves spills the ring (+70 %); row groups 4 + 4 + 4 + 1 with 51 KB of LDS cost
 // 2 % for the extra barrier pair and gain nothing while the registers hold the kernel at two waves.
-// Workgroup = one CHAIN = (pair, strip of FBI_OW columns, direction), all rows.  Block ids that differ by 8 are the two
-// directions of a strip: they read the same two R images (each is the other's gather target), walk down in step, and
-// are placed on the SAME XCD (observed round-robin dispatch; this is for L2 reuse only, never for correctness): within
-// a group of 8 * nd consecutive ids, id % 8 picks the strip and id / 8 the direction.
+// Workgroup = (pair, strip of FBI_OW columns), all rows, both directions (two waves each).
 //
 // Why whole columns.  OpenCV's vertical running sum, term for term (FarnebackUpdateFlow_Blur; oracle/c/farneback.c:263-281):
 //   vsum  = M[0] * (m + 2)  [float product]  + M[1] + ... + M[m-1]          (rows clamped to H - 1)
@@ -894,16 +891,19 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float 
 // So the remedy is not in the kernel but in the batch: the host layer sizes a launch to a whole number of rounds
 // (tf_farneback_batch_hint: 21 pairs = 1974 chains = 96 % of two rounds at 5424^2), which a stack of frames allows.
 template <int NB, int ABL>
-__global__ void __launch_bounds__(FBI_T, 2)
+__global__ void __launch_bounds__(2 * FBI_T, 2)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
 {
-    __shared__ double vrow[FBI_G * 5 * FBI_VS];
-    const int gx = ((a.nx + 7) / 8) * 8 * a.nd;
-    const int b = blockIdx.x / gx, gid = blockIdx.x - b * gx;
-    const int grp = gid / (8 * a.nd), rem = gid % (8 * a.nd);
-    const int q = rem / 8;
-    const int sx = grp * 8 + rem % 8;
-    if (sx >= a.nx) return;
+    // BOTH directions of a strip in ONE workgroup: waves 0 - 1 walk the column strip for direction dir[0], waves 2 - 3 for
+    // dir[1], in step (they share the barriers).  Each direction reads its own expansion row by row and gathers from the
+    // other's -- the very rows the other direction is reading: with the two in one workgroup every R row is fetched from
+    // HBM once instead of twice (as separate workgroups they drift apart, and an XCD's L2 turns over every few
+    // microseconds at this kernel's rate: measured traffic was that of NO sharing, 1.6 - 1.9 x the compulsory bytes).
+    // Occupancy is unchanged: 4 waves and 64 KB of LDS per workgroup, two workgroups per CU.
+    __shared__ double vrow_all[2][FBI_G * 5 * FBI_VS];
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x / FBI_T); // wave-uniform: 0 / 1 (one direction only: 128 threads, q = 0)
+    double *vrow = vrow_all[q];
+    const int b = blockIdx.x / a.nx, sx = blockIdx.x - b * a.nx;
     const int d = a.dir[q];                                            // 0: prev -> next, 1: next -> prev
     FbIterCtx c;
     const float *R0 = a.R[d] + b * a.bs_R, *R1 = a.R[1 - d] + b * a.bs_R;
@@ -921,7 +921,7 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
     }
     c.fin = (const char *)(a.fin[q] + b * a.bs_fin[q]); c.fout = (char *)(a.fout[q] + b * a.bs_fout[q]);
     c.H = H; c.W = W;
-    c.j = threadIdx.x;
+    c.j = threadIdx.x - q * FBI_T;
     c.dj = c.j + (c.j >> 2);
     c.tg = c.j / FBI_Q; c.tq = c.j - c.tg * FBI_Q;
     c.x_strip = sx * FBI_OW;
@@ -1101,16 +1101,17 @@ static int fb_levels(int64_t H, int64_t W, const tf_farneback_params *p) {
     return k;
 }
 
-static size_t fb_pair_floats(int64_t H, int64_t W) {
-    // per pair: tmp (n + 2H + 64), blur, I, R[2] (5n each), M (5n, unfused fallback only), 2 flow scratch (2n each)
+static size_t fb_pair_floats(int64_t H, int64_t W, bool fused) {
+    // per pair: tmp (n + 2H + 64), blur, I, R[2] (5n each), 2 flow scratch (2n each); the 5-plane matrix M (5n) only for the
+    // unfused fallback (window sizes other than 13): the fused iteration never stores it
     const size_t n = (size_t)H * W;
-    return tf_align_up(n + 2 * (size_t)H + 64, 64) + 2 * tf_align_up(n, 64) + 15 * tf_align_up(n, 64) + 2 * tf_align_up(2 * n, 64);
+    return tf_align_up(n + 2 * (size_t)H + 64, 64) + 2 * tf_align_up(n, 64) + (fused ? 10 : 15) * tf_align_up(n, 64) + 2 * tf_align_up(2 * n, 64);
 }
 
 extern "C" size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const tf_farneback_params *p)
 {
     if (B <= 0 || H <= 0 || W <= 0 || !p) return 0;
-    return (size_t)B * fb_pair_floats(H, W) * sizeof(float) + 8192;
+    return (size_t)B * fb_pair_floats(H, W, p->win_size == FBI_WIN) * sizeof(float) + 8192;
 }
 
 // Pairs per tf_farneback_batch call that fill the GPU best.  The iteration kernel runs one workgroup per (pair, strip,
@@ -1122,8 +1123,8 @@ extern "C" int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneb
     if (H <= 0 || W <= 0 || !p || max_pairs < 1) return 0;
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    const int64_t slots = 4ll * n_cu, per_pair = 2 * ((W + FBI_OW - 1) / FBI_OW);
-    const size_t per_pair_bytes = fb_pair_floats(H, W) * sizeof(float);
+    const int64_t slots = 2ll * n_cu, per_pair = (W + FBI_OW - 1) / FBI_OW;   // both directions in one 4-wave workgroup
+    const size_t per_pair_bytes = fb_pair_floats(H, W, p->win_size == FBI_WIN) * sizeof(float);
     int64_t cap = max_pairs;
     if (max_bytes > 0 && (int64_t)(max_bytes / per_pair_bytes) < cap) cap = (int64_t)(max_bytes / per_pair_bytes);
     if (cap < 1) cap = 1;
@@ -1165,7 +1166,7 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
     const int64_t bs_R = 5 * bs_n, bs_f = (int64_t)tf_align_up(2 * n, 64);
     float *tmp = ar.take<float>(bs_tmp * B), *blur = ar.take<float>(bs_n * B), *I = ar.take<float>(bs_n * B);
     float *R[2] = {ar.take<float>(bs_R * B), ar.take<float>(bs_R * B)};
-    float *M = ar.take<float>(bs_R * B);
+    float *M = p->win_size == FBI_WIN ? nullptr : ar.take<float>(bs_R * B);      // unfused fallback only
     float *fbuf[2] = {ar.take<float>(bs_f * B), ar.take<float>(bs_f * B)};
     if (!ar.ok()) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
 
@@ -1276,7 +1277,7 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
         if (fused) {
             // whole columns per workgroup (k_fb_iter): parallelism = strips x directions x pairs
             const int nx = (w + FBI_OW - 1) / FBI_OW;
-            const dim3 gi((unsigned)(((nx + 7) / 8) * 8 * nd * B), 1, 1);
+            const dim3 gi((unsigned)(nx * B), 1, 1), bi(FBI_T * nd);
             FbIterArgs ia;
             ia.R[0] = R[0]; ia.R[1] = R[1]; ia.bs_R = bs_R; ia.nd = nd; ia.nx = nx;
             for (int it = 0; it < p->num_iters; it++) {
@@ -1289,9 +1290,9 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
                 {
                     TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd * B, s);
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
-                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1>), gi, dim3(FBI_T), 0, s, ia, h, w, plane);
-                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2>), gi, dim3(FBI_T), 0, s, ia, h, w, plane);
-                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0>), gi, dim3(FBI_T), 0, s, ia, h, w, plane);
+                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1>), gi, bi, 0, s, ia, h, w, plane);
+                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2>), gi, bi, 0, s, ia, h, w, plane);
+                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0>), gi, bi, 0, s, ia, h, w, plane);
                 }
                 for (int q = 0; q < nd; q++) cur[dirs[q]] = 1 - cur[dirs[q]];
             }

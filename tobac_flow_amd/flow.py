@@ -271,18 +271,35 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     interp = select_interp_mode(interp_method) if smoothing_passes > 0 else 1
     # The fused iteration kernel walks whole columns (OpenCV's running column sums cannot be split over rows,
     # csrc/farneback.hip), so its parallelism is strips x directions x PAIRS and a launch costs a whole number of rounds
-    # of resident workgroups: the library says which batch size fills its last round best (21 pairs at 5424^2), and the
-    # pairs of the stack are spread evenly over the batches.  TF_FLOW_BATCH overrides (development switch).
+    # of resident workgroups.  Batches are as large as the scratch budget allows (the coarse pyramid levels have few
+    # columns: they only fill the GPU with many pairs), cut where the library says a launch's last round is fullest
+    # (tf_farneback_batch_hint: 43 or 21 pairs at 5424^2); what is left at the end goes into one batch, which never
+    # costs more rounds than splitting it.  TF_FLOW_BATCH fixes the batch size (development switch).
     n_pairs = T - 1
-    if "TF_FLOW_BATCH" in os.environ:
-        chunk = max(1, int(os.environ["TF_FLOW_BATCH"]))
-    elif n_pairs > 0 and hasattr(of_model, "params"):
-        budget = int(float(os.environ.get("TF_FLOW_WORKSPACE_GB", "80")) * 1e9)
-        chunk = max(1, int(L.tf_farneback_batch_hint(H, W, ctypes.byref(of_model.params), n_pairs, budget)))
+    sizes = []
+    if "TF_FLOW_BATCH" in os.environ or n_pairs <= 0 or not hasattr(of_model, "params"):
+        chunk = max(1, int(os.environ.get("TF_FLOW_BATCH", "16")))
+        n_b = max(1, -(-n_pairs // chunk))
+        edges = [round(k * n_pairs / n_b) for k in range(n_b + 1)]
+        sizes = [b - a for a, b in zip(edges[:-1], edges[1:]) if b > a]
     else:
-        chunk = 16
-    n_batches = max(1, -(-n_pairs // chunk))
-    starts = [round(k * n_pairs / n_batches) for k in range(n_batches + 1)]
+        # budget: TF_FLOW_WORKSPACE_GB (default 115), and never more than 60 % of what the device has free now (the stages
+        # after the flow need room too, and a caching allocator's free blocks are not one contiguous range)
+        budget = float(os.environ.get("TF_FLOW_WORKSPACE_GB", "115")) * 1e9
+        free = t.cuda.mem_get_info()[0] + (t.cuda.memory_reserved() - t.cuda.memory_allocated())
+        budget = int(max(min(budget, 0.6 * free), 1))
+        # scratch of the library + the batch's 8-bit frames and raw flow vectors (this function's own buffers)
+        per_pair = max(1, int(L.tf_farneback_workspace_bytes_batch(1, H, W, ctypes.byref(of_model.params))) + H * W * (2 + 16))
+        cap = max(1, budget // per_pair)
+        left = n_pairs
+        while left > 0:
+            B = left if left <= cap else max(1, int(L.tf_farneback_batch_hint(H, W, ctypes.byref(of_model.params), left, budget)))
+            sizes.append(B)
+            left -= B
+    n_batches = len(sizes)
+    starts = [0]
+    for B in sizes:
+        starts.append(starts[-1] + B)
     # TF_FLOW_OVERLAP=1: a second stream for the per-pair stages after the Farneback batch.  Off by default: measured on
     # config F (144 x 5424^2) it gains 1.5 % (5033 vs 5110 ms per step) -- every kernel involved fills the GPU by itself
     # -- and the HIP-event kernel timing of bench.py cannot attribute time to kernels that run side by side.
@@ -345,6 +362,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                 refine_and_smooth()
     if side is not None:
         main.wait_stream(side)
+    if n_batches > 0 and sizes and max(sizes) > 16:
+        # a large batch's scratch (tens of GB) goes back to the caching allocator: the next call carves it out again at no
+        # cost, and the stages after the flow (Sobel, watershed, labels of a whole stack) can use the memory meanwhile
+        _lib.release_workspaces("farneback")
     # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping
     _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
                "tf_flow_finalize")
