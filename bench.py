@@ -35,25 +35,36 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); the device-
 
 
 # library profile name -> kernel symbol prefix in the rocprofv3 counter files
-_KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<4, 0>", "vr_sor": "k_vr_sor_tile", "vr_system": "void k_vr_system<true>",
+_KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<", "vr_sor": "void k_vr_sor_tile<false>", "vr_system": "void k_vr_system<true, false>",
                   "sobel": "void k_sobel27<2, double, 2, true>", "fb_polyexp": "k_fb_polyexp"}
 _TRAFFIC_FILE = "profiles/round3_pmc_traffic_bench.json"
 _TRAFFIC_WORKLOAD = ("F", 144, 5424, 5424, 1)      # (config, frames, height, width, vr_steps) the counter passes were recorded on
 
 
-def _traffic(profile_name):
-    """HBM bytes per launch of one kernel from the committed rocprofv3 counter passes over THIS benchmark
-    (`rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline` and the same with
-    WRITE_SIZE: separate passes, FETCH_SIZE doubled for wide reads as MI355X_MICROARCH.md prescribes; summarised by
-    tools/pmc_traffic_json.py).  The benchmark cannot run the profiler on itself, so the figure belongs to the build
-    the file was recorded with; None if the file or the kernel is missing."""
+def _traffic(profile_name, alg_bytes_per_launch):
+    """HBM bytes per launch of one kernel from the committed rocprofv3 counter passes (`rocprofv3 --pmc FETCH_SIZE -- python3
+    bench.py --frames 62 --n-windows 5 --steps 1 --warmup 0 --no-cpu-baseline` and the same with WRITE_SIZE: separate
+    passes, FETCH_SIZE doubled for wide reads as MI355X_MICROARCH.md prescribes; summarised by tools/pmc_traffic_json.py).
+    The passes run a 62-frame stack of the same frame size and stage settings (a full 144-frame step has more dispatches
+    than rocprofiler's counter collection survives): the bytes of a launch are proportional to the frame pairs in it, so
+    the recorded per-launch figure is scaled by the ratio of the ALGORITHMIC bytes per launch of this run and of the
+    recorded one (both in the file / this run's profile).  The benchmark cannot run the profiler on itself, so the figure
+    belongs to the build the file was recorded with; None if the file or the kernel is missing."""
     try:
         with open(os.path.join(ROOT, _TRAFFIC_FILE)) as fh:
-            k = json.load(fh)["kernels"][_KERNEL_SYMBOL[profile_name]]
-        return {"bytes_per_launch": k["fetch_bytes_corrected_per_launch"] + k["write_bytes_per_launch"],
-                "fetch_bytes_raw": k["fetch_bytes_raw_per_launch"], "fetch_bytes_corrected": k["fetch_bytes_corrected_per_launch"],
-                "write_bytes": k["write_bytes_per_launch"], "launches_profiled": k["launches"], "source": _TRAFFIC_FILE}
-    except (OSError, ValueError, KeyError, TypeError):
+            doc = json.load(fh)
+        k = next(v for name, v in doc["kernels"].items() if name.startswith(_KERNEL_SYMBOL[profile_name]))   # symbol prefix
+        rec = doc.get("recorded_on") or {}
+        scale = 1.0
+        per_kernel = rec.get("algorithmic_bytes_per_launch")
+        rec_alg = per_kernel.get(profile_name) if isinstance(per_kernel, dict) else None
+        if rec_alg:
+            scale = alg_bytes_per_launch / float(rec_alg)
+        return {"bytes_per_launch": (k["fetch_bytes_corrected_per_launch"] + k["write_bytes_per_launch"]) * scale,
+                "fetch_bytes_raw": k["fetch_bytes_raw_per_launch"] * scale, "fetch_bytes_corrected": k["fetch_bytes_corrected_per_launch"] * scale,
+                "write_bytes": k["write_bytes_per_launch"] * scale, "launches_profiled": k["launches"], "source": _TRAFFIC_FILE,
+                "scaled_by_pairs_per_launch": round(scale, 4), "recorded_on": rec.get("workload")}
+    except (OSError, ValueError, KeyError, TypeError, AttributeError, StopIteration):
         return None
 
 
@@ -318,7 +329,7 @@ def main():
             name, (calls, ms, by) = dom
             achieved = by / (ms * 1e-3) / 1e9
             # the counter passes were recorded on the default workload: their per-launch bytes say nothing about another size
-            tr = _traffic(name) if (a.config, T, H, W, a.vr_steps) == _TRAFFIC_WORKLOAD and full_size else None
+            tr = _traffic(name, by / calls) if (a.config, T, H, W, a.vr_steps) == _TRAFFIC_WORKLOAD and full_size else None
             roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr["bytes_per_launch"] if tr else None,
                     "launches": calls, "avg_launch_us": round(ms * 1e3 / calls, 2),
@@ -326,7 +337,8 @@ def main():
                     "share_of_step": round(ms / (dt * 1e3), 4),
                     "traffic_detail": tr,
                     "all_kernels": {k: {"ms_per_step": round(v[1] / a.steps, 3),
-                                        "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[2] > 0 else None}
+                                        "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[2] > 0 else None,
+                                        "launches": v[0], "algorithmic_bytes_per_launch": round(v[2] / v[0], 1)}
                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
             if tr:                                       # what the kernel really moves, at the measured launch time
                 roof["traffic_GBps"] = round(tr["bytes_per_launch"] / (ms * 1e-3 / calls) / 1e9, 1)
@@ -379,7 +391,8 @@ def main():
         stage_of = {"to8bit_pair": "flow", "fb_gaussian_blur": "flow", "fb_resize": "flow", "fb_polyexp": "flow",
                     "fb_update_matrices": "flow", "fb_blur_solve": "flow", "fb_iteration_fused": "flow", "smooth_flow": "flow",
                     "vr_prepare": "refinement", "vr_system": "refinement", "vr_sor": "refinement",
-                    "convolve": "sobel", "sobel": "sobel", "ws_setup": "watershed", "ws_relax_sweep": "watershed", "ws_labels": "watershed"}
+                    "convolve": "sobel", "sobel": "sobel", "ws_setup": "watershed", "ws_relax_sweep": "watershed", "ws_labels": "watershed",
+                    "binary_morph": "seeds"}
         stage_ms = {}
         for k, v in prof.items():
             stage_ms[stage_of.get(k, "other")] = stage_ms.get(stage_of.get(k, "other"), 0.0) + v[1] / a.steps

@@ -30,7 +30,7 @@ std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_free;
 std::mutex g_mu;
 const char *g_names[TFK_COUNT] = {"to8bit_pair", "fb_gaussian_blur", "fb_resize", "fb_polyexp", "fb_update_matrices",
-    "fb_blur_solve", "fb_iteration_fused", "smooth_flow", "convolve", "sobel", "ws_setup", "ws_relax_sweep", "ws_labels", "vr_prepare", "vr_system", "vr_sor"};
+    "fb_blur_solve", "fb_iteration_fused", "smooth_flow", "convolve", "sobel", "ws_setup", "ws_relax_sweep", "ws_labels", "vr_prepare", "vr_system", "vr_sor", "binary_morph"};
 hipEvent_t get_event() {
     if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;

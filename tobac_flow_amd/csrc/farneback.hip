@@ -682,8 +682,9 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2]; };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
 #ifndef FBI_NB
-#define FBI_NB 4                    // rows whose gathers are in flight together
-#endif
+#define FBI_NB 2                    // rows whose gathers are in flight together.  Round 3, four-wave workgroups: 2 / 3 / 4 / 5 rows ->
+#endif                              // 16.2 / 16.8 / 18.9 / 22.4 ms per level-0 launch of 21 pairs (4: 10 spilled registers, 5: more); round 2's
+                                    // two-wave workgroups did not care (116.3 / 116.1 / 116.3 ms per step for 2 / 4 / 5)
 
 // Addressing: per-thread 64-bit byte offsets from per-item base pointers.  (A variant with wave-uniform bases + 32-bit
 // offsets, the global_load "saddr + voffset" form, saves 7 % of the VALU instructions and runs 12 % SLOWER at 5424^2:

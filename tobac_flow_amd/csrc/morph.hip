@@ -112,7 +112,7 @@ extern "C" int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t 
     for (int it = 0; it < iterations; it++) {
         // ping-pong so that the last iteration writes `out`
         uint8_t *dst = ((iterations - 1 - it) % 2 == 0) ? out : tmp;
-        TfProfScope ps(TFK_CONVOLVE, 2.0 * (double)T * H * W, s);
+        TfProfScope ps(TFK_MORPH, 2.0 * (double)T * H * W, s);
         if (words) hipLaunchKernelGGL(k_binary_morph4, grid4, block, 0, s, (const uint32_t *)src, T, (int)H, (int)(W / 4), rw, op, border_value, (uint32_t *)dst);
         else hipLaunchKernelGGL(k_binary_morph, grid, block, 0, s, src, T, (int)H, (int)W, tp, op, border_value, dst);
         src = dst;

@@ -80,6 +80,7 @@ __device__ __forceinline__ int tf_clampi(int v, int lo, int hi) { return v < lo 
 enum TfKernelId {
     TFK_TO8BIT = 0, TFK_FB_BLUR, TFK_FB_RESIZE, TFK_FB_POLYEXP, TFK_FB_MATRICES, TFK_FB_BLUR_SOLVE, TFK_FB_ITER,
     TFK_SMOOTH, TFK_CONVOLVE, TFK_SOBEL, TFK_WS_SETUP, TFK_WS_RELAX, TFK_WS_LABELS, TFK_VR_PREPARE, TFK_VR_SYSTEM, TFK_VR_SOR,
+    TFK_MORPH,
     TFK_COUNT
 };
 extern bool g_tf_prof_on;

@@ -29,7 +29,21 @@ for k in sorted(set(fetch) | set(write)):
                   "fetch_bytes_raw_per_launch": sum(f) / len(f) * 1024 if f else None,
                   "fetch_bytes_corrected_per_launch": sum(f) / len(f) * 2048 if f else None,
                   "write_bytes_per_launch": sum(w) / len(w) * 1024 if w else None}
+# optional 4th argument: the JSON line bench.py printed in one of the counter passes -- the workload the passes ran on and the
+# algorithmic bytes per launch of its dominant kernel, so that bench.py can scale the per-launch traffic to a run whose
+# launches hold a different number of frame pairs (bytes per launch are proportional to the pairs in the launch)
+recorded = None
+if len(sys.argv) > 4:
+    try:
+        line = [l for l in open(sys.argv[4]).read().splitlines() if l.startswith("{")][-1]
+        b = json.loads(line)
+        recorded = {"workload": b["config"]["workload"],
+                    "algorithmic_bytes_per_launch": {k: v["algorithmic_bytes_per_launch"] for k, v in b["roofline"]["all_kernels"].items()},
+                    "launches": {k: v["launches"] for k, v in b["roofline"]["all_kernels"].items()}}
+    except (OSError, ValueError, KeyError, IndexError):
+        recorded = None
 json.dump({"unit": "bytes per launch, mean over all launches of the run (warm-up included)",
+           "recorded_on": recorded,
            "correction": "FETCH_SIZE x 2 for 16 B / lane coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM)",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected_per_launch"] or 0) * kv[1]["launches"])[:14]:

@@ -14,5 +14,5 @@ rm -rf gpurun_out/${tag}_prof
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 600 rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --frames 62 --n-windows 5 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${tag}_pmc_$c.json 2> gpurun_out/${tag}_pmc_$c.err || echo "pmc pass $c failed"
 done
-python tools/pmc_traffic_json.py gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE gpurun_out/${tag}_pmc_traffic_bench.json | head -8
+python tools/pmc_traffic_json.py gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE gpurun_out/${tag}_pmc_traffic_bench.json gpurun_out/${tag}_pmc_FETCH_SIZE.json | head -8
 rm -rf gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE
