@@ -13,17 +13,25 @@ def _structure27(structure):
     return np.ascontiguousarray(s, np.uint8)
 
 
+def _as_u8_mask(x):
+    """non-zero -> 1 as a contiguous uint8 tensor; a bool tensor is reinterpreted in place (its bytes are 0 / 1 already)"""
+    t = _lib.torch()
+    if x.dtype == t.bool:
+        return x.contiguous().view(t.uint8)
+    return (x != 0).contiguous().view(t.uint8)
+
+
 def _binary(t_in, structure, op, iterations, border_value):
     t = _lib.torch()
     L = _lib.lib()
-    x = (t_in != 0).to(t.uint8).contiguous()
+    x = _as_u8_mask(t_in)
     T, H, W = x.shape
     out = t.empty_like(x)
     tmp = t.empty_like(x) if iterations > 1 else None
     st = _structure27(structure)
     _lib.check(L.tf_binary_morph(_lib.ptr(x), T, H, W, st.ctypes.data_as(_lib._P), op, int(iterations), int(bool(border_value)),
                                  _lib.ptr(out), _lib.ptr(tmp), _lib.stream_ptr()), "tf_binary_morph")
-    return out.to(t.bool)
+    return out.view(t.bool)                       # the kernels write 0 / 1
 
 
 def binary_erosion(x, structure, iterations=1, border_value=0):
@@ -92,7 +100,7 @@ def label(x, structure=None):
     import scipy.ndimage as ndi
     t = _lib.torch()
     L = _lib.lib()
-    xb = (x != 0).to(t.uint8).contiguous()
+    xb = _as_u8_mask(x)
     T, H, W = xb.shape
     st = _structure27(ndi.generate_binary_structure(3, 1) if structure is None else structure)
     out = t.empty((T, H, W), dtype=t.int32, device=xb.device)
