@@ -263,37 +263,39 @@ def main():
     nbr = neighbour_offsets(1)
     ws_stats = []                                            # tf_watershed stats of every window of every step (warmup included)
 
-    def window(flow_all, lo, hi):
-        """the hot path over frames lo .. hi - 1: one label volume per channel"""
-        w = bt[lo:hi]
-        # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame pair
-        # does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426)
-        flow = flow_all.window(lo, hi)
+    def flood_window(flow, w, c):
+        """seeds -> edge field -> watershed of channel c over the window `w` of the stack (Flow `flow`): one label volume"""
+        lin, seeds = anvil_seeds(w + CHANNEL_OFFSETS[c] if c else w)
+        if a.single_label_seeds:
+            seeds = torch.clamp(seeds, max=1)
+        # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
+        e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
-        out = []
-        for c in range(C):
-            lin, seeds = anvil_seeds(w + CHANNEL_OFFSETS[c] if c else w)
-            if a.single_label_seeds:
-                seeds = torch.clamp(seeds, max=1)
-            # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
-            e = get_combined_edge_field(flow, lin, dtype=np.float32)
-            st = {}
-            out.append(watershed_dev(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="ignore"))
-            ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
-        return out
+        st = {}
+        lab = watershed_dev(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="ignore")
+        ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
+        return lab
 
     def step(vr_steps=None):
+        """one pass over the stack; returns (stitched windows of the LAST channel, objects per channel)"""
         vr = a.vr_steps if vr_steps is None else vr_steps
-        per_channel = [[] for _ in range(C)]
         # flow of all T - 1 frame pairs of the stack, ONCE (the frames two windows share are not computed twice), in batches
         # sized by the library (tf_farneback_batch_hint)
         flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic")
-        for lo, hi in bounds:
-            for c, lab in enumerate(window(flow_all, lo, hi)):
-                per_channel[c].append(lab)
+        objects, out = [], None
+        for c in range(C):                                   # channels one after the other: one channel's labels resident
+            out = None
+            wins = []
+            for lo, hi in bounds:
+                # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame
+                # pair does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426)
+                wins.append(flood_window(flow_all.window(lo, hi), bt[lo:hi], c))
+            # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
+            out = stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins
+            del wins
+            objects.append(int(max(int(w.max()) for w in out)))
         del flow_all
-        # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
-        return [stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins for wins in per_channel]
+        return out, objects
 
     def barrier():
         if dist is not None:
@@ -307,15 +309,14 @@ def main():
     _lib.profile_enable(not a.no_kernel_events)
     _lib.profile_collect()
     t0 = time.perf_counter()
-    out_labels = None
+    out_labels, n_objects = None, []
     for _ in range(a.steps):
         out_labels = None                                    # the previous step's labels are released before the next step's exist
-        out_labels = step()
+        out_labels, n_objects = step()
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
-    n_objects = int(max(int(w.max()) for w in out_labels[0]))
     del out_labels
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=bt.device)
@@ -374,7 +375,7 @@ def main():
                           "sharding": f"one {T}-frame segment per GPU cut from one sequence, consecutive segments share {a.overlap} frames; "
                                       "label IDs stitched over all windows of all ranks by the reference's overlap rule "
                                       "(>= 5 px and >= 0.5, linking.py:49-161): one neighbour message per rank boundary + all-gathers of pair lists",
-                          "objects_after_stitch": n_objects},
+                          "objects_after_stitch": n_objects[0] if len(n_objects) == 1 else n_objects},
                "rate_over_computed_window_frames_Mpix_s": round(world * a.steps * frames_computed * H * W / dt / 1e6, 2),
                "roofline": roof}
         # which watershed schedule the timed windows ran: stats[5] = 1 / 0 probe (speculative root phase + conflict test,

@@ -119,3 +119,29 @@ def test_flow_batches_and_stream_overlap_do_not_change_the_flow(monkeypatch):
             torch.cuda.synchronize()
             for g, w in ((got.forward_flow, want.forward_flow), (got.backward_flow, want.backward_flow)):
                 assert torch.equal(torch.nan_to_num(g, nan=-777.0), torch.nan_to_num(w, nan=-777.0)), (batch, overlap)
+
+
+def test_a_batch_that_does_not_fit_is_halved_and_the_flow_is_the_same(monkeypatch):
+    """_calculate_flow_impl sizes its Farneback batches from an ESTIMATE of the free memory; a batch whose scratch cannot
+    be allocated after all (fragmented allocator) is halved and tried again, together with the batches after it -- the
+    flow does not change.  Simulated here with a model that refuses every batch of more than two pairs."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow
+    from tools.synth import blob_stack
+    bt = blob_stack(10, 120, 168, seed=4)
+    want = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    refused = []
+    real = FarnebackFlow.calc_batch_dev
+
+    def picky(self, prev, nxt, fwd_out, bwd_out, tag="farneback"):
+        if prev.shape[0] > 2:
+            refused.append(int(prev.shape[0]))
+            raise torch.OutOfMemoryError("simulated: scratch for %d pairs does not fit" % prev.shape[0])
+        return real(self, prev, nxt, fwd_out, bwd_out, tag)
+
+    monkeypatch.setattr(FarnebackFlow, "calc_batch_dev", picky)
+    got = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    assert refused and max(refused) == 9                               # 9 pairs -> 4, 4, 1 -> 2, 2, 2, 2, 1
+    for g, w in ((got.forward_flow, want.forward_flow), (got.backward_flow, want.backward_flow)):
+        assert torch.equal(torch.nan_to_num(g, nan=-777.0), torch.nan_to_num(w, nan=-777.0))

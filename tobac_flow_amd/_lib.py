@@ -215,7 +215,13 @@ def workspace(nbytes, tag="default"):
         if cur is None or cur.numel() < nbytes:
             _WS[key] = None
             cur = None                           # drop the old buffer BEFORE the new one is allocated (they can be > 100 GB)
-            cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
+            try:
+                cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
+            except t.OutOfMemoryError:
+                # the scratch is ONE block: free memory that the caching allocator holds in fragments cannot serve it.
+                # Hand the cache back to the driver once and try again (slow -- seconds for > 100 GB -- hence only here)
+                t.cuda.empty_cache()
+                cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
             _WS[key] = cur
     return cur
 

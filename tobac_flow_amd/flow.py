@@ -284,10 +284,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         sizes = [b - a for a, b in zip(edges[:-1], edges[1:]) if b > a]
     else:
         # budget: TF_FLOW_WORKSPACE_GB (default 115), and never more than 60 % of what the device has free now (the stages
-        # after the flow need room too, and a caching allocator's free blocks are not one contiguous range)
+        # after the flow need room too)
         budget = float(os.environ.get("TF_FLOW_WORKSPACE_GB", "115")) * 1e9
         free = t.cuda.mem_get_info()[0] + (t.cuda.memory_reserved() - t.cuda.memory_allocated())
-        budget = int(max(min(budget, 0.6 * free), 1))
+        budget = int(max(min(budget, 0.6 * free), 1))      # (_lib.workspace empties the allocator's cache if fragments are in the way)
         # scratch of the library + the batch's 8-bit frames and raw flow vectors (this function's own buffers)
         per_pair = max(1, int(L.tf_farneback_workspace_bytes_batch(1, H, W, ctypes.byref(of_model.params))) + H * W * (2 + 16))
         cap = max(1, budget // per_pair)
@@ -309,10 +309,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         side = _side_stream(main)
         forward.record_stream(side)
         backward.record_stream(side)
-    for i0, i1 in zip(starts[:-1], starts[1:]):
-        B = i1 - i0
+
+    def run_batch(i0, B):
         if B <= 0:
-            continue
+            return
         prev8 = _lib.empty((B, H, W), t.uint8)
         next8 = _lib.empty((B, H, W), t.uint8)
         for b in range(B):
@@ -331,7 +331,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
             bk = _lib.empty((B, H, W, 2), t.float32)
         of_model.calc_batch_dev(prev8, next8, f, bk)
         if vr_steps == 0 and smoothing_passes == 0:
-            continue
+            return
 
         def refine_and_smooth(i0=i0, B=B, prev8=prev8, next8=next8, f=f, bk=bk):
             if vr_steps > 0:                     # flow.py:513-519, before the smoothing (flow.py:521-525)
@@ -360,6 +360,25 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
             with t.cuda.stream(side):
                 side.wait_event(ready)
                 refine_and_smooth()
+    # a batch that does not fit (the budget above is an estimate; a caching allocator's free memory can be fragmented) is
+    # halved and tried again, and so are the batches after it
+    pending = [(a_, b_ - a_) for a_, b_ in zip(starts[:-1], starts[1:])]
+    while pending:
+        i0, B = pending.pop(0)
+        try:
+            run_batch(i0, B)
+        except t.OutOfMemoryError:
+            if B <= 1:
+                raise
+            _lib.release_workspaces("farneback")
+            t.cuda.empty_cache()
+            half = B // 2
+            todo, pending = [(i0, B)] + pending, []
+            for j0, Bj in todo:
+                while Bj > half:
+                    pending.append((j0, half))
+                    j0, Bj = j0 + half, Bj - half
+                pending.append((j0, Bj))
     if side is not None:
         main.wait_stream(side)
     if n_batches > 0 and sizes and max(sizes) > 16:
