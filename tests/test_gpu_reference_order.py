@@ -166,3 +166,64 @@ def test_raveled_flood_along_a_path_of_several_thousand_pixels(tf):
     path = int(mask2.sum())
     assert path > 5000
     assert np.array_equal(out.reshape(H, W) == 5, mask2 == 1)
+
+
+def test_full_disk_frames_with_component_seeds_in_reference_order():
+    """3 x 5424 x 5424 with SURVEY 8(d)'s component-labelled seeds: reference order against the C twin of the reference's
+    kernel in its own semantics (tie_mode 0), every voxel; the twin needs ~15 s."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from oracle import ws_oracle
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    from tools.synth import anvil_seeds, blob_stack
+    bt = blob_stack(3, 5424, 5424, seed=20240601, t0=12)
+    fl = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    lin, seeds = anvil_seeds(bt)
+    e = get_combined_edge_field(fl, lin, dtype=np.float32)
+    fw, bw = fl._dev_flows()
+    st = {}
+    lab = watershed_dev(fw, bw, e, seeds, None, neighbour_offsets(1), stats=st, on_ambiguous="reference")
+    want = ws_oracle.watershed(fw.cpu().numpy(), bw.cpu().numpy(), e.cpu().numpy(), seeds.cpu().numpy(), None, 1, tie_mode=0)
+    got = lab.cpu().numpy()
+    print("3 x 5424^2, component seeds: ambiguous voxels %d, reference order %s" % (st["ambiguous_pixels"], st["reference_order"]))
+    assert np.array_equal(got, want), f"{int((got != want).sum())} px differ from the reference kernel"
+
+
+def test_reference_order_cost_on_a_full_disk_window():
+    """the cost of the reference order on a 12 x 5424 x 5424 window (353 M voxels; no oracle at
+    this size).  Properties: outside the voxels the default mode REPORTS as depending on the order of equal-valued
+    markers, both modes give the same label; inside them the label is one of the labels of the tying seeds (here: it
+    stays a valid seed label); the call returns clean (no warning)."""
+    import time
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    from tools.synth import anvil_seeds, blob_stack
+    bt = blob_stack(12, 5424, 5424, seed=20240601, t0=0)
+    fl = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    lin, seeds = anvil_seeds(bt)
+    e = get_combined_edge_field(fl, lin, dtype=np.float32)
+    fw, bw = fl._dev_flows()
+    nbr = neighbour_offsets(1)
+    st0, st1 = {}, {}
+    base, rep = watershed_dev(fw, bw, e, seeds, None, nbr, stats=st0, on_ambiguous="ignore", return_ambiguous=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    base2 = watershed_dev(fw, bw, e, seeds, None, nbr, on_ambiguous="ignore")
+    torch.cuda.synchronize()
+    t_default = time.perf_counter() - t0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        t0 = time.perf_counter()
+        ref = watershed_dev(fw, bw, e, seeds, None, nbr, stats=st1, on_ambiguous="reference")
+        torch.cuda.synchronize()
+        t_ref = time.perf_counter() - t0
+    print("12 x 5424^2 window: default flood %.3f s, reference-order flood %.3f s; %d voxels depend on the order of equal-valued "
+          "markers, %d of them change; replay %s" % (t_default, t_ref, st0["ambiguous_pixels"], int((ref != base).sum()), st1["reference_order"]))
+    assert torch.equal(base, base2)
+    assert st0["ambiguous_pixels"] > 0 and st1["reference_order"]["replayed_pops"] > 0
+    differs = ref != base
+    assert not bool((differs & ((rep & 1) == 0)).any())                # only reported voxels can change
+    assert bool((ref[seeds != 0] == seeds[seeds != 0]).all()) and int((ref == 0).sum()) == 0
