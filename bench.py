@@ -282,6 +282,10 @@ def main():
         # flow of all T - 1 frame pairs of the stack, ONCE (the frames two windows share are not computed twice), in batches
         # sized by the library (tf_farneback_batch_hint)
         flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic")
+        if T * H * W * (1 + 4 + C) * 4 > 0.6 * torch.cuda.mem_get_info()[1]:
+            # a stack whose frames + flow vectors + one channel's labels take most of the device (F3: 34 + 136 + 44 GB):
+            # the Farneback scratch goes back to the allocator (create_flow would otherwise keep it for the next call)
+            _lib.release_workspaces("farneback")
         objects, out = [], None
         for c in range(C):                                   # channels one after the other: one channel's labels resident
             out = None

@@ -226,6 +226,15 @@ def workspace(nbytes, tag="default"):
     return cur
 
 
+def workspace_bytes(tag):
+    """size of the scratch buffer this (device, stream) holds under `tag` (0 if none)"""
+    t = torch()
+    key = (tag, device().index, t.cuda.current_stream().cuda_stream)
+    with _WS_LOCK:
+        cur = _WS.get(key)
+    return 0 if cur is None else int(cur.numel())
+
+
 def release_workspaces(tag=None):
     """Hand the scratch buffers (all, or those of one tag) back to torch's caching allocator."""
     with _WS_LOCK:

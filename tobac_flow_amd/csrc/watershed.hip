@@ -42,6 +42,8 @@ typedef unsigned long long u64;
 #define WS_MAX_NBR 26
 #define WS_MAX_DEPTH TF_WS_MAX_DEPTH
 #define WS_BATCH 32
+#define WS_K2(c, i) ((c).KM[2 * (int64_t)(i)])
+#define WS_M1(c, i) ((c).KM[2 * (int64_t)(i) + 1])
 
 struct WsGeom {
     int64_t T; int H, W; int64_t plane;
@@ -52,7 +54,8 @@ struct WsGeom {
 struct WsC {               // compact arrays
     int64_t R; int n_nbr;
     const u64 *pix; const unsigned *val; const int *nbr;
-    u64 *K2, *M1, *C[WS_MAX_DEPTH], *Rt;
+    u64 *KM;               // K2 and M1 of a pixel side by side ({K2, M1}[R], 16-byte aligned): phase A reads both with one load
+    u64 *C[WS_MAX_DEPTH], *Rt;
     int *Llo, *Lhi;        // smallest / largest label among the roots of all fully matching candidates (root phase)
     const u64 *emask;      // per pixel p, bit i: out-edge i is a CANDIDATE edge (K2[p] == M1[nbr i]); bit 32 + i: nbr i is an entry
 };
@@ -140,7 +143,7 @@ k_ws_cid(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, cons
 __global__ void __launch_bounds__(256)
 k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, const float *__restrict__ bwd,
              const int *__restrict__ cid, WsGeom g, u64 *__restrict__ pix, unsigned *__restrict__ val,
-             int *__restrict__ nbr, u64 *__restrict__ K2, u64 *__restrict__ M1, int *__restrict__ nan_flag)
+             int *__restrict__ nbr, u64 *__restrict__ KM, int *__restrict__ nan_flag)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     const int64_t t = blockIdx.z;
@@ -163,8 +166,7 @@ k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, con
         if (n >= 0) { cn = cid[n]; if (cn < 0) cn = -1; }
         nbr[id * g.n_nbr + i] = cn;
     }
-    K2[id] = marker ? ((u64)v << 32) : WS_INF;
-    M1[id] = WS_INF;
+    *(ulonglong2 *)&KM[2 * id] = make_ulonglong2(marker ? ((u64)v << 32) : WS_INF, WS_INF);
 }
 
 // ---- the reference's own raveled form (tf_watershed_raveled) -------------------------------------------------------
@@ -220,7 +222,7 @@ k_wsr_relevant(const uint8_t *__restrict__ cls, WsRavel g, uint8_t *__restrict__
 
 __global__ void __launch_bounds__(256)
 k_wsr_compact(const float *__restrict__ image, const int *__restrict__ cid, WsRavel g, u64 *__restrict__ pix,
-              unsigned *__restrict__ val, int *__restrict__ nbr, u64 *__restrict__ K2, u64 *__restrict__ M1, int *__restrict__ nan_flag)
+              unsigned *__restrict__ val, int *__restrict__ nbr, u64 *__restrict__ KM, int *__restrict__ nan_flag)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.n) return;
@@ -240,8 +242,7 @@ k_wsr_compact(const float *__restrict__ image, const int *__restrict__ cid, WsRa
         if (n >= 0) { cn = cid[n]; if (cn < 0) cn = -1; }
         nbr[id * g.n_nbr + i] = cn;
     }
-    K2[id] = marker ? ((u64)v << 32) : WS_INF;
-    M1[id] = WS_INF;
+    *(ulonglong2 *)&KM[2 * id] = make_ulonglong2(marker ? ((u64)v << 32) : WS_INF, WS_INF);
 }
 
 // in place: output[i] = label of its root seed for every flooded pixel (seeds and everything else untouched)
@@ -353,14 +354,16 @@ __device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, int w, boo
             // relaxed L2 atomics only: the key is loaded after the exchange has returned (the flag is cleared BEFORE
             // the key is read, so a later decrease re-queues the pixel); the id loads above are already in flight
             const int dep = inq ? ws_after(atomicExch(&inq[p], 0)) : 0;
-            kp = ws_load(&c.K2[p] + dep);
+            kp = ws_load(&WS_K2(c, p) + 2 * dep);
         }
         const u64 lp = kp >> 32;
         u64 vn[WS_NB], m1[WS_NB], k2[WS_NB];
 #pragma unroll
         for (int j = 0; j < WS_NB; j++) {
             const int q = n[j] >= 0 ? n[j] : 0;
-            vn[j] = c.val[q]; m1[j] = c.M1[q]; k2[j] = c.K2[q];
+            vn[j] = c.val[q];
+            const ulonglong2 km = *(const ulonglong2 *)&WS_K2(c, q);
+            k2[j] = km.x; m1[j] = km.y;
         }
         u64 cand[WS_NB], old[WS_NB];
 #pragma unroll
@@ -369,8 +372,8 @@ __device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, int w, boo
             old[j] = 0ull;                                             // "no improvement"
             if (n[j] >= 0) {
                 // keys only decrease, so a (possibly stale, i.e. larger) plain read is a safe pre-filter
-                if (kp < m1[j]) atomicMin(&c.M1[n[j]], kp);
-                if (cand[j] < k2[j]) old[j] = atomicMin(&c.K2[n[j]], cand[j]);
+                if (kp < m1[j]) atomicMin(&WS_M1(c, n[j]), kp);
+                if (cand[j] < k2[j]) old[j] = atomicMin(&WS_K2(c, n[j]), cand[j]);
             }
         }
         int was_q[WS_NB];                                              // raw returns: consumed only after all are issued
@@ -427,7 +430,7 @@ k_ws_edge_masks(WsC c, u64 *__restrict__ emask)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= c.R) return;
-    const u64 kp = c.K2[p];
+    const u64 kp = WS_K2(c, p);
     u64 m = 0ull;
     if (kp != WS_INF) {
         const int *np = c.nbr + p * c.n_nbr;
@@ -436,7 +439,11 @@ k_ws_edge_masks(WsC c, u64 *__restrict__ emask)
 #pragma unroll
             for (int j = 0; j < WS_NB; j++) n[j] = i0 + j < c.n_nbr ? np[i0 + j] : -1;
 #pragma unroll
-            for (int j = 0; j < WS_NB; j++) { const int q = n[j] >= 0 ? n[j] : 0; m1[j] = c.M1[q]; kn[j] = c.K2[q]; vn[j] = c.val[q]; }
+            for (int j = 0; j < WS_NB; j++) {
+                const int q = n[j] >= 0 ? n[j] : 0;
+                const ulonglong2 km = *(const ulonglong2 *)&WS_K2(c, q);
+                kn[j] = km.x; m1[j] = km.y; vn[j] = c.val[q];
+            }
 #pragma unroll
             for (int j = 0; j < WS_NB; j++)
                 if (n[j] >= 0 && m1[j] == kp) {
@@ -473,7 +480,7 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
             // return value as an address term), so a later decrease re-queues p: no lost update
             const int dep = inq ? ws_after(atomicExch(&inq[p], 0)) : 0;
             em = c.emask[p];                     // final since phase A (0 for a pixel phase A never reached)
-            kp = c.K2[p];
+            kp = WS_K2(c, p);
             own = ws_load(&dst[p] + dep);
             if (root) { own_lo = ws_load_i(&c.Llo[p] + dep); own_hi = ws_load_i(&c.Lhi[p] + dep); }
             for (int j = 1; j < k; j++) cp[j] = c.C[j][p];
@@ -575,7 +582,7 @@ k_ws_origins(WsC c, int depth, int *__restrict__ org)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= c.R) return;
-    const u64 kp = c.K2[p];
+    const u64 kp = WS_K2(c, p);
     if (kp == WS_INF || c.Rt[p] == WS_INF) return;
     const int lo = c.Llo[p], hi = c.Lhi[p];
     u64 cp[WS_MAX_DEPTH];
@@ -970,7 +977,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     if (R > 0) {
         u64 *pix = ar.take<u64>(R); unsigned *val = ar.take<unsigned>(R); int *nbr = ar.take<int>(R * n_nbr);
         c.pix = pix; c.val = val; c.nbr = nbr;
-        c.K2 = ar.take<u64>(R); c.M1 = ar.take<u64>(R);
+        c.KM = ar.take<u64>(2 * R);
         for (int k = 1; k < depth_max; k++) c.C[k] = ar.take<u64>(R);
         c.Rt = ar.take<u64>(R);
         c.Llo = ar.take<int>(R); c.Lhi = ar.take<int>(R); org = ar.take<int>(R);
@@ -986,8 +993,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         TF_CHECK_HIP(hipMemsetAsync(d_nan, 0, sizeof(int), s));
         {
             TfProfScope ps(TFK_WS_SETUP, 0.0, s);
-            if (rv) hipLaunchKernelGGL(k_wsr_compact, dim3(nb1), dim3(256), 0, s, field, (const int *)cid, *rv, pix, val, nbr, c.K2, c.M1, d_nan);
-            else hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.K2, c.M1, d_nan);
+            if (rv) hipLaunchKernelGGL(k_wsr_compact, dim3(nb1), dim3(256), 0, s, field, (const int *)cid, *rv, pix, val, nbr, c.KM, d_nan);
+            else hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.KM, d_nan);
         }
         TF_CHECK_LAUNCH();
         {   // the reference's `smaller()` (_watershed.pyx:161-164) is not an order on NaN: its heap then pops in an order

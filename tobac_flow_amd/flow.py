@@ -286,8 +286,9 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         # budget: TF_FLOW_WORKSPACE_GB (default 115), and never more than 60 % of what the device has free now (the stages
         # after the flow need room too)
         budget = float(os.environ.get("TF_FLOW_WORKSPACE_GB", "115")) * 1e9
+        held = _lib.workspace_bytes("farneback")           # scratch kept from the previous call: reusable as it is
         free = t.cuda.mem_get_info()[0] + (t.cuda.memory_reserved() - t.cuda.memory_allocated())
-        budget = int(max(min(budget, 0.6 * free), 1))      # (_lib.workspace empties the allocator's cache if fragments are in the way)
+        budget = int(max(min(budget, held + 0.6 * free), 1))   # (_lib.workspace empties the allocator's cache if fragments are in the way)
         # scratch of the library + the batch's 8-bit frames and raw flow vectors (this function's own buffers)
         per_pair = max(1, int(L.tf_farneback_workspace_bytes_batch(1, H, W, ctypes.byref(of_model.params))) + H * W * (2 + 16))
         cap = max(1, budget // per_pair)
@@ -296,6 +297,8 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
             B = left if left <= cap else max(1, int(L.tf_farneback_batch_hint(H, W, ctypes.byref(of_model.params), left, budget)))
             sizes.append(B)
             left -= B
+    if os.environ.get("TF_FLOW_DEBUG"):
+        print("flow: %d pairs in batches %s" % (n_pairs, sizes), flush=True)
     n_batches = len(sizes)
     starts = [0]
     for B in sizes:
@@ -368,6 +371,9 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         try:
             run_batch(i0, B)
         except t.OutOfMemoryError:
+            if os.environ.get("TF_FLOW_DEBUG"):
+                print("flow: batch of %d pairs does not fit (free %.1f GB, cached %.1f GB): halving" % (
+                    B, t.cuda.mem_get_info()[0] / 1e9, (t.cuda.memory_reserved() - t.cuda.memory_allocated()) / 1e9), flush=True)
             if B <= 1:
                 raise
             _lib.release_workspaces("farneback")
@@ -382,9 +388,13 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     if side is not None:
         main.wait_stream(side)
     if n_batches > 0 and sizes and max(sizes) > 16:
-        # a large batch's scratch (tens of GB) goes back to the caching allocator: the next call carves it out again at no
-        # cost, and the stages after the flow (Sobel, watershed, labels of a whole stack) can use the memory meanwhile
-        _lib.release_workspaces("farneback")
+        # A large batch's scratch (tens of GB) stays allocated for the next call (carving one block of that size out of a
+        # caching allocator's free fragments fails more often than not: measured, bench.py fell back to half batches from
+        # its second step on) -- unless the device is nearly full: then the stages after the flow (Sobel, watershed, the
+        # labels of a whole stack) need the memory more
+        free_now, total = t.cuda.mem_get_info()
+        if free_now + (t.cuda.memory_reserved() - t.cuda.memory_allocated()) < 0.2 * total:
+            _lib.release_workspaces("farneback")
     # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping
     _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
                "tf_flow_finalize")
