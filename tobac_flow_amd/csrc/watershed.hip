@@ -26,7 +26,7 @@
 //
 // Data layout: the volume itself only carries cid int32[N] (compact id of floodable pixels,
 // -2-id for boundary markers, -1 for everything else) and cls u8[N].  All keys live in COMPACT
-// arrays over the R = (#floodable + #boundary markers) relevant pixels, ids in raster order:
+// arrays over the R = (#floodable + #boundary markers) relevant pixels, ids in TILE order (WS_TILE, below; raster order in the raveled form):
 //   pix u64[R] raster index (top bit: marker), val u32[R] ordered field key, nbr int32[R][n_nbr] compact ids of the
 //   floodable out-neighbours (flow displacement already applied), K2, M1, C_1.., Rt u64[R].
 // Sweeps are frontier driven: two ping-pong queues of compact ids hold the pixels whose key just
@@ -49,7 +49,27 @@ struct WsGeom {
     int64_t T; int H, W; int64_t plane;
     int n_nbr;
     int8_t dt[WS_MAX_NBR], dy[WS_MAX_NBR], dx[WS_MAX_NBR];
+    int n_tx;              // tiles per row of tiles (tiled compact ids, below)
 };
+
+// COMPACT IDS IN TILE ORDER (round 3).  The relevant pixels are numbered by an exclusive scan of their flags.  In raster
+// order a pixel's y neighbours lie a row's worth of ids away and its t neighbours a frame's worth (megabytes in the key
+// arrays): the floodable set of a detect_anvils field is made of bands a few pixels wide, so a sweep touched one or two
+// useful entries per cache line it pulled -- L2 hit rate 35 %, ~1 KB fetched from HBM per relevant pixel and phase.
+// The scan therefore runs over the flags in the order (tile row, tile column, t, y in tile, x in tile) with 16 x 16
+// pixel tiles through ALL frames: the six (or 26) neighbours of a pixel, flow displacement included, then carry ids a few
+// hundred apart.  Nothing depends on the order of the ids: the tie-break of last resort is the RASTER index of the root
+// marker, which the root phase carries as such (default mode) or as the reference's pop rank (TF_WS_REFERENCE_ORDER).
+#ifndef WS_TILE
+#define WS_TILE 16
+#endif
+__device__ __forceinline__ int64_t ws_vpos(const WsGeom &g, int64_t t, int y, int x) {
+    const int64_t tile = (int64_t)(y / WS_TILE) * g.n_tx + x / WS_TILE;
+    return ((tile * g.T + t) * WS_TILE + (y % WS_TILE)) * WS_TILE + (x % WS_TILE);
+}
+static int64_t ws_virtual_voxels(int64_t T, int64_t H, int64_t W) {
+    return T * ((H + WS_TILE - 1) / WS_TILE * WS_TILE) * ((W + WS_TILE - 1) / WS_TILE * WS_TILE);
+}
 
 struct WsC {               // compact arrays
     int64_t R; int n_nbr;
@@ -125,7 +145,21 @@ k_ws_relevant(const uint8_t *__restrict__ cls, const float *__restrict__ fwd, co
             for (int j = 0; j < 8; j++) f |= v[j] == 1;
         }
     }
-    flag[p] = f;
+    flag[ws_vpos(g, t, y, x)] = f;               // (the padding positions of edge tiles were zeroed by the caller)
+}
+
+// the same numbering for the (t, y, x) entry points, whose scan runs in tile order
+__global__ void __launch_bounds__(256)
+k_ws_cid_tiled(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, const int *__restrict__ scan, WsGeom g,
+               int *__restrict__ cid)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x >= g.W || y >= g.H) return;
+    const int64_t p = t * g.plane + (int64_t)y * g.W + x, k = ws_vpos(g, t, y, x);
+    int c = -1;
+    if (flag[k]) c = cls[p] == 1 ? scan[k] : -2 - scan[k];
+    cid[p] = c;
 }
 
 // cid from the exclusive scan of flag: id (floodable), -2-id (boundary marker), -1 otherwise
@@ -247,17 +281,17 @@ k_wsr_compact(const float *__restrict__ image, const int *__restrict__ cid, WsRa
 
 // in place: output[i] = label of its root seed for every flooded pixel (seeds and everything else untouched)
 __global__ void __launch_bounds__(256)
-k_wsr_labels(const int *__restrict__ cid, const u64 *__restrict__ Rt, const u64 *__restrict__ pix, int32_t *output, int64_t n)
+k_wsr_labels(const int *__restrict__ cid, const u64 *__restrict__ Rt, const u64 *__restrict__ pix, int ranked, int32_t *output, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int c = cid[i];
-    if (c >= 0 && output[i] == 0) { const u64 r = Rt[c]; if (r != WS_INF) output[i] = output[pix[r & 0xFFFFFFFFull] & ~WS_MARKER_BIT]; }
+    if (c >= 0 && output[i] == 0) { const u64 r = Rt[c]; if (r != WS_INF) output[i] = output[ranked ? (pix[r & 0xFFFFFFFFull] & ~WS_MARKER_BIT) : r]; }
 }
 
-// chain arrays of a marker: C_k = 0 for every k; root key = (pop rank among equal keys << 32) | compact id.
-// rank == nullptr: rank = compact id, i.e. the markers' raster order (= the reference's marker_locations order);
-// otherwise the pop rank the reference's heap gives the marker (ws_reference_ranks below).
+// chain arrays of a marker: C_k = 0 for every k; root key: rank == nullptr (default): the marker's RASTER index (= the
+// reference's marker_locations order); otherwise (pop rank the reference's heap gives the marker << 32) | compact id
+// (ws_reference_ranks below).  The label kernels are told which of the two a root key is (`ranked`).
 __global__ void __launch_bounds__(256)
 k_ws_init_level(const u64 *__restrict__ pix, u64 *__restrict__ dst, int64_t R, int is_root, const int *__restrict__ rank)
 {
@@ -265,7 +299,7 @@ k_ws_init_level(const u64 *__restrict__ pix, u64 *__restrict__ dst, int64_t R, i
     if (i >= R) return;
     const u64 px = pix[i];
     const bool marker = (px & WS_MARKER_BIT) != 0ull;
-    const u64 root = ((u64)(unsigned)(rank ? rank[i] : (int)i) << 32) | (u64)(unsigned)i;
+    const u64 root = rank ? (((u64)(unsigned)rank[i] << 32) | (u64)(unsigned)i) : (px & ~WS_MARKER_BIT);
     dst[i] = marker ? (is_root ? root : 0ull) : WS_INF;
 }
 
@@ -630,7 +664,7 @@ k_ws_count_ambiguous(WsC c, const int *__restrict__ org, unsigned long long *__r
 // (TF_WS_AMB_DEPTH)
 __global__ void __launch_bounds__(256)
 k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, const u64 *__restrict__ Rt,
-            const u64 *__restrict__ pix, const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ org,
+            const u64 *__restrict__ pix, int ranked, const int *__restrict__ lo, const int *__restrict__ hi, const int *__restrict__ org,
             int32_t *__restrict__ labels, uint8_t *__restrict__ amb, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -641,7 +675,7 @@ k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, co
     if (l == 0 && c >= 0) {
         const u64 r = Rt[c];
         if (r != WS_INF) {
-            l = markers[pix[r & 0xFFFFFFFFull] & ~WS_MARKER_BIT];      // root key = (rank << 32) | compact id of the marker
+            l = markers[ranked ? (pix[r & 0xFFFFFFFFull] & ~WS_MARKER_BIT) : r];   // root key: raster index, or (rank << 32) | compact id
             if (amb) a = (uint8_t)((lo[c] != hi[c] ? 1 : 0) | ((org[c] & 3) << 1));
         }
     }
@@ -674,12 +708,12 @@ k_ws_seed_list(const uint8_t *__restrict__ cls, const int *__restrict__ scan, co
 // largest marker value (ordered key) below which the order of equal-valued markers decides a label: every origin
 // with complete chains ties down to markers of ONE value, the value of its own root
 __global__ void __launch_bounds__(256)
-k_ws_tie_value_max(WsC c, const int *__restrict__ org, unsigned *__restrict__ vmax)
+k_ws_tie_value_max(WsC c, const int *__restrict__ org, const float *__restrict__ field, unsigned *__restrict__ vmax)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.R || !(org[i] & 1)) return;
-    const u64 r = c.Rt[i];
-    if (r != WS_INF) atomicMax(vmax, c.val[r & 0xFFFFFFFFull]);
+    const u64 r = c.Rt[i];                               // default-mode root key: the raster index of the root marker
+    if (r != WS_INF) atomicMax(vmax, ws_ordkey(field[r]));
 }
 
 struct WsU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
@@ -718,9 +752,10 @@ static int ws_scan_flags(const uint8_t *flag, int *scan, int64_t N, void *tmp, s
     return TF_OK;
 }
 
-static size_t ws_full_bytes(int64_t N) {
-    // cls + flag + scan + cid + scan temp + flags
-    return tf_align_up((size_t)N, 256) * 2 + tf_align_up((size_t)N * 4, 256) * 2 + tf_align_up(ws_scan_temp_bytes(N), 256) + 4096;
+static size_t ws_full_bytes(int64_t N, int64_t NV) {
+    // cls, cid over the N voxels; flag, scan over the NV >= N scan positions (tile order pads edge tiles); scan temp, flags
+    return tf_align_up((size_t)N, 256) + tf_align_up((size_t)NV, 256) + tf_align_up((size_t)N * 4, 256) + tf_align_up((size_t)NV * 4, 256)
+         + tf_align_up(ws_scan_temp_bytes(NV), 256) + 4096;
 }
 static size_t ws_compact_bytes(int64_t R, int n_nbr, int depth) {
     // pix + val + nbr + keys + queues
@@ -735,7 +770,7 @@ extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, 
     if (T <= 0 || H <= 0 || W <= 0 || chain_depth < 1 || chain_depth > WS_MAX_DEPTH || n_nbr < 1 || n_nbr > WS_MAX_NBR) return 0;
     const int64_t N = T * H * W;
     if (max_relevant <= 0 || max_relevant > N) max_relevant = N;
-    return ws_full_bytes(N) + ws_compact_bytes(max_relevant, n_nbr, chain_depth);
+    return ws_full_bytes(N, ws_virtual_voxels(T, H, W)) + ws_compact_bytes(max_relevant, n_nbr, chain_depth);
 }
 
 struct WsQueues { int *q[2]; int *cnt; int *inq; int qcap; int *h_cnt; int64_t *processed; };
@@ -915,18 +950,19 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     // the raveled twin addresses voxels through int32 strides like the reference; the (T, H, W) entry points index in
     // 64 bits and are bounded by memory (and by 2^30 RELEVANT pixels, checked after the scan)
     TF_REQUIRE(N > 0 && (rv ? N <= 0x7fffffffll : N <= (1ll << 36)), "tf_watershed: too many voxels per call (use time windows)");
-    if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(1, n_nbr, depth_max)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
+    const int64_t NV = rv ? N : ws_virtual_voxels(T, H, W);           // scan positions (tile order pads edge tiles)
+    if (ws_bytes < ws_full_bytes(N, NV) + ws_compact_bytes(1, n_nbr, depth_max)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
     hipStream_t s = (hipStream_t)stream;
-    WsGeom g; g.T = T; g.H = (int)H; g.W = (int)W; g.plane = H * W; g.n_nbr = n_nbr;
+    WsGeom g; g.T = T; g.H = (int)H; g.W = (int)W; g.plane = H * W; g.n_nbr = n_nbr; g.n_tx = (int)((W + WS_TILE - 1) / WS_TILE);
     for (int i = 0; i < n_nbr && !rv; i++) {
         g.dt[i] = nbr_host[i * 3]; g.dy[i] = nbr_host[i * 3 + 1]; g.dx[i] = nbr_host[i * 3 + 2];
         TF_REQUIRE(abs(g.dt[i]) <= 1 && abs(g.dy[i]) <= 1 && abs(g.dx[i]) <= 1, "tf_watershed: neighbour offset out of range");
     }
     for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = 0;
     TfArena ar(ws, ws_bytes);
-    uint8_t *cls = ar.take<uint8_t>(N), *flag = ar.take<uint8_t>(N);
-    int *scan = ar.take<int>(N), *cid = ar.take<int>(N);
-    const size_t scan_bytes = ws_scan_temp_bytes(N);
+    uint8_t *cls = ar.take<uint8_t>(N), *flag = ar.take<uint8_t>(NV);
+    int *scan = ar.take<int>(NV), *cid = ar.take<int>(N);
+    const size_t scan_bytes = ws_scan_temp_bytes(NV);
     char *scan_tmp = ar.take<char>(scan_bytes ? scan_bytes : 1);
     int *d_flags = ar.take<int>(WS_BATCH + 8);
     unsigned long long *d_cnt = ar.take<unsigned long long>(4);
@@ -954,18 +990,20 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             hipLaunchKernelGGL(k_wsr_relevant, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, *rv, flag);
         } else {
             hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
+            if (NV > N) TF_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)NV, s));   // padding positions of the edge tiles
             hipLaunchKernelGGL(k_ws_relevant, grid, block, 0, s, cls, fwd, bwd, g, flag);
         }
         TF_CHECK_LAUNCH();
-        const int rc_scan = ws_scan_flags(flag, scan, N, scan_tmp, scan_bytes, s, &R);
+        const int rc_scan = ws_scan_flags(flag, scan, NV, scan_tmp, scan_bytes, s, &R);
         if (rc_scan) return rc_scan;
     }
     st[6] = R;
-    if (ws_bytes < ws_full_bytes(N) + ws_compact_bytes(R > 0 ? R : 1, n_nbr, depth_max)) {
+    if (ws_bytes < ws_full_bytes(N, NV) + ws_compact_bytes(R > 0 ? R : 1, n_nbr, depth_max)) {
         tf_set_error("tf_watershed: workspace too small for %lld relevant pixels", (long long)R);
         return TF_ENOMEM;
     }
-    hipLaunchKernelGGL(k_ws_cid, dim3(nb1), dim3(256), 0, s, cls, flag, scan, N, cid);
+    if (rv) hipLaunchKernelGGL(k_ws_cid, dim3(nb1), dim3(256), 0, s, cls, flag, scan, N, cid);
+    else hipLaunchKernelGGL(k_ws_cid_tiled, grid, block, 0, s, (const uint8_t *)cls, (const uint8_t *)flag, (const int *)scan, g, cid);
     TF_CHECK_LAUNCH();
     int h_cnt[WS_BATCH + 8];
     WsC c; memset(&c, 0, sizeof(c));
@@ -1065,7 +1103,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             TF_CHECK_HIP(hipEventRecord(ev0, s));
             unsigned *d_vmax = (unsigned *)(d_cnt + 3);
             TF_CHECK_HIP(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), s));
-            hipLaunchKernelGGL(k_ws_tie_value_max, dim3(nbr_blocks), dim3(256), 0, s, c, (const int *)org, d_vmax);
+            hipLaunchKernelGGL(k_ws_tie_value_max, dim3(nbr_blocks), dim3(256), 0, s, c, (const int *)org, field, d_vmax);
             hipLaunchKernelGGL(k_ws_flag_seeds, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, N, flag);
             TF_CHECK_LAUNCH();
             unsigned h_vmax = 0;
@@ -1124,8 +1162,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     st[8] = depth; st[9] = (int64_t)h_amb[0]; st[10] = (int64_t)h_amb[1]; st[11] = (int64_t)h_amb[2];
     {
         TfProfScope ps(TFK_WS_LABELS, 12.0 * (double)N, s);
-        if (rv) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)cid, (const u64 *)c.Rt, c.pix, labels, N); }
-        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, c.pix, c.Llo, c.Lhi, org, labels,
+        if (rv) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)cid, (const u64 *)c.Rt, c.pix, reference_order_applied ? 1 : 0, labels, N); }
+        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, c.pix, reference_order_applied ? 1 : 0, c.Llo, c.Lhi, org, labels,
                                 R > 0 ? amb_out : nullptr, N);
     }
     TF_CHECK_LAUNCH();
@@ -1180,7 +1218,7 @@ extern "C" size_t tf_watershed_raveled_workspace_bytes(int64_t n, int n_structur
 {
     if (n <= 0 || n > 0x7fffffffll || max_depth < 1 || max_depth > WS_MAX_DEPTH || n_structure < 1 || n_structure > WS_MAX_NBR) return 0;
     if (max_relevant <= 0 || max_relevant > n) max_relevant = n;
-    return ws_full_bytes(n) + ws_compact_bytes(max_relevant, n_structure, max_depth);
+    return ws_full_bytes(n, n) + ws_compact_bytes(max_relevant, n_structure, max_depth);
 }
 
 extern "C" int tf_watershed_raveled_ex(const float *image, int64_t n, const int64_t *marker_locations, int64_t n_markers,
