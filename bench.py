@@ -154,12 +154,21 @@ def cv2_parity(seed=20240601):
     locs = ref.copy()                                        # the map as utils/flow_utils.py:84-87 builds it
     locs[:, :, 0] += np.arange(img.shape[1])
     locs[:, :, 1] += np.arange(img.shape[0])[:, np.newaxis]
-    for name, inter in (("nearest", cv2.INTER_NEAREST), ("linear", cv2.INTER_LINEAR), ("cubic", cv2.INTER_CUBIC)):
+    for name, inter in (("nearest", cv2.INTER_NEAREST), ("linear", cv2.INTER_LINEAR), ("cubic", cv2.INTER_CUBIC),
+                        ("lanczos", cv2.INTER_LANCZOS4)):
         want = cv2.remap(img, locs, None, inter, None, cv2.BORDER_CONSTANT, np.nan)
         have = warp_flow(img, ref, method=name)
         both = np.isfinite(want) & np.isfinite(have)
         out[f"remap_{name}_max_abs_diff"] = float(np.abs(want - have)[both].max())
         out[f"remap_{name}_nan_mask_equal"] = bool(np.array_equal(np.isnan(want), np.isnan(have)))
+    # cv2.VariationalRefinement (flow.py:359, 513-519): the same refinement of the same input flow
+    if hasattr(cv2, "VariationalRefinement"):
+        from tobac_flow_amd.flow import VariationalRefinement
+        want = cv2.VariationalRefinement.create().calc(p8[0], p8[1], ref.copy())
+        have = VariationalRefinement.create().calc(p8[0], p8[1], ref.copy())
+        out["varref_max_abs_diff"] = float(np.abs(np.asarray(want) - np.asarray(have)).max())
+    else:
+        out["varref_max_abs_diff"] = None
     return out
 
 

@@ -699,9 +699,11 @@ def test_farneback_and_remap_against_opencv_when_it_is_installed(tf):
     res = bench.cv2_parity()
     assert res["status"] == "pinned"
     assert res["farneback_max_abs_diff"] <= 1e-4
-    for name in ("nearest", "linear", "cubic"):
+    for name in ("nearest", "linear", "cubic", "lanczos"):
         assert res[f"remap_{name}_nan_mask_equal"]
         assert res[f"remap_{name}_max_abs_diff"] <= (0 if name == "nearest" else 1e-3)
+    if res["varref_max_abs_diff"] is not None:                # cv2.VariationalRefinement on the same input flow
+        assert res["varref_max_abs_diff"] <= 1e-4
 
 
 @pytest.mark.parametrize("kw", [dict(win_size=9), dict(win_size=15, num_iters=3), dict(poly_n=7, poly_sigma=1.5),
