@@ -322,10 +322,13 @@ def main():
     _lib.profile_enable(not a.no_kernel_events)
     _lib.profile_collect()
     t0 = time.perf_counter()
-    out_labels, n_objects = None, []
+    out_labels, n_objects, step_ms = None, [], []
     for _ in range(a.steps):
         out_labels = None                                    # the previous step's labels are released before the next step's exist
+        ts = time.perf_counter()
         out_labels, n_objects = step()
+        torch.cuda.synchronize()                             # (a step ends with the stitch's host-side union-find anyway)
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 1))
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_collect()
@@ -376,7 +379,7 @@ def main():
                else f"Mpix/s end-to-end flow+sobel+watershed, {H}x{W} frames", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
                "unit": "Mpix/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist is not None else 1,
                "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / a.steps * 1e3, 2), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": what,
                           "frames_delivered_per_step": T, "window_frames_computed_per_step": frames_computed, "channels": C,

@@ -325,6 +325,14 @@ int tf_linearise(const float *field, int64_t n, double lower, double upper, floa
 int tf_label_extent(const int32_t *labels, const uint8_t *mask, int64_t T, int64_t H, int64_t W, int n_labels,
                     int *tmin, int *tmax, uint8_t *hit, void *stream);
 int tf_apply_lut(const int32_t *labels, int64_t n, const int32_t *lut, int n_lut, int32_t *out, void *stream);
+/* the same gather with ids <= 0 passed through (window stitch, tobac_flow/linking.py:153-161: background -1 and 0 keep
+ * their value while the positive ids are renumbered) */
+int tf_apply_lut_keep_nonpositive(const int32_t *labels, int64_t n, const int32_t *lut, int n_lut, int32_t *out, void *stream);
+/* The elementwise glue of detect_anvils' seeds (tobac_flow/detection.py:547-561, 590-617) in two passes:
+ * tf_field_masks: ge1 = field >= 1, le0_or_nan = (field <= 0) | isnan(field), isnan_out = isnan(field) as 0 / 1 bytes;
+ * tf_merge_seeds: seeds = (bg | isnan) ? -1 : comp. */
+int tf_field_masks(const float *field, int64_t n, uint8_t *ge1, uint8_t *le0_or_nan, uint8_t *isnan_out, void *stream);
+int tf_merge_seeds(const int32_t *comp, const uint8_t *bg, const uint8_t *isnan_in, int64_t n, int32_t *seeds, void *stream);
 /* tf_label: scipy.ndimage.label(input, structure) for a (T, H, W) uint8 volume and a centro-symmetric 3x3x3
  *   structuring element -- used as tobac_flow/utils/label_utils.py:143-180 flat_label (time planes of the structure
  *   zeroed) and for 3-D labelling.  Component numbers follow SciPy (raster order of each component's first pixel).

@@ -511,3 +511,27 @@ def test_detect_cores_without_candidates_behaves_like_the_reference():
         assert outcome[0][1] is outcome[1][1] is ValueError
     else:
         assert outcome[0][1].max() == 0 and np.array_equal(outcome[0][1], outcome[1][1])
+
+
+def test_anvil_seeds_equal_the_scipy_recipe():
+    """tools/synth.anvil_seeds (what bench.py computes inside its timed region: SURVEY 8(d)'s marker recipe through
+    tf_linearise, tf_field_masks, tf_binary_morph, tf_label, tf_merge_seeds) against the same recipe in numpy / SciPy
+    (detection.py:547-561, 590-617): a stack with a NaN patch, erode distances 1 and 2."""
+    import torch
+    from tobac_flow_amd.utils import linearise_field
+    from tools.synth import anvil_seeds
+    rng = np.random.default_rng(12)
+    bt = (ndi.gaussian_filter(rng.normal(size=(6, 90, 132)), (0.7, 4, 4)) * 120 + 262).astype(np.float32)
+    bt[2, 20:31, 40:57] = np.nan
+    s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
+    for erode in (1, 2):
+        lin, seeds = anvil_seeds(torch.from_numpy(bt).cuda(), 270.0, 250.0, erode_distance=erode)
+        want_lin = linearise_field(bt, 270, 250).astype(np.float32)
+        assert np.array_equal(lin.cpu().numpy(), want_lin, equal_nan=True)
+        want = ndi.label(ndi.binary_erosion(want_lin >= 1, structure=s))[0].astype(np.int32)
+        nan = np.isnan(want_lin)
+        bg = ndi.binary_erosion(np.logical_or(want_lin <= 0, nan), structure=np.ones([3, 3, 3]), iterations=erode, border_value=1)
+        bg[nan] = True
+        want[bg] = -1
+        assert (want > 0).any() and (want == -1).any() and (want == 0).any()
+        assert np.array_equal(seeds.cpu().numpy(), want)

@@ -74,6 +74,9 @@ _PROTOS = {
     "tf_linearise": (_c.c_int, [_P, _c.c_int64, _c.c_double, _c.c_double, _P, _P]),
     "tf_label_extent": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _P, _P, _P, _P]),
     "tf_apply_lut": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int, _P, _P]),
+    "tf_apply_lut_keep_nonpositive": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int, _P, _P]),
+    "tf_field_masks": (_c.c_int, [_P, _c.c_int64, _P, _P, _P, _P]),
+    "tf_merge_seeds": (_c.c_int, [_P, _P, _P, _c.c_int64, _P, _P]),
     "tf_label_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64]),
     "tf_label": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _c.c_size_t, _P]),
     "tf_pair_counts_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),

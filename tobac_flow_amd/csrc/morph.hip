@@ -194,6 +194,60 @@ extern "C" int tf_apply_lut(const int32_t *labels, int64_t n, const int32_t *lut
     return TF_OK;
 }
 
+// the same, ids <= 0 kept as they are (the window stitch: background seeds -1 and unlabelled 0 pass through)
+__global__ void __launch_bounds__(256)
+k_apply_lut_keep(const int32_t *__restrict__ labels, int64_t n, const int32_t *__restrict__ lut, int n_lut, int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = labels[i];
+    out[i] = l <= 0 ? l : (l < n_lut ? lut[l] : 0);
+}
+
+extern "C" int tf_apply_lut_keep_nonpositive(const int32_t *labels, int64_t n, const int32_t *lut, int n_lut, int32_t *out, void *stream)
+{
+    TF_REQUIRE(labels && lut && out && n > 0 && n_lut > 0, "tf_apply_lut_keep_nonpositive: bad arguments");
+    hipLaunchKernelGGL(k_apply_lut_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, labels, n, lut, n_lut, out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+// ---- the elementwise glue of detect_anvils' seeds in two passes (detection.py:547-561, 590-617) ----------------------------
+// tf_field_masks: ge1 = field >= 1 (markers = field >= 1, :551-552), le0 = (field <= 0) | isnan(field) (the mask
+// get_watershed_mask erodes, :608-609), isnan = isnan(field) (:607, :616): three byte masks from one read of the field.
+// tf_merge_seeds: seeds = (bg | isnan) ? -1 : comp  (`mask[wh_field_nan] = True; eroded_markers[mask] = -1`, :616, :558).
+__global__ void __launch_bounds__(256)
+k_field_masks(const float *__restrict__ f, int64_t n, uint8_t *__restrict__ ge1, uint8_t *__restrict__ le0, uint8_t *__restrict__ isn)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = f[i];
+    const bool nan = v != v;
+    ge1[i] = v >= 1.f; le0[i] = (v <= 0.f) || nan; isn[i] = nan;
+}
+__global__ void __launch_bounds__(256)
+k_merge_seeds(const int32_t *__restrict__ comp, const uint8_t *__restrict__ bg, const uint8_t *__restrict__ isn, int64_t n,
+              int32_t *__restrict__ seeds)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    seeds[i] = (bg[i] | isn[i]) ? -1 : comp[i];
+}
+extern "C" int tf_field_masks(const float *field, int64_t n, uint8_t *ge1, uint8_t *le0_or_nan, uint8_t *isnan_out, void *stream)
+{
+    TF_REQUIRE(field && ge1 && le0_or_nan && isnan_out && n > 0, "tf_field_masks: bad arguments");
+    hipLaunchKernelGGL(k_field_masks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, field, n, ge1, le0_or_nan, isnan_out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+extern "C" int tf_merge_seeds(const int32_t *comp, const uint8_t *bg, const uint8_t *isnan_in, int64_t n, int32_t *seeds, void *stream)
+{
+    TF_REQUIRE(comp && bg && isnan_in && seeds && n > 0, "tf_merge_seeds: bad arguments");
+    hipLaunchKernelGGL(k_merge_seeds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, comp, bg, isnan_in, n, seeds);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
 // ---- connected-component labelling: scipy.ndimage.label(input, structure) ---------------------------------
 // Union-find on the GPU.  Roots are the smallest raster index of each component, so numbering components by
 // ascending root (an exclusive scan over the root flags) reproduces SciPy's numbering, which labels

@@ -60,6 +60,27 @@ def linearise_field(field, lower_threshold, upper_threshold):
     return out
 
 
+def field_masks(field):
+    """(field >= 1, (field <= 0) | isnan(field), isnan(field)) as bool tensors from ONE read of a float32 field
+    (tf_field_masks: the thresholds of detect_anvils' seeds, detection.py:551-552, 607-609)"""
+    t = _lib.torch()
+    f = field.to(t.float32).contiguous()
+    ge1, le0, isn = (t.empty(f.shape, dtype=t.uint8, device=f.device) for _ in range(3))
+    _lib.check(_lib.lib().tf_field_masks(_lib.ptr(f), f.numel(), _lib.ptr(ge1), _lib.ptr(le0), _lib.ptr(isn), _lib.stream_ptr()),
+               "tf_field_masks")
+    return ge1.view(t.bool), le0.view(t.bool), isn.view(t.bool)
+
+
+def merge_seeds(comp, bg, isnan):
+    """seeds = -1 where (bg | isnan) else comp (tf_merge_seeds; detection.py:558, 616)"""
+    t = _lib.torch()
+    c = comp.to(t.int32).contiguous()
+    out = t.empty_like(c)
+    _lib.check(_lib.lib().tf_merge_seeds(_lib.ptr(c), _lib.ptr(_as_u8_mask(bg)), _lib.ptr(_as_u8_mask(isnan)), c.numel(), _lib.ptr(out),
+                                         _lib.stream_ptr()), "tf_merge_seeds")
+    return out
+
+
 def label_extent(labels, mask=None):
     """(lengths, hit): for labels 1..max the extent along the leading axis (analysis.find_object_lengths) and whether
     the label overlaps `mask` (analysis.mask_labels); numpy arrays of length max label."""

@@ -277,8 +277,7 @@ def apply_global_lut(labels, lut):
     lab = labels.to(torch.int32).contiguous()
     lut_t = torch.from_numpy(np.ascontiguousarray(lut, np.int32)).to(lab.device)
     out = torch.empty_like(lab)
-    _lib.check(_lib.lib().tf_apply_lut(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut_t.numel(), _lib.ptr(out),
-                                       _lib.stream_ptr()), "tf_apply_lut")
-    if bool((lab.min() < 0).item()):                 # tf_apply_lut maps ids outside the table to 0: put negatives back
-        out = torch.where(lab < 0, lab, out)
+    # ids <= 0 (background seeds -1, unlabelled 0) pass through in the same pass
+    _lib.check(_lib.lib().tf_apply_lut_keep_nonpositive(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut_t.numel(), _lib.ptr(out),
+                                                        _lib.stream_ptr()), "tf_apply_lut_keep_nonpositive")
     return out

@@ -110,10 +110,11 @@ def anvil_seeds(bt, lower=270.0, upper=250.0, erode_distance=1):
     component ids, as the drop-in scripts pass them (scripts/dcc_detect_goes.py:221-235) -- and -1 where
     get_watershed_mask(field_lin, erode_distance) (detection.py:547-561).  Returns (field_lin f32, seeds i32)."""
     import scipy.ndimage as ndi
-    import torch
     from tobac_flow_amd import ndimage_dev as nd
-    from tobac_flow_amd.detection import get_watershed_mask
     lin = nd.linearise_field(bt, lower, upper)
     s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
-    comp = nd.label(nd.binary_erosion(lin >= 1, s))[0]
-    return lin, torch.where(get_watershed_mask(lin, erode_distance=erode_distance), torch.full_like(comp, -1), comp)
+    ge1, le0, isn = nd.field_masks(lin)                      # one pass instead of four elementwise ones
+    comp = nd.label(nd.binary_erosion(ge1, s))[0]
+    # get_watershed_mask (detection.py:590-617): (field <= 0 | NaN) eroded by the full cube, border_value 1, NaNs kept
+    bg = nd.binary_erosion(le0, np.ones([3, 3, 3]), iterations=erode_distance, border_value=1)
+    return lin, nd.merge_seeds(comp, bg, isn)
