@@ -661,8 +661,9 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 }
 
 // ---- fused iteration: UpdateMatrices -> 13x13 box sums (double) -> 2x2 solve -----------------------
-// One launch = one Farnebaeck iteration of BOTH directions for a batch of frame pairs.  A workgroup of FBI_T = 128
-// threads (two waves) owns a strip of FBI_OW = 116 output columns (+ 6 halo columns each side) over the WHOLE height.
+// One launch = one Farnebaeck iteration of BOTH directions for a batch of frame pairs.  A workgroup owns a strip of
+// FBI_OW = 116 output columns (+ 6 halo columns each side) over the WHOLE height, with FBI_T = 128 threads (two waves)
+// per direction: 256 threads when both directions run (round 3), so that they share the R rows they both read.
 // Thread j walks DOWN its column: at every row it evaluates M = UpdateMatrices(R0, R1, flow_old) in
 // registers, keeps the last 13 rows of M in a register ring and the running 13-row column sums in
 // double (OpenCV's recurrence, float-rounded differences included); the five column sums go to an LDS row, from
@@ -671,7 +672,7 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 // the kernel moves R0 (20 B) + R1 (20 B) + flow in (8 B) + flow out (8 B).
 // The per-row evaluation is BRANCH-FREE (out-of-image gathers read a valid dummy address and are
 // discarded by selects) so that the loads of FBI_NB rows are in flight together, and the flow of the next
-// row group is fetched before the LDS phase of the current one.  Occupancy: two waves per SIMD = four workgroups per CU.
+// row group is fetched before the LDS phase of the current one.  Occupancy: two waves per SIMD = two four-wave workgroups per CU.
 #define FBI_M 6
 #define FBI_WIN (2 * FBI_M + 1)
 #ifndef FBI_T
@@ -776,7 +777,7 @@ __device__ __forceinline__ void fb_taps_eval(const FbIterCtx &c, int s, const Fb
 // LDS row of column sums: column i lives at i + i/4 (one pad per four) so that both access patterns are
 // conflict-free: the vertical phase writes consecutive i, the horizontal phase reads i = 4 q + k (stride 5).
 #define FBI_VS (FBI_T + FBI_T / 4)
-#define FBI_Q (FBI_OW / 4)          // 61 quads of 4 outputs per strip row
+#define FBI_Q (FBI_OW / 4)          // 29 quads of 4 outputs per strip row
 
 // horizontal phase for one (row g, quad q): 16 column sums per channel -> four 13-wide window sums ->
 // four 2x2 solves.  The four windows share the ten middle terms.
@@ -820,7 +821,8 @@ __device__ __forceinline__ void fb_iter_quad(const FbIterCtx &c, int yo, int g, 
 //   1. evaluate M for NB rows at a time (their loads in flight together), slide the 13-row column sums,
 //      park them in LDS,
 //   2. fetch the flow of the next group's GN rows,
-//   3. one barrier, then the horizontal phase: thread t takes (row t / 61, quad t % 61).
+//   3. one barrier, then the horizontal phase: thread t takes (row t / 29, quad t % 29); a 5-row group has 145 items,
+//      so its threads 0 .. 16 take a second one.
 // ABL 1 (development aid, env TF_FBI_ABLATE=1): synthetic M instead of the gathers; ABL 2: the gathers read row 0 only
 // (same instructions, cache-resident data).
 template <int K0, int G, int GN, int NB, int ABL>
