@@ -10,7 +10,7 @@ marker-controlled watershed) on 5424 x 5424 GOES-16 full-disk-sized frames, one 
 A step is one pass of the hot path over one STACK resident in HBM -- by default BASELINE.json's config F, 144 frames of
 5424 x 5424 -- processed the production way (scripts/dcc_detect_goes.py:153): twelve time windows sharing four frames:
     create_flow(Farneback, vr_steps=1, smoothing_passes=1, interp_method="cubic") over the stack's 143 frame pairs, once
-    per window:  Flow.window (= the Flow create_flow(window) would give, bit for bit: only the end frames differ)
+    per window:  Flow.window_view (= the Flow create_flow(window) would give, bit for bit: only the end frames differ)
                  seeds (linearise_field -> binary_erosion -> label: window-local component ids; -1 background)
                  Flow.sobel(uphill, cubic, float64) -> combined edge field
                  Flow.watershed(connectivity 1)
@@ -301,8 +301,11 @@ def main():
             wins = []
             for lo, hi in bounds:
                 # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame
-                # pair does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426)
-                wins.append(flood_window(flow_all.window(lo, hi), bt[lo:hi], c))
+                # pair does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426);
+                # window_view patches those two frames in the stack's arrays for the duration of the block instead of
+                # copying the window's 7.5 GB of flow vectors (Flow.window)
+                with flow_all.window_view(lo, hi) as flow_w:
+                    wins.append(flood_window(flow_w, bt[lo:hi], c))
             # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
             out = stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins
             del wins
@@ -388,7 +391,7 @@ def main():
                           "seeds": ("every positive seed = 1 (detect_anvils(markers=None))" if a.single_label_seeds else
                                     "SURVEY 8(d): label(binary_erosion(field_lin >= 1)) per window on the device (component ids), "
                                     "-1 where get_watershed_mask(field_lin); computed inside the timed region"),
-                          "stages": f"create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.window + seeds + Flow.sobel(uphill, cubic, f64) "
+                          "stages": f"create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.window_view + seeds + Flow.sobel(uphill, cubic, f64) "
                                     "+ edge field + Flow.watershed(connectivity 1)" + (" + stitch" if n_windows > 1 or world > 1 else ""),
                           "sharding": f"one {T}-frame segment per GPU cut from one sequence, consecutive segments share {a.overlap} frames; "
                                       "label IDs stitched over all windows of all ranks by the reference's overlap rule "

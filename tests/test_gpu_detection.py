@@ -144,7 +144,9 @@ def test_get_combined_filters_runs_and_matches_any_reduction(scene):
 
 
 # ----------------------------------------------------------------------------- section 8f-2: ndimage glue on the GPU
-@pytest.mark.parametrize("width", [45, 48, 4, 260])          # 45: byte-per-thread kernel; multiples of 4: the word kernel (k_binary_morph4)
+# 45: byte-per-thread kernel; multiples of 4: the word kernel (k_binary_morph4); multiples of 16: k_binary_morph16 (16: one
+# thread per row, 1040: 65 threads = two waves per row)
+@pytest.mark.parametrize("width", [45, 48, 4, 260, 16, 1040])
 @pytest.mark.parametrize("iterations,border", [(1, 0), (1, 1), (3, 0), (2, 1)])
 def test_binary_morphology_matches_scipy(iterations, border, width):
     import torch

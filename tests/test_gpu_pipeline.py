@@ -100,6 +100,39 @@ def test_flow_window_equals_create_flow_on_the_slice():
     assert not np.shares_memory(got.forward_flow, whole_np.forward_flow)         # a window never aliases the stack it was cut from
 
 
+def test_flow_window_view_is_the_window_without_the_copy_and_restores_the_stack():
+    """`with flow.window_view(a, b) as w` (what bench.py floods its windows through): w equals window(a, b) bit for bit,
+    aliases the stack's arrays, and the stack is bit-identical to what it was once the block is left -- also when the
+    block raises."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tools.synth import blob_stack
+    bt = blob_stack(8, 96, 130, seed=5)
+    whole = tf.create_flow(bt, model="Farneback", vr_steps=0, smoothing_passes=1, interp_method="linear")
+    f0, b0 = whole.forward_flow.clone(), whole.backward_flow.clone()
+    same = lambda x, y: torch.equal(torch.nan_to_num(x, nan=-777.0), torch.nan_to_num(y, nan=-777.0))
+    for a, b in ((0, 8), (0, 3), (2, 7), (5, 8), (3, 4), (0, 1), (7, 8)):
+        want = whole.window(a, b)
+        with whole.window_view(a, b) as w:
+            assert w.shape == want.shape
+            assert same(w.forward_flow, want.forward_flow) and same(w.backward_flow, want.backward_flow), (a, b)
+            assert w.forward_flow.data_ptr() == whole.forward_flow[a].data_ptr()
+        assert same(whole.forward_flow, f0) and same(whole.backward_flow, b0), (a, b)
+    with pytest.raises(RuntimeError, match="inside"):
+        with whole.window_view(2, 6):
+            raise RuntimeError("inside")
+    assert same(whole.forward_flow, f0) and same(whole.backward_flow, b0)
+    with pytest.raises(ValueError):
+        with whole.window_view(4, 4):
+            pass
+    whole_np = tf.Flow(f0.cpu().numpy(), b0.cpu().numpy())
+    want = whole_np.window(2, 6)
+    with whole_np.window_view(2, 6) as w:
+        assert np.array_equal(w.forward_flow, want.forward_flow, equal_nan=True) and np.array_equal(w.backward_flow, want.backward_flow, equal_nan=True)
+        assert np.shares_memory(w.forward_flow, whole_np.forward_flow)
+    assert np.array_equal(whole_np.forward_flow, f0.cpu().numpy(), equal_nan=True) and np.array_equal(whole_np.backward_flow, b0.cpu().numpy(), equal_nan=True)
+
+
 def test_flow_batches_and_stream_overlap_do_not_change_the_flow(monkeypatch):
     """The flow of a stack does not depend on how its pairs are batched, nor on whether the refinement / smoothing of a
     batch runs on the second stream while the next batch's Farneback is under way (flow.py: _calculate_flow_impl)."""

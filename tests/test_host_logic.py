@@ -58,6 +58,33 @@ def test_select_of_model_errors():
         tf.select_of_model("not_an_of_model")
 
 
+def test_flow_window_and_window_view_on_host_arrays():
+    """Flow.window mirrors the end frames of the cut (flow.py:425-426); window_view is the same window on the stack's own
+    memory, which is restored when the block is left."""
+    import tobac_flow_amd.flow as tf
+    rng = np.random.default_rng(2)
+    fw = rng.normal(size=(6, 4, 5, 2)).astype(np.float32)
+    bw = rng.normal(size=(6, 4, 5, 2)).astype(np.float32)
+    fw[-1], bw[0] = -bw[-1], -fw[0]
+    f0, b0 = fw.copy(), bw.copy()
+    whole = tf.Flow(fw, bw)
+    for a, b in ((0, 6), (1, 4), (0, 2), (3, 6), (2, 3)):
+        w = whole.window(a, b)
+        assert w.shape == (b - a, 4, 5) and not np.shares_memory(w.forward_flow, fw)
+        if b - a > 1:
+            assert np.array_equal(w.forward_flow[:-1], f0[a:b - 1]) and np.array_equal(w.forward_flow[-1], -b0[b - 1])
+            assert np.array_equal(w.backward_flow[1:], b0[a + 1:b]) and np.array_equal(w.backward_flow[0], -f0[a])
+        else:
+            assert np.isnan(w.forward_flow).all() and np.isnan(w.backward_flow).all()
+        with whole.window_view(a, b) as v:
+            assert np.shares_memory(v.forward_flow, fw)
+            assert np.array_equal(v.forward_flow, w.forward_flow, equal_nan=True)
+            assert np.array_equal(v.backward_flow, w.backward_flow, equal_nan=True)
+        assert np.array_equal(fw, f0) and np.array_equal(bw, b0)
+    with pytest.raises(ValueError):
+        whole.window(3, 3)
+
+
 def test_flow_object_contract():
     import tobac_flow_amd.flow as tf
     from tobac_flow_amd.core import AbstractFlow

@@ -84,6 +84,55 @@ k_binary_morph4(const uint32_t *__restrict__ in, int64_t T, int H, int W4, Morph
     out[t * plane4 + (int64_t)y * W4 + x4] = r;
 }
 
+// Sixteen pixels per thread (one uint4; W % 16 == 0, buffers 16-byte aligned): per (dt, dy) row one 16-byte load plus,
+// for dx = -1 / +1, the two neighbour words for the edge bytes -- a quarter of the load instructions of the word form
+// (2.2 -> 0.87 ms per call on a 16 x 5424^2 window).
+__global__ void __launch_bounds__(256)
+k_binary_morph16(const uint4 *__restrict__ in, int64_t T, int H, int W16, MorphRows rw, int op, int border,
+                 uint4 *__restrict__ out)
+{
+    const int x16 = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x16 >= W16 || y >= H) return;
+    const int64_t plane16 = (int64_t)H * W16;
+    const uint32_t bw = border ? 0x01010101u : 0u, bb = border ? 1u : 0u;
+    const uint32_t init = op == 0 ? 0x01010101u : 0u;
+    uint32_t r[4] = {init, init, init, init};
+    const int s = op == 0 ? 1 : -1;                   // SciPy reflects the structure for the dilation
+    for (int i = 0; i < rw.n; i++) {
+        const int64_t tt = t + s * rw.dt[i];
+        const int yy = y + s * rw.dy[i];
+        uint32_t c[4] = {bw, bw, bw, bw}, l = bb, rt = bb;
+        if (tt >= 0 && tt < T && yy >= 0 && yy < H) {
+            const uint4 *row = in + tt * plane16 + (int64_t)yy * W16;
+            const uint4 v = row[x16];
+            c[0] = morph_norm(v.x); c[1] = morph_norm(v.y); c[2] = morph_norm(v.z); c[3] = morph_norm(v.w);
+            if (rw.dxmask[i] & 5) {
+                const uint32_t *words = (const uint32_t *)row;
+                if (x16 > 0) l = morph_norm(words[4 * x16 - 1]) >> 24;
+                if (x16 + 1 < W16) rt = morph_norm(words[4 * x16 + 4]) & 1u;
+            }
+        }
+        const uint32_t m = rw.dxmask[i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t lb = k == 0 ? l : c[k - 1] >> 24, rb = k == 3 ? rt : c[k + 1] & 1u;
+            const uint32_t left = (c[k] << 8) | lb, right = (c[k] >> 8) | (rb << 24);
+            const uint32_t lo = s == 1 ? left : right, hi = s == 1 ? right : left;
+            if (op == 0) {
+                if (m & 1) r[k] &= lo;
+                if (m & 2) r[k] &= c[k];
+                if (m & 4) r[k] &= hi;
+            } else {
+                if (m & 1) r[k] |= lo;
+                if (m & 2) r[k] |= c[k];
+                if (m & 4) r[k] |= hi;
+            }
+        }
+    }
+    out[t * plane16 + (int64_t)y * W16 + x16] = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
 extern "C" int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *structure_host,
                                int op, int iterations, int border_value, uint8_t *out, uint8_t *tmp, void *stream)
 {
@@ -108,12 +157,15 @@ extern "C" int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t 
     // word form: rows of whole words, every buffer 4-byte aligned
     const bool words = W % 4 == 0 && ((uintptr_t)in % 4 == 0) && ((uintptr_t)out % 4 == 0) && (!tmp || (uintptr_t)tmp % 4 == 0);
     const dim3 grid4((unsigned)((W / 4 + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
+    const bool quads = W % 16 == 0 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!tmp || (uintptr_t)tmp % 16 == 0);
+    const dim3 grid16((unsigned)((W / 16 + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
     const uint8_t *src = in;
     for (int it = 0; it < iterations; it++) {
         // ping-pong so that the last iteration writes `out`
         uint8_t *dst = ((iterations - 1 - it) % 2 == 0) ? out : tmp;
         TfProfScope ps(TFK_MORPH, 2.0 * (double)T * H * W, s);
-        if (words) hipLaunchKernelGGL(k_binary_morph4, grid4, block, 0, s, (const uint32_t *)src, T, (int)H, (int)(W / 4), rw, op, border_value, (uint32_t *)dst);
+        if (quads) hipLaunchKernelGGL(k_binary_morph16, grid16, block, 0, s, (const uint4 *)src, T, (int)H, (int)(W / 16), rw, op, border_value, (uint4 *)dst);
+        else if (words) hipLaunchKernelGGL(k_binary_morph4, grid4, block, 0, s, (const uint32_t *)src, T, (int)H, (int)(W / 4), rw, op, border_value, (uint32_t *)dst);
         else hipLaunchKernelGGL(k_binary_morph, grid, block, 0, s, src, T, (int)H, (int)W, tp, op, border_value, dst);
         src = dst;
     }

@@ -119,7 +119,12 @@ k_ws_classify(const int32_t *__restrict__ markers, const int8_t *__restrict__ ma
     cls[i] = m != 0 ? 2 : ((mask ? mask[i] != 0 : true) ? 1 : 0);
 }
 
-// flag = 1 for floodable pixels and for markers with at least one floodable out-neighbour
+// flag = 1 for floodable pixels and for markers with at least one floodable out-neighbour.
+// NN = the neighbour count as a compile-time constant (6 / 18 / 26: connectivity 1 / 2 / 3), 0 = any count.  With a run-time
+// count every g.dt[i] / dy / dx is a scalar load from the kernel arguments followed by a wait and a branch (the generic form
+// compiled to 97 branches and 49 scalar loads); unrolled, the table sits in scalar registers and a marker's NN neighbour
+// classes are in flight together.
+template <int NN>
 __global__ void __launch_bounds__(256)
 k_ws_relevant(const uint8_t *__restrict__ cls, const float *__restrict__ fwd, const float *__restrict__ bwd, WsGeom g,
               uint8_t *__restrict__ flag)
@@ -133,16 +138,28 @@ k_ws_relevant(const uint8_t *__restrict__ cls, const float *__restrict__ fwd, co
     if (c == 2) {
         const float2 fw = ((const float2 *)fwd)[p], bw = ((const float2 *)bwd)[p];
         const int fx = ws_round_flow(fw.x), fy = ws_round_flow(fw.y), bx = ws_round_flow(bw.x), by = ws_round_flow(bw.y);
-        // eight neighbour classes in flight at a time (a marker inside a marker region has to look at all of them)
-        for (int i0 = 0; i0 < g.n_nbr && !f; i0 += 8) {
-            uint8_t v[8];
+        if (NN > 0) {
+            uint8_t v[NN > 0 ? NN : 1];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int64_t n = i0 + j < g.n_nbr ? ws_neighbour(g, t, y, x, fx, fy, bx, by, i0 + j) : -1;
-                v[j] = n >= 0 ? cls[n] : 0;
+            for (int j = 0; j < NN; j++) {               // branch-free: a missing neighbour reads p itself and is discarded
+                const int64_t n = ws_neighbour(g, t, y, x, fx, fy, bx, by, j);
+                const uint8_t vn = cls[n >= 0 ? n : p];
+                v[j] = n >= 0 ? vn : 0;
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) f |= v[j] == 1;
+            for (int j = 0; j < NN; j++) f |= v[j] == 1;
+        } else {
+            // eight neighbour classes in flight at a time (a marker inside a marker region has to look at all of them)
+            for (int i0 = 0; i0 < g.n_nbr && !f; i0 += 8) {
+                uint8_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int64_t n = i0 + j < g.n_nbr ? ws_neighbour(g, t, y, x, fx, fy, bx, by, i0 + j) : -1;
+                    v[j] = n >= 0 ? cls[n] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) f |= v[j] == 1;
+            }
         }
     }
     flag[ws_vpos(g, t, y, x)] = f;               // (the padding positions of edge tiles were zeroed by the caller)
@@ -174,6 +191,7 @@ k_ws_cid(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, cons
     cid[i] = c;
 }
 
+template <int NN>
 __global__ void __launch_bounds__(256)
 k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, const float *__restrict__ bwd,
              const int *__restrict__ cid, WsGeom g, u64 *__restrict__ pix, unsigned *__restrict__ val,
@@ -194,11 +212,23 @@ k_ws_compact(const float *__restrict__ field, const float *__restrict__ fwd, con
     const unsigned v = ws_ordkey(fv);
     pix[id] = (u64)p | (marker ? WS_MARKER_BIT : 0ull);
     val[id] = v;
-    for (int i = 0; i < g.n_nbr; i++) {
-        const int64_t n = ws_neighbour(g, t, y, x, fx, fy, bx, by, i);
-        int cn = -1;
-        if (n >= 0) { cn = cid[n]; if (cn < 0) cn = -1; }
-        nbr[id * g.n_nbr + i] = cn;
+    if (NN > 0) {                                // (see k_ws_relevant: table in scalar registers, all loads in flight together)
+        int cn[NN > 0 ? NN : 1];
+#pragma unroll
+        for (int i = 0; i < NN; i++) {
+            const int64_t n = ws_neighbour(g, t, y, x, fx, fy, bx, by, i);
+            const int cv = cid[n >= 0 ? n : p];
+            cn[i] = n >= 0 ? cv : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < NN; i++) nbr[id * NN + i] = cn[i] < 0 ? -1 : cn[i];
+    } else {
+        for (int i = 0; i < g.n_nbr; i++) {
+            const int64_t n = ws_neighbour(g, t, y, x, fx, fy, bx, by, i);
+            int cn = -1;
+            if (n >= 0) { cn = cid[n]; if (cn < 0) cn = -1; }
+            nbr[id * g.n_nbr + i] = cn;
+        }
     }
     *(ulonglong2 *)&KM[2 * id] = make_ulonglong2(marker ? ((u64)v << 32) : WS_INF, WS_INF);
 }
@@ -991,7 +1021,10 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         } else {
             hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
             if (NV > N) TF_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)NV, s));   // padding positions of the edge tiles
-            hipLaunchKernelGGL(k_ws_relevant, grid, block, 0, s, cls, fwd, bwd, g, flag);
+            if (n_nbr == 6) hipLaunchKernelGGL(k_ws_relevant<6>, grid, block, 0, s, cls, fwd, bwd, g, flag);
+            else if (n_nbr == 18) hipLaunchKernelGGL(k_ws_relevant<18>, grid, block, 0, s, cls, fwd, bwd, g, flag);
+            else if (n_nbr == 26) hipLaunchKernelGGL(k_ws_relevant<26>, grid, block, 0, s, cls, fwd, bwd, g, flag);
+            else hipLaunchKernelGGL(k_ws_relevant<0>, grid, block, 0, s, cls, fwd, bwd, g, flag);
         }
         TF_CHECK_LAUNCH();
         const int rc_scan = ws_scan_flags(flag, scan, NV, scan_tmp, scan_bytes, s, &R);
@@ -1032,7 +1065,10 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         {
             TfProfScope ps(TFK_WS_SETUP, 0.0, s);
             if (rv) hipLaunchKernelGGL(k_wsr_compact, dim3(nb1), dim3(256), 0, s, field, (const int *)cid, *rv, pix, val, nbr, c.KM, d_nan);
-            else hipLaunchKernelGGL(k_ws_compact, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.KM, d_nan);
+            else if (n_nbr == 6) hipLaunchKernelGGL(k_ws_compact<6>, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.KM, d_nan);
+            else if (n_nbr == 18) hipLaunchKernelGGL(k_ws_compact<18>, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.KM, d_nan);
+            else if (n_nbr == 26) hipLaunchKernelGGL(k_ws_compact<26>, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.KM, d_nan);
+            else hipLaunchKernelGGL(k_ws_compact<0>, grid, block, 0, s, field, fwd, bwd, cid, g, pix, val, nbr, c.KM, d_nan);
         }
         TF_CHECK_LAUNCH();
         {   // the reference's `smaller()` (_watershed.pyx:161-164) is not an order on NaN: its heap then pops in an order
