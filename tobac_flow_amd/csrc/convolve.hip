@@ -207,8 +207,13 @@ k_convolve(const typename StackTraits<TS>::In *__restrict__ data, const float *_
 // Measured and NOT adopted (round 2, 12 x 5424^2, fused edge-field variant, 9.9 ms as it stands): staging the two
 // warped-frame regions and the same-step tile of a workgroup in LDS (64 x 4 pixels per workgroup: 18.3 ms; 64 x 16:
 // 12.3 ms; the same structure with the LDS path switched off: 10.7 ms).  The patch loads hit L1 / L2 and are not what
-// bounds the kernel: per pixel it issues ~560 unfused FP32 operations for the two bicubic planes (the reference's
-// 16-term row-major sums admit no sharing between taps) plus ~190 FP64 ones at half rate, a VALU floor of ~5 ms.
+// bounds the kernel: per pixel it issues 944 vector instructions (round-3 counters, profiles/round3_sobel_pmc.txt: the two
+// bicubic planes' 2 x 9 x 16-term row-major sums, which admit no sharing between taps, ~245 float64 operations for the 27
+// differences and their weighted sums, coordinates / alignment tests / coefficients), and 1.74e9 issued wave instructions
+// per launch against 1.72e9 issue slots: the kernel runs AT the VALU issue limit; its time is its instruction count.
+// Round 3, measured and not kept: both warped planes in one pass with every multiply / add of the two planes a packed
+// instruction (v_pk_mul_f32 / v_pk_add_f32): 889 instructions, 108 registers, 9.82 vs 9.9 ms -- packed instructions issue
+// at ~5 instead of ~4.4 cycles (tools/microbench/pk_rate.hip), the count drops by 6 %, the time by 1 %.
 // Also measured: requesting everything a pixel reads before the arithmetic starts (both flows, the same-step
 // neighbourhood and BOTH warped patches: two dependent memory round trips instead of five) costs 166 VGPRs / three
 // waves per SIMD and runs in 11.1 ms; with only the first patch requested early (114 VGPRs, four waves) 10.0 ms;

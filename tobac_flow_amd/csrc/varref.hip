@@ -137,8 +137,6 @@ __device__ __forceinline__ float vr_div_shared(float n, VrRcp k)
     return __builtin_amdgcn_div_fixupf(__fmaf_rn(e, k.r, q), k.d, n);     // the fix-up keeps the sign of a zero numerator
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));   // operand pair of the packed float instructions (v_pk_mul_f32, v_pk_add_f32)
-
 __global__ void __launch_bounds__(256)
 k_vr_selftest_divide(unsigned long long seed, int64_t count, unsigned long long *__restrict__ mismatches)
 {
@@ -334,6 +332,19 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 // Measured alternatives (12 x 5424^2, ms per step for all 110 launches): 128 x 64 tile, thread -> pair q = t + 512 k
 // (row and pair parity vary inside a wave: per-pixel index arithmetic, activity predicates and value selects between the
 // two pixels of a pair), 256 VGPRs: 93.2; the same with 1024 threads / 7 pairs / 128 VGPRs and a small spill: 95.9.
+// Round 3, measured and not adopted (packed float instructions, v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two operations
+// per lane, 1.8 x the scalar float rate in isolation, tools/microbench/pk_rate.hip):
+//  * the (u, v) components of a pixel as one register pair, the two sigma sums packed (8 instead of 16 instructions per
+//    update; the own weight then has to come from LDS, or the register pairs spill): 5.36 instead of 5.46 ms for ONE
+//    refinement on an idle GPU, but 299 instead of 269 ms of kernel time per 48-frame step inside bench.py, back to back
+//    with the other stages (with the weight in registers and one spilled register: 338 ms) -- under sustained load the
+//    packed form is the slower one;
+//  * two ROWS of a thread per packed instruction, the six multiply-adds of the two rows' divisions packed as well (72
+//    instead of 2 x 49 instructions per pair of updates on paper): transposes between the (u, v) layout in LDS and the
+//    row-pair layout in registers, wait states between dependent packed operations and 20 spilled registers: 6.30 ms.
+// What an update costs is its two sequential IEEE divisions (2 x 11 instructions, the reciprocal at quarter rate): v needs
+// the new u, so they cannot be paired, and a per-pixel reciprocal kept across the ten half sweeps would need 52 more
+// registers than the 229 the kernel has.
 #define VRT_W 108
 #define VRT_H 84
 #define VRT_HALO 10
@@ -346,17 +357,6 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 #define VRT_LDS_BYTES (2 * VRT_RH * VRT_PW * 12)
 static_assert(VRT_PW == 64 && VRT_RH % VRT_WAVES == 0, "one wave per region row, whole rows per wave");
 
-// Round 3: the (u, v) components of a pixel are one register pair, so the two sigma sums of an update are packed float
-// instructions (two operations per lane at the issue cost of one; tools/microbench/pk_rate.hip: 1.8 x the scalar rate).
-// Measured and NOT adopted: two ROWS of a thread per packed instruction (register pairs (row 2 kp, row 2 kp + 1), the six
-// multiply-adds of the two rows' divisions packed as well): 72 instead of 2 x 49 instructions per pair of updates on
-// paper, but the transposes between the (u, v) layout in LDS and the row-pair layout in registers, the wait states of
-// dependent packed operations and 20 spilled registers made it slower (6.30 vs 5.36 ms per refinement at 5424^2).
-#define VRT_ROW (VRT_WAVES * VRT_PW)               // elements between two consecutive rows of a thread
-// A pixel's own weight is read back from LDS in the sweeps instead of being held in a register: with the (b1, b2) register
-// pairs of the packed form the kernel otherwise needs 257+ registers and spills (measured: 5.36 ms per refinement at 5424^2
-// this way, 5.46 before the packed form)
-#define VRT_OWN_WEIGHT_LDS 1
 template <bool FAST>
 __global__ void __launch_bounds__(VRT_THREADS, 2)
 k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
@@ -376,18 +376,11 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
     for (int ci = 0; ci < 2; ci++) {
         const int lp = ci ^ par0;
         e_[ci] = (lp + wv) & 1;
-        own_[ci] = (lp * VRT_RH + wv) * VRT_PW + cp;                   // + k * VRT_ROW
+        own_[ci] = (lp * VRT_RH + wv) * VRT_PW + cp;                   // + k * VRT_WAVES * VRT_PW
         const int c = 2 * cp + e_[ci], x = x0 + c;
         colact[ci] = c > 0 && c < VRT_RW - 1 && x >= 0 && x < W;
     }
-    float a11[VRT_K][2], a22[VRT_K][2], a12[VRT_K][2];
-    v2f b12[VRT_K][2];                                 // (b1, b2)
-#ifndef VRT_OWN_WEIGHT_LDS
-    float wp[VRT_K][2];
-#else
-    float wown[VRT_K][2];                              // load phase only: the sweeps read a pixel's own weight back from LDS
-#define wp wown
-#endif
+    float a11[VRT_K][2], a22[VRT_K][2], b1[VRT_K][2], b2[VRT_K][2], a12[VRT_K][2], wp[VRT_K][2];
     // Load phase, ordered so that MANY loads are in flight per wave: an LDS store right behind its own load makes the
     // compiler wait for everything issued before it (the first version ran 26 dependent round trips per thread).
     // 1. dW of one colour at a time into temporaries, then into LDS; 2. all systems and weights straight into their
@@ -407,7 +400,7 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
             }
         }
 #pragma unroll
-        for (int k = 0; k < VRT_K; k++) l_dw[own_[ci] + k * VRT_ROW] = t[k];
+        for (int k = 0; k < VRT_K; k++) l_dw[own_[ci] + k * VRT_WAVES * VRT_PW] = t[k];
     }
 #pragma unroll
     for (int k = 0; k < VRT_K; k++) {
@@ -419,9 +412,8 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
             const int64_t p = in ? (int64_t)y * W + x : 0;
             const float4 sv = S[p];
             const float av = A12[p], wv_ = wt[p];
-            a11[k][ci] = in ? sv.x : 1.f; a22[k][ci] = in ? sv.y : 1.f;
+            a11[k][ci] = in ? sv.x : 1.f; a22[k][ci] = in ? sv.y : 1.f; b1[k][ci] = in ? sv.z : 0.f; b2[k][ci] = in ? sv.w : 0.f;
             if (FAST) { a11[k][ci] = __builtin_amdgcn_rcpf(a11[k][ci]); a22[k][ci] = __builtin_amdgcn_rcpf(a22[k][ci]); }   // divide once, multiply ten times
-            b12[k][ci] = (v2f){in ? sv.z : 0.f, in ? sv.w : 0.f};
             a12[k][ci] = in ? av : 0.f;
             wp[k][ci] = in ? wv_ : 0.f;
         }
@@ -429,7 +421,7 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
 #pragma unroll
     for (int k = 0; k < VRT_K; k++) {
 #pragma unroll
-        for (int ci = 0; ci < 2; ci++) l_wt[own_[ci] + k * VRT_ROW] = wp[k][ci];
+        for (int ci = 0; ci < 2; ci++) l_wt[own_[ci] + k * VRT_WAVES * VRT_PW] = wp[k][ci];
     }
     __syncthreads();
     for (int s = 0; s < n_half; s += 2) {
@@ -440,27 +432,22 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
             const int reach = s + ci + 1;                              // 1-based index of this half sweep
 #pragma unroll
             for (int k = 0; k < VRT_K; k++) {
-                const int r = wv + k * VRT_WAVES, y = y0 + r, o = k * VRT_ROW;
+                const int r = wv + k * VRT_WAVES, y = y0 + r, o = k * VRT_WAVES * VRT_PW;
                 if (r < reach || r > VRT_RH - 1 - reach || y < 0 || y >= H) continue;      // wave-uniform
                 if (colact[ci]) {
-                    // (u, v) as one register pair: the four weight x neighbour products, their sum and "+ b" are packed
-                    // operations -- 8 instructions instead of 16; the two divisions stay sequential (v needs the new u)
-                    const v2f *l2 = (const v2f *)l_dw;
-                    const v2f dl = l2[lft + o], dr = l2[rgt + o], du_ = l2[opb + o - VRT_PW], dd = l2[opb + o + VRT_PW];
+                    const float2 dl = l_dw[lft + o], dr = l_dw[rgt + o];
+                    const float2 du_ = l_dw[opb + o - VRT_PW], dd = l_dw[opb + o + VRT_PW];
                     const float wl = l_wt[lft + o], wu = l_wt[opb + o - VRT_PW];
-#ifndef VRT_OWN_WEIGHT_LDS
                     const float w = wp[k][ci];
-#else
-                    const float w = l_wt[own_[ci] + o];
-#endif
                     float2 d = l_dw[own_[ci] + o];
-                    const v2f sb = wl * dl + w * dr + wu * du_ + w * dd + b12[k][ci];
+                    const float sigmaU = wl * dl.x + w * dr.x + wu * du_.x + w * dd.x;
+                    const float sigmaV = wl * dl.y + w * dr.y + wu * du_.y + w * dd.y;
                     if (FAST) {
-                        d.x += omega * ((sb.x - d.y * a12[k][ci]) * a11[k][ci] - d.x);
-                        d.y += omega * ((sb.y - d.x * a12[k][ci]) * a22[k][ci] - d.y);
+                        d.x += omega * ((sigmaU + b1[k][ci] - d.y * a12[k][ci]) * a11[k][ci] - d.x);
+                        d.y += omega * ((sigmaV + b2[k][ci] - d.x * a12[k][ci]) * a22[k][ci] - d.y);
                     } else {
-                        d.x += omega * ((sb.x - d.y * a12[k][ci]) / a11[k][ci] - d.x);
-                        d.y += omega * ((sb.y - d.x * a12[k][ci]) / a22[k][ci] - d.y);
+                        d.x += omega * ((sigmaU + b1[k][ci] - d.y * a12[k][ci]) / a11[k][ci] - d.x);
+                        d.y += omega * ((sigmaV + b2[k][ci] - d.x * a12[k][ci]) / a22[k][ci] - d.y);
                     }
                     l_dw[own_[ci] + o] = d;
                 }
@@ -477,12 +464,11 @@ k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const
             const int c = 2 * cp + e_[ci], x = x0 + c;
             if (c < VRT_HALO || c >= VRT_HALO + VRT_W || x >= W) continue;
             const int64_t p = (int64_t)y * W + x;
-            float2 d = l_dw[own_[ci] + k * VRT_ROW];
+            float2 d = l_dw[own_[ci] + k * VRT_WAVES * VRT_PW];
             if (Wadd) { const float2 w = Wadd[p]; d = make_float2(w.x + d.x, w.y + d.y); }   // last iteration: the refined flow
             dW_out[p] = d;
         }
     }
-#undef wp
 }
 
 __global__ void __launch_bounds__(256)
@@ -580,13 +566,12 @@ extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int
             const bool last = it == params->fixed_point_iterations - 1;
             TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + (dW_cur ? 8.0 : 0.0) + (last ? 8.0 : 0.0) + 8.0) * (double)n, s);
             float2 *dst = last ? (float2 *)flow : (dW_cur == dW ? dW2 : dW);
-            const dim3 gt((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H);
             if (fast)
-                hipLaunchKernelGGL(k_vr_sor_tile<true>, gt, dim3(VRT_THREADS),
+                hipLaunchKernelGGL(k_vr_sor_tile<true>, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
                                    VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
                                    2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);
             else
-                hipLaunchKernelGGL(k_vr_sor_tile<false>, gt, dim3(VRT_THREADS),
+                hipLaunchKernelGGL(k_vr_sor_tile<false>, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
                                    VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
                                    2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);
             dW_cur = dst;
