@@ -323,6 +323,11 @@ def main():
         out_labels = None                                    # live until the next step starts (otherwise the first timed step
         out_labels, _ = step()                               # pays fresh device allocations: +0.7 s measured)
     barrier()
+    if os.environ.get("TF_BENCH_MEMDEBUG"):
+        ms_ = torch.cuda.memory_stats()
+        print("after warmup: device allocs %d frees %d retries %d, reserved %.1f GB" % (
+            ms_.get("num_device_alloc", -1), ms_.get("num_device_free", -1), ms_.get("num_alloc_retries", -1),
+            torch.cuda.memory_reserved() / 1e9), file=sys.stderr, flush=True)
     n_warm = len(ws_stats)
     _lib.profile_enable(not a.no_kernel_events)
     _lib.profile_collect()
@@ -334,6 +339,11 @@ def main():
         out_labels, n_objects = step()
         torch.cuda.synchronize()                             # (a step ends with the stitch's host-side union-find anyway)
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 1))
+        if os.environ.get("TF_BENCH_MEMDEBUG"):              # development aid: does a timed step still grow the allocator's pool?
+            ms_ = torch.cuda.memory_stats()
+            print("step %d: %.1f ms, device allocs %d frees %d retries %d, reserved %.1f GB" % (
+                len(step_ms), step_ms[-1], ms_.get("num_device_alloc", -1), ms_.get("num_device_free", -1),
+                ms_.get("num_alloc_retries", -1), torch.cuda.memory_reserved() / 1e9), file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_collect()

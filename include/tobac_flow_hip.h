@@ -100,8 +100,9 @@ size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const
 /* How many pairs to hand to tf_farneback_batch at a time.  OpenCV's box filter carries the float rounding of its running
  * column sums down a whole column (optflowgf.cpp FarnebackUpdateFlow_Blur: `vsum[x] += srow1[x] - srow0[x]`), so the
  * iteration kernel cannot split the rows of a column over workgroups: its parallelism is strips x directions x pairs,
- * and a launch costs a whole number of "rounds" of resident workgroups.  Returns the batch size <= max_pairs whose
- * workspace fits max_bytes (0 = no limit) and whose last round is fullest (21 pairs at 5424 x 5424, 16 at 3712 x 3712). */
+ * and a launch costs a whole number of "rounds" of resident workgroups, at every pyramid level.  Returns the batch size
+ * <= max_pairs whose workspace fits max_bytes (0 = no limit) with the best ratio of work to rounds x rows summed over
+ * the levels -- the largest one within 1 % of the best (42 pairs at 5424 x 5424 on 256 CUs: full rounds at levels 0, 1, 2). */
 int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneback_params *p, int64_t max_pairs, size_t max_bytes);
 int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B, int64_t img_stride,
                        int64_t H, int64_t W, const tf_farneback_params *p,

@@ -230,21 +230,21 @@ def workspace(nbytes, tag="default"):
 
 
 def workspace_bytes(tag):
-    """size of the scratch buffer this (device, stream) holds under `tag` (0 if none)"""
+    """bytes of scratch this (device, stream) holds under `tag` and its sub-tags `tag_*` (0 if none)"""
     t = torch()
-    key = (tag, device().index, t.cuda.current_stream().cuda_stream)
+    dev, stream = device().index, t.cuda.current_stream().cuda_stream
     with _WS_LOCK:
-        cur = _WS.get(key)
-    return 0 if cur is None else int(cur.numel())
+        return sum(int(v.numel()) for k, v in _WS.items()
+                   if v is not None and k[1] == dev and k[2] == stream and (k[0] == tag or k[0].startswith(tag + "_")))
 
 
 def release_workspaces(tag=None):
-    """Hand the scratch buffers (all, or those of one tag) back to torch's caching allocator."""
+    """Hand the scratch buffers (all, or those of one tag and of its sub-tags `tag_*`) back to torch's caching allocator."""
     with _WS_LOCK:
         if tag is None:
             _WS.clear()
         else:
-            for key in [k for k in _WS if k[0] == tag]:
+            for key in [k for k in _WS if k[0] == tag or k[0].startswith(tag + "_")]:
                 del _WS[key]
 
 

@@ -305,10 +305,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     interp = select_interp_mode(interp_method) if smoothing_passes > 0 else 1
     # The fused iteration kernel walks whole columns (OpenCV's running column sums cannot be split over rows,
     # csrc/farneback.hip), so its parallelism is strips x directions x PAIRS and a launch costs a whole number of rounds
-    # of resident workgroups.  Batches are as large as the scratch budget allows (the coarse pyramid levels have few
-    # columns: they only fill the GPU with many pairs), cut where the library says a launch's last round is fullest
-    # (tf_farneback_batch_hint: 43 or 21 pairs at 5424^2); what is left at the end goes into one batch, which never
-    # costs more rounds than splitting it.  TF_FLOW_BATCH fixes the batch size (development switch).
+    # of resident workgroups -- at every pyramid level.  Within the scratch budget the library picks the batch whose
+    # rounds are fullest summed over the levels (tf_farneback_batch_hint: 42 pairs at 5424^2 -- full rounds at levels 0, 1
+    # and 2 -- rather than the 54 that fit); what is left at the end goes into one batch, which never costs more rounds
+    # than splitting it.  TF_FLOW_BATCH fixes the batch size (development switch).
     n_pairs = T - 1
     sizes = []
     if "TF_FLOW_BATCH" in os.environ or n_pairs <= 0 or not hasattr(of_model, "params"):
@@ -347,11 +347,35 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         forward.record_stream(side)
         backward.record_stream(side)
 
+    # The 8-bit frames and the raw (unsmoothed) flow vectors of a batch -- 2 x 1.6 GB and 2 x 9.9 GB for 42 pairs at 5424^2
+    # -- live in buffers that stay allocated for the next batch and the next call, like the library's scratch: as fresh
+    # tensors per batch they were carved out of the caching allocator's blocks in a different way in every call, and the
+    # second call of a process paid two more device allocations (25 GB, 0.65 s: bench.py's first timed step).  With the
+    # second stream (TF_FLOW_OVERLAP) two batches are in flight and each needs its own: fresh tensors then.
+    pool = {"B_max": max(sizes) if sizes else 0}             # (shrinks when a batch has to be halved)
+    pooled = side is None and pool["B_max"] > 0
+
+    def batch_buffers(B):
+        n8, nraw, B_max = H * W, H * W * 2 * 4, max(pool["B_max"], B)
+        if pooled:
+            u8 = _lib.workspace(2 * B_max * n8, "farneback_u8")
+            prev8, next8 = u8[:B * n8].view(B, H, W), u8[B_max * n8:(B_max + B) * n8].view(B, H, W)
+        else:
+            prev8, next8 = _lib.empty((B, H, W), t.uint8), _lib.empty((B, H, W), t.uint8)
+        if smoothing_passes == 0:
+            return prev8, next8, None, None
+        if pooled:
+            raw = _lib.workspace(2 * B_max * nraw, "farneback_raw")
+            f = raw[:B * nraw].view(t.float32).view(B, H, W, 2)
+            bk = raw[B_max * nraw:(B_max + B) * nraw].view(t.float32).view(B, H, W, 2)
+        else:
+            f, bk = _lib.empty((B, H, W, 2), t.float32), _lib.empty((B, H, W, 2), t.float32)
+        return prev8, next8, f, bk
+
     def run_batch(i0, B):
         if B <= 0:
             return
-        prev8 = _lib.empty((B, H, W), t.uint8)
-        next8 = _lib.empty((B, H, W), t.uint8)
+        prev8, next8, f, bk = batch_buffers(B)
         for b in range(B):
             fa, fb = frame_pairs(i0 + b)
             if linear:
@@ -363,9 +387,6 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                 next8[b].copy_(_lib.to_dev(p8[1]))
         if smoothing_passes == 0:
             f, bk = forward[i0:i0 + B], backward[i0 + 1:i0 + 1 + B]
-        else:
-            f = _lib.empty((B, H, W, 2), t.float32)
-            bk = _lib.empty((B, H, W, 2), t.float32)
         of_model.calc_batch_dev(prev8, next8, f, bk)
         if vr_steps == 0 and smoothing_passes == 0:
             return
@@ -413,6 +434,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
             _lib.release_workspaces("farneback")
             t.cuda.empty_cache()
             half = B // 2
+            pool["B_max"] = half
             todo, pending = [(i0, B)] + pending, []
             for j0, Bj in todo:
                 while Bj > half:
