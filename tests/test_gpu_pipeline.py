@@ -2,10 +2,12 @@
 refinement -> detect_cores -> get_anvil_markers -> detect_anvils (thick, thin) -> the output-file label contract and the
 per-label statistics.  Every stage has its own parity test; this one checks that the stages fit together (dtypes, label
 ranges, containers) and that the contract's variables are consistent with each other and with the oracle's restatement."""
+import os
 import warnings
 
 import numpy as np
 import pytest
+import scipy.ndimage as ndi
 
 from helpers import blob_sequence
 from oracle import np_dataset
@@ -178,3 +180,51 @@ def test_a_batch_that_does_not_fit_is_halved_and_the_flow_is_the_same(monkeypatc
     assert refused and max(refused) == 9                               # 9 pairs -> 4, 4, 1 -> 2, 2, 2, 2, 1
     for g, w in ((got.forward_flow, want.forward_flow), (got.backward_flow, want.backward_flow)):
         assert torch.equal(torch.nan_to_num(g, nan=-777.0), torch.nan_to_num(w, nan=-777.0))
+
+
+def _rccl_one_rank_worker(rank, port, wins, overlap, out_dir):
+    import torch
+    import torch.distributed as dist
+    from tobac_flow_amd.parallel import stitch_rank_windows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    got = stitch_rank_windows([torch.from_numpy(w).cuda() for w in wins], overlap=overlap, _force_collectives=True)
+    for j, g in enumerate(got):
+        assert g.is_cuda
+        np.save(os.path.join(out_dir, f"w{j}.npy"), g.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stitch_collectives_over_rccl_in_a_one_rank_group(tmp_path):
+    """The collective path of parallel.stitch_rank_windows (all_gather of counts and pair lists on DEVICE tensors over RCCL,
+    pair counting and LUT passes on the GPU) in the only process group a one-GPU box can form: one rank.  Same labels as
+    stitch_window_list.  (The neighbour message between ranks is covered by the gloo tests, tests/test_distributed_cpu.py.)"""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from tobac_flow_amd.parallel import stitch_window_list, window_bounds
+    rng = np.random.default_rng(11)
+    overlap, n_windows = 4, 3
+    T, H, W = 6 * n_windows + overlap, 48, 64
+    truth = ndi.label(ndi.gaussian_filter(rng.normal(size=(T, H, W)), (2.0, 1.5, 1.5)) > 0.03)[0].astype(np.int32)
+    truth[:, :2, :2] = -1
+    wins = []
+    for a, b in window_bounds(T, n_windows, overlap):
+        w = truth[a:b].copy()
+        ids = np.unique(w[w > 0])
+        perm = np.zeros(max(int(w.max()), 0) + 1, np.int32)
+        perm[ids] = rng.permutation(len(ids)) + 1
+        w[w > 0] = perm[w[w > 0]]
+        wins.append(w)
+    want = [x.cpu().numpy() for x in stitch_window_list([torch.from_numpy(w).cuda() for w in wins], overlap=overlap)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_one_rank_worker, args=(port, wins, overlap, str(tmp_path)), nprocs=1, join=True)
+    for j in range(n_windows):
+        assert np.array_equal(np.load(tmp_path / f"w{j}.npy"), want[j]), j

@@ -174,7 +174,7 @@ def stitch_window_list(windows, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=
 
 
 def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=LINK_ATOL, rtol=LINK_RTOL,
-                        short_overlap_ok=False):
+                        short_overlap_ok=False, _force_collectives=False):
     """Make the positive label IDs of ALL windows of ALL ranks globally consistent.
 
     windows: this rank's list of (T_w, H, W) int32 label tensors, consecutive windows sharing `overlap` frames; the
@@ -187,17 +187,18 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
       3. all_gather of the (boundary, id_left, id_right) triples found on each rank's boundaries (its internal ones and
          the one to its right neighbour), padded to the longest list -- a few KB..MB; every rank then runs the same
          union-find and rewrites its own windows (tf_apply_lut).
-    Without an initialised process group (or world size 1) this is stitch_window_list."""
+    Without an initialised process group (or world size 1) this is stitch_window_list (`_force_collectives`: tests run
+    the collective path in a one-rank RCCL group, the only kind a one-GPU box can form)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _force_collectives):
         return stitch_window_list(windows, min_overlap, overlap, atol, rtol, short_overlap_ok)
     if len(windows) == 0:
         raise ValueError("every rank must hold at least one window")
     dev = windows[0].device
     if dist.get_backend(group) == "gloo" and windows[0].is_cuda:
         # gloo has no GPU collectives for these ops: stage the exchanged frames through the host
-        out = stitch_rank_windows([w.cpu() for w in windows], group, min_overlap, overlap, atol, rtol, short_overlap_ok)
+        out = stitch_rank_windows([w.cpu() for w in windows], group, min_overlap, overlap, atol, rtol, short_overlap_ok, _force_collectives)
         return [w.to(dev) for w in out]
     atol, rtol, sel = _rule(min_overlap, overlap, atol, rtol, short_overlap_ok)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
