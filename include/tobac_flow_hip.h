@@ -141,6 +141,12 @@ int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, con
  * tobac_flow/utils/flow_utils.py:80-99 + np.nanmean).  Outputs must not alias inputs. */
 int tf_smooth_flow_step(const float *fwd, const float *bwd, int64_t H, int64_t W, int interp,
                         float *fwd_out, float *bwd_out, void *stream);
+/* The same step with create_flow's clip (tobac_flow/flow.py:60-63, np.minimum(np.maximum(v, -max), max): NaN propagates)
+ * applied to what it stores -- for the LAST smoothing pass of a stack: clipping is elementwise, so it may ride on the
+ * store of the stage that produces the final vectors instead of costing another pass over both flow arrays
+ * (tf_flow_finalize_ends then only mirrors the two end frames).  max_value = +inf: no clip. */
+int tf_smooth_flow_step_clip(const float *fwd, const float *bwd, int64_t H, int64_t W, int interp,
+                             float *fwd_out, float *bwd_out, float max_value, void *stream);
 
 /* single-image warp: tobac_flow/utils/flow_utils.py:80-99 warp_flow (BORDER_CONSTANT NaN) */
 int tf_warp_flow(const float *img, const float *flow, int64_t H, int64_t W, int interp,
@@ -151,6 +157,10 @@ int tf_warp_flow(const float *img, const float *flow, int64_t H, int64_t W, int 
  * tobac_flow/flow.py:60-61 (clip both to [-max_value, max_value]); in place. */
 int tf_flow_finalize(float *fwd, float *bwd, int64_t T, int64_t H, int64_t W, float max_value,
                      void *stream);
+/* tobac_flow/flow.py:425-426 alone, for a stack whose interior is already clipped (tf_smooth_flow_step_clip): writes
+ * forward[T - 1] = -backward[T - 1] and backward[0] = -forward[0] (clipped like the rest), touches nothing else. */
+int tf_flow_finalize_ends(float *fwd, float *bwd, int64_t T, int64_t H, int64_t W, float max_value,
+                          void *stream);
 
 /* ---- a8-a13: semi-Lagrangian convolve / sobel / diff ------------------------------------------
  * replaces tobac_flow/convolve.py:248-348 convolve (with :8-86 warp_flow, :89-144

@@ -135,6 +135,28 @@ def test_flow_window_view_is_the_window_without_the_copy_and_restores_the_stack(
     assert np.array_equal(whole_np.forward_flow, f0.cpu().numpy(), equal_nan=True) and np.array_equal(whole_np.backward_flow, b0.cpu().numpy(), equal_nan=True)
 
 
+@pytest.mark.parametrize("smoothing_passes", [0, 1, 2])
+def test_create_flow_clip_is_the_elementwise_clip_of_the_unclipped_flow(smoothing_passes):
+    """create_flow clips both flow arrays to +-max_value (flow.py:60-63) and mirrors the end frames (flow.py:425-426).  With
+    smoothing the clip rides on the last smoothing pass's store (tf_smooth_flow_step_clip) and only the end frames are
+    written afterwards (tf_flow_finalize_ends); without, one pass does both (tf_flow_finalize).  Either way the result is
+    np.clip of the unclipped flow, NaN kept, and a single-frame stack is all NaN."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tools.synth import blob_stack
+    bt = blob_stack(5, 120, 150, seed=9)
+    kw = dict(model="Farneback", vr_steps=0, smoothing_passes=smoothing_passes, interp_method="linear")
+    free = tf.create_flow(bt, max_value=1e9, **kw)
+    assert float(free.forward_flow.abs().max()) > 0.5                     # the clip below does cut something
+    for mv in (0.4, 20):
+        got = tf.create_flow(bt, max_value=mv, **kw)
+        for g, f in ((got.forward_flow, free.forward_flow), (got.backward_flow, free.backward_flow)):
+            assert torch.equal(g, torch.clamp(f, -mv, mv))
+        assert torch.equal(got.forward_flow[-1], -got.backward_flow[-1]) and torch.equal(got.backward_flow[0], -got.forward_flow[0])
+    one = tf.create_flow(bt[:1], max_value=0.4, **kw)
+    assert bool(torch.isnan(one.forward_flow).all()) and bool(torch.isnan(one.backward_flow).all())
+
+
 def test_flow_batches_and_stream_overlap_do_not_change_the_flow(monkeypatch):
     """The flow of a stack does not depend on how its pairs are batched, nor on whether the refinement / smoothing of a
     batch runs on the second stream while the next batch's Farneback is under way (flow.py: _calculate_flow_impl)."""

@@ -50,8 +50,10 @@ _PROTOS = {
     "tf_varref": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.POINTER(VarRefParams), _P, _P, _c.c_size_t, _P]),
     "tf_varref_ex": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.POINTER(VarRefParams), _P, _c.c_int, _P, _c.c_size_t, _P]),
     "tf_smooth_flow_step": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P, _P]),
+    "tf_smooth_flow_step_clip": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P, _c.c_float, _P]),
     "tf_warp_flow": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P]),
     "tf_flow_finalize": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float, _P]),
+    "tf_flow_finalize_ends": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float, _P]),
     "tf_convolve": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int,
                                _c.c_double, _c.c_int, _P, _c.c_int, _c.c_int64, _c.c_int64, _P]),
     "tf_edge_field": (_c.c_int, [_P, _P, _c.c_int64, _P, _c.c_int, _P]),

@@ -559,10 +559,12 @@ __device__ __forceinline__ float nanmean2(float a, float b) {
     return (float)((double)s / (double)cnt);
 }
 
+__device__ __forceinline__ float flow_clip(float v, float maxv) { return (v != v) ? v : fminf(fmaxf(v, -maxv), maxv); }
+
 template <int METHOD>
 __global__ void __launch_bounds__(256)
 k_smooth(const float *__restrict__ fwd, const float *__restrict__ bwd, int H, int W,
-         float *__restrict__ fo, float *__restrict__ bo)
+         float *__restrict__ fo, float *__restrict__ bo, float maxv)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= W || y >= H) return;
@@ -572,12 +574,14 @@ k_smooth(const float *__restrict__ fwd, const float *__restrict__ bwd, int H, in
     const float bmx = tf_loc(b.x, 0, x), bmy = tf_loc(b.y, 0, y);
     float2 r;
     const float2 wb = sample_flow2<METHOD>(bwd, H, W, fmx, fmy);
-    r.x = nanmean2(f.x, -wb.x);
-    r.y = nanmean2(f.y, -wb.y);
+    // maxv: create_flow's clip (flow.py:60-63, np.minimum(np.maximum(v, -max), max): NaN propagates) applied to what is
+    // stored; +inf = no clip (tf_smooth_flow_step, and every pass but the last of tf_smooth_flow_step_clip's callers)
+    r.x = flow_clip(nanmean2(f.x, -wb.x), maxv);
+    r.y = flow_clip(nanmean2(f.y, -wb.y), maxv);
     ((float2 *)fo)[pix] = r;
     const float2 wf = sample_flow2<METHOD>(fwd, H, W, bmx, bmy);
-    r.x = nanmean2(b.x, -wf.x);
-    r.y = nanmean2(b.y, -wf.y);
+    r.x = flow_clip(nanmean2(b.x, -wf.x), maxv);
+    r.y = flow_clip(nanmean2(b.y, -wf.y), maxv);
     ((float2 *)bo)[pix] = r;
 }
 
@@ -598,23 +602,36 @@ extern "C" int tf_warp_flow(const float *img, const float *flow, int64_t H, int6
     return TF_OK;
 }
 
-extern "C" int tf_smooth_flow_step(const float *fwd, const float *bwd, int64_t H, int64_t W, int interp,
-                                   float *fwd_out, float *bwd_out, void *stream)
+static int smooth_flow_step(const float *fwd, const float *bwd, int64_t H, int64_t W, int interp,
+                            float *fwd_out, float *bwd_out, float max_value, void *stream)
 {
     TF_REQUIRE(fwd && bwd && fwd_out && bwd_out, "tf_smooth_flow_step: null pointer");
     TF_REQUIRE(fwd_out != fwd && fwd_out != bwd && bwd_out != fwd && bwd_out != bwd, "tf_smooth_flow_step: outputs alias inputs");
     TF_REQUIRE(H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15), "tf_smooth_flow_step: bad shape");
     TF_REQUIRE(interp >= 0 && interp <= 3, "tf_smooth_flow_step: bad interp");
+    TF_REQUIRE(max_value >= 0.f, "tf_smooth_flow_step_clip: max_value must be >= 0 (+inf: no clip)");
     if (interp == TF_INTERP_LANCZOS) { const int rc = ensure_lanczos_table(); if (rc) return rc; }
     dim3 block(64, 4), grid((W + 63) / 64, (H + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
     TfProfScope ps(TFK_SMOOTH, 48.0 * (double)H * W, s);
-    if (interp == 0) hipLaunchKernelGGL(k_smooth<0>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
-    else if (interp == 1) hipLaunchKernelGGL(k_smooth<1>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
-    else if (interp == 3) hipLaunchKernelGGL(k_smooth<3>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
-    else hipLaunchKernelGGL(k_smooth<2>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out);
+    if (interp == 0) hipLaunchKernelGGL(k_smooth<0>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out, max_value);
+    else if (interp == 1) hipLaunchKernelGGL(k_smooth<1>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out, max_value);
+    else if (interp == 3) hipLaunchKernelGGL(k_smooth<3>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out, max_value);
+    else hipLaunchKernelGGL(k_smooth<2>, grid, block, 0, s, fwd, bwd, (int)H, (int)W, fwd_out, bwd_out, max_value);
     TF_CHECK_LAUNCH();
     return TF_OK;
+}
+
+extern "C" int tf_smooth_flow_step(const float *fwd, const float *bwd, int64_t H, int64_t W, int interp,
+                                   float *fwd_out, float *bwd_out, void *stream)
+{
+    return smooth_flow_step(fwd, bwd, H, W, interp, fwd_out, bwd_out, INFINITY, stream);
+}
+
+extern "C" int tf_smooth_flow_step_clip(const float *fwd, const float *bwd, int64_t H, int64_t W, int interp,
+                                        float *fwd_out, float *bwd_out, float max_value, void *stream)
+{
+    return smooth_flow_step(fwd, bwd, H, W, interp, fwd_out, bwd_out, max_value, stream);
 }
 
 __global__ void k_flow_finalize(float *__restrict__ fwd, float *__restrict__ bwd, int64_t T, int64_t plane2, float maxv)
@@ -639,6 +656,29 @@ extern "C" int tf_flow_finalize(float *fwd, float *bwd, int64_t T, int64_t H, in
     const int64_t plane2 = H * W * 2;
     dim3 block(256), grid((unsigned)((plane2 + 255) / 256), (unsigned)T);
     hipLaunchKernelGGL(k_flow_finalize, grid, block, 0, (hipStream_t)stream, fwd, bwd, T, plane2, max_value);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
+// The two END frames only (flow.py:425-426), for stacks whose interior was clipped where it was produced
+// (tf_smooth_flow_step_clip): forward[T - 1] = -backward[T - 1], backward[0] = -forward[0], clipped like the rest.
+// The full pass reads and writes both flow arrays once more -- 136 GB for 144 x 5424^2.
+__global__ void k_flow_finalize_ends(float *__restrict__ fwd, float *__restrict__ bwd, int64_t T, int64_t plane2, float maxv)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane2) return;
+    const int64_t last = (T - 1) * plane2 + i;
+    const float f_last = flow_clip(-bwd[last], maxv);
+    fwd[last] = f_last;
+    bwd[i] = flow_clip(-(T == 1 ? f_last : fwd[i]), maxv);
+}
+
+extern "C" int tf_flow_finalize_ends(float *fwd, float *bwd, int64_t T, int64_t H, int64_t W, float max_value, void *stream)
+{
+    TF_REQUIRE(fwd && bwd, "tf_flow_finalize_ends: null pointer");
+    TF_REQUIRE(T > 0 && H > 0 && W > 0 && T < 65536, "tf_flow_finalize_ends: bad shape");
+    const int64_t plane2 = H * W * 2;
+    hipLaunchKernelGGL(k_flow_finalize_ends, dim3((unsigned)((plane2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fwd, bwd, T, plane2, max_value);
     TF_CHECK_LAUNCH();
     return TF_OK;
 }

@@ -118,6 +118,24 @@ k_ws_classify(const int32_t *__restrict__ markers, const int8_t *__restrict__ ma
     const int32_t m = markers[i];
     cls[i] = m != 0 ? 2 : ((mask ? mask[i] != 0 : true) ? 1 : 0);
 }
+// four voxels per thread (markers 16-byte aligned, mask and cls 4-byte aligned): 16-byte loads, one word store
+__global__ void __launch_bounds__(256)
+k_ws_classify4(const int32_t *__restrict__ markers, const int8_t *__restrict__ mask, int64_t n, uint8_t *__restrict__ cls)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 3 < n) {
+        const int4 m = *(const int4 *)(markers + i);
+        const uint32_t k = mask ? *(const uint32_t *)(mask + i) : 0xffffffffu;
+        const int mm[4] = {m.x, m.y, m.z, m.w};
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) out |= (uint32_t)(mm[j] != 0 ? 2 : (((k >> (8 * j)) & 0xffu) ? 1 : 0)) << (8 * j);
+        *(uint32_t *)(cls + i) = out;
+    } else {
+        for (int64_t j = i; j < n; j++) cls[j] = markers[j] != 0 ? 2 : ((mask ? mask[j] != 0 : true) ? 1 : 0);
+    }
+}
 
 // flag = 1 for floodable pixels and for markers with at least one floodable out-neighbour.
 // NN = the neighbour count as a compile-time constant (6 / 18 / 26: connectivity 1 / 2 / 3), 0 = any count.  With a run-time
@@ -1019,7 +1037,9 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             TF_REQUIRE(h_bad != 2, "tf_watershed_raveled: output must be non-zero at every marker location (_watershed.pyx:241-244)");
             hipLaunchKernelGGL(k_wsr_relevant, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, *rv, flag);
         } else {
-            hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
+            if ((uintptr_t)markers % 16 == 0 && (uintptr_t)cls % 4 == 0 && (!mask || (uintptr_t)mask % 4 == 0))
+                hipLaunchKernelGGL(k_ws_classify4, dim3((unsigned)(((N + 3) / 4 + 255) / 256)), dim3(256), 0, s, markers, mask, N, cls);
+            else hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
             if (NV > N) TF_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)NV, s));   // padding positions of the edge tiles
             if (n_nbr == 6) hipLaunchKernelGGL(k_ws_relevant<6>, grid, block, 0, s, cls, fwd, bwd, g, flag);
             else if (n_nbr == 18) hipLaunchKernelGGL(k_ws_relevant<18>, grid, block, 0, s, cls, fwd, bwd, g, flag);

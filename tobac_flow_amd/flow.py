@@ -402,8 +402,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                     last = k == smoothing_passes - 1
                     fo = forward[i0 + b] if last else t.empty_like(fi)
                     bo = backward[i0 + 1 + b] if last else t.empty_like(bi)
-                    _lib.check(L.tf_smooth_flow_step(_lib.ptr(fi), _lib.ptr(bi), H, W, interp, _lib.ptr(fo), _lib.ptr(bo),
-                                                     _lib.stream_ptr()), "tf_smooth_flow_step")
+                    # the clip of create_flow rides on the store of the LAST pass (elementwise: same values as a pass of its
+                    # own over both arrays afterwards, which cost 23 ms per 144 x 5424^2 stack)
+                    _lib.check(L.tf_smooth_flow_step_clip(_lib.ptr(fi), _lib.ptr(bi), H, W, interp, _lib.ptr(fo), _lib.ptr(bo),
+                                                          max_value if last else float("inf"), _lib.stream_ptr()), "tf_smooth_flow_step")
                     fi, bi = fo, bo
 
         if side is None:
@@ -451,9 +453,14 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         free_now, total = t.cuda.mem_get_info()
         if free_now + (t.cuda.memory_reserved() - t.cuda.memory_allocated()) < 0.2 * total:
             _lib.release_workspaces("farneback")
-    # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping
-    _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
-               "tf_flow_finalize")
+    # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping.  With smoothing the interior is already
+    # clipped (above): only the two end frames are left to write
+    if smoothing_passes > 0 or max_value == float("inf"):
+        _lib.check(L.tf_flow_finalize_ends(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
+                   "tf_flow_finalize_ends")
+    else:
+        _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
+                   "tf_flow_finalize")
     if on_device:
         return forward, backward
     return forward.cpu().numpy(), backward.cpu().numpy()
