@@ -58,6 +58,51 @@ def test_select_of_model_errors():
         tf.select_of_model("not_an_of_model")
 
 
+def _stitch_lut_loops(counts, pairs_per_boundary):
+    """the stitch as plain loops (a union-find that attaches the larger root to the smaller, numbering by smallest member)"""
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    n = int(offs[-1])
+    parent = np.arange(n + 1)
+
+    def find(i):
+        while parent[i] != i:
+            parent[i] = parent[parent[i]]
+            i = parent[i]
+        return i
+    for r, pairs in enumerate(pairs_per_boundary):
+        for a, b in np.asarray(pairs, np.int64).reshape(-1, 2):
+            ra, rb = find(offs[r] + a), find(offs[r + 1] + b)
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+    root = np.array([find(i) for i in range(n + 1)])
+    new, nxt = np.zeros(n + 1, np.int64), 0
+    for i in range(1, n + 1):
+        if root[i] == i:
+            nxt += 1
+            new[i] = nxt
+    new = new[root]
+    return [np.concatenate([[0], new[offs[r] + 1: offs[r + 1] + 1]]) for r in range(len(counts))]
+
+
+def test_stitch_lut_equals_the_loop_form_on_random_graphs():
+    """parallel.stitch_lut (sparse connected components, every rank runs it after every step) against the loop form:
+    windows without labels, boundaries without pairs, chains over many windows, repeated pairs."""
+    from tobac_flow_amd.parallel import stitch_lut
+    rng = np.random.default_rng(5)
+    for _ in range(150):
+        n_win = int(rng.integers(1, 8))
+        counts = [int(c) for c in rng.integers(0, 12, size=n_win)]
+        pairs = []
+        for r in range(n_win - 1):
+            k = int(rng.integers(0, 12)) if counts[r] and counts[r + 1] else 0
+            pairs.append(np.stack([rng.integers(1, counts[r] + 1, size=k), rng.integers(1, counts[r + 1] + 1, size=k)], 1)
+                         if k else np.zeros((0, 2), np.int64))
+        got, want = stitch_lut(counts, pairs), _stitch_lut_loops(counts, pairs)
+        assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want)), (counts, pairs)
+    with pytest.raises(ValueError):
+        stitch_lut([2, 2], [np.array([[3, 1]])])
+
+
 def test_flow_window_and_window_view_on_host_arrays():
     """Flow.window mirrors the end frames of the cut (flow.py:425-426); window_view is the same window on the stack's own
     memory, which is restored when the block is left."""

@@ -25,35 +25,42 @@ def window_bounds(T, world, overlap=1):
     return [(edges[i], edges[i + 1] + overlap) for i in range(world)]
 
 
-def _find(parent, i):
-    while parent[i] != i:
-        parent[i] = parent[parent[i]]
-        i = parent[i]
-    return i
-
-
 def stitch_lut(counts, pairs_per_boundary):
     """Global relabelling tables from per-rank label counts and per-boundary (id_left, id_right) pairs.
 
     counts[r] = number of labels (max id) of rank r; pairs_per_boundary[r] = (k, 2) array of label
     pairs that coincide in the frame shared by rank r and rank r+1.  Returns one LUT per rank
     (index = local id, value = global id, contiguous from 1 in order of first appearance over
-    (rank, local id)), identical on every rank."""
+    (rank, local id)), identical on every rank.
+
+    The stitched objects are the connected components of the pair graph (linking.py:153-161); a component is numbered by
+    its smallest member (rank-major, then local id).  Vectorised: every rank runs this after every step, and with eight
+    ranks of twelve windows (4 x 10^5 labels, 2 x 10^5 pairs) a Python-loop union-find took 0.6 s of a 4.3 s step."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
     offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     n = int(offs[-1])
-    parent = np.arange(n + 1)
+    us, vs = [], []
     for r, pairs in enumerate(pairs_per_boundary):
-        for a, b in np.asarray(pairs, np.int64).reshape(-1, 2):
-            ra, rb = _find(parent, offs[r] + a), _find(parent, offs[r + 1] + b)
-            if ra != rb:
-                parent[max(ra, rb)] = min(ra, rb)
-    root = np.array([_find(parent, i) for i in range(n + 1)])
+        p = np.asarray(pairs, np.int64).reshape(-1, 2)
+        if p.size:
+            if p.min() < 1 or p[:, 0].max() > counts[r] or p[:, 1].max() > counts[r + 1]:
+                raise ValueError("stitch_lut: a pair names a label outside 1 .. count of its window")
+            us.append(offs[r] + p[:, 0])
+            vs.append(offs[r + 1] + p[:, 1])
+    node = np.arange(n + 1, dtype=np.int64)
+    if us:
+        u, v = np.concatenate(us), np.concatenate(vs)
+        n_comp, comp = connected_components(coo_matrix((np.ones(u.size, np.int8), (u, v)), shape=(n + 1, n + 1)), directed=False)
+        smallest = np.full(n_comp, n + 1, np.int64)
+        np.minimum.at(smallest, comp, node)                  # smallest member of every component
+        root = smallest[comp]
+    else:
+        root = node
+    is_root = root == node
+    is_root[0] = False                                       # index 0 is "no label"
     new = np.zeros(n + 1, np.int64)
-    nxt = 0
-    for i in range(1, n + 1):           # canonical numbering: by smallest member
-        if root[i] == i:
-            nxt += 1
-            new[i] = nxt
+    new[is_root] = np.arange(1, int(is_root.sum()) + 1)      # canonical numbering: by smallest member
     new = new[root]
     return [np.concatenate([[0], new[offs[r] + 1: offs[r + 1] + 1]]) for r in range(len(counts))]
 
@@ -240,11 +247,10 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
     flat = np.concatenate(triples, 0).reshape(-1) if triples else np.zeros(0, np.int64)
     gathered = gather_i64(torch.from_numpy(flat))
     n_total = int(first_window[-1])
-    pairs = [[] for _ in range(n_total - 1)]
-    for g in gathered:
-        for b, x, y in g.numpy().reshape(-1, 3):
-            pairs[int(b)].append((int(x), int(y)))
-    pairs = [np.asarray(p, np.int64).reshape(-1, 2) for p in pairs]
+    triples_all = np.concatenate([g.numpy().reshape(-1, 3) for g in gathered], 0) if gathered else np.zeros((0, 3), np.int64)
+    triples_all = triples_all[np.argsort(triples_all[:, 0], kind="stable")]
+    cuts = np.searchsorted(triples_all[:, 0], np.arange(1, n_total - 1))
+    pairs = [p.reshape(-1, 2) for p in np.split(triples_all[:, 1:], cuts)] if n_total > 1 else []
     all_counts = [int(v) for c in counts for v in c.tolist()]
     luts = stitch_lut(all_counts, pairs)
     return [apply_global_lut(w, luts[first_window[rank] + k]) for k, w in enumerate(windows)]
