@@ -100,8 +100,25 @@ k_fb_blur3_fused(const TIn *__restrict__ src, int H, int W, const FbKernel kk, f
 #pragma unroll
     for (int j = 0; j < 6; j++) xs[j] = fb_reflect101(min(x0 - 1 + j, W), W);      // columns x0 - 1 .. x0 + 4 (past-the-end ones unused)
     float v0[6], vu[6], vd[6];
+    // uint8 rows of whole, aligned words (the production case): the six bytes of a row come from three word loads -- the
+    // word of the four pixels and its two neighbours -- instead of six byte loads
+    bool words = false;
+    if (sizeof(TIn) == 1) {
+        words = (W & 3) == 0 && (bs_src & 3) == 0 && ((uintptr_t)src & 3) == 0 && x0 >= 4 && x0 + 8 <= W;
+        if (words) {
+            auto row6 = [&](const TIn *S, float (&v)[6]) {
+                const uint32_t *p = (const uint32_t *)(S + x0);
+                const uint32_t l = p[-1], c = p[0], r = p[1];
+                v[0] = (float)(l >> 24); v[1] = (float)(c & 0xffu); v[2] = (float)((c >> 8) & 0xffu); v[3] = (float)((c >> 16) & 0xffu);
+                v[4] = (float)(c >> 24); v[5] = (float)(r & 0xffu);
+            };
+            row6(S0, v0); row6(Su, vu); row6(Sd, vd);
+        }
+    }
+    if (!words) {
 #pragma unroll
-    for (int j = 0; j < 6; j++) { v0[j] = (float)S0[xs[j]]; vu[j] = (float)Su[xs[j]]; vd[j] = (float)Sd[xs[j]]; }
+        for (int j = 0; j < 6; j++) { v0[j] = (float)S0[xs[j]]; vu[j] = (float)Su[xs[j]]; vd[j] = (float)Sd[xs[j]]; }
+    }
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {

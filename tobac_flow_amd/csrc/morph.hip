@@ -464,6 +464,35 @@ k_ccl_flatten(int64_t n, int *__restrict__ parent, uint8_t *__restrict__ isroot)
     isroot[i] = r == (int)i;
 }
 
+// Numbering the roots in ascending order = an exclusive scan of the root flags, of which only the values AT the roots are
+// ever read.  Instead of a device-wide scan that writes one int per voxel (1.9 GB for a 16 x 5424^2 window, 1.3 ms): the
+// roots of every 256-voxel block are counted, the block counts are scanned (n / 256 values), and a second pass over the
+// flags adds a block-local prefix (ballot + popcount) and stores the rank of the roots only.
+__global__ void __launch_bounds__(256)
+k_ccl_count_roots(int64_t n, const uint8_t *__restrict__ isroot, int *__restrict__ block_count) {
+    __shared__ int part[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool f = i < n && isroot[i];
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ void __launch_bounds__(256)
+k_ccl_rank_roots(int64_t n, const uint8_t *__restrict__ isroot, const int *__restrict__ block_base, int *__restrict__ rank) {
+    __shared__ int part[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool f = i < n && isroot[i];
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = __popcll(m);
+    __syncthreads();
+    if (!f) return;
+    int before = __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) before += part[w];
+    rank[i] = block_base[blockIdx.x] + before;
+}
+
 __global__ void __launch_bounds__(256)
 k_ccl_number(int64_t n, const int *__restrict__ parent, const int *__restrict__ rank, int32_t *__restrict__ labels) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,17 +501,14 @@ k_ccl_number(int64_t n, const int *__restrict__ parent, const int *__restrict__ 
     labels[i] = r < 0 ? 0 : rank[r] + 1;
 }
 
-struct CclU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
-typedef hipcub::TransformInputIterator<int, CclU8ToInt, const uint8_t *> CclFlagIter;
-
 extern "C" size_t tf_label_workspace_bytes(int64_t T, int64_t H, int64_t W)
 {
     if (T <= 0 || H <= 0 || W <= 0) return 0;
     const int64_t n = T * H * W;
     size_t scan = 0;
-    CclFlagIter it((const uint8_t *)nullptr, CclU8ToInt());
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, it, (int *)nullptr, (int)(n > 0x7fffffff ? 0x7fffffff : n));
-    return tf_align_up((size_t)n * 4, 256) * 2 + tf_align_up((size_t)n, 256) + tf_align_up(scan, 256) + 4096;
+    const int64_t nblk = (n + 255) / 256;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int *)nullptr, (int *)nullptr, (int)(nblk > 0x7fffffff ? 0x7fffffff : nblk));
+    return tf_align_up((size_t)n * 4, 256) * 2 + tf_align_up((size_t)n, 256) + 2 * tf_align_up((size_t)nblk * 4, 256) + tf_align_up(scan, 256) + 4096;
 }
 
 // labels: int32 (T, H, W) out; n_labels_host: number of components.  Synchronises the stream.
@@ -504,9 +530,10 @@ extern "C" int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, cons
     TfArena ar(ws, ws_bytes);
     int *parent = ar.take<int>(n), *rank = ar.take<int>(n);
     uint8_t *isroot = ar.take<uint8_t>(n);
+    const int64_t nblk = (n + 255) / 256;
+    int *block_count = ar.take<int>(nblk), *block_base = ar.take<int>(nblk);
     size_t scan_bytes = 0;
-    CclFlagIter it0((const uint8_t *)nullptr, CclU8ToInt());
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, it0, (int *)nullptr, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const int *)nullptr, (int *)nullptr, (int)nblk);
     char *scan_tmp = ar.take<char>(scan_bytes ? scan_bytes : 1);
     if (!ar.ok()) { tf_set_error("tf_label: workspace too small"); return TF_ENOMEM; }
     const unsigned nb = (unsigned)((n + 255) / 256);
@@ -516,15 +543,16 @@ extern "C" int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, cons
     if (tp.n) hipLaunchKernelGGL(k_ccl_union, grid, block, 0, s, in, T, (int)H, (int)W, tp, parent);
     hipLaunchKernelGGL(k_ccl_flatten, dim3(nb), dim3(256), 0, s, n, parent, isroot);
     TF_CHECK_LAUNCH();
-    CclFlagIter it(isroot, CclU8ToInt());
-    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, it, rank, (int)n, s));
+    hipLaunchKernelGGL(k_ccl_count_roots, dim3(nb), dim3(256), 0, s, n, (const uint8_t *)isroot, block_count);
+    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, (const int *)block_count, block_base, (int)nblk, s));
+    hipLaunchKernelGGL(k_ccl_rank_roots, dim3(nb), dim3(256), 0, s, n, (const uint8_t *)isroot, (const int *)block_base, rank);
     hipLaunchKernelGGL(k_ccl_number, dim3(nb), dim3(256), 0, s, n, parent, rank, labels);
     TF_CHECK_LAUNCH();
-    int last_rank = 0; uint8_t last_root = 0;
-    TF_CHECK_HIP(hipMemcpyAsync(&last_rank, rank + n - 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    TF_CHECK_HIP(hipMemcpyAsync(&last_root, isroot + n - 1, 1, hipMemcpyDeviceToHost, s));
+    int last_base = 0, last_count = 0;
+    TF_CHECK_HIP(hipMemcpyAsync(&last_base, block_base + nblk - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipMemcpyAsync(&last_count, block_count + nblk - 1, sizeof(int), hipMemcpyDeviceToHost, s));
     TF_CHECK_HIP(hipStreamSynchronize(s));
-    if (n_labels_host) *n_labels_host = last_rank + last_root;
+    if (n_labels_host) *n_labels_host = last_base + last_count;
     return TF_OK;
 }
 
