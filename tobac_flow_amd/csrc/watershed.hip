@@ -183,6 +183,56 @@ k_ws_relevant(const uint8_t *__restrict__ cls, const float *__restrict__ fwd, co
     flag[ws_vpos(g, t, y, x)] = f;               // (the padding positions of edge tiles were zeroed by the caller)
 }
 
+// Connectivity 1 (the six face neighbours), four pixels per thread (W % 4 == 0, cls / flag 4-byte and the flows 16-byte
+// aligned): the classes of a pixel quad, of the quads above and below and of the two edge bytes decide the four in-plane
+// neighbours without further loads; only markers that found no floodable in-plane neighbour read their two flow-displaced
+// t -+ 1 neighbours.  17 loads per quad at most instead of 4 x 10.
+__global__ void __launch_bounds__(256)
+k_ws_relevant6x4(const uint8_t *__restrict__ cls, const float *__restrict__ fwd, const float *__restrict__ bwd, WsGeom g,
+                 uint8_t *__restrict__ flag)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    if (x0 >= g.W || y >= g.H) return;
+    const int64_t p0 = t * g.plane + (int64_t)y * g.W + x0;
+    const uint32_t c = *(const uint32_t *)(cls + p0);
+    const uint32_t is1 = c & 0x01010101u & ~((c >> 1) & 0x01010101u);          // bytes equal to 1 (classes are 0 / 1 / 2)
+    const uint32_t is2 = (c >> 1) & 0x01010101u;                                // bytes equal to 2
+    uint32_t rel = is1;
+    if (is2) {
+        // floodable (class 1) flags of the in-plane neighbours, one byte per pixel of the quad
+        const uint32_t up = y > 0 ? *(const uint32_t *)(cls + p0 - g.W) : 0u, dn = y + 1 < g.H ? *(const uint32_t *)(cls + p0 + g.W) : 0u;
+        const uint32_t lb = x0 > 0 ? cls[p0 - 1] : 0u, rb = x0 + 4 < g.W ? cls[p0 + 4] : 0u;
+        const uint32_t one = 0x01010101u;
+        auto ones = [&](uint32_t w) { return w & one & ~((w >> 1) & one); };
+        uint32_t hit = ones(up) | ones(dn) | ones((c << 8) | lb) | ones((c >> 8) | (rb << 24));
+        uint32_t need = is2 & ~hit;                                             // markers still undecided: look at t -+ 1
+        rel |= is2 & hit;
+        if (need) {
+            const float4 fa = *(const float4 *)(fwd + 2 * p0), fb = *(const float4 *)(fwd + 2 * p0 + 4);
+            const float4 ba = *(const float4 *)(bwd + 2 * p0), bb = *(const float4 *)(bwd + 2 * p0 + 4);
+            const float fx[4] = {fa.x, fa.z, fb.x, fb.z}, fy[4] = {fa.y, fa.w, fb.y, fb.w};
+            const float bx[4] = {ba.x, ba.z, bb.x, bb.z}, by[4] = {ba.y, ba.w, bb.y, bb.w};
+            uint8_t vn[4], vp[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // missing neighbours (outside the volume) and decided pixels read the pixel itself and are discarded
+                const bool want = (need >> (8 * j)) & 1u;
+                const int xn = x0 + j + ws_round_flow(fx[j]), yn = y + ws_round_flow(fy[j]);
+                const int xp = x0 + j + ws_round_flow(bx[j]), yp = y + ws_round_flow(by[j]);
+                const bool okn = want && t + 1 < g.T && (unsigned)xn < (unsigned)g.W && (unsigned)yn < (unsigned)g.H;
+                const bool okp = want && t > 0 && (unsigned)xp < (unsigned)g.W && (unsigned)yp < (unsigned)g.H;
+                const uint8_t a = cls[okn ? (t + 1) * g.plane + (int64_t)yn * g.W + xn : p0 + j];
+                const uint8_t b = cls[okp ? (t - 1) * g.plane + (int64_t)yp * g.W + xp : p0 + j];
+                vn[j] = okn ? a : 0; vp[j] = okp ? b : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) rel |= (uint32_t)(vn[j] == 1 || vp[j] == 1) << (8 * j);
+        }
+    }
+    *(uint32_t *)(flag + ws_vpos(g, t, y, x0)) = rel;        // (x0 % 4 == 0: the quad lies in one tile row; padding positions zeroed by the caller)
+}
+
 // the same numbering for the (t, y, x) entry points, whose scan runs in tile order
 __global__ void __launch_bounds__(256)
 k_ws_cid_tiled(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, const int *__restrict__ scan, WsGeom g,
@@ -1041,7 +1091,13 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
                 hipLaunchKernelGGL(k_ws_classify4, dim3((unsigned)(((N + 3) / 4 + 255) / 256)), dim3(256), 0, s, markers, mask, N, cls);
             else hipLaunchKernelGGL(k_ws_classify, dim3(nb1), dim3(256), 0, s, markers, mask, N, cls);
             if (NV > N) TF_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)NV, s));   // padding positions of the edge tiles
-            if (n_nbr == 6) hipLaunchKernelGGL(k_ws_relevant<6>, grid, block, 0, s, cls, fwd, bwd, g, flag);
+            bool faces = n_nbr == 6;                        // the six face neighbours, in any order?
+            for (int i = 0; faces && i < 6; i++) faces = abs(g.dt[i]) + abs(g.dy[i]) + abs(g.dx[i]) == 1;
+            for (int i = 0; faces && i < 6; i++) for (int j = 0; j < i; j++) faces = faces && !(g.dt[i] == g.dt[j] && g.dy[i] == g.dy[j] && g.dx[i] == g.dx[j]);
+            if (faces && W % 4 == 0 && (uintptr_t)cls % 4 == 0 && (uintptr_t)flag % 4 == 0 && (uintptr_t)fwd % 16 == 0 && (uintptr_t)bwd % 16 == 0)
+                hipLaunchKernelGGL(k_ws_relevant6x4, dim3((unsigned)((W / 4 + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T), block, 0, s,
+                                   (const uint8_t *)cls, fwd, bwd, g, flag);
+            else if (n_nbr == 6) hipLaunchKernelGGL(k_ws_relevant<6>, grid, block, 0, s, cls, fwd, bwd, g, flag);
             else if (n_nbr == 18) hipLaunchKernelGGL(k_ws_relevant<18>, grid, block, 0, s, cls, fwd, bwd, g, flag);
             else if (n_nbr == 26) hipLaunchKernelGGL(k_ws_relevant<26>, grid, block, 0, s, cls, fwd, bwd, g, flag);
             else hipLaunchKernelGGL(k_ws_relevant<0>, grid, block, 0, s, cls, fwd, bwd, g, flag);
