@@ -247,6 +247,46 @@ k_ws_cid_tiled(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag
     cid[p] = c;
 }
 
+// The same ids WITHOUT a device-wide scan over one int per voxel (1.9 GB written and read back per 16 x 5424^2 window): a
+// scan position block of 256 = one 16 x 16 tile of one frame.  k_ws_count_tiles counts the flags of every tile-frame, the
+// counts are scanned (NV / 256 values, 64-bit: the total is checked against 2^30 afterwards), and k_ws_cid_tiles -- one
+// workgroup per tile-frame, thread = pixel of the tile -- adds the prefix inside the tile (ballot + popcount).
+__global__ void __launch_bounds__(256)
+k_ws_count_tiles(const uint8_t *__restrict__ flag, long long *__restrict__ count)
+{
+    __shared__ int part[4];
+    const bool f = flag[(int64_t)blockIdx.x * 256 + threadIdx.x] != 0;
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ void __launch_bounds__(256)
+k_ws_cid_tiles(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, const long long *__restrict__ base, WsGeom g,
+               int *__restrict__ cid)
+{
+    __shared__ int part[4];
+    const int64_t b = blockIdx.x, tile = b / g.T, t = b - tile * g.T;
+    const int ty = (int)(tile / g.n_tx), tx = (int)(tile - (int64_t)ty * g.n_tx);
+    const int y = ty * WS_TILE + (int)(threadIdx.x / WS_TILE), x = tx * WS_TILE + (int)(threadIdx.x % WS_TILE);
+    const bool f = flag[b * 256 + threadIdx.x] != 0;              // (padding positions of edge tiles hold 0)
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = __popcll(m);
+    __syncthreads();
+    if (x >= g.W || y >= g.H) return;
+    const int64_t p = t * g.plane + (int64_t)y * g.W + x;
+    int c = -1;
+    if (f) {
+        int before = __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; w++) before += part[w];
+        const int id = (int)(base[b] + before);
+        c = cls[p] == 1 ? id : -2 - id;
+    }
+    cid[p] = c;
+}
+static_assert(WS_TILE * WS_TILE == 256, "one scan block = one tile of one frame");
+
 // cid from the exclusive scan of flag: id (floodable), -2-id (boundary marker), -1 otherwise
 __global__ void __launch_bounds__(256)
 k_ws_cid(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, const int *__restrict__ scan, int64_t n,
@@ -1069,6 +1109,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     dim3 block(64, 4, 1), grid(rv ? 1 : (g.W + 63) / 64, rv ? 1 : (g.H + 3) / 4, rv ? 1 : (unsigned)T);
     const unsigned nb1 = (unsigned)((N + 255) / 256);
     int64_t R = 0;
+    bool tiles = false;
     {
         TfProfScope ps(TFK_WS_SETUP, 29.0 * (double)N, s);
         if (rv) {
@@ -1103,8 +1144,27 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             else hipLaunchKernelGGL(k_ws_relevant<0>, grid, block, 0, s, cls, fwd, bwd, g, flag);
         }
         TF_CHECK_LAUNCH();
-        const int rc_scan = ws_scan_flags(flag, scan, NV, scan_tmp, scan_bytes, s, &R);
-        if (rc_scan) return rc_scan;
+        // tiled ids: per-tile counts + a scan of the counts (k_ws_cid_tiles adds the prefix inside a tile); the `scan` array
+        // (NV ints) holds the 64-bit counts and bases (2 x NV / 256 x 8 bytes)
+        const int64_t n_tiles = NV / 256;
+        size_t tile_scan_bytes = 0;
+        if (!rv) (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tile_scan_bytes, (const long long *)nullptr, (long long *)nullptr, (int)n_tiles);
+        tiles = !rv && NV % 256 == 0 && n_tiles > 0 && n_tiles < 0x7fffffffll && tile_scan_bytes <= scan_bytes;
+        if (tiles) {
+            long long *t_count = (long long *)scan, *t_base = t_count + n_tiles;
+            hipLaunchKernelGGL(k_ws_count_tiles, dim3((unsigned)n_tiles), dim3(256), 0, s, (const uint8_t *)flag, t_count);
+            size_t tb = scan_bytes;
+            TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, (const long long *)t_count, t_base, (int)n_tiles, s));
+            long long h_last[2] = {0, 0};
+            TF_CHECK_HIP(hipMemcpyAsync(&h_last[0], t_base + n_tiles - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipMemcpyAsync(&h_last[1], t_count + n_tiles - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            R = h_last[0] + h_last[1];
+            TF_REQUIRE(R <= 0x3fffff00ll, "tf_watershed: more than 2^30 relevant pixels in one call (use time windows)");
+        } else {
+            const int rc_scan = ws_scan_flags(flag, scan, NV, scan_tmp, scan_bytes, s, &R);
+            if (rc_scan) return rc_scan;
+        }
     }
     st[6] = R;
     if (ws_bytes < ws_full_bytes(N, NV) + ws_compact_bytes(R > 0 ? R : 1, n_nbr, depth_max)) {
@@ -1112,6 +1172,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         return TF_ENOMEM;
     }
     if (rv) hipLaunchKernelGGL(k_ws_cid, dim3(nb1), dim3(256), 0, s, cls, flag, scan, N, cid);
+    else if (tiles) hipLaunchKernelGGL(k_ws_cid_tiles, dim3((unsigned)(NV / 256)), dim3(256), 0, s, (const uint8_t *)cls, (const uint8_t *)flag,
+                                       (const long long *)((long long *)scan + NV / 256), g, cid);
     else hipLaunchKernelGGL(k_ws_cid_tiled, grid, block, 0, s, (const uint8_t *)cls, (const uint8_t *)flag, (const int *)scan, g, cid);
     TF_CHECK_LAUNCH();
     int h_cnt[WS_BATCH + 8];
