@@ -250,40 +250,51 @@ k_ws_cid_tiled(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag
 // The same ids WITHOUT a device-wide scan over one int per voxel (1.9 GB written and read back per 16 x 5424^2 window): a
 // scan position block of 256 = one 16 x 16 tile of one frame.  k_ws_count_tiles counts the flags of every tile-frame, the
 // counts are scanned (NV / 256 values, 64-bit: the total is checked against 2^30 afterwards), and k_ws_cid_tiles -- one
-// workgroup per tile-frame, thread = pixel of the tile -- adds the prefix inside the tile (ballot + popcount).
+// wave per tile-frame -- adds the prefix inside the tile (ballots + popcounts).
+// One WAVE per tile-frame, a thread = four consecutive pixels of a tile row (one word of flags, one int4 of ids): the
+// prefix inside the tile comes from four ballots, no LDS, no barrier.
 __global__ void __launch_bounds__(256)
-k_ws_count_tiles(const uint8_t *__restrict__ flag, long long *__restrict__ count)
+k_ws_count_tiles(const uint8_t *__restrict__ flag, int64_t n_tiles, long long *__restrict__ count)
 {
-    __shared__ int part[4];
-    const bool f = flag[(int64_t)blockIdx.x * 256 + threadIdx.x] != 0;
-    const unsigned long long m = __ballot(f);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_tiles) return;                                      // (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = *(const uint32_t *)(flag + b * 256 + lane * 4);
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) c += __popcll(__ballot(((w >> (8 * j)) & 0xffu) != 0));
+    if (lane == 0) count[b] = c;
 }
 __global__ void __launch_bounds__(256)
-k_ws_cid_tiles(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, const long long *__restrict__ base, WsGeom g,
-               int *__restrict__ cid)
+k_ws_cid_tiles(const uint8_t *__restrict__ cls, const uint8_t *__restrict__ flag, const long long *__restrict__ base, int64_t n_tiles,
+               WsGeom g, int *__restrict__ cid)
 {
-    __shared__ int part[4];
-    const int64_t b = blockIdx.x, tile = b / g.T, t = b - tile * g.T;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_tiles) return;                                      // (wave-uniform)
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = b / g.T, t = b - tile * g.T;
     const int ty = (int)(tile / g.n_tx), tx = (int)(tile - (int64_t)ty * g.n_tx);
-    const int y = ty * WS_TILE + (int)(threadIdx.x / WS_TILE), x = tx * WS_TILE + (int)(threadIdx.x % WS_TILE);
-    const bool f = flag[b * 256 + threadIdx.x] != 0;              // (padding positions of edge tiles hold 0)
-    const unsigned long long m = __ballot(f);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) part[wave] = __popcll(m);
-    __syncthreads();
-    if (x >= g.W || y >= g.H) return;
-    const int64_t p = t * g.plane + (int64_t)y * g.W + x;
-    int c = -1;
-    if (f) {
-        int before = __popcll(m & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; w++) before += part[w];
-        const int id = (int)(base[b] + before);
-        c = cls[p] == 1 ? id : -2 - id;
+    const int y = ty * WS_TILE + lane / 4, x0 = tx * WS_TILE + (lane & 3) * 4;
+    const uint32_t w = *(const uint32_t *)(flag + b * 256 + lane * 4);      // (padding positions of edge tiles hold 0)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    bool f[4]; unsigned long long m[4];
+    int before = 0;                                                // flags of the lanes below, all four byte positions
+#pragma unroll
+    for (int j = 0; j < 4; j++) { f[j] = ((w >> (8 * j)) & 0xffu) != 0; m[j] = __ballot(f[j]); before += __popcll(m[j] & below); }
+    if (y >= g.H || x0 >= g.W) return;
+    const int64_t p0 = t * g.plane + (int64_t)y * g.W + x0;
+    const int id0 = (int)base[b] + before;
+    int c[4], run = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c[j] = -1;
+        if (f[j]) { const int id = id0 + run; c[j] = cls[p0 + j] == 1 ? id : -2 - id; run++; }
     }
-    cid[p] = c;
+    if (x0 + 3 < g.W && (((uintptr_t)(cid + p0)) & 15) == 0) *(int4 *)(cid + p0) = make_int4(c[0], c[1], c[2], c[3]);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (x0 + j < g.W) cid[p0 + j] = c[j];
+    }
 }
 static_assert(WS_TILE * WS_TILE == 256, "one scan block = one tile of one frame");
 
@@ -1152,7 +1163,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         tiles = !rv && NV % 256 == 0 && n_tiles > 0 && n_tiles < 0x7fffffffll && tile_scan_bytes <= scan_bytes;
         if (tiles) {
             long long *t_count = (long long *)scan, *t_base = t_count + n_tiles;
-            hipLaunchKernelGGL(k_ws_count_tiles, dim3((unsigned)n_tiles), dim3(256), 0, s, (const uint8_t *)flag, t_count);
+            hipLaunchKernelGGL(k_ws_count_tiles, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, (const uint8_t *)flag, n_tiles, t_count);
             size_t tb = scan_bytes;
             TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, (const long long *)t_count, t_base, (int)n_tiles, s));
             long long h_last[2] = {0, 0};
@@ -1172,8 +1183,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         return TF_ENOMEM;
     }
     if (rv) hipLaunchKernelGGL(k_ws_cid, dim3(nb1), dim3(256), 0, s, cls, flag, scan, N, cid);
-    else if (tiles) hipLaunchKernelGGL(k_ws_cid_tiles, dim3((unsigned)(NV / 256)), dim3(256), 0, s, (const uint8_t *)cls, (const uint8_t *)flag,
-                                       (const long long *)((long long *)scan + NV / 256), g, cid);
+    else if (tiles) hipLaunchKernelGGL(k_ws_cid_tiles, dim3((unsigned)((NV / 256 + 3) / 4)), dim3(256), 0, s, (const uint8_t *)cls, (const uint8_t *)flag,
+                                       (const long long *)((long long *)scan + NV / 256), NV / 256, g, cid);
     else hipLaunchKernelGGL(k_ws_cid_tiled, grid, block, 0, s, (const uint8_t *)cls, (const uint8_t *)flag, (const int *)scan, g, cid);
     TF_CHECK_LAUNCH();
     int h_cnt[WS_BATCH + 8];
