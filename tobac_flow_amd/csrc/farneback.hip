@@ -602,7 +602,9 @@ k_fb_polyexp5(const float *__restrict__ I, int H, int W, FbPoly pp, float *__res
         for (int k = 1; k <= n; k++) {
             const double tg = a[m + k] + a[m - k];
             g0 = g[k];
-            b1 += tg * g0; b4 += tg * xxg[k];
+            // tg and the coefficients are float values: their product is exact in double, so ONE fused multiply-add returns
+            // exactly the value of the reference's multiply followed by its add
+            b1 = __fma_rn(tg, (double)g0, b1); b4 = __fma_rn(tg, (double)xxg[k], b4);
             b2 += (a[m + k] - a[m - k]) * xg[k];
             b3 += (b[m + k] + b[m - k]) * g0;
             b6 += (b[m + k] - b[m - k]) * xg[k];
