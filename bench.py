@@ -219,6 +219,10 @@ def main():
                     help="frames consecutive windows (and ranks) share; the stitch compares all but the first and last of them")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--tie-order", choices=["raster", "reference"], default="raster",
+                    help="equal-valued markers whose pop order decides a label: raster order (default; such voxels are counted in "
+                         "`watershed`) or the reference heap's own order (on_ambiguous='reference': labels bit for bit the "
+                         "reference's, at the cost of a sequential host replay per flood that has such ties)")
     ap.add_argument("--single-label-seeds", action="store_true",
                     help="round-2 seeds (every positive seed = 1, detect_anvils(markers=None)) instead of component-labelled ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -271,6 +275,7 @@ def main():
         bt[f0:f1] = blob_stack(f1 - f0, H, W, seed=20240601, t0=rank * (T - a.overlap) + f0)
     nbr = neighbour_offsets(1)
     ws_stats = []                                            # tf_watershed stats of every window of every step (warmup included)
+    ref_order_us = []                                        # --tie-order reference: host replay time of every flood that needed it
 
     def flood_window(flow, w, c):
         """seeds -> edge field -> watershed of channel c over the window `w` of the stack (Flow `flow`): one label volume"""
@@ -281,7 +286,9 @@ def main():
         e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
         st = {}
-        lab = watershed_dev(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="ignore")
+        lab = watershed_dev(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="reference" if a.tie_order == "reference" else "ignore")
+        if st.get("reference_order", {}).get("microseconds", 0) > 0:
+            ref_order_us.append(st["reference_order"]["microseconds"])
         ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
         return lab
 
@@ -418,7 +425,11 @@ def main():
                             "chain_depth_used": int(timed[:, 8].max()), "chain_depth_used_min": int(timed[:, 8].min()),
                             "pixels_depending_on_equal_valued_marker_order": int(timed[:, 9].sum() // a.steps),
                             "marker_tie_points": int(timed[:, 10].sum() // a.steps), "ties_left_by_depth_cut_off": int(timed[:, 11].sum()),
-                            "floods_probing": int((timed[:, 5] >= 0).sum()), "floods_skipping_root_phase": int((timed[:, 5] < 0).sum())}
+                            "floods_probing": int((timed[:, 5] >= 0).sum()), "floods_skipping_root_phase": int((timed[:, 5] < 0).sum()),
+                            "tie_order": a.tie_order}
+        if a.tie_order == "reference":
+            out["watershed"]["reference_order_replays"] = len(ref_order_us)          # warm-up floods included
+            out["watershed"]["reference_order_replay_ms_mean"] = round(float(np.mean(ref_order_us)) / 1e3, 1) if ref_order_us else 0.0
         # per-stage rates, and the measured device-to-device copy rate as the practical HBM ceiling
         stage_of = {"to8bit_pair": "flow", "fb_gaussian_blur": "flow", "fb_resize": "flow", "fb_polyexp": "flow",
                     "fb_update_matrices": "flow", "fb_blur_solve": "flow", "fb_iteration_fused": "flow", "smooth_flow": "flow",

@@ -260,9 +260,15 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
  *   keys only, no labels -- up to the largest marker value at which such a tie occurs, and returns each marker's pop
  *   rank; the device then repeats its root phase with the pop rank in place of the raster index as the last component
  *   of the chain comparison, and writes the labels.  The call returns TF_OK: the labels are the reference's bit for
- *   bit.  Cost: sequential, O((seeds + flooded pixels below that value) log n) on one host core, plus the transfer of
- *   the flood graph (28 B per relevant pixel) and of 8 B per seed; nothing extra when no such tie exists.
- *   stats[13] = items the replay popped, [14] = seeds, [15] = microseconds the whole detour took (0 if not needed). */
+ *   bit.  Only the heap items at or below that value have to be followed: every other item compares larger than all of
+ *   them and only matters through the heap position it occupies, so the replay keeps those "small" items alone (an
+ *   occupancy bitmap over the positions + a position -> item table) and the device lists and sends only the seeds
+ *   among them.  Cost: sequential, O(small items x log n) bit tests on one host core, plus the transfer of the flood
+ *   graph (28 B per relevant pixel) and 12 B per small seed; nothing extra when no such tie exists.  (With more small
+ *   seeds than relevant pixels -- no staging room -- or TF_WS_REFERENCE_DENSE=1 in the environment: the dense form,
+ *   every seed sent and pushed.)
+ *   stats[13] = items the replay popped, [14] = seeds the replay was given, [15] = microseconds the whole detour took
+ *   (0 if not needed). */
 #define TF_WS_REFERENCE_ORDER 2
 int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
                     const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,

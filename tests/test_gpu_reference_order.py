@@ -112,8 +112,29 @@ def test_reference_order_costs_nothing_when_no_tie_matters(tf, golden_ws):
     c = golden_ws["E_const_plateau_c1"]
     lab = watershed_dev(_lib.to_dev(c["fwd"], torch.float32), _lib.to_dev(c["bwd"], torch.float32), _lib.to_dev(c["field"], torch.float32),
                         _lib.to_dev(c["markers"], torch.int32), None, neighbour_offsets(int(c["conn"])), stats=st, on_ambiguous="reference")
-    assert st["reference_order"]["replayed_pops"] > 0 and st["reference_order"]["seeds"] == int((c["markers"] != 0).sum())
+    # the replay is handed the seeds at or below the largest tie value only (all of them on a constant plateau)
+    assert st["reference_order"]["replayed_pops"] > 0 and 0 < st["reference_order"]["seeds"] <= int((c["markers"] != 0).sum())
     assert np.array_equal(lab.cpu().numpy(), c["labels"])
+
+
+@pytest.mark.parametrize("seed", range(0, 24, 2))
+def test_sparse_and_dense_replay_agree(tf, seed, monkeypatch):
+    """ws_reference_ranks_sparse (the default: only the heap items at or below the largest tie value are followed, the
+    others are anonymous occupants of their positions) against ws_reference_ranks (every seed pushed;
+    TF_WS_REFERENCE_DENSE=1): same labels, same number of replayed pops, never more seeds."""
+    import torch
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    fwd, bwd, field, markers, mask, conn = _tie_heavy_case(seed)
+    args = (_lib.to_dev(fwd, torch.float32), _lib.to_dev(bwd, torch.float32), _lib.to_dev(field, torch.float32),
+            _lib.to_dev(markers, torch.int32), None if mask is None else _lib.to_dev(mask.astype(np.int8), torch.int8), neighbour_offsets(conn))
+    st_sparse, st_dense = {}, {}
+    lab_sparse = watershed_dev(*args, stats=st_sparse, on_ambiguous="reference").cpu().numpy()
+    monkeypatch.setenv("TF_WS_REFERENCE_DENSE", "1")
+    lab_dense = watershed_dev(*args, stats=st_dense, on_ambiguous="reference").cpu().numpy()
+    assert np.array_equal(lab_sparse, lab_dense)
+    a, b = st_sparse["reference_order"], st_dense["reference_order"]
+    assert a["replayed_pops"] == b["replayed_pops"] and a["seeds"] <= b["seeds"]
 
 
 def test_config_C_window_with_component_seeds_in_reference_order(tf):

@@ -33,6 +33,8 @@
 // changed; a sweep costs work proportional to the frontier, not to the volume.
 #include "tf_common.h"
 #include <string.h>
+#include <time.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <hipcub/hipcub.hpp>
 
@@ -832,6 +834,49 @@ k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, co
     if (amb) amb[i] = a;
 }
 
+// SMALL seeds: the seeds whose key is <= vmax.  Only their order matters to the replay (ws_reference_ranks_sparse below), and
+// they are few (0.3 % of the seeds of a detect_anvils window): they are listed in seed order -- per 256-voxel block a count,
+// a scan of the counts, then the list written at block base + prefix inside the block -- with their seed number `k` (= their
+// position in the reference's heap when they are pushed), value key and compact id.
+__global__ void __launch_bounds__(256)
+k_ws_small_count(const uint8_t *__restrict__ cls, const float *__restrict__ field, int64_t n, unsigned vmax, int *__restrict__ count)
+{
+    __shared__ int part[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool f = i < n && cls[i] == 2 && ws_ordkey(field[i]) <= vmax;
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ void __launch_bounds__(256)
+k_ws_small_list(const uint8_t *__restrict__ cls, const int *__restrict__ scan, const int *__restrict__ cid,
+                const float *__restrict__ field, int64_t n, unsigned vmax, const int *__restrict__ base,
+                int *__restrict__ out_k, unsigned *__restrict__ out_val, int *__restrict__ out_cid)
+{
+    __shared__ int part[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned key = 0;
+    bool f = i < n && cls[i] == 2;
+    if (f) { key = ws_ordkey(field[i]); f = key <= vmax; }
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = __popcll(m);
+    __syncthreads();
+    if (!f) return;
+    int slot = base[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) slot += part[w];
+    const int c = cid[i];
+    out_k[slot] = scan[i]; out_val[slot] = key; out_cid[slot] = c <= -2 ? -2 - c : -1;
+}
+// 1 for the markers of the compact set (the replay never pushes them as flooded pixels)
+__global__ void __launch_bounds__(256)
+k_ws_marker_bytes(const u64 *__restrict__ pix, int64_t R, uint8_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) out[i] = (pix[i] & WS_MARKER_BIT) ? 1 : 0;
+}
+
 // ---- reference order of equal-valued markers (TF_WS_REFERENCE_ORDER) ------------------------------------------------
 // flag[i] = 1 for every seed (cls 2): their exclusive scan numbers the seeds in raster order = marker_locations order
 __global__ void __launch_bounds__(256)
@@ -1077,6 +1122,163 @@ static int64_t ws_reference_ranks(int64_t M, const unsigned *seed_val, const int
     return popped;
 }
 
+// THE SAME REPLAY WITHOUT THE LARGE ITEMS (round 3).  Call an item SMALL when the loop above would still pop it --
+// v < vmax, or v == vmax with age 0 -- and LARGE otherwise.  A small item compares smaller than every large one, the heap
+// order keeps every descendant of a large node large, and the loop stops at the first large top: so whatever the large items
+// do among themselves (which of them a sift moves where) never moves a small item, and the trajectory of the small items
+// depends on the large ones only through the POSITIONS they occupy.  The replay therefore keeps the small items alone --
+// an occupancy bitmap over the heap positions plus a position -> item table -- and treats every other position below
+// `items` as an anonymous large item: pushing a large item just lengthens the heap; a small item sifting up walks through
+// unoccupied ancestors without a comparison; a large item sifting down from the root follows the smaller of its small
+// children until both children are large.  With S small seeds out of M (S / M = 0.3 % on detect_anvils fields) the replay
+// costs O(S log M) bit tests instead of M pushes, and only the small seeds cross PCIe.  Same ranks as ws_reference_ranks
+// (tests/test_gpu_reference_order.py compares the two; TF_WS_REFERENCE_DENSE=1 selects the dense form).
+struct WsPosMap {                                                       // open addressing, linear probing, backward-shift deletion
+    int64_t *key = nullptr; WsRefItem *val = nullptr; size_t cap = 0, n = 0;
+    ~WsPosMap() { free(key); free(val); }
+    static size_t hash(int64_t k) { uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull; return (size_t)(x ^ (x >> 29)); }
+    bool init(size_t want) {
+        cap = 1024; while (cap < want) cap <<= 1;
+        key = (int64_t *)malloc(cap * sizeof(int64_t)); val = (WsRefItem *)malloc(cap * sizeof(WsRefItem));
+        if (!key || !val) return false;
+        for (size_t i = 0; i < cap; i++) key[i] = -1;
+        n = 0;
+        return true;
+    }
+    bool grow() {
+        WsPosMap b; if (!b.init(cap * 2)) return false;
+        for (size_t i = 0; i < cap; i++) if (key[i] >= 0) b.put_nogrow(key[i], val[i]);
+        std::swap(key, b.key); std::swap(val, b.val); std::swap(cap, b.cap); std::swap(n, b.n);
+        return true;
+    }
+    void put_nogrow(int64_t k, const WsRefItem &v) {
+        size_t i = hash(k) & (cap - 1);
+        while (key[i] >= 0 && key[i] != k) i = (i + 1) & (cap - 1);
+        if (key[i] < 0) n++;
+        key[i] = k; val[i] = v;
+    }
+    bool put(int64_t k, const WsRefItem &v) { if ((n + 1) * 2 > cap && !grow()) return false; put_nogrow(k, v); return true; }
+    WsRefItem get(int64_t k) const {                                  // the key must be present
+        size_t i = hash(k) & (cap - 1);
+        while (key[i] != k) i = (i + 1) & (cap - 1);
+        return val[i];
+    }
+    void erase(int64_t k) {                                           // the key must be present
+        size_t i = hash(k) & (cap - 1);
+        while (key[i] != k) i = (i + 1) & (cap - 1);
+        size_t j = i;
+        for (;;) {
+            j = (j + 1) & (cap - 1);
+            if (key[j] < 0) break;
+            const size_t h = hash(key[j]) & (cap - 1);
+            // the entry at j may move to the hole at i unless its home slot lies cyclically in (i, j]
+            if ((i <= j) ? (i < h && h <= j) : (i < h || h <= j)) continue;
+            key[i] = key[j]; val[i] = val[j]; i = j;
+        }
+        key[i] = -1; n--;
+    }
+};
+
+static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const int *sk, const unsigned *sval, const int *scid, int64_t R,
+                                         const uint8_t *is_marker, const unsigned *val, const int *nbr, int n_nbr, unsigned vmax, int *rank)
+{
+    // an item = (key, id) with key = (v << 32) | age: `smaller` (:161-164) is the order of the keys.  LARGE = the all-ones
+    // key: larger than every small item (value keys stop at that of +inf, NaN fields are refused), equal to itself -- a
+    // sift never swaps two of them, which is all the replay needs to know about the large items.
+    struct Item { u64 key; int32_t id; int32_t pad; };
+    const Item LARGE{~0ull, -1, 0};
+    const int64_t max_items = M + R + 1;
+    // The small items form an ancestor-closed set (every ancestor of a small item is small): they sit in the top of the
+    // heap.  Positions below `n_top` -- a power of two >= 4 S -- are a plain array initialised to LARGE (the two children
+    // of a node share a cache line: the sift-down of a pop walks through adjacent memory, as in the reference); deeper
+    // positions, which small items only pass through on their way up, are an occupancy bitmap + a hash table.
+    int64_t n_top = 1024;
+    while (n_top < 4 * S && n_top < (1ll << 26)) n_top <<= 1;
+    if (n_top > max_items) n_top = max_items;
+    Item *top = (Item *)malloc((size_t)n_top * sizeof(Item));
+    uint64_t *occ = (uint64_t *)calloc((size_t)((max_items + 63) / 64), sizeof(uint64_t));    // position holds a small item
+    uint8_t *state = (uint8_t *)malloc((size_t)(R > 0 ? R : 1));                                // 1: already pushed / a marker
+    WsPosMap deep;
+    if (!top || !occ || !state || !deep.init(1 << 16)) { free(top); free(occ); free(state); return -1; }
+    memset(top, 0xFF, (size_t)n_top * sizeof(Item));                                            // key = ~0: LARGE everywhere
+    memcpy(state, is_marker, (size_t)R);
+    bool oom = false;
+    // the bitmap covers ALL positions: a small item on its way up walks through unoccupied ancestors on bit tests alone
+    // (the top of the bitmap stays in cache; the item array of the top region, 16 B per position, does not)
+    auto has = [&](int64_t p) { return (occ[p >> 6] >> (p & 63)) & 1ull; };
+    auto load = [&](int64_t p) -> Item {
+        if (p < n_top) return top[p];
+        if (!has(p)) return LARGE;
+        const WsRefItem e = deep.get(p);
+        return Item{((u64)e.v << 32) | (uint32_t)e.age, e.id, 0};
+    };
+    auto store = [&](int64_t p, const Item &e) {
+        const bool was = has(p), is = e.key != ~0ull;
+        if (is != was) occ[p >> 6] ^= 1ull << (p & 63);
+        if (p < n_top) { top[p] = e; return; }
+        if (!is) { if (was) deep.erase(p); return; }
+        if (!deep.put(p, WsRefItem{(unsigned)(e.key >> 32), (int32_t)(e.key & 0xffffffffu), e.id})) oom = true;
+    };
+    // _watershed.pyx:120-152 for a small item entering at position `child` (a large one only lengthens the heap)
+    auto push_small = [&](int64_t child, const Item &e) {
+        while (child > 0) {
+            const int64_t parent = (child + 1) / 2 - 1;
+            if (has(parent)) {
+                const Item pe = load(parent);
+                if (!(e.key < pe.key)) break;
+                store(child, pe);
+                store(parent, LARGE);                                    // (rewritten by the next step or by the final store)
+            }
+            child = parent;                                              // a large parent moves down: nothing to record
+        }
+        store(child, e);
+    };
+    for (int64_t j = 0; j < S; j++) push_small(sk[j], Item{(u64)sval[j] << 32, scid[j], 0});    // seed k enters at position k, age 0
+    int64_t items = M;
+    for (int64_t i = 0; i < R; i++) rank[i] = -1;
+    int64_t age = 1, popped = 0;
+    int n_ranked = 0;
+    while (items > 0 && !oom) {
+        const Item e = load(0);
+        if (e.key == ~0ull) break;                                       // a large top ends the replay
+        items -= 1;                                                      // :67-111
+        if (items > 0) {
+            const Item x = load(items);
+            store(items, LARGE);
+            int64_t i = 0;
+            for (;;) {
+                const int64_t l = 2 * i + 1, r = 2 * i + 2;
+                if (l >= items) break;
+                int64_t smallest = i;
+                Item cur = x;
+                const Item le = load(l);
+                if (le.key < cur.key) { smallest = l; cur = le; }
+                if (r < items) { const Item re = load(r); if (re.key < cur.key) { smallest = r; cur = re; } }
+                if (smallest == i) break;
+                store(i, cur);
+                i = smallest;
+            }
+            store(i, x);
+        } else store(0, LARGE);
+        popped++;
+        if (e.id < 0) continue;
+        if ((e.key & 0xffffffffull) == 0) rank[e.id] = n_ranked++;      // a marker (age 0): its pop rank
+        const int *np = nbr + (int64_t)e.id * n_nbr;
+        for (int k = 0; k < n_nbr; k++) {                                // :308-341
+            const int n = np[k];
+            if (n < 0 || state[n]) continue;
+            state[n] = 1;
+            age += 1;
+            const unsigned v = val[n];
+            if (v < vmax) push_small(items, Item{((u64)v << 32) | (uint32_t)age, n, 0});      // (v == vmax with age != 0 is large)
+            items += 1;
+        }
+    }
+    for (int64_t i = 0; i < R; i++) if (rank[i] < 0) rank[i] = (int)(n_ranked + i);
+    free(top); free(occ); free(state);
+    return oom ? -1 : popped;
+}
+
 // One call = classification / compaction, phase A, then root phases at increasing chain depth until the exactness
 // check finds no origin whose chains were cut off (or depth_max is reached).
 // `rv` != nullptr: the raveled form (tf_watershed_raveled): `field` = image, `markers` = `labels` = output (in place),
@@ -1283,6 +1485,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             // Labels hang on the order of equal-valued markers: get the reference's (ws_reference_ranks) and repeat the
             // root phase with the pop rank in place of the raster index.  Chain levels, origins and label sets do not
             // depend on that order, only the choice among tying candidates does.
+            timespec ts_enter; clock_gettime(CLOCK_MONOTONIC, &ts_enter);
             hipEvent_t ev0, ev1;
             TF_CHECK_HIP(hipEventCreate(&ev0)); TF_CHECK_HIP(hipEventCreate(&ev1));
             TF_CHECK_HIP(hipEventRecord(ev0, s));
@@ -1296,37 +1499,110 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             int64_t M = 0;
             const int rc_seeds = ws_scan_flags(flag, scan, N, scan_tmp, scan_bytes, s, &M);          // synchronises
             if (rc_seeds) { tf_set_error("tf_watershed: TF_WS_REFERENCE_ORDER needs at most 2^30 seeds per call (use time windows)"); return rc_seeds; }
-            unsigned *h_seed_val = (unsigned *)malloc((size_t)(M > 0 ? M : 1) * sizeof(unsigned));
-            int *h_seed_cid = (int *)malloc((size_t)(M > 0 ? M : 1) * sizeof(int));
+            const bool ref_debug = getenv("TF_WS_REF_DEBUG") != nullptr;                   // development aid: where the detour's time goes
+            auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+            const double t_begin = now_ms();
+            if (ref_debug) fprintf(stderr, "reference order: tie value + seed numbering %.0f ms\n", t_begin - (ts_enter.tv_sec * 1e3 + ts_enter.tv_nsec * 1e-6));
+            // the flood graph (value keys and out-neighbours of the relevant pixels) and the ranks
             unsigned *h_val = (unsigned *)malloc((size_t)R * sizeof(unsigned));
             int *h_nbr = (int *)malloc((size_t)R * n_nbr * sizeof(int));
             int *h_rank = (int *)malloc((size_t)R * sizeof(int));
+            unsigned *h_seed_val = nullptr; int *h_seed_cid = nullptr, *h_seed_k = nullptr; uint8_t *h_marker = nullptr;
             int rc2 = TF_OK;
             int64_t popped = -1;
-            if (!h_seed_val || !h_seed_cid || !h_val || !h_nbr || !h_rank) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
-            // the seed list travels through the (now idle) frontier queues, 2R entries at a time
-            unsigned *stg_val = (unsigned *)Q.q[0]; int *stg_cid = Q.q[1];
-            const int64_t cap = 2 * R;
-            for (int64_t c0 = 0; c0 < M && rc2 == TF_OK; c0 += cap) {
-                const int64_t cnt = M - c0 < cap ? M - c0 : cap;
-                hipLaunchKernelGGL(k_ws_seed_list, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, (const int *)scan, (const int *)cid,
-                                   field, N, c0, cap, stg_val, stg_cid);
-                if (hipGetLastError() != hipSuccess ||
-                    hipMemcpyAsync(h_seed_val + c0, stg_val, (size_t)cnt * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                    hipMemcpyAsync(h_seed_cid + c0, stg_cid, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                    hipStreamSynchronize(s) != hipSuccess) { tf_set_error("tf_watershed: seed list transfer failed"); rc2 = TF_EHIP; }
-            }
+            if (!h_val || !h_nbr || !h_rank) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
             if (rc2 == TF_OK &&
                 (hipMemcpyAsync(h_val, c.val, (size_t)R * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
                  hipMemcpyAsync(h_nbr, c.nbr, (size_t)R * n_nbr * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
                  hipStreamSynchronize(s) != hipSuccess)) { tf_set_error("tf_watershed: flood graph transfer failed"); rc2 = TF_EHIP; }
-            if (rc2 == TF_OK) {
-                popped = ws_reference_ranks(M, h_seed_val, h_seed_cid, R, h_val, h_nbr, n_nbr, h_vmax, h_rank);
-                if (popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
+            const double t_graph = now_ms();
+            // SPARSE form (ws_reference_ranks_sparse): only the seeds with a key <= vmax are listed and sent.  The flag array
+            // is idle once the seeds are numbered: it holds the per-block counts, their scan and the marker bytes
+            const bool force_dense = getenv("TF_WS_REFERENCE_DENSE") != nullptr;            // A/B and test aid (read per call)
+            const int64_t nb256 = (N + 255) / 256;
+            size_t small_scan_bytes = 0;
+            (void)hipcub::DeviceScan::ExclusiveSum(nullptr, small_scan_bytes, (const int *)nullptr, (int *)nullptr, (int)(nb256 < 0x7fffffffll ? nb256 : 1));
+            bool sparse = rc2 == TF_OK && !force_dense && nb256 < 0x7fffffffll && small_scan_bytes <= scan_bytes &&
+                          (size_t)nb256 * 8 + (size_t)R + 64 <= (size_t)(rv ? N : NV);
+            int64_t S = 0;
+            if (sparse) {
+                int *s_count = (int *)flag, *s_base = s_count + nb256;
+                uint8_t *d_marker = (uint8_t *)(s_base + nb256);
+                hipLaunchKernelGGL(k_ws_small_count, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)cls, field, N, h_vmax, s_count);
+                size_t tb = scan_bytes;
+                int h_last[2] = {0, 0};
+                if (hipGetLastError() != hipSuccess ||
+                    hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, (const int *)s_count, s_base, (int)nb256, s) != hipSuccess ||
+                    hipMemcpyAsync(&h_last[0], s_base + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipMemcpyAsync(&h_last[1], s_count + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess) { tf_set_error("tf_watershed: small-seed count failed"); rc2 = TF_EHIP; }
+                S = (int64_t)h_last[0] + h_last[1];
+                // the list is staged in the idle frontier queues and the rank array: R entries each at least
+                if (rc2 == TF_OK && S > R) sparse = false;
+                if (rc2 == TF_OK && sparse) {
+                    int *stg_k = Q.q[0]; unsigned *stg_val = (unsigned *)Q.q[1]; int *stg_cid = rank_dev;
+                    h_seed_k = (int *)malloc((size_t)(S > 0 ? S : 1) * sizeof(int));
+                    h_seed_val = (unsigned *)malloc((size_t)(S > 0 ? S : 1) * sizeof(unsigned));
+                    h_seed_cid = (int *)malloc((size_t)(S > 0 ? S : 1) * sizeof(int));
+                    h_marker = (uint8_t *)malloc((size_t)R);
+                    if (!h_seed_k || !h_seed_val || !h_seed_cid || !h_marker) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
+                    if (rc2 == TF_OK) {
+                        hipLaunchKernelGGL(k_ws_small_list, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)cls, (const int *)scan, (const int *)cid,
+                                           field, N, h_vmax, (const int *)s_base, stg_k, stg_val, stg_cid);
+                        hipLaunchKernelGGL(k_ws_marker_bytes, dim3(nbr_blocks), dim3(256), 0, s, c.pix, R, d_marker);
+                        if (hipGetLastError() != hipSuccess ||
+                            (S > 0 && (hipMemcpyAsync(h_seed_k, stg_k, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                                       hipMemcpyAsync(h_seed_val, stg_val, (size_t)S * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                                       hipMemcpyAsync(h_seed_cid, stg_cid, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess)) ||
+                            hipMemcpyAsync(h_marker, d_marker, (size_t)R, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                            hipStreamSynchronize(s) != hipSuccess) { tf_set_error("tf_watershed: small-seed list transfer failed"); rc2 = TF_EHIP; }
+                    }
+                    const double t_list = now_ms();
+                    if (rc2 == TF_OK) {
+                        popped = ws_reference_ranks_sparse(M, S, h_seed_k, h_seed_val, h_seed_cid, R, h_marker, h_val, h_nbr, n_nbr, h_vmax, h_rank);
+                        if (popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
+                    }
+                    if (ref_debug)
+                        fprintf(stderr, "reference order: %lld seeds, %lld at or below the tie value, %lld relevant pixels; graph to host %.0f ms, "
+                                "small-seed list %.0f ms, replay %.0f ms (%lld pops)\n", (long long)M, (long long)S, (long long)R,
+                                t_graph - t_begin, t_list - t_graph, now_ms() - t_list, (long long)popped);
+                }
             }
+            if (rc2 == TF_OK && !sparse) {
+                // DENSE form: every seed is sent and pushed (more small seeds than staging room, or TF_WS_REFERENCE_DENSE)
+                free(h_seed_val); free(h_seed_cid);
+                h_seed_val = (unsigned *)malloc((size_t)(M > 0 ? M : 1) * sizeof(unsigned));
+                h_seed_cid = (int *)malloc((size_t)(M > 0 ? M : 1) * sizeof(int));
+                if (!h_seed_val || !h_seed_cid) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
+                if (sparse == false && rc2 == TF_OK && !force_dense) {
+                    // the flag array was reused above: number the seeds again
+                    hipLaunchKernelGGL(k_ws_flag_seeds, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, N, flag);
+                    int64_t M2 = 0;
+                    const int rc_again = ws_scan_flags(flag, scan, N, scan_tmp, scan_bytes, s, &M2);
+                    if (rc_again) rc2 = rc_again;
+                }
+                // the seed list travels through the (now idle) frontier queues, 2R entries at a time
+                unsigned *stg_val = (unsigned *)Q.q[0]; int *stg_cid = Q.q[1];
+                const int64_t cap = 2 * R;
+                for (int64_t c0 = 0; c0 < M && rc2 == TF_OK; c0 += cap) {
+                    const int64_t cnt = M - c0 < cap ? M - c0 : cap;
+                    hipLaunchKernelGGL(k_ws_seed_list, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, (const int *)scan, (const int *)cid,
+                                       field, N, c0, cap, stg_val, stg_cid);
+                    if (hipGetLastError() != hipSuccess ||
+                        hipMemcpyAsync(h_seed_val + c0, stg_val, (size_t)cnt * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                        hipMemcpyAsync(h_seed_cid + c0, stg_cid, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                        hipStreamSynchronize(s) != hipSuccess) { tf_set_error("tf_watershed: seed list transfer failed"); rc2 = TF_EHIP; }
+                }
+                if (rc2 == TF_OK) {
+                    popped = ws_reference_ranks(M, h_seed_val, h_seed_cid, R, h_val, h_nbr, n_nbr, h_vmax, h_rank);
+                    if (popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
+                }
+            }
+            const double t_replayed = now_ms();
             if (rc2 == TF_OK && (hipMemcpyAsync(rank_dev, h_rank, (size_t)R * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
                                  hipStreamSynchronize(s) != hipSuccess)) { tf_set_error("tf_watershed: rank transfer failed"); rc2 = TF_EHIP; }
-            free(h_seed_val); free(h_seed_cid); free(h_val); free(h_nbr); free(h_rank);
+            free(h_seed_val); free(h_seed_cid); free(h_seed_k); free(h_marker); free(h_val); free(h_nbr); free(h_rank);
+            if (ref_debug) fprintf(stderr, "reference order: rank upload + frees %.0f ms\n", now_ms() - t_replayed);
             if (rc2) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc2; }
             hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1, (const int *)rank_dev);
             hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, markers, c.Llo, c.Lhi, R);
@@ -1340,7 +1616,12 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             float ms = 0.f;
             TF_CHECK_HIP(hipEventElapsedTime(&ms, ev0, ev1));
             (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-            st[13] = popped; st[14] = M; st[15] = (int64_t)(ms * 1000.0f);
+            if (getenv("TF_WS_REF_DEBUG")) {
+                timespec ts_exit; clock_gettime(CLOCK_MONOTONIC, &ts_exit);
+                fprintf(stderr, "reference order: whole detour %.0f ms on the host clock, %.0f ms by the stream's events\n",
+                        (ts_exit.tv_sec - ts_enter.tv_sec) * 1e3 + (ts_exit.tv_nsec - ts_enter.tv_nsec) * 1e-6, ms);
+            }
+            st[13] = popped; st[14] = sparse ? S : M; st[15] = (int64_t)(ms * 1000.0f);
             reference_order_applied = true;
         }
     }
