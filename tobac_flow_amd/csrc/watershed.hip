@@ -1570,6 +1570,8 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             }
             if (rc2 == TF_OK && !sparse) {
                 // DENSE form: every seed is sent and pushed (more small seeds than staging room, or TF_WS_REFERENCE_DENSE)
+                if (ref_debug) fprintf(stderr, "reference order: dense replay: %lld seeds, %lld at or below the tie value (key %u), %lld relevant pixels\n",
+                                       (long long)M, (long long)S, h_vmax, (long long)R);
                 free(h_seed_val); free(h_seed_cid);
                 h_seed_val = (unsigned *)malloc((size_t)(M > 0 ? M : 1) * sizeof(unsigned));
                 h_seed_cid = (int *)malloc((size_t)(M > 0 ? M : 1) * sizeof(int));
