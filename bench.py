@@ -219,10 +219,21 @@ def main():
                     help="frames consecutive windows (and ranks) share; the stitch compares all but the first and last of them")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
-    ap.add_argument("--tie-order", choices=["raster", "reference"], default="raster",
-                    help="equal-valued markers whose pop order decides a label: raster order (default; such voxels are counted in "
-                         "`watershed`) or the reference heap's own order (on_ambiguous='reference': labels bit for bit the "
-                         "reference's, at the cost of a sequential host replay per flood that has such ties)")
+    ap.add_argument("--tie-order", choices=["raster", "reference"], default="reference",
+                    help="equal-valued markers whose pop order decides a label: the reference heap's own order (default = the "
+                         "library's default, on_ambiguous='reference': labels bit for bit the reference's; a sequential host replay "
+                         "per flood that has such ties, run on worker threads beside the next windows' device work) or raster order "
+                         "(such voxels are counted in `watershed`)")
+    ap.add_argument("--inflight", type=int, default=6,
+                    help="floods in flight per rank (each owns ~5 GB of scratch at 16 x 5424^2): window k's host replay runs on a "
+                         "worker thread while the device floods windows k+1 ...; 1 = strictly one after the other")
+    ap.add_argument("--rotate", type=int, default=3,
+                    help="the timed steps visit this many different T-frame stacks of the synthetic sequence in turn (offsets "
+                         "0, s, 2s, ... frames with s = --rotate-shift), all resident before the timed region: the data-dependent "
+                         "memos of the host layer see changing input, as in a production sweep")
+    ap.add_argument("--rotate-shift", type=int, default=7, help="frame offset between consecutive rotated stacks (not a multiple "
+                    "of the window stride: no window of one step repeats a window of another)")
+    ap.add_argument("--no-raster-subreport", action="store_true", help="skip the one extra (untimed) step in raster tie order")
     ap.add_argument("--single-label-seeds", action="store_true",
                     help="round-2 seeds (every positive seed = 1, detect_anvils(markers=None)) instead of component-labelled ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -258,7 +269,9 @@ def main():
     from tobac_flow_amd import _lib
     from tobac_flow_amd.detection import get_combined_edge_field
     from tobac_flow_amd.parallel import stitch_rank_windows, window_bounds
-    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_begin
     from tools.synth import anvil_seeds, blob_stack
 
     cT, cH, cW, cN, C = CONFIGS[a.config]
@@ -269,16 +282,23 @@ def main():
     # rank r holds frames r * (T - overlap) ... of ONE sequence: its last `overlap` frames are rank r + 1's first ones.
     # Resident in HBM before the timed region: the brightness-temperature stack (generated in blocks of frames: torch's
     # own kernels index in 32 bits, tools/synth.py).  Everything else -- seeds included -- is computed inside the step.
-    bt = torch.empty((T, H, W), dtype=torch.float32, device="cuda")
-    for f0 in range(0, T, 12):
-        f1 = min(f0 + 12, T)
-        bt[f0:f1] = blob_stack(f1 - f0, H, W, seed=20240601, t0=rank * (T - a.overlap) + f0)
+    # The timed steps rotate over `--rotate` stacks cut from that sequence at offsets 0, s, 2s, ... (a step that
+    # floods the identical stack every time keeps the host layer's memos perfectly warm): ONE buffer of T + (rotate - 1) s frames.
+    n_rot = max(1, a.rotate)
+    T_all = T + (n_rot - 1) * a.rotate_shift
+    bt_all = torch.empty((T_all, H, W), dtype=torch.float32, device="cuda")
+    for f0 in range(0, T_all, 12):
+        f1 = min(f0 + 12, T_all)
+        bt_all[f0:f1] = blob_stack(f1 - f0, H, W, seed=20240601, t0=rank * (T - a.overlap) + f0)
     nbr = neighbour_offsets(1)
     ws_stats = []                                            # tf_watershed stats of every window of every step (warmup included)
-    ref_order_us = []                                        # --tie-order reference: host replay time of every flood that needed it
+    ref_order = []                                           # reference order: (detour microseconds, replay form, replay us, export us) per flood that needed it
+    tie_mode = {"order": a.tie_order}
+    replay_pool = ThreadPoolExecutor(max_workers=max(1, min(a.inflight, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
-    def flood_window(flow, w, c):
-        """seeds -> edge field -> watershed of channel c over the window `w` of the stack (Flow `flow`): one label volume"""
+    def flood_begin(flow, w, c):
+        """seeds -> edge field -> device part of the watershed of channel c over the window `w` of the stack (Flow `flow`);
+        the host replay of the reference's heap order (if this window needs one) starts on a worker thread"""
         lin, seeds = anvil_seeds(w + CHANNEL_OFFSETS[c] if c else w)
         if a.single_label_seeds:
             seeds = torch.clamp(seeds, max=1)
@@ -286,14 +306,23 @@ def main():
         e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
         st = {}
-        lab = watershed_dev(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="reference" if a.tie_order == "reference" else "ignore")
+        job = watershed_begin(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore")
+        fut = replay_pool.submit(job.replay) if job.needs_replay else None
+        return job, fut, st
+
+    def flood_finish(job, fut, st):
+        """pop ranks applied, labels written: one label volume"""
+        if fut is not None:
+            fut.result()
+        lab = job.finish()
         if st.get("reference_order", {}).get("microseconds", 0) > 0:
-            ref_order_us.append(st["reference_order"]["microseconds"])
+            d = st["reference_order_detail"]
+            ref_order.append((st["reference_order"]["microseconds"], d["replay_form"], d["replay_us"], d["export_us"]))
         ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
         return lab
 
-    def step(vr_steps=None):
-        """one pass over the stack; returns (stitched windows of the LAST channel, objects per channel)"""
+    def step(bt, vr_steps=None):
+        """one pass over the stack `bt`; returns (stitched windows of the LAST channel, objects per channel)"""
         vr = a.vr_steps if vr_steps is None else vr_steps
         # flow of all T - 1 frame pairs of the stack, ONCE (the frames two windows share are not computed twice), in batches
         # sized by the library (tf_farneback_batch_hint)
@@ -306,13 +335,19 @@ def main():
         for c in range(C):                                   # channels one after the other: one channel's labels resident
             out = None
             wins = []
+            pending = deque()                                # floods in flight, oldest first
             for lo, hi in bounds:
+                while len(pending) >= max(1, a.inflight):
+                    wins.append(flood_finish(*pending.popleft()))
                 # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame
                 # pair does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426);
                 # window_view patches those two frames in the stack's arrays for the duration of the block instead of
-                # copying the window's 7.5 GB of flow vectors (Flow.window)
+                # copying the window's 7.5 GB of flow vectors (Flow.window).  Only the device part of the flood reads the
+                # flows (its neighbour table has the displacements applied): the job is finished outside the block.
                 with flow_all.window_view(lo, hi) as flow_w:
-                    wins.append(flood_window(flow_w, bt[lo:hi], c))
+                    pending.append(flood_begin(flow_w, bt[lo:hi], c))
+            while pending:
+                wins.append(flood_finish(*pending.popleft()))
             # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
             out = stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins
             del wins
@@ -325,10 +360,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def stack_of(i):
+        off = (i % n_rot) * a.rotate_shift
+        return bt_all[off:off + T]
+
     out_labels = None
-    for _ in range(a.warmup):                                # same memory pattern as the timed steps: the previous step's labels
+    for i in range(a.warmup):                                # same memory pattern as the timed steps: the previous step's labels
         out_labels = None                                    # live until the next step starts (otherwise the first timed step
-        out_labels, _ = step()                               # pays fresh device allocations: +0.7 s measured)
+        out_labels, _ = step(stack_of(i))                    # pays fresh device allocations: +0.7 s measured)
     barrier()
     if os.environ.get("TF_BENCH_MEMDEBUG"):
         ms_ = torch.cuda.memory_stats()
@@ -340,10 +379,12 @@ def main():
     _lib.profile_collect()
     t0 = time.perf_counter()
     n_objects, step_ms = [], []
-    for _ in range(a.steps):
+    objects_per_step = []
+    for i in range(a.steps):
         out_labels = None                                    # the previous step's labels are released before the next step's exist
         ts = time.perf_counter()
-        out_labels, n_objects = step()
+        out_labels, n_objects = step(stack_of(a.warmup + i))
+        objects_per_step.append(n_objects[0] if len(n_objects) == 1 else n_objects)
         torch.cuda.synchronize()                             # (a step ends with the stitch's host-side union-find anyway)
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 1))
         if os.environ.get("TF_BENCH_MEMDEBUG"):              # development aid: does a timed step still grow the allocator's pool?
@@ -356,8 +397,20 @@ def main():
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
     del out_labels
+    n_timed = len(ws_stats)
+    raster_ms = None
+    if a.tie_order == "reference" and not a.no_raster_subreport:
+        # sub-report, outside the timed region: ONE step with equal-valued markers in raster order (on_ambiguous="ignore")
+        tie_mode["order"] = "raster"
+        barrier()
+        ts = time.perf_counter()
+        out_labels, _ = step(stack_of(a.warmup + a.steps))
+        barrier()
+        raster_ms = (time.perf_counter() - ts) * 1e3
+        del out_labels
+        tie_mode["order"] = a.tie_order
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=bt.device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=bt_all.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
@@ -392,6 +445,7 @@ def main():
                  "F3": "BASELINE config F3: full-disk-sized stack, three channels sharing one Flow",
                  "C": "BASELINE config C: GOES-16 CONUS-sized stack", "window": "sub-report: ONE window per step"}
         what = (f"{names[a.config]}: {T}x{H}x{W} float32 frames per GPU per step" + (f" x {C} channels" if C > 1 else "") +
+                (f" ({n_rot} different stacks of the synthetic sequence visited in turn)" if n_rot > 1 else "") +
                 (f", processed as {n_windows} time windows sharing {a.overlap} frames: flow of the {T - 1} frame pairs once for the stack, "
                  f"then per window Sobel edge field + seeds + watershed ({frames_computed} window frames for {T} delivered) + stitch of "
                  f"the label ids over all windows, all inside the timed region" if n_windows > 1 else ""))
@@ -413,12 +467,14 @@ def main():
                           "sharding": f"one {T}-frame segment per GPU cut from one sequence, consecutive segments share {a.overlap} frames; "
                                       "label IDs stitched over all windows of all ranks by the reference's overlap rule "
                                       "(>= 5 px and >= 0.5, linking.py:49-161): one neighbour message per rank boundary + all-gathers of pair lists",
-                          "objects_after_stitch": n_objects[0] if len(n_objects) == 1 else n_objects},
+                          "input_rotation": f"{n_rot} stacks at frame offsets {[k * a.rotate_shift for k in range(n_rot)]} of the sequence, visited in turn (warm-up steps first)",
+                          "objects_after_stitch": n_objects[0] if len(n_objects) == 1 else n_objects,
+                          "objects_after_stitch_per_step": objects_per_step},
                "rate_over_computed_window_frames_Mpix_s": round(world * a.steps * frames_computed * H * W / dt / 1e6, 2),
                "roofline": roof}
         # which watershed schedule the timed windows ran: stats[5] = 1 / 0 probe (speculative root phase + conflict test,
         # conflict found / not found), -1 = root phase skipped on the conflict memo of watershed.py (identical labels)
-        timed = np.array(ws_stats[n_warm:], np.int64)
+        timed = np.array(ws_stats[n_warm:n_timed], np.int64)
         out["watershed"] = {"floods_timed": int(len(timed)),
                             "sweeps_per_phase_mean_per_flood": [round(float(v), 1) for v in timed[:, :5].mean(0)],
                             "sweeps_per_phase_last_flood": timed[-1][:5].tolist(), "relevant_pixels_last_flood": int(timed[-1][6]),
@@ -426,10 +482,24 @@ def main():
                             "pixels_depending_on_equal_valued_marker_order": int(timed[:, 9].sum() // a.steps),
                             "marker_tie_points": int(timed[:, 10].sum() // a.steps), "ties_left_by_depth_cut_off": int(timed[:, 11].sum()),
                             "floods_probing": int((timed[:, 5] >= 0).sum()), "floods_skipping_root_phase": int((timed[:, 5] < 0).sum()),
-                            "tie_order": a.tie_order}
+                            "tie_order": a.tie_order,
+                            "labels_bit_exact_with_the_reference": a.tie_order == "reference" and int(timed[:, 11].sum()) == 0,
+                            "floods_in_flight": a.inflight}
         if a.tie_order == "reference":
-            out["watershed"]["reference_order_replays"] = len(ref_order_us)          # warm-up floods included
-            out["watershed"]["reference_order_replay_ms_mean"] = round(float(np.mean(ref_order_us)) / 1e3, 1) if ref_order_us else 0.0
+            ro = ref_order                                                          # warm-up floods included
+            out["watershed"]["reference_order"] = {
+                "replays": len(ro), "sparse_replays": sum(1 for r in ro if r[1] == "sparse"), "dense_replays": sum(1 for r in ro if r[1] == "dense"),
+                "detour_ms_mean": round(float(np.mean([r[0] for r in ro])) / 1e3, 1) if ro else 0.0,
+                "host_replay_ms_mean": round(float(np.mean([r[2] for r in ro])) / 1e3, 1) if ro else 0.0,
+                "host_replay_ms_max": round(float(np.max([r[2] for r in ro])) / 1e3, 1) if ro else 0.0,
+                "export_ms_mean": round(float(np.mean([r[3] for r in ro])) / 1e3, 1) if ro else 0.0,
+                "replay_threads": replay_pool._max_workers,
+                "note": "host replays run on worker threads beside the next windows' device work (tf_watershed_begin / _replay / _finish)"}
+            if raster_ms is not None:
+                out["watershed"]["raster_order_subreport"] = {
+                    "ms_per_step": round(raster_ms, 1), "Mpix_per_s": round(world * T * H * W / (raster_ms * 1e-3) / 1e6, 1),
+                    "labels_bit_exact_with_the_reference": False,
+                    "note": "one extra step outside the timed region with on_ambiguous='ignore' (equal-valued markers in raster order)"}
         # per-stage rates, and the measured device-to-device copy rate as the practical HBM ceiling
         stage_of = {"to8bit_pair": "flow", "fb_gaussian_blur": "flow", "fb_resize": "flow", "fb_polyexp": "flow",
                     "fb_update_matrices": "flow", "fb_blur_solve": "flow", "fb_iteration_fused": "flow", "smooth_flow": "flow",
@@ -445,7 +515,7 @@ def main():
                                           "note": "step time minus the library's kernel time: seeds' torch glue, stitch, launches, syncs"}
         if roof is not None:
             n_copy = 1 << 28                                                  # float32 elements: 1 GiB read + 1 GiB written
-            src = torch.empty(n_copy, dtype=torch.float32, device=bt.device).normal_()
+            src = torch.empty(n_copy, dtype=torch.float32, device=bt_all.device).normal_()
             dst = torch.empty_like(src)
             dst.copy_(src)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -252,23 +252,24 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
  *   label conflicts (exact plateaus, as in detect_anvils), where the speculative root phase is wasted
  *   work.  With the flag stats_host[1] = 0 and stats_host[5] = -1 (speculative phase not run). */
 #define TF_WS_SKIP_FAST_PATH 1
-/* TF_WS_REFERENCE_ORDER (tf_watershed_ex2, tf_watershed_raveled_ex): when labels hang on the order of EQUAL-VALUED
- *   MARKERS (the case otherwise reported as TF_WS_AMBIGUOUS), reproduce the order the reference's binary heap gives
- *   them.  That order is a by-product of the heap's array mechanics (_watershed.pyx:67-152, 278-284) and depends on
- *   every push and pop before it, so it cannot be derived from the tied markers alone: a first-party host routine of
+/* TF_WS_REFERENCE_ORDER (tf_watershed_ex2, tf_watershed_begin, tf_watershed_raveled_ex): when labels hang on the order
+ *   of EQUAL-VALUED MARKERS (the case otherwise reported as TF_WS_AMBIGUOUS), reproduce the order the reference's binary
+ *   heap gives them.  That order is a by-product of the heap's array mechanics (_watershed.pyx:67-152, 278-284) and depends
+ *   on every push and pop before it, so it cannot be derived from the tied markers alone: a first-party host routine of
  *   this library replays the heap's push / pop / sift sequence over the compact flood graph the device has built --
  *   keys only, no labels -- up to the largest marker value at which such a tie occurs, and returns each marker's pop
  *   rank; the device then repeats its root phase with the pop rank in place of the raster index as the last component
  *   of the chain comparison, and writes the labels.  The call returns TF_OK: the labels are the reference's bit for
  *   bit.  Only the heap items at or below that value have to be followed: every other item compares larger than all of
  *   them and only matters through the heap position it occupies, so the replay keeps those "small" items alone (an
- *   occupancy bitmap over the positions + a position -> item table) and the device lists and sends only the seeds
- *   among them.  Cost: sequential, O(small items x log n) bit tests on one host core, plus the transfer of the flood
- *   graph (28 B per relevant pixel) and 12 B per small seed; nothing extra when no such tie exists.  (With more small
- *   seeds than relevant pixels -- no staging room -- or TF_WS_REFERENCE_DENSE=1 in the environment: the dense form,
- *   every seed sent and pushed.)
- *   stats[13] = items the replay popped, [14] = seeds the replay was given, [15] = microseconds the whole detour took
- *   (0 if not needed). */
+ *   occupancy bitmap over the positions + a position -> item table), and the device sends only the seeds among them
+ *   (heap position, key, id: 16 B each) and the SUB-GRAPH the replay can reach: the pixels it can pop plus their
+ *   out-neighbours (key + neighbour row each; ~1 % of the relevant pixels on a detect_anvils window), through pinned
+ *   host memory the library keeps between calls.  Cost: sequential, O(small items x log n) bit tests on one host core;
+ *   nothing extra when no such tie exists.  (With more small seeds than relevant pixels -- no staging room -- or
+ *   TF_WS_REFERENCE_DENSE=1 in the environment: the dense form, every seed sent and pushed.)
+ *   stats[13] = items the replay popped, [14] = seeds the replay was given, [15] = microseconds the detour took on the
+ *   host clock (export + replay + repeated root phase; 0 if not needed). */
 #define TF_WS_REFERENCE_ORDER 2
 int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
                     const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
@@ -287,6 +288,32 @@ int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *m
                      const int8_t *nbr_host, int n_nbr, int chain_depth, int max_depth, int flags,
                      int32_t *labels, uint8_t *ambiguous, void *ws, size_t ws_bytes,
                      int64_t *stats_host, void *stream);
+
+/* One flood in three parts (round 4): the replay of TF_WS_REFERENCE_ORDER is host work, so the replays of several time
+ * windows can run on worker threads while the device floods the next windows.
+ *   tf_watershed_begin   tf_watershed_ex2 up to the exactness check (same arguments, no outputs yet); if the reference
+ *                        order is asked for and needed, also the export of what the replay reads.  TF_OK: *job_out is a
+ *                        job that MUST be passed to tf_watershed_finish or tf_watershed_abandon; any other code: no job.
+ *                        `ws`, `markers` and the job belong together until then: the workspace must not be used by
+ *                        another call (one workspace per flood in flight).  stats_host as far as known at this point.
+ *   tf_watershed_needs_replay   1 if tf_watershed_replay has work to do
+ *   tf_watershed_replay  the host replay; no HIP call, any thread, different jobs concurrently.  Optional: finish runs it
+ *                        if the caller did not.
+ *   tf_watershed_finish  pop ranks to the device, root phase repeated with them, labels (and report) written; frees the
+ *                        job; return codes and stats of tf_watershed_ex2.  Synchronises the stream.
+ *   tf_watershed_abandon frees a job without finishing it. */
+int tf_watershed_begin(const float *field, const int32_t *markers, const int8_t *mask,
+                       const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                       const int8_t *nbr_host, int n_nbr, int chain_depth, int max_depth, int flags,
+                       void *ws, size_t ws_bytes, int64_t *stats_host, void *stream, void **job_out);
+int tf_watershed_needs_replay(const void *job);
+int tf_watershed_replay(void *job);
+int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguous, int64_t *stats_host);
+void tf_watershed_abandon(void *job);
+/* info (8 x int64): [0] replay form (0 none, 1 sparse, 2 dense), [1] seeds, [2] seeds at or below the tie value,
+ * [3] pixels of the exported sub-graph, [4] relevant pixels, [5] microseconds of the export, [6] microseconds of the
+ * replay (-1: not run yet), [7] ordered key of the tie value */
+int tf_watershed_job_info(const void *job, int64_t *info);
 
 /* tf_watershed_raveled: the reference's only native seam, argument for argument --
  *   tobac_flow/_watershed.pyx:222-233  watershed_raveled(image, marker_locations, structure, forward_offset,

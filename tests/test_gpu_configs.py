@@ -118,14 +118,16 @@ def test_config_S_whole_pipeline_matches_the_oracle():
     assert markers.max() >= 3 and (markers == -1).any()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        labels = flow.watershed(edges, markers, connectivity=ndi.generate_binary_structure(3, 1))
-        labels2, report = tf.watershed(fwd, bwd, edges, markers, connectivity=1, return_ambiguous=True)
-    ref_mode = flow.watershed(edges, markers, connectivity=ndi.generate_binary_structure(3, 1), on_ambiguous="reference")
+        labels = flow.watershed(edges, markers, connectivity=ndi.generate_binary_structure(3, 1), on_ambiguous="warn")
+        labels2, report = tf.watershed(fwd, bwd, edges, markers, connectivity=1, return_ambiguous=True, on_ambiguous="warn")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                               # the DEFAULT call: the reference's labels, nothing to report
+        ref_mode = flow.watershed(edges, markers, connectivity=ndi.generate_binary_structure(3, 1))
     assert np.array_equal(labels, labels2)
     ideal = ws_oracle.watershed(fwd, bwd, edges, markers, None, 1, tie_mode=1)
     ref = ws_oracle.watershed(fwd, bwd, edges, markers, None, 1)     # tie_mode 0: the reference kernel's own semantics
-    assert np.array_equal(ref_mode, ref)                             # reference order: the reference's labels, every voxel
-    assert np.array_equal(labels, ideal)                             # default mode: raster order of equal-valued markers ...
+    assert np.array_equal(ref_mode, ref)                             # default = reference order: the reference's labels, every voxel
+    assert np.array_equal(labels, ideal)                             # opt-out mode: raster order of equal-valued markers ...
     assert not ((labels != ref) & ((report & 1) == 0)).any()         # ... and whatever differs from the reference is reported
     mask = field >= 0.5
     got_l = flow.label(mask, overlap=0.5, absolute_overlap=5)
@@ -187,8 +189,8 @@ def _windowed_detection(frames_of, T, n_windows, overlap, oracle):
         # window-local object ids: connected components of the seeds on the device (tf_label = scipy.ndimage.label)
         comp = torch.where(markers < 0, markers, nd.label(markers > 0)[0])
         with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            lab = fl.watershed(e, comp, connectivity=1, on_ambiguous="reference" if oracle else "warn")
+            warnings.simplefilter("error")                           # default call = the reference's own order: clean
+            lab = fl.watershed(e, comp, connectivity=1)
         if oracle:
             from oracle import ws_oracle
             ref = ws_oracle.watershed(fl.forward_flow.cpu().numpy(), fl.backward_flow.cpu().numpy(), e.cpu().numpy(),
@@ -258,7 +260,7 @@ def _stack_detection_full_size(T, H, W, n_windows, overlap, offsets=(0.0,), seed
             lin, seeds = anvil_seeds(bt[a:b] + off if off else bt[a:b])
             e = get_combined_edge_field(fl, lin, dtype=np.float32)   # detection.py:620-642 (NaN -> +inf)
             with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
+                warnings.simplefilter("error")                       # the default call: reference order, nothing to warn about
                 labs.append(fl.watershed(e, seeds, connectivity=1))
             del fl, lin, seeds, e
         out = stitch_window_list(labs, overlap=overlap)

@@ -279,9 +279,10 @@ def test_watershed_golden_bit_exact(tf, golden_ws, name):
 
 @pytest.mark.parametrize("name,final_depth", [("C_quant4_c1", 3), ("C_quant32_c1", 6), ("E_const_plateau_c1", 3)])
 def test_watershed_tie_heavy_goldens(tf, golden_ws, name, final_depth):
-    """Tie-heavy inputs, default arguments.  The library deepens the chain comparison on its own (C_quant32 needs six
-    levels) and REPORTS the pixels whose label hangs on the order of equal-valued markers -- the one thing the
-    reference decides by the internal state of its heap.  Checked here: the labels equal the sequential flood under
+    """Tie-heavy inputs in the raster-order mode (on_ambiguous="warn": the opt-out since round 4; the default reproduces the
+    reference's heap order, tests/test_gpu_reference_order.py).  The library deepens the chain comparison on its own
+    (C_quant32 needs six levels) and REPORTS the pixels whose label hangs on the order of equal-valued markers -- the one
+    thing the reference decides by the internal state of its heap.  Checked here: the labels equal the sequential flood under
     the idealised marker order bit for bit; every pixel that differs from the reference's own output is reported; and
     the report is exactly the one the numpy model of the contract computes (tests/ws_parallel_model.py)."""
     import sys, os, warnings
@@ -293,7 +294,7 @@ def test_watershed_tie_heavy_goldens(tf, golden_ws, name, final_depth):
     conn = int(c["conn"])
     with pytest.warns(WatershedAmbiguityWarning):
         got, rep = tf.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], mask=c.get("mask"), connectivity=conn,
-                                return_ambiguous=True)
+                                return_ambiguous=True, on_ambiguous="warn")
     ideal = ws_oracle.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn, tie_mode=1)
     assert np.array_equal(got, ideal), f"{int((got != ideal).sum())} px differ from the idealised-order oracle"
     differs = got != c["labels"]
@@ -763,8 +764,9 @@ def test_lanczos_interpolation_matches_oracle_everywhere_it_is_accepted(tf):
 def test_watershed_raveled_twin_takes_the_references_own_arguments(tf, golden_ws, name):
     """tobac_flow_amd._watershed.watershed_raveled = the reference's native seam (_watershed.pyx:222-233), same twelve
     arguments, `output` mutated in place: fed with exactly what watershed.py:59-149 prepares (oracle/ws_oracle.prepare:
-    padding, raveled neighbourhood, raveled int32 flow offsets) it returns the reference's golden labels -- and, on the
-    tie-heavy goldens, the idealised-order labels with a warning."""
+    padding, raveled neighbourhood, raveled int32 flow offsets) it returns the reference's golden labels -- on the
+    tie-heavy goldens too (default since round 4: the reference heap's own order of equal-valued markers); with
+    reference_order=False those two give the idealised-order labels with a warning."""
     import warnings
     from oracle import ws_oracle
     from tobac_flow_amd._watershed import watershed_raveled
@@ -775,17 +777,22 @@ def test_watershed_raveled_twin_takes_the_references_own_arguments(tf, golden_ws
     out = p["out"].ravel().copy()
     args = (np.ascontiguousarray(p["field"].ravel()), p["markers"].astype(np.intp), p["nbr"].astype(np.intp), p["fwd_off"],
             p["bwd_off"], p["fwd_loc"], p["bwd_loc"], p["mask"], p["strides"].astype(np.int32), 0.0, out, False)
+    pd = p["pad"]
+    tie_heavy = name in ("C_quant4_c1", "E_const_plateau_c1")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                # the default: nothing left to warn about
+        assert watershed_raveled(*args) is None
+    o = out.reshape(p["out"].shape)
+    assert np.array_equal(o[pd[0]:o.shape[0] - pd[0], pd[1]:o.shape[1] - pd[1], pd[2]:o.shape[2] - pd[2]], c["labels"])
+    assert not o[:pd[0]].any() and not o[:, :pd[1]].any() and not o[:, :, :pd[2]].any()          # the padding ring stays 0
+    out[...] = p["out"].ravel()
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
-        assert watershed_raveled(*args) is None
-    pd = p["pad"]
-    o = out.reshape(p["out"].shape)
+        assert watershed_raveled(*args, reference_order=False) is None
     got = o[pd[0]:o.shape[0] - pd[0], pd[1]:o.shape[1] - pd[1], pd[2]:o.shape[2] - pd[2]]
-    tie_heavy = name in ("C_quant4_c1", "E_const_plateau_c1")
     want = ws_oracle.watershed(c["fwd"], c["bwd"], c["field"], c["markers"], c.get("mask"), conn, tie_mode=1) if tie_heavy else c["labels"]
     assert np.array_equal(got, want)
     assert any(issubclass(w.category, WatershedAmbiguityWarning) for w in rec) == tie_heavy
-    assert not o[:pd[0]].any() and not o[:, :pd[1]].any() and not o[:, :, :pd[2]].any()          # the padding ring stays 0
 
 
 def test_watershed_raveled_argument_checks(tf):

@@ -617,3 +617,25 @@ def test_short_overlaps_link_nothing_unless_opted_in():
         assert int(out[0].max()) == 1 and int(out[1].max()) == 1            # opted in: one object
     out = stitch_window_list([torch.from_numpy(left), torch.from_numpy(right)])          # default overlap = 4: [1:-1] compared
     assert int(out[1].max()) == 1
+
+
+def test_anvil_inputs_blocked_path_equals_the_single_block(monkeypatch):
+    """tools/synth.anvil_inputs processes volumes beyond torch's 32-bit pooling limit in blocks of frames with a
+    one-frame halo; the round-3 block size left every block two frames over the guard, so the path could only raise.
+    With the limit patched small the blocked result must equal the unblocked one (first / last / interior blocks)."""
+    import torch
+    from tools import synth
+    rng = np.random.default_rng(5)
+    bt = torch.from_numpy((265.0 + 12.0 * rng.standard_normal((23, 20, 24))).astype(np.float32))
+    bt[3, 2:6, 3:9] = float("nan")
+    bt[11, 10:14, 0:5] = float("nan")
+    lin0, m0 = synth.anvil_inputs(bt)
+    assert (m0 > 0).any() and (m0 < 0).any() and (m0 == 0).any()
+    for frames_per_block in (1, 3, 7):
+        monkeypatch.setattr(synth, "_TORCH_INDEX_LIMIT", (frames_per_block + 4) * 22 * 26)
+        assert synth._padded_elements(23, 20, 24) > synth._TORCH_INDEX_LIMIT          # the blocked path is really taken
+        lin, m = synth.anvil_inputs(bt)
+        assert torch.equal(m, m0) and torch.equal(torch.nan_to_num(lin, nan=-7.0), torch.nan_to_num(lin0, nan=-7.0))
+    monkeypatch.setattr(synth, "_TORCH_INDEX_LIMIT", 4 * 22 * 26)                   # not even one frame + halo + padding
+    with pytest.raises(ValueError):
+        synth.anvil_inputs(bt)

@@ -22,10 +22,11 @@ def _flat(a, dtype, name):
 
 
 def watershed_raveled(image, marker_locations, structure, forward_offset, backward_offset, forward_offset_locations,
-                      backward_offset_locations, mask, strides, compactness, output, wsl, reference_order=False):
+                      backward_offset_locations, mask, strides, compactness, output, wsl, reference_order=True):
     """Perform the watershed on a raveled image and neighbourhood (reference: _watershed.pyx:222-344).
-    `reference_order=True` (not in the reference): equal-valued markers pop in the order the reference's heap gives them
-    (TF_WS_REFERENCE_ORDER, include/tobac_flow_hip.h) instead of marker_locations order + a warning."""
+    `reference_order` (not in the reference; default True since round 4): equal-valued markers pop in the order the
+    reference's heap gives them (TF_WS_REFERENCE_ORDER, include/tobac_flow_hip.h) -- the result of the reference's own
+    call; False: marker_locations order + a warning when a label depends on it."""
     t = _lib.torch()
     L = _lib.lib()
     image = _flat(image, np.float32, "image")

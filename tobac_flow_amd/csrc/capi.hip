@@ -61,9 +61,12 @@ extern "C" int tf_profile_collect(int64_t *calls, double *ms, double *bytes) {
     return TF_OK;
 }
 
-// The library keeps no device memory of its own (every workspace is the caller's); the only pooled resource is the HIP
-// events of the timing facility.  tf_shutdown() turns timing off and destroys them; the library stays usable.
+// The library keeps no device memory of its own (every workspace is the caller's); the pooled resources are the HIP
+// events of the timing facility and the host scratch of the watershed's reference-order replays (csrc/watershed.hip).
+// tf_shutdown() turns timing off and releases both; the library stays usable.
+void tf_ws_host_pool_release();
 extern "C" int tf_shutdown(void) {
+    tf_ws_host_pool_release();
     std::lock_guard<std::mutex> lk(g_mu);
     g_tf_prof_on = false;
     for (auto &r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

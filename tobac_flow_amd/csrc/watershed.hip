@@ -37,6 +37,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <hipcub/hipcub.hpp>
+#include <new>
 
 typedef unsigned long long u64;
 #define WS_INF 0xFFFFFFFFFFFFFFFFull
@@ -834,70 +835,120 @@ k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, co
     if (amb) amb[i] = a;
 }
 
-// SMALL seeds: the seeds whose key is <= vmax.  Only their order matters to the replay (ws_reference_ranks_sparse below), and
-// they are few (0.3 % of the seeds of a detect_anvils window): they are listed in seed order -- per 256-voxel block a count,
-// a scan of the counts, then the list written at block base + prefix inside the block -- with their seed number `k` (= their
-// position in the reference's heap when they are pushed), value key and compact id.
+// ---- reference order of equal-valued markers (TF_WS_REFERENCE_ORDER): what the device hands the host replay ----------
+// SEED NUMBERS.  Seed k of the reference (marker_locations order = raster order) enters its heap at position k.  The
+// numbers come from per-block counts: one workgroup per 256 voxels counts its seeds and its SMALL seeds (key <= vmax: the
+// only ones the sparse replay follows), the two count arrays are scanned in 64 bits (a whole config-F stack flooded in one
+// call has more than 2^31 seeds), and the list kernels add the prefix inside the block (ballots + popcounts).  No array
+// over the voxels is written for this (round 3 flagged the seeds in one pass over the volume and scanned one int per
+// voxel: 2.4 GB written and read back per 16 x 5424^2 window).
 __global__ void __launch_bounds__(256)
-k_ws_small_count(const uint8_t *__restrict__ cls, const float *__restrict__ field, int64_t n, unsigned vmax, int *__restrict__ count)
+k_ws_seed_counts(const uint8_t *__restrict__ cls, const float *__restrict__ field, int64_t n, unsigned vmax,
+                 int *__restrict__ n_seed, int *__restrict__ n_small)
 {
-    __shared__ int part[4];
+    __shared__ int part[2][4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool f = i < n && cls[i] == 2 && ws_ordkey(field[i]) <= vmax;
-    const unsigned long long m = __ballot(f);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
+    const bool sd = i < n && cls[i] == 2;
+    const bool sm = sd && ws_ordkey(field[i]) <= vmax;
+    const unsigned long long ms = __ballot(sd), mm = __ballot(sm);
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = __popcll(ms); part[1][threadIdx.x >> 6] = __popcll(mm); }
     __syncthreads();
-    if (threadIdx.x == 0) count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) {
+        n_seed[blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        n_small[blockIdx.x] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    }
 }
+// the small seeds in seed order: heap position k (64-bit), value key, id in the exported sub-graph (-1: nobody floods from it)
 __global__ void __launch_bounds__(256)
-k_ws_small_list(const uint8_t *__restrict__ cls, const int *__restrict__ scan, const int *__restrict__ cid,
-                const float *__restrict__ field, int64_t n, unsigned vmax, const int *__restrict__ base,
-                int *__restrict__ out_k, unsigned *__restrict__ out_val, int *__restrict__ out_cid)
+k_ws_small_list(const uint8_t *__restrict__ cls, const int *__restrict__ cid, const float *__restrict__ field, int64_t n, unsigned vmax,
+                const long long *__restrict__ base_seed, const long long *__restrict__ base_small, const int *__restrict__ subid,
+                long long *__restrict__ out_k, unsigned *__restrict__ out_val, int *__restrict__ out_id)
 {
-    __shared__ int part[4];
+    __shared__ int part[2][4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned key = 0;
-    bool f = i < n && cls[i] == 2;
-    if (f) { key = ws_ordkey(field[i]); f = key <= vmax; }
-    const unsigned long long m = __ballot(f);
+    const bool sd = i < n && cls[i] == 2;
+    bool sm = false;
+    if (sd) { key = ws_ordkey(field[i]); sm = key <= vmax; }
+    const unsigned long long ms = __ballot(sd), mm = __ballot(sm);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) part[wave] = __popcll(m);
+    if (lane == 0) { part[0][wave] = __popcll(ms); part[1][wave] = __popcll(mm); }
     __syncthreads();
-    if (!f) return;
-    int slot = base[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; w++) slot += part[w];
+    if (!sm) return;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    long long k = base_seed[blockIdx.x] + __popcll(ms & below), slot = base_small[blockIdx.x] + __popcll(mm & below);
+    for (int w = 0; w < wave; w++) { k += part[0][w]; slot += part[1][w]; }
     const int c = cid[i];
-    out_k[slot] = scan[i]; out_val[slot] = key; out_cid[slot] = c <= -2 ? -2 - c : -1;
+    const int id = c <= -2 ? -2 - c : -1;
+    out_k[slot] = k; out_val[slot] = key; out_id[slot] = (id >= 0 && subid) ? subid[id] : id;
 }
-// 1 for the markers of the compact set (the replay never pushes them as flooded pixels)
+// dense form: seeds number c0 .. c0 + cap - 1: value key and sub-graph id
 __global__ void __launch_bounds__(256)
-k_ws_marker_bytes(const u64 *__restrict__ pix, int64_t R, uint8_t *__restrict__ out)
+k_ws_seed_list(const uint8_t *__restrict__ cls, const int *__restrict__ cid, const float *__restrict__ field, int64_t n,
+               const long long *__restrict__ base_seed, int64_t c0, int64_t cap, const int *__restrict__ subid,
+               unsigned *__restrict__ out_val, int *__restrict__ out_id)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < R) out[i] = (pix[i] & WS_MARKER_BIT) ? 1 : 0;
-}
-
-// ---- reference order of equal-valued markers (TF_WS_REFERENCE_ORDER) ------------------------------------------------
-// flag[i] = 1 for every seed (cls 2): their exclusive scan numbers the seeds in raster order = marker_locations order
-__global__ void __launch_bounds__(256)
-k_ws_flag_seeds(const uint8_t *__restrict__ cls, int64_t n, uint8_t *__restrict__ flag)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = cls[i] == 2;
-}
-// seeds number c0 .. c0 + cap - 1 (raster order): value key and compact id (-1: no floodable out-neighbour)
-__global__ void __launch_bounds__(256)
-k_ws_seed_list(const uint8_t *__restrict__ cls, const int *__restrict__ scan, const int *__restrict__ cid,
-               const float *__restrict__ field, int64_t n, int64_t c0, int64_t cap, unsigned *__restrict__ out_val,
-               int *__restrict__ out_cid)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || cls[i] != 2) return;
-    const int64_t k = (int64_t)scan[i] - c0;
+    __shared__ int part[4];
+    const long long b0 = base_seed[blockIdx.x];
+    if (b0 >= c0 + cap || b0 + 256 <= c0) return;                  // (uniform) no seed of this block falls into the chunk
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool sd = i < n && cls[i] == 2;
+    const unsigned long long ms = __ballot(sd);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) part[wave] = __popcll(ms);
+    __syncthreads();
+    if (!sd) return;
+    long long k = b0 + __popcll(ms & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) k += part[w];
+    k -= c0;
     if (k < 0 || k >= cap) return;
     const int c = cid[i];
+    const int id = c <= -2 ? -2 - c : -1;
     out_val[k] = ws_ordkey(field[i]);
-    out_cid[k] = c <= -2 ? -2 - c : -1;
+    out_id[k] = (id >= 0 && subid) ? subid[id] : id;
+}
+// THE SUB-GRAPH THE REPLAY CAN REACH.  The replay pops an item only while its key is at or below the tie value: P = the
+// relevant markers with a key <= vmax and the floodable pixels with a key < vmax.  It looks at the out-neighbours of what
+// it pops (pushed or not yet, small or large): Q = P + the out-neighbours of P.  On a detect_anvils window P is the rim of
+// the saturated cores, ~1 % of the relevant pixels: only Q's keys and P's neighbour rows cross PCIe (round 3 sent the whole
+// neighbour table, 28 B per relevant pixel, ~1 GB per 16 x 5424^2 window).
+__device__ __forceinline__ bool ws_poppable(const WsC &c, int64_t i, unsigned vmax) {
+    const unsigned v = c.val[i];
+    return (c.pix[i] & WS_MARKER_BIT) ? v <= vmax : v < vmax;
+}
+__global__ void __launch_bounds__(256)
+k_ws_sub_mark(WsC c, unsigned vmax, uint8_t *__restrict__ in_q)       // in_q zeroed by the caller
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.R || !ws_poppable(c, i, vmax)) return;
+    in_q[i] = 1;
+    const int *np = c.nbr + i * c.n_nbr;
+    for (int j = 0; j < c.n_nbr; j++) { const int n = np[j]; if (n >= 0) in_q[n] = 1; }     // (every writer stores 1)
+}
+__global__ void __launch_bounds__(256)
+k_ws_sub_export(WsC c, unsigned vmax, const uint8_t *__restrict__ in_q, const int *__restrict__ subid,
+                unsigned *__restrict__ out_val, int *__restrict__ out_nbr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.R || !in_q[i]) return;
+    const int64_t q = subid[i];
+    out_val[q] = c.val[i];
+    const bool pop = ws_poppable(c, i, vmax);
+    const int *np = c.nbr + i * c.n_nbr;
+    for (int j = 0; j < c.n_nbr; j++) { const int n = pop ? np[j] : -1; out_nbr[q * c.n_nbr + j] = n >= 0 ? subid[n] : -1; }
+}
+// pop ranks back on the compact set: a marker the replay popped gets its rank, every other one keeps its place after all
+// of those (no label depends on their order)
+__global__ void __launch_bounds__(256)
+k_ws_scatter_ranks(const uint8_t *__restrict__ in_q, const int *__restrict__ subid, const int *__restrict__ rank_q, int n_ranked,
+                   int64_t R, int *__restrict__ rank)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    int r = -1;
+    if (!in_q) r = rank_q[i];                                     // identity ids: the sub-graph is the whole compact set
+    else if (in_q[i]) r = rank_q[subid[i]];
+    rank[i] = r >= 0 ? r : (int)(n_ranked + i);
 }
 // largest marker value (ordered key) below which the order of equal-valued markers decides a label: every origin
 // with complete chains ties down to markers of ONE value, the value of its own root
@@ -949,7 +1000,7 @@ static int ws_scan_flags(const uint8_t *flag, int *scan, int64_t N, void *tmp, s
 static size_t ws_full_bytes(int64_t N, int64_t NV) {
     // cls, cid over the N voxels; flag, scan over the NV >= N scan positions (tile order pads edge tiles); scan temp, flags
     return tf_align_up((size_t)N, 256) + tf_align_up((size_t)NV, 256) + tf_align_up((size_t)N * 4, 256) + tf_align_up((size_t)NV * 4, 256)
-         + tf_align_up(ws_scan_temp_bytes(NV), 256) + 4096;
+         + tf_align_up(ws_scan_temp_bytes(NV), 256) + tf_align_up((size_t)((N + 255) / 256) * 24 + 64, 256) + 4096;   // ... and the per-block seed counts / bases of the reference-order export
 }
 static size_t ws_compact_bytes(int64_t R, int n_nbr, int depth) {
     // pix + val + nbr + keys + queues
@@ -1053,20 +1104,64 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
 // of another value pushed in between, or a pixel flooded from a lower marker, moves tied items up and down the array
 // (two tied markers A, B and one smaller item X pushed between them pop X, B, A; without X: A, B) -- so it cannot be
 // derived from the tied markers alone: the mechanics have to be replayed with every item in place.  This routine is
-// that replay, on the host, over the compact flood graph the device has already built: the same push / pop / sift
-// rules, item for item, with the keys only (no labels are computed here -- the device flood does that, with the pop
-// rank returned here as the last component of its chain comparison).  It stops as soon as every marker whose rank can
-// matter has popped: at the first top item above `vmax`, the largest marker value at which the device found chains
+// that replay, on the host, over the sub-graph of the compact flood graph the device exports (k_ws_sub_*): the same push
+// / pop / sift rules, item for item, with the keys only (no labels are computed here -- the device flood does that, with
+// the pop rank returned here as the last component of its chain comparison).  It stops as soon as every marker whose rank
+// can matter has popped: at the first top item above `vmax`, the largest marker value at which the device found chains
 // that tie down to equal-valued markers of different labels.
-struct WsRefItem { unsigned v; int32_t age; int32_t id; };             // id: compact id, or -1 for a seed nobody floods from
+// Ids are sub-graph ids (nQ of them): `val` their value keys, `nbr` the rows of floodable out-neighbours (rows of ids the
+// replay can pop are filled, see k_ws_sub_export), seeds carry -1 when nobody floods from them (ballast the heap needs).
+// rank[id] = pop rank of a marker, -1 if it did not pop; *n_ranked = markers popped.  Returns the pops, -1: out of memory.
+struct WsRefItem { unsigned v; int32_t age; int32_t id; };
 static inline bool ws_ref_smaller(const WsRefItem &a, const WsRefItem &b) { return a.v != b.v ? a.v < b.v : a.age < b.age; }
 
-static int64_t ws_reference_ranks(int64_t M, const unsigned *seed_val, const int *seed_cid, int64_t R, const unsigned *val,
-                                  const int *nbr, int n_nbr, unsigned vmax, int *rank)
+// host scratch of the replays: plain memory kept between calls (a dense replay touches ~6 GB: as fresh mallocs that is
+// ~1.5 M page faults per call) and pinned memory for the device -> host exports; grow-only, freed by tf_shutdown()
+#include <vector>
+namespace {
+struct WsHostBuf { void *p; size_t bytes; bool pinned; };
+std::mutex g_ws_host_mu;
+std::vector<WsHostBuf> g_ws_host_free;
+}
+static WsHostBuf ws_host_take(size_t bytes, bool pinned)
 {
-    WsRefItem *h = (WsRefItem *)malloc((size_t)(M + R + 1) * sizeof(WsRefItem));     // every pixel is pushed at most once
-    uint8_t *state = (uint8_t *)calloc((size_t)(R > 0 ? R : 1), 1);                  // 1: already pushed / a marker
-    if (!h || !state) { free(h); free(state); return -1; }
+    if (bytes == 0) bytes = 64;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_host_mu);
+        int best = -1;
+        for (size_t i = 0; i < g_ws_host_free.size(); i++) {
+            const WsHostBuf &b = g_ws_host_free[i];
+            if (b.pinned == pinned && b.bytes >= bytes && (best < 0 || b.bytes < g_ws_host_free[best].bytes)) best = (int)i;
+        }
+        if (best >= 0) { WsHostBuf b = g_ws_host_free[best]; g_ws_host_free.erase(g_ws_host_free.begin() + best); return b; }
+    }
+    WsHostBuf b{nullptr, bytes + bytes / 8, pinned};                // a little slack: the next window is rarely the same size
+    if (pinned) { if (hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; } }
+    else b.p = malloc(b.bytes);
+    if (!b.p) b.bytes = 0;
+    return b;
+}
+static void ws_host_give(WsHostBuf &b)
+{
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(g_ws_host_mu);
+    g_ws_host_free.push_back(b);
+    b.p = nullptr; b.bytes = 0;
+}
+void tf_ws_host_pool_release()                                      // tf_shutdown()
+{
+    std::lock_guard<std::mutex> lk(g_ws_host_mu);
+    for (auto &b : g_ws_host_free) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
+    g_ws_host_free.clear();
+}
+
+static int64_t ws_reference_ranks(int64_t M, const unsigned *seed_val, const int *seed_id, int64_t nQ, const unsigned *val,
+                                  const int *nbr, int n_nbr, unsigned vmax, int *rank, int *n_ranked_out)
+{
+    WsHostBuf hb = ws_host_take((size_t)(M + nQ + 1) * sizeof(WsRefItem), false);     // every pixel is pushed at most once
+    WsRefItem *h = (WsRefItem *)hb.p;
+    uint8_t *state = (uint8_t *)calloc((size_t)(nQ > 0 ? nQ : 1), 1);                   // 1: already pushed
+    if (!h || !state) { ws_host_give(hb); free(state); return -1; }
     int64_t items = 0;
     auto push = [&](const WsRefItem &e) {                                              // _watershed.pyx:120-152
         int64_t child = items;
@@ -1078,11 +1173,8 @@ static int64_t ws_reference_ranks(int64_t M, const unsigned *seed_val, const int
             else break;
         }
     };
-    for (int64_t i = 0; i < M; i++) {                                                  // :278-284, marker_locations order
-        if (seed_cid[i] >= 0) state[seed_cid[i]] = 1;
-        push(WsRefItem{seed_val[i], 0, seed_cid[i]});
-    }
-    for (int64_t i = 0; i < R; i++) rank[i] = -1;
+    for (int64_t i = 0; i < M; i++) push(WsRefItem{seed_val[i], 0, seed_id[i]});      // :278-284, marker_locations order
+    for (int64_t i = 0; i < nQ; i++) rank[i] = -1;
     int64_t age = 1, popped = 0;
     int n_ranked = 0;
     while (items > 0) {
@@ -1116,9 +1208,8 @@ static int64_t ws_reference_ranks(int64_t M, const unsigned *seed_val, const int
             push(WsRefItem{val[n], (int32_t)age, n});                                  // Py_ssize_t -> int32 store, :338
         }
     }
-    // markers that did not pop keep their raster order, after all that did (no label depends on their order)
-    for (int64_t i = 0; i < R; i++) if (rank[i] < 0) rank[i] = (int)(n_ranked + i);
-    free(h); free(state);
+    *n_ranked_out = n_ranked;
+    ws_host_give(hb); free(state);
     return popped;
 }
 
@@ -1179,15 +1270,15 @@ struct WsPosMap {                                                       // open 
     }
 };
 
-static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const int *sk, const unsigned *sval, const int *scid, int64_t R,
-                                         const uint8_t *is_marker, const unsigned *val, const int *nbr, int n_nbr, unsigned vmax, int *rank)
+static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *sk, const unsigned *sval, const int *sid, int64_t nQ,
+                                         const unsigned *val, const int *nbr, int n_nbr, unsigned vmax, int *rank, int *n_ranked_out)
 {
     // an item = (key, id) with key = (v << 32) | age: `smaller` (:161-164) is the order of the keys.  LARGE = the all-ones
     // key: larger than every small item (value keys stop at that of +inf, NaN fields are refused), equal to itself -- a
     // sift never swaps two of them, which is all the replay needs to know about the large items.
     struct Item { u64 key; int32_t id; int32_t pad; };
     const Item LARGE{~0ull, -1, 0};
-    const int64_t max_items = M + R + 1;
+    const int64_t max_items = M + nQ + 1;
     // The small items form an ancestor-closed set (every ancestor of a small item is small): they sit in the top of the
     // heap.  Positions below `n_top` -- a power of two >= 4 S -- are a plain array initialised to LARGE (the two children
     // of a node share a cache line: the sift-down of a pop walks through adjacent memory, as in the reference); deeper
@@ -1197,11 +1288,10 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const int *sk, co
     if (n_top > max_items) n_top = max_items;
     Item *top = (Item *)malloc((size_t)n_top * sizeof(Item));
     uint64_t *occ = (uint64_t *)calloc((size_t)((max_items + 63) / 64), sizeof(uint64_t));    // position holds a small item
-    uint8_t *state = (uint8_t *)malloc((size_t)(R > 0 ? R : 1));                                // 1: already pushed / a marker
+    uint8_t *state = (uint8_t *)calloc((size_t)(nQ > 0 ? nQ : 1), 1);                          // 1: already pushed
     WsPosMap deep;
     if (!top || !occ || !state || !deep.init(1 << 16)) { free(top); free(occ); free(state); return -1; }
     memset(top, 0xFF, (size_t)n_top * sizeof(Item));                                            // key = ~0: LARGE everywhere
-    memcpy(state, is_marker, (size_t)R);
     bool oom = false;
     // the bitmap covers ALL positions: a small item on its way up walks through unoccupied ancestors on bit tests alone
     // (the top of the bitmap stays in cache; the item array of the top region, 16 B per position, does not)
@@ -1233,9 +1323,9 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const int *sk, co
         }
         store(child, e);
     };
-    for (int64_t j = 0; j < S; j++) push_small(sk[j], Item{(u64)sval[j] << 32, scid[j], 0});    // seed k enters at position k, age 0
+    for (int64_t j = 0; j < S; j++) push_small((int64_t)sk[j], Item{(u64)sval[j] << 32, sid[j], 0});    // seed k enters at position k, age 0
     int64_t items = M;
-    for (int64_t i = 0; i < R; i++) rank[i] = -1;
+    for (int64_t i = 0; i < nQ; i++) rank[i] = -1;
     int64_t age = 1, popped = 0;
     int n_ranked = 0;
     while (items > 0 && !oom) {
@@ -1274,23 +1364,188 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const int *sk, co
             items += 1;
         }
     }
-    for (int64_t i = 0; i < R; i++) if (rank[i] < 0) rank[i] = (int)(n_ranked + i);
+    *n_ranked_out = n_ranked;
     free(top); free(occ); free(state);
     return oom ? -1 : popped;
 }
 
-// One call = classification / compaction, phase A, then root phases at increasing chain depth until the exactness
-// check finds no origin whose chains were cut off (or depth_max is reached).
+// ---- one flood = a JOB in three parts ---------------------------------------------------------------------------------
+//   begin   (device)  classification / compaction, phase A, chain + root phases at increasing depth until the exactness
+//                     check finds no origin whose chains were cut off; with TF_WS_REFERENCE_ORDER and labels that hang on
+//                     the order of equal-valued markers: the tie value, the seed numbers and the sub-graph the replay can
+//                     reach, copied into pinned host memory
+//   replay  (host)    the reference heap's mechanics for the pop ranks -- no HIP call, any thread: the replays of several
+//                     windows run side by side while the device floods the next ones
+//   finish  (device)  pop ranks up, root phase repeated with them, labels written
+// tf_watershed_ex2 and friends run the three back to back; tf_watershed_begin / _replay / _finish expose them.
+struct tf_ws_job {
+    const float *field; const int32_t *markers; const int8_t *mask;
+    int64_t T, H, W, N, NV, R;
+    int n_nbr, depth0, depth_max, flags;
+    hipStream_t s;
+    bool raveled;
+    WsGeom g;
+    uint8_t *cls, *flag; int *scan, *cid; char *scan_tmp; size_t scan_bytes;
+    int *d_flags; unsigned long long *d_cnt; char *seed_blocks;
+    WsC c; WsQueues Q; int *org, *rank_dev;
+    int h_cnt[WS_BATCH + 8];
+    int depth; int64_t max_sweeps;
+    unsigned long long h_amb[4];
+    int64_t st[TF_WS_NSTATS];
+    // reference order
+    bool need_replay, replay_done, applied, sparse, identity;
+    int64_t M, S, nQ; unsigned vmax;
+    WsHostBuf hb_val, hb_nbr, hb_rank, hb_sk, hb_sval, hb_sid;
+    int64_t popped; int n_ranked; int replay_rc;
+    double ms_export, ms_replay;
+};
+
+static double ws_now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static bool ws_env(const char *name) { return getenv(name) != nullptr; }
+
+static void ws_job_free(tf_ws_job *j)
+{
+    if (!j) return;
+    ws_host_give(j->hb_val); ws_host_give(j->hb_nbr); ws_host_give(j->hb_rank);
+    ws_host_give(j->hb_sk); ws_host_give(j->hb_sval); ws_host_give(j->hb_sid);
+    delete j;
+}
+
+// device -> pinned host, waits
+static int ws_to_host(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return TF_OK;
+    TF_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    return TF_OK;
+}
+
+struct WsIntToLL { __host__ __device__ __forceinline__ long long operator()(int v) const { return (long long)v; } };
+typedef hipcub::TransformInputIterator<long long, WsIntToLL, const int *> WsCountIter;
+
+// begin, part 2: what the host replay needs (see tf_ws_job)
+static int ws_job_export(tf_ws_job *j)
+{
+    const double t_enter = ws_now_ms();
+    hipStream_t s = j->s;
+    const WsC &c = j->c;
+    const int64_t R = j->R, N = j->N;
+    const int nn = j->n_nbr;
+    const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
+    static const bool ref_debug = ws_env("TF_WS_REF_DEBUG");           // development aid: where the detour's time goes
+    const bool force_dense = ws_env("TF_WS_REFERENCE_DENSE");          // A/B and test aid (read per call: the tests toggle it)
+    // the largest marker value at which the order of equal-valued markers decides a label
+    unsigned *d_vmax = (unsigned *)(j->d_cnt + 3);
+    TF_CHECK_HIP(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_ws_tie_value_max, dim3(nbr_blocks), dim3(256), 0, s, c, (const int *)j->org, j->field, d_vmax);
+    TF_CHECK_LAUNCH();
+    unsigned h_vmax = 0;
+    TF_CHECK_HIP(hipMemcpyAsync(&h_vmax, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    j->vmax = h_vmax;
+    // seed numbers: per-block counts of seeds / small seeds and their 64-bit scans, in the idle flag array
+    const int64_t nb256 = (N + 255) / 256;
+    TF_REQUIRE(nb256 < 0x7fffffffll, "tf_watershed: too many voxels for the seed numbering");
+    int *n_seed = (int *)j->seed_blocks, *n_small = n_seed + nb256;
+    long long *base_seed = (long long *)(((uintptr_t)(n_small + nb256) + 15) & ~(uintptr_t)15), *base_small = base_seed + nb256;
+    size_t need = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need, WsCountIter((const int *)nullptr, WsIntToLL()), (long long *)nullptr, (int)nb256);
+    TF_REQUIRE(need <= j->scan_bytes, "tf_watershed: scan scratch too small for the seed numbering");
+    hipLaunchKernelGGL(k_ws_seed_counts, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, j->field, N, h_vmax, n_seed, n_small);
+    TF_CHECK_LAUNCH();
+    size_t tb = j->scan_bytes;
+    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(j->scan_tmp, tb, WsCountIter(n_seed, WsIntToLL()), base_seed, (int)nb256, s));
+    tb = j->scan_bytes;
+    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(j->scan_tmp, tb, WsCountIter(n_small, WsIntToLL()), base_small, (int)nb256, s));
+    long long h_last[4] = {0, 0, 0, 0}; int h_lastc[2] = {0, 0};
+    TF_CHECK_HIP(hipMemcpyAsync(&h_last[0], base_seed + nb256 - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipMemcpyAsync(&h_last[1], base_small + nb256 - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipMemcpyAsync(&h_lastc[0], n_seed + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipMemcpyAsync(&h_lastc[1], n_small + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    // the sub-graph: Q = poppable pixels + their out-neighbours (flags in the idle scan array, ids in the idle in-queue flags)
+    uint8_t *in_q = (uint8_t *)j->scan;
+    int *subid = j->Q.inq;
+    TF_CHECK_HIP(hipMemsetAsync(in_q, 0, (size_t)R, s));
+    hipLaunchKernelGGL(k_ws_sub_mark, dim3(nbr_blocks), dim3(256), 0, s, c, h_vmax, in_q);
+    TF_CHECK_LAUNCH();
+    int64_t nQ = 0;
+    {
+        const int rc = ws_scan_flags(in_q, subid, R, j->scan_tmp, j->scan_bytes, s, &nQ);       // synchronises
+        if (rc) return rc;
+    }
+    j->M = h_last[0] + h_lastc[0]; j->S = h_last[1] + h_lastc[1];
+    // compact export if the translated rows fit the staging room (the two idle frontier queues), else the whole compact
+    // set with its own ids
+    j->identity = nQ * nn > 2 * R + 64;
+    if (j->identity) nQ = R;
+    j->nQ = nQ;
+    // the small seeds are staged in Rt / Llo / Lhi (idle until the root phase is repeated): R entries each
+    j->sparse = !force_dense && j->S <= R;
+    const double t_numbered = ws_now_ms();
+    j->hb_val = ws_host_take((size_t)nQ * sizeof(unsigned), true);
+    j->hb_nbr = ws_host_take((size_t)nQ * nn * sizeof(int), true);
+    j->hb_rank = ws_host_take((size_t)nQ * sizeof(int), true);
+    const int64_t n_list = j->sparse ? j->S : j->M;
+    if (j->sparse) j->hb_sk = ws_host_take((size_t)n_list * sizeof(long long), true);
+    j->hb_sval = ws_host_take((size_t)n_list * sizeof(unsigned), true);
+    j->hb_sid = ws_host_take((size_t)n_list * sizeof(int), true);
+    if (!j->hb_val.p || !j->hb_nbr.p || !j->hb_rank.p || (j->sparse && !j->hb_sk.p) || !j->hb_sval.p || !j->hb_sid.p) {
+        tf_set_error("tf_watershed: out of host memory for the reference-order replay");
+        return TF_ENOMEM;
+    }
+    if (j->identity) {
+        if (ws_to_host(j->hb_val.p, c.val, (size_t)R * sizeof(unsigned), s) || ws_to_host(j->hb_nbr.p, c.nbr, (size_t)R * nn * sizeof(int), s)) return TF_EHIP;
+    } else {
+        unsigned *stg_val = (unsigned *)j->Q.q[0]; int *stg_nbr = j->Q.q[1];
+        hipLaunchKernelGGL(k_ws_sub_export, dim3(nbr_blocks), dim3(256), 0, s, c, h_vmax, (const uint8_t *)in_q, (const int *)subid, stg_val, stg_nbr);
+        TF_CHECK_LAUNCH();
+        if (ws_to_host(j->hb_val.p, stg_val, (size_t)nQ * sizeof(unsigned), s) || ws_to_host(j->hb_nbr.p, stg_nbr, (size_t)nQ * nn * sizeof(int), s)) return TF_EHIP;
+    }
+    const int *subid_or_null = j->identity ? nullptr : subid;
+    if (j->sparse) {
+        long long *stg_k = (long long *)c.Rt; unsigned *stg_val = (unsigned *)c.Llo; int *stg_id = c.Lhi;
+        hipLaunchKernelGGL(k_ws_small_list, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N, h_vmax,
+                           (const long long *)base_seed, (const long long *)base_small, subid_or_null, stg_k, stg_val, stg_id);
+        TF_CHECK_LAUNCH();
+        if (ws_to_host(j->hb_sk.p, stg_k, (size_t)j->S * sizeof(long long), s) || ws_to_host(j->hb_sval.p, stg_val, (size_t)j->S * sizeof(unsigned), s) ||
+            ws_to_host(j->hb_sid.p, stg_id, (size_t)j->S * sizeof(int), s)) return TF_EHIP;
+        TF_CHECK_HIP(hipStreamSynchronize(s));
+    } else {
+        // DENSE form: every seed is sent (more small seeds than staging room, or TF_WS_REFERENCE_DENSE); the list travels
+        // through the frontier queues, 2R entries at a time
+        TF_CHECK_HIP(hipStreamSynchronize(s));                          // the sub-graph has left the queues
+        unsigned *stg_val = (unsigned *)j->Q.q[0]; int *stg_id = j->Q.q[1];
+        const int64_t cap = 2 * R;
+        for (int64_t c0 = 0; c0 < j->M; c0 += cap) {
+            const int64_t cnt = j->M - c0 < cap ? j->M - c0 : cap;
+            hipLaunchKernelGGL(k_ws_seed_list, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N,
+                               (const long long *)base_seed, c0, cap, subid_or_null, stg_val, stg_id);
+            TF_CHECK_LAUNCH();
+            if (ws_to_host((unsigned *)j->hb_sval.p + c0, stg_val, (size_t)cnt * sizeof(unsigned), s) ||
+                ws_to_host((int *)j->hb_sid.p + c0, stg_id, (size_t)cnt * sizeof(int), s)) return TF_EHIP;
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+        }
+    }
+    j->need_replay = true;
+    j->ms_export = ws_now_ms() - t_enter;
+    if (ref_debug)
+        fprintf(stderr, "reference order: %lld seeds, %lld at or below the tie value (key %u), %lld relevant pixels, sub-graph %lld%s, %s form; "
+                "tie value + numbering %.1f ms, export %.1f ms\n", (long long)j->M, (long long)j->S, h_vmax, (long long)R, (long long)nQ,
+                j->identity ? " (whole compact set)" : "", j->sparse ? "sparse" : "dense", t_numbered - t_enter, ws_now_ms() - t_numbered);
+    return TF_OK;
+}
+
 // `rv` != nullptr: the raveled form (tf_watershed_raveled): `field` = image, `markers` = `labels` = output (in place),
 // seeds = rv_locs; T, H, W, fwd, bwd, nbr_host unused.
-static int ws_run(const float *field, const int32_t *markers, const int8_t *mask,
-                  const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
-                  const int8_t *nbr_host, int n_nbr, int depth0, int depth_max, int flags, int32_t *labels,
-                  uint8_t *amb_out, void *ws, size_t ws_bytes, int64_t *st, void *stream,
-                  const WsRavel *rv = nullptr, const int64_t *rv_locs = nullptr, int64_t rv_n_locs = 0)
+static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers, const int8_t *mask,
+                        const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                        const int8_t *nbr_host, int n_nbr, int depth0, int depth_max, int flags,
+                        void *ws, size_t ws_bytes, void *stream,
+                        const WsRavel *rv = nullptr, const int64_t *rv_locs = nullptr, int64_t rv_n_locs = 0)
 {
+    int64_t *st = j->st;
+    for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = 0;
     TF_REQUIRE((flags & ~(TF_WS_SKIP_FAST_PATH | TF_WS_REFERENCE_ORDER)) == 0, "tf_watershed: unknown flag");
-    TF_REQUIRE(field && markers && labels && ws, "tf_watershed: null pointer");
+    TF_REQUIRE(field && markers && ws, "tf_watershed: null pointer");
     if (!rv) {
         TF_REQUIRE(fwd && bwd && nbr_host, "tf_watershed: null pointer");
         TF_REQUIRE(T > 0 && H > 0 && W > 0 && H < (1 << 15) && W < (1 << 15) && T < 65536, "tf_watershed: bad shape");
@@ -1304,12 +1559,14 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     const int64_t NV = rv ? N : ws_virtual_voxels(T, H, W);           // scan positions (tile order pads edge tiles)
     if (ws_bytes < ws_full_bytes(N, NV) + ws_compact_bytes(1, n_nbr, depth_max)) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
     hipStream_t s = (hipStream_t)stream;
-    WsGeom g; g.T = T; g.H = (int)H; g.W = (int)W; g.plane = H * W; g.n_nbr = n_nbr; g.n_tx = (int)((W + WS_TILE - 1) / WS_TILE);
+    WsGeom &g = j->g;
+    g.T = T; g.H = (int)H; g.W = (int)W; g.plane = H * W; g.n_nbr = n_nbr; g.n_tx = (int)((W + WS_TILE - 1) / WS_TILE);
     for (int i = 0; i < n_nbr && !rv; i++) {
         g.dt[i] = nbr_host[i * 3]; g.dy[i] = nbr_host[i * 3 + 1]; g.dx[i] = nbr_host[i * 3 + 2];
         TF_REQUIRE(abs(g.dt[i]) <= 1 && abs(g.dy[i]) <= 1 && abs(g.dx[i]) <= 1, "tf_watershed: neighbour offset out of range");
     }
-    for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = 0;
+    j->field = field; j->markers = markers; j->mask = mask; j->T = T; j->H = H; j->W = W; j->N = N; j->NV = NV;
+    j->n_nbr = n_nbr; j->depth0 = depth0; j->depth_max = depth_max; j->flags = flags; j->s = s; j->raveled = rv != nullptr;
     TfArena ar(ws, ws_bytes);
     uint8_t *cls = ar.take<uint8_t>(N), *flag = ar.take<uint8_t>(NV);
     int *scan = ar.take<int>(NV), *cid = ar.take<int>(N);
@@ -1317,7 +1574,10 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     char *scan_tmp = ar.take<char>(scan_bytes ? scan_bytes : 1);
     int *d_flags = ar.take<int>(WS_BATCH + 8);
     unsigned long long *d_cnt = ar.take<unsigned long long>(4);
+    j->seed_blocks = ar.take<char>((size_t)((N + 255) / 256) * 24 + 64);
     if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
+    j->cls = cls; j->flag = flag; j->scan = scan; j->cid = cid; j->scan_tmp = scan_tmp; j->scan_bytes = scan_bytes;
+    j->d_flags = d_flags; j->d_cnt = d_cnt;
 
     dim3 block(64, 4, 1), grid(rv ? 1 : (g.W + 63) / 64, rv ? 1 : (g.H + 3) / 4, rv ? 1 : (unsigned)T);
     const unsigned nb1 = (unsigned)((N + 255) / 256);
@@ -1347,7 +1607,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             if (NV > N) TF_CHECK_HIP(hipMemsetAsync(flag, 0, (size_t)NV, s));   // padding positions of the edge tiles
             bool faces = n_nbr == 6;                        // the six face neighbours, in any order?
             for (int i = 0; faces && i < 6; i++) faces = abs(g.dt[i]) + abs(g.dy[i]) + abs(g.dx[i]) == 1;
-            for (int i = 0; faces && i < 6; i++) for (int j = 0; j < i; j++) faces = faces && !(g.dt[i] == g.dt[j] && g.dy[i] == g.dy[j] && g.dx[i] == g.dx[j]);
+            for (int i = 0; faces && i < 6; i++) for (int k = 0; k < i; k++) faces = faces && !(g.dt[i] == g.dt[k] && g.dy[i] == g.dy[k] && g.dx[i] == g.dx[k]);
             if (faces && W % 4 == 0 && (uintptr_t)cls % 4 == 0 && (uintptr_t)flag % 4 == 0 && (uintptr_t)fwd % 16 == 0 && (uintptr_t)bwd % 16 == 0)
                 hipLaunchKernelGGL(k_ws_relevant6x4, dim3((unsigned)((W / 4 + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T), block, 0, s,
                                    (const uint8_t *)cls, fwd, bwd, g, flag);
@@ -1380,6 +1640,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         }
     }
     st[6] = R;
+    j->R = R;
     if (ws_bytes < ws_full_bytes(N, NV) + ws_compact_bytes(R > 0 ? R : 1, n_nbr, depth_max)) {
         tf_set_error("tf_watershed: workspace too small for %lld relevant pixels", (long long)R);
         return TF_ENOMEM;
@@ -1389,27 +1650,24 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
                                        (const long long *)((long long *)scan + NV / 256), NV / 256, g, cid);
     else hipLaunchKernelGGL(k_ws_cid_tiled, grid, block, 0, s, (const uint8_t *)cls, (const uint8_t *)flag, (const int *)scan, g, cid);
     TF_CHECK_LAUNCH();
-    int h_cnt[WS_BATCH + 8];
-    WsC c; memset(&c, 0, sizeof(c));
+    WsC &c = j->c; memset(&c, 0, sizeof(c));
     c.R = R; c.n_nbr = n_nbr;
-    int *org = nullptr;
-    int depth = 0;
-    bool reference_order_applied = false;
-    unsigned long long h_amb[4] = {0, 0, 0, 0};
+    j->org = nullptr; j->rank_dev = nullptr;
+    j->depth = 0;
     if (R > 0) {
         u64 *pix = ar.take<u64>(R); unsigned *val = ar.take<unsigned>(R); int *nbr = ar.take<int>(R * n_nbr);
         c.pix = pix; c.val = val; c.nbr = nbr;
         c.KM = ar.take<u64>(2 * R);
         for (int k = 1; k < depth_max; k++) c.C[k] = ar.take<u64>(R);
         c.Rt = ar.take<u64>(R);
-        c.Llo = ar.take<int>(R); c.Lhi = ar.take<int>(R); org = ar.take<int>(R);
-        int *rank_dev = ar.take<int>(R);
+        c.Llo = ar.take<int>(R); c.Lhi = ar.take<int>(R); j->org = ar.take<int>(R);
+        j->rank_dev = ar.take<int>(R);
         u64 *emask = ar.take<u64>(R);
         c.emask = emask;
-        WsQueues Q;
+        WsQueues &Q = j->Q;
         Q.qcap = (int)(2 * R < 0x7fffff00ll ? 2 * R : 0x7fffff00ll);
         Q.q[0] = ar.take<int>(2 * R + 64); Q.q[1] = ar.take<int>(2 * R + 64); Q.inq = ar.take<int>(R);
-        Q.cnt = d_flags; Q.h_cnt = h_cnt; Q.processed = &st[7];
+        Q.cnt = d_flags; Q.h_cnt = j->h_cnt; Q.processed = &st[7];
         if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
         int *d_nan = d_flags + WS_BATCH + 4;
         TF_CHECK_HIP(hipMemsetAsync(d_nan, 0, sizeof(int), s));
@@ -1438,6 +1696,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         // T + H + W times a detour factor on a (T, H, W) grid; the raveled form knows no shape, there the only safe bound
         // is the number of relevant pixels itself (a snake-shaped mask floods one pixel per sweep)
         const int64_t max_sweeps = rv ? 4096 + 2 * R : 4096 + 512 * (T + H + W);
+        j->max_sweeps = max_sweeps;
         int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0]);
         if (rc) return rc;
         {
@@ -1450,7 +1709,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
         // inputs known to contain exact plateaus: the labels are the same either way, only the work differs.
         const bool speculate = !((flags & TF_WS_SKIP_FAST_PATH) && depth0 > 1);
         st[5] = speculate ? 0 : -1;
-        depth = speculate ? 1 : depth0;
+        int depth = speculate ? 1 : depth0;
         int levels_done = 0;                        // C_1 .. C_levels_done are final
         for (;;) {
             for (int k = levels_done + 1; k < depth; k++) {
@@ -1470,168 +1729,84 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
             if (rc) return rc;
             if (speculate && depth == 1) st[1] = sw; else st[2 + (depth < 3 ? depth - 1 : 2)] += sw;
             st[12] += 1;
-            TF_CHECK_HIP(hipMemsetAsync(org, 0, (size_t)R * sizeof(int), s));
+            TF_CHECK_HIP(hipMemsetAsync(j->org, 0, (size_t)R * sizeof(int), s));
             TF_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), s));
-            hipLaunchKernelGGL(k_ws_origins, dim3(nbr_blocks), dim3(256), 0, s, c, depth, org);
-            hipLaunchKernelGGL(k_ws_count_ambiguous, dim3(nbr_blocks), dim3(256), 0, s, c, org, d_cnt);
+            hipLaunchKernelGGL(k_ws_origins, dim3(nbr_blocks), dim3(256), 0, s, c, depth, j->org);
+            hipLaunchKernelGGL(k_ws_count_ambiguous, dim3(nbr_blocks), dim3(256), 0, s, c, j->org, d_cnt);
             TF_CHECK_LAUNCH();
-            TF_CHECK_HIP(hipMemcpyAsync(h_amb, d_cnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipMemcpyAsync(j->h_amb, d_cnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             TF_CHECK_HIP(hipStreamSynchronize(s));
-            if (speculate && depth == 1) st[5] = h_amb[2] != 0;
-            if (h_amb[2] == 0 || depth >= depth_max) break;
+            if (speculate && depth == 1) st[5] = j->h_amb[2] != 0;
+            if (j->h_amb[2] == 0 || depth >= depth_max) break;
             depth = depth < depth0 ? depth0 : depth + 1;
         }
-        if ((flags & TF_WS_REFERENCE_ORDER) && h_amb[1] > 0 && h_amb[2] == 0) {
-            // Labels hang on the order of equal-valued markers: get the reference's (ws_reference_ranks) and repeat the
-            // root phase with the pop rank in place of the raster index.  Chain levels, origins and label sets do not
-            // depend on that order, only the choice among tying candidates does.
-            timespec ts_enter; clock_gettime(CLOCK_MONOTONIC, &ts_enter);
-            hipEvent_t ev0, ev1;
-            TF_CHECK_HIP(hipEventCreate(&ev0)); TF_CHECK_HIP(hipEventCreate(&ev1));
-            TF_CHECK_HIP(hipEventRecord(ev0, s));
-            unsigned *d_vmax = (unsigned *)(d_cnt + 3);
-            TF_CHECK_HIP(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), s));
-            hipLaunchKernelGGL(k_ws_tie_value_max, dim3(nbr_blocks), dim3(256), 0, s, c, (const int *)org, field, d_vmax);
-            hipLaunchKernelGGL(k_ws_flag_seeds, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, N, flag);
-            TF_CHECK_LAUNCH();
-            unsigned h_vmax = 0;
-            TF_CHECK_HIP(hipMemcpyAsync(&h_vmax, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            int64_t M = 0;
-            const int rc_seeds = ws_scan_flags(flag, scan, N, scan_tmp, scan_bytes, s, &M);          // synchronises
-            if (rc_seeds) { tf_set_error("tf_watershed: TF_WS_REFERENCE_ORDER needs at most 2^30 seeds per call (use time windows)"); return rc_seeds; }
-            const bool ref_debug = getenv("TF_WS_REF_DEBUG") != nullptr;                   // development aid: where the detour's time goes
-            auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-            const double t_begin = now_ms();
-            if (ref_debug) fprintf(stderr, "reference order: tie value + seed numbering %.0f ms\n", t_begin - (ts_enter.tv_sec * 1e3 + ts_enter.tv_nsec * 1e-6));
-            // the flood graph (value keys and out-neighbours of the relevant pixels) and the ranks
-            unsigned *h_val = (unsigned *)malloc((size_t)R * sizeof(unsigned));
-            int *h_nbr = (int *)malloc((size_t)R * n_nbr * sizeof(int));
-            int *h_rank = (int *)malloc((size_t)R * sizeof(int));
-            unsigned *h_seed_val = nullptr; int *h_seed_cid = nullptr, *h_seed_k = nullptr; uint8_t *h_marker = nullptr;
-            int rc2 = TF_OK;
-            int64_t popped = -1;
-            if (!h_val || !h_nbr || !h_rank) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
-            if (rc2 == TF_OK &&
-                (hipMemcpyAsync(h_val, c.val, (size_t)R * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                 hipMemcpyAsync(h_nbr, c.nbr, (size_t)R * n_nbr * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                 hipStreamSynchronize(s) != hipSuccess)) { tf_set_error("tf_watershed: flood graph transfer failed"); rc2 = TF_EHIP; }
-            const double t_graph = now_ms();
-            // SPARSE form (ws_reference_ranks_sparse): only the seeds with a key <= vmax are listed and sent.  The flag array
-            // is idle once the seeds are numbered: it holds the per-block counts, their scan and the marker bytes
-            const bool force_dense = getenv("TF_WS_REFERENCE_DENSE") != nullptr;            // A/B and test aid (read per call)
-            const int64_t nb256 = (N + 255) / 256;
-            size_t small_scan_bytes = 0;
-            (void)hipcub::DeviceScan::ExclusiveSum(nullptr, small_scan_bytes, (const int *)nullptr, (int *)nullptr, (int)(nb256 < 0x7fffffffll ? nb256 : 1));
-            bool sparse = rc2 == TF_OK && !force_dense && nb256 < 0x7fffffffll && small_scan_bytes <= scan_bytes &&
-                          (size_t)nb256 * 8 + (size_t)R + 64 <= (size_t)(rv ? N : NV);
-            int64_t S = 0;
-            if (sparse) {
-                int *s_count = (int *)flag, *s_base = s_count + nb256;
-                uint8_t *d_marker = (uint8_t *)(s_base + nb256);
-                hipLaunchKernelGGL(k_ws_small_count, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)cls, field, N, h_vmax, s_count);
-                size_t tb = scan_bytes;
-                int h_last[2] = {0, 0};
-                if (hipGetLastError() != hipSuccess ||
-                    hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, (const int *)s_count, s_base, (int)nb256, s) != hipSuccess ||
-                    hipMemcpyAsync(&h_last[0], s_base + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                    hipMemcpyAsync(&h_last[1], s_count + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                    hipStreamSynchronize(s) != hipSuccess) { tf_set_error("tf_watershed: small-seed count failed"); rc2 = TF_EHIP; }
-                S = (int64_t)h_last[0] + h_last[1];
-                // the list is staged in the idle frontier queues and the rank array: R entries each at least
-                if (rc2 == TF_OK && S > R) sparse = false;
-                if (rc2 == TF_OK && sparse) {
-                    int *stg_k = Q.q[0]; unsigned *stg_val = (unsigned *)Q.q[1]; int *stg_cid = rank_dev;
-                    h_seed_k = (int *)malloc((size_t)(S > 0 ? S : 1) * sizeof(int));
-                    h_seed_val = (unsigned *)malloc((size_t)(S > 0 ? S : 1) * sizeof(unsigned));
-                    h_seed_cid = (int *)malloc((size_t)(S > 0 ? S : 1) * sizeof(int));
-                    h_marker = (uint8_t *)malloc((size_t)R);
-                    if (!h_seed_k || !h_seed_val || !h_seed_cid || !h_marker) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
-                    if (rc2 == TF_OK) {
-                        hipLaunchKernelGGL(k_ws_small_list, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)cls, (const int *)scan, (const int *)cid,
-                                           field, N, h_vmax, (const int *)s_base, stg_k, stg_val, stg_cid);
-                        hipLaunchKernelGGL(k_ws_marker_bytes, dim3(nbr_blocks), dim3(256), 0, s, c.pix, R, d_marker);
-                        if (hipGetLastError() != hipSuccess ||
-                            (S > 0 && (hipMemcpyAsync(h_seed_k, stg_k, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                                       hipMemcpyAsync(h_seed_val, stg_val, (size_t)S * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                                       hipMemcpyAsync(h_seed_cid, stg_cid, (size_t)S * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess)) ||
-                            hipMemcpyAsync(h_marker, d_marker, (size_t)R, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                            hipStreamSynchronize(s) != hipSuccess) { tf_set_error("tf_watershed: small-seed list transfer failed"); rc2 = TF_EHIP; }
-                    }
-                    const double t_list = now_ms();
-                    if (rc2 == TF_OK) {
-                        popped = ws_reference_ranks_sparse(M, S, h_seed_k, h_seed_val, h_seed_cid, R, h_marker, h_val, h_nbr, n_nbr, h_vmax, h_rank);
-                        if (popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
-                    }
-                    if (ref_debug)
-                        fprintf(stderr, "reference order: %lld seeds, %lld at or below the tie value, %lld relevant pixels; graph to host %.0f ms, "
-                                "small-seed list %.0f ms, replay %.0f ms (%lld pops)\n", (long long)M, (long long)S, (long long)R,
-                                t_graph - t_begin, t_list - t_graph, now_ms() - t_list, (long long)popped);
-                }
-            }
-            if (rc2 == TF_OK && !sparse) {
-                // DENSE form: every seed is sent and pushed (more small seeds than staging room, or TF_WS_REFERENCE_DENSE)
-                if (ref_debug) fprintf(stderr, "reference order: dense replay: %lld seeds, %lld at or below the tie value (key %u), %lld relevant pixels\n",
-                                       (long long)M, (long long)S, h_vmax, (long long)R);
-                free(h_seed_val); free(h_seed_cid);
-                h_seed_val = (unsigned *)malloc((size_t)(M > 0 ? M : 1) * sizeof(unsigned));
-                h_seed_cid = (int *)malloc((size_t)(M > 0 ? M : 1) * sizeof(int));
-                if (!h_seed_val || !h_seed_cid) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
-                if (sparse == false && rc2 == TF_OK && !force_dense) {
-                    // the flag array was reused above: number the seeds again
-                    hipLaunchKernelGGL(k_ws_flag_seeds, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, N, flag);
-                    int64_t M2 = 0;
-                    const int rc_again = ws_scan_flags(flag, scan, N, scan_tmp, scan_bytes, s, &M2);
-                    if (rc_again) rc2 = rc_again;
-                }
-                // the seed list travels through the (now idle) frontier queues, 2R entries at a time
-                unsigned *stg_val = (unsigned *)Q.q[0]; int *stg_cid = Q.q[1];
-                const int64_t cap = 2 * R;
-                for (int64_t c0 = 0; c0 < M && rc2 == TF_OK; c0 += cap) {
-                    const int64_t cnt = M - c0 < cap ? M - c0 : cap;
-                    hipLaunchKernelGGL(k_ws_seed_list, dim3(nb1), dim3(256), 0, s, (const uint8_t *)cls, (const int *)scan, (const int *)cid,
-                                       field, N, c0, cap, stg_val, stg_cid);
-                    if (hipGetLastError() != hipSuccess ||
-                        hipMemcpyAsync(h_seed_val + c0, stg_val, (size_t)cnt * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                        hipMemcpyAsync(h_seed_cid + c0, stg_cid, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
-                        hipStreamSynchronize(s) != hipSuccess) { tf_set_error("tf_watershed: seed list transfer failed"); rc2 = TF_EHIP; }
-                }
-                if (rc2 == TF_OK) {
-                    popped = ws_reference_ranks(M, h_seed_val, h_seed_cid, R, h_val, h_nbr, n_nbr, h_vmax, h_rank);
-                    if (popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); rc2 = TF_ENOMEM; }
-                }
-            }
-            const double t_replayed = now_ms();
-            if (rc2 == TF_OK && (hipMemcpyAsync(rank_dev, h_rank, (size_t)R * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
-                                 hipStreamSynchronize(s) != hipSuccess)) { tf_set_error("tf_watershed: rank transfer failed"); rc2 = TF_EHIP; }
-            free(h_seed_val); free(h_seed_cid); free(h_seed_k); free(h_marker); free(h_val); free(h_nbr); free(h_rank);
-            if (ref_debug) fprintf(stderr, "reference order: rank upload + frees %.0f ms\n", now_ms() - t_replayed);
-            if (rc2) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc2; }
-            hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1, (const int *)rank_dev);
-            hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, markers, c.Llo, c.Lhi, R);
-            TF_CHECK_LAUNCH();
-            int64_t sw = 0;
-            rc = ws_run_phase(c, depth, depth, Q, s, max_sweeps, &sw);
-            if (rc) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc; }
-            st[2 + (depth < 3 ? depth - 1 : 2)] += sw;
-            TF_CHECK_HIP(hipEventRecord(ev1, s));
-            TF_CHECK_HIP(hipEventSynchronize(ev1));
-            float ms = 0.f;
-            TF_CHECK_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-            (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-            if (getenv("TF_WS_REF_DEBUG")) {
-                timespec ts_exit; clock_gettime(CLOCK_MONOTONIC, &ts_exit);
-                fprintf(stderr, "reference order: whole detour %.0f ms on the host clock, %.0f ms by the stream's events\n",
-                        (ts_exit.tv_sec - ts_enter.tv_sec) * 1e3 + (ts_exit.tv_nsec - ts_enter.tv_nsec) * 1e-6, ms);
-            }
-            st[13] = popped; st[14] = sparse ? S : M; st[15] = (int64_t)(ms * 1000.0f);
-            reference_order_applied = true;
+        j->depth = depth;
+        if ((flags & TF_WS_REFERENCE_ORDER) && j->h_amb[1] > 0 && j->h_amb[2] == 0) {
+            // Labels hang on the order of equal-valued markers: the host replay (ws_reference_ranks*) gives the reference's,
+            // and finish repeats the root phase with the pop rank in place of the raster index.  Chain levels, origins and
+            // label sets do not depend on that order, only the choice among tying candidates does.
+            rc = ws_job_export(j);
+            if (rc) return rc;
         }
     }
-    st[8] = depth; st[9] = (int64_t)h_amb[0]; st[10] = (int64_t)h_amb[1]; st[11] = (int64_t)h_amb[2];
+    st[8] = j->depth; st[9] = (int64_t)j->h_amb[0]; st[10] = (int64_t)j->h_amb[1]; st[11] = (int64_t)j->h_amb[2];
+    return TF_OK;
+}
+
+// host only: no HIP call, any thread
+static int ws_job_replay(tf_ws_job *j)
+{
+    if (!j->need_replay || j->replay_done) return j->replay_rc;
+    const double t0 = ws_now_ms();
+    int n_ranked = 0;
+    if (j->sparse)
+        j->popped = ws_reference_ranks_sparse(j->M, j->S, (const long long *)j->hb_sk.p, (const unsigned *)j->hb_sval.p, (const int *)j->hb_sid.p,
+                                              j->nQ, (const unsigned *)j->hb_val.p, (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked);
+    else
+        j->popped = ws_reference_ranks(j->M, (const unsigned *)j->hb_sval.p, (const int *)j->hb_sid.p, j->nQ, (const unsigned *)j->hb_val.p,
+                                       (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked);
+    j->n_ranked = n_ranked;
+    j->replay_done = true;
+    j->ms_replay = ws_now_ms() - t0;
+    if (j->popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); j->replay_rc = TF_ENOMEM; }
+    static const bool ref_debug = ws_env("TF_WS_REF_DEBUG");
+    if (ref_debug) fprintf(stderr, "reference order: replay %.1f ms (%lld pops, %d markers ranked)\n", j->ms_replay, (long long)j->popped, n_ranked);
+    return j->replay_rc;
+}
+
+static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
+{
+    TF_REQUIRE(labels, "tf_watershed: null pointer");
+    hipStream_t s = j->s;
+    int64_t *st = j->st;
+    const WsC &c = j->c;
+    const int64_t R = j->R, N = j->N;
+    const unsigned nb1 = (unsigned)((N + 255) / 256);
+    if (j->need_replay) {
+        int rc = ws_job_replay(j);                                       // (a no-op if the caller has run it)
+        if (rc) return rc;
+        const double t0 = ws_now_ms();
+        const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
+        int *stg_rank = j->Q.q[0];
+        TF_CHECK_HIP(hipMemcpyAsync(stg_rank, j->hb_rank.p, (size_t)j->nQ * sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_ws_scatter_ranks, dim3(nbr_blocks), dim3(256), 0, s, j->identity ? (const uint8_t *)nullptr : (const uint8_t *)j->scan,
+                           (const int *)j->Q.inq, (const int *)stg_rank, j->n_ranked, R, j->rank_dev);
+        hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1, (const int *)j->rank_dev);
+        hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, j->markers, c.Llo, c.Lhi, R);
+        TF_CHECK_LAUNCH();
+        int64_t sw = 0;
+        rc = ws_run_phase(c, j->depth, j->depth, j->Q, s, j->max_sweeps, &sw);
+        if (rc) return rc;
+        st[2 + (j->depth < 3 ? j->depth - 1 : 2)] += sw;
+        st[12] += 1;
+        j->applied = true;
+        st[13] = j->popped; st[14] = j->sparse ? j->S : j->M;
+        st[15] = (int64_t)((j->ms_export + j->ms_replay + (ws_now_ms() - t0)) * 1000.0);
+    }
     {
         TfProfScope ps(TFK_WS_LABELS, 12.0 * (double)N, s);
-        if (rv) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)cid, (const u64 *)c.Rt, c.pix, reference_order_applied ? 1 : 0, labels, N); }
-        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, markers, cid, c.Rt, c.pix, reference_order_applied ? 1 : 0, c.Llo, c.Lhi, org, labels,
+        if (j->raveled) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)j->cid, (const u64 *)c.Rt, c.pix, j->applied ? 1 : 0, labels, N); }
+        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, j->markers, j->cid, c.Rt, c.pix, j->applied ? 1 : 0, c.Llo, c.Lhi, j->org, labels,
                                 R > 0 ? amb_out : nullptr, N);
     }
     TF_CHECK_LAUNCH();
@@ -1640,11 +1815,78 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     if (st[11] > 0) {
         tf_set_error("tf_watershed: %lld pixel(s) still tie at chain depth %d (the compared chains are cut off); "
                      "labels written, but they may differ from the reference there: raise max_depth",
-                     (long long)st[11], depth);
+                     (long long)st[11], j->depth);
         return TF_EDEPTH;
     }
     // reference order applied: the labels ARE the reference's, whatever its heap did with the equal-valued markers
-    return (st[9] > 0 && !reference_order_applied) ? TF_WS_AMBIGUOUS : TF_OK;
+    return (st[9] > 0 && !j->applied) ? TF_WS_AMBIGUOUS : TF_OK;
+}
+
+static tf_ws_job *ws_job_new()
+{
+    tf_ws_job *j = new (std::nothrow) tf_ws_job;
+    if (!j) return nullptr;
+    memset((void *)j, 0, sizeof(*j));
+    return j;
+}
+
+static int ws_run(const float *field, const int32_t *markers, const int8_t *mask,
+                  const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                  const int8_t *nbr_host, int n_nbr, int depth0, int depth_max, int flags, int32_t *labels,
+                  uint8_t *amb_out, void *ws, size_t ws_bytes, int64_t *st, void *stream,
+                  const WsRavel *rv = nullptr, const int64_t *rv_locs = nullptr, int64_t rv_n_locs = 0)
+{
+    for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = 0;
+    TF_REQUIRE(labels, "tf_watershed: null pointer");
+    tf_ws_job *j = ws_job_new();
+    if (!j) { tf_set_error("tf_watershed: out of host memory"); return TF_ENOMEM; }
+    int rc = ws_job_begin(j, field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, depth0, depth_max, flags, ws, ws_bytes, stream, rv, rv_locs, rv_n_locs);
+    if (rc == TF_OK) rc = ws_job_finish(j, labels, amb_out);
+    for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = j->st[i];
+    ws_job_free(j);
+    return rc;
+}
+
+extern "C" int tf_watershed_begin(const float *field, const int32_t *markers, const int8_t *mask,
+                                  const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
+                                  const int8_t *nbr_host, int n_nbr, int chain_depth, int max_depth, int flags,
+                                  void *ws, size_t ws_bytes, int64_t *stats_host, void *stream, void **job_out)
+{
+    TF_REQUIRE(job_out, "tf_watershed_begin: null pointer");
+    *job_out = nullptr;
+    tf_ws_job *j = ws_job_new();
+    if (!j) { tf_set_error("tf_watershed: out of host memory"); return TF_ENOMEM; }
+    const int rc = ws_job_begin(j, field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, chain_depth, max_depth, flags, ws, ws_bytes, stream);
+    if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = j->st[i];
+    if (rc != TF_OK) { ws_job_free(j); return rc; }
+    *job_out = j;
+    return TF_OK;
+}
+extern "C" int tf_watershed_needs_replay(const void *job) { return job && ((const tf_ws_job *)job)->need_replay ? 1 : 0; }
+extern "C" int tf_watershed_replay(void *job)
+{
+    TF_REQUIRE(job, "tf_watershed_replay: null job");
+    return ws_job_replay((tf_ws_job *)job);
+}
+extern "C" int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguous, int64_t *stats_host)
+{
+    TF_REQUIRE(job, "tf_watershed_finish: null job");
+    tf_ws_job *j = (tf_ws_job *)job;
+    const int rc = ws_job_finish(j, labels, ambiguous);
+    if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = j->st[i];
+    ws_job_free(j);
+    return rc;
+}
+extern "C" void tf_watershed_abandon(void *job) { ws_job_free((tf_ws_job *)job); }
+extern "C" int tf_watershed_job_info(const void *job, int64_t *info)
+{
+    TF_REQUIRE(job && info, "tf_watershed_job_info: null pointer");
+    const tf_ws_job *j = (const tf_ws_job *)job;
+    info[0] = j->need_replay ? (j->sparse ? 1 : 2) : 0;
+    info[1] = j->M; info[2] = j->S; info[3] = j->nQ; info[4] = j->R;
+    info[5] = (int64_t)(j->ms_export * 1000.0); info[6] = j->replay_done ? (int64_t)(j->ms_replay * 1000.0) : -1;
+    info[7] = (int64_t)j->vmax;
+    return TF_OK;
 }
 
 extern "C" int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *mask,

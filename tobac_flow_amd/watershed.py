@@ -6,6 +6,7 @@ ValueErrors).  The reference pads the volume and calls its Cython heap flood
 include/tobac_flow_hip.h) on the unpadded volume: out-of-volume neighbours are rejected by
 coordinate tests, which is what the zero-padded mask achieves in the reference.
 """
+import ctypes
 import warnings
 
 import numpy as np
@@ -84,27 +85,127 @@ _REPROBE = 8
 TF_WS_SKIP_FAST_PATH, TF_WS_REFERENCE_ORDER = 1, 2
 
 
-def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
-                  expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="warn", return_ambiguous=False):
-    """Device-resident core: torch tensors in (field f32, markers i32, mask i8 or None), labels out.
+_SLOTS_LOCK = __import__("threading").Lock()
+_slots_busy = set()
+
+
+def _take_slot():
+    """workspace slot of a flood in flight: every job owns one scratch buffer (tag `watershed_job<k>`) until it is finished"""
+    with _SLOTS_LOCK:
+        k = 0
+        while k in _slots_busy:
+            k += 1
+        _slots_busy.add(k)
+        return k
+
+
+def _give_slot(k):
+    with _SLOTS_LOCK:
+        _slots_busy.discard(k)
+
+
+class WatershedJob:
+    """One flood in flight (tf_watershed_begin / _replay / _finish, include/tobac_flow_hip.h): `watershed_begin` has run the
+    device part up to the exactness check; if labels hang on the order of equal-valued markers (and on_ambiguous is
+    "reference") `needs_replay` is True and `replay()` -- pure host work, no GIL, any thread -- computes the reference
+    heap's pop ranks; `finish()` applies them and returns the labels.  Several jobs may be in flight: the replays of earlier
+    windows run on worker threads while the device floods the next ones (bench.py).  `finish()` runs the replay itself
+    if nobody has."""
+
+    def __init__(self, handle, slot, ws, keep, shape, on_ambiguous, return_ambiguous, stats, st):
+        self._h, self._slot, self._ws, self._keep = handle, slot, ws, keep
+        self._shape, self._on_ambiguous, self._return_ambiguous, self._stats, self._st = shape, on_ambiguous, return_ambiguous, stats, st
+        self.needs_replay = bool(_lib.lib().tf_watershed_needs_replay(handle))
+        self.info = self._info()
+
+    def _info(self):
+        a = np.zeros(8, np.int64)
+        _lib.lib().tf_watershed_job_info(self._h, a.ctypes.data_as(_lib._P))
+        return {"replay_form": ("none", "sparse", "dense")[int(a[0])], "seeds": int(a[1]), "seeds_at_or_below_tie_value": int(a[2]),
+                "subgraph_pixels": int(a[3]), "relevant_pixels": int(a[4]), "export_us": int(a[5]), "replay_us": int(a[6])}
+
+    def replay(self):
+        if self._h is not None and self.needs_replay:
+            _lib.check(_lib.lib().tf_watershed_replay(self._h), "tf_watershed_replay")
+        return self
+
+    def abandon(self):
+        if self._h is not None:
+            _lib.lib().tf_watershed_abandon(self._h)
+            self._h = None
+            self._ws = self._keep = None
+            _give_slot(self._slot)
+
+    def __del__(self):
+        try:
+            self.abandon()
+        except Exception:                                    # interpreter shutdown
+            pass
+
+    def finish(self):
+        if self._h is None:
+            raise RuntimeError("WatershedJob.finish: the job has already been finished or abandoned")
+        t = _lib.torch()
+        L = _lib.lib()
+        labels = _lib.empty(self._shape, t.int32)
+        amb = _lib.empty(self._shape, t.uint8) if self._return_ambiguous else None
+        st = self._st
+        if self.needs_replay:
+            self.replay()
+            self.info = self._info()
+        h, self._h = self._h, None
+        try:
+            rc = L.tf_watershed_finish(h, _lib.ptr(labels), _lib.ptr(amb), st.ctypes.data_as(_lib._P))
+        finally:
+            self._ws = self._keep = None
+            _give_slot(self._slot)
+        if rc not in (TF_WS_AMBIGUOUS, TF_EDEPTH):
+            _lib.check(rc, "tf_watershed")
+        stats, on_ambiguous = self._stats, self._on_ambiguous
+        if stats is not None:
+            stats["sweeps"] = st[:8].tolist()
+            stats["chain_depth"] = int(st[8])
+            stats["ambiguous_pixels"] = int(st[9])
+            stats["marker_tie_origins"] = int(st[10])
+            stats["depth_origins"] = int(st[11])
+            stats["reference_order"] = {"replayed_pops": int(st[13]), "seeds": int(st[14]), "microseconds": int(st[15])}
+            stats["reference_order_detail"] = self.info
+        if rc == TF_EDEPTH:
+            msg = (f"watershed: {int(st[11])} pixel(s) still tie at chain depth {int(st[8])} (the deepest allowed); "
+                   f"{int(st[9])} label(s) may differ from the reference")
+            if on_ambiguous == "ignore":
+                warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=3)
+            else:
+                raise WatershedDepthError(msg)
+        elif rc == TF_WS_AMBIGUOUS and on_ambiguous != "ignore":
+            msg = (f"watershed: the labels of {int(st[9])} pixel(s) depend on the order in which the reference's binary heap "
+                   f"pops equal-valued markers ({int(st[10])} tie point(s)); resolved by the markers' raster order")
+            if on_ambiguous == "raise":
+                raise WatershedAmbiguityError(msg)
+            warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=3)
+        return (labels, amb) if self._return_ambiguous else labels
+
+
+def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
+                    expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="reference", return_ambiguous=False):
+    """Device-resident core, first part: torch tensors in (field f32, markers i32, mask i8 or None) -> WatershedJob.
 
     expect_conflict: True / False force the scheduling hint, None (default) uses the per-shape memo.
     Exactness contract (include/tobac_flow_hip.h, tf_watershed_ex2): the library deepens the chain comparison on its
-    own up to `max_chain_depth` and reports every pixel whose label still hangs on a last-resort tie-break.
-      * ties between equal-valued markers (the reference resolves them by the internal state of its heap): labels
-        follow the markers' raster order; `on_ambiguous` = "warn" (default) / "raise" / "ignore";
-        `on_ambiguous="reference"`: the library replays the reference heap's push / pop mechanics on the host
-        (TF_WS_REFERENCE_ORDER, include/tobac_flow_hip.h) to get the markers' pop ranks and floods with those: the
-        labels are then the reference's bit for bit, at the cost of a sequential pass (stats["reference_order"]);
+    own up to `max_chain_depth` and knows every pixel whose label still hangs on a last-resort tie-break.
+      * ties between equal-valued markers (the reference resolves them by the internal state of its heap):
+        `on_ambiguous="reference"` (the default since round 4: the result of the reference's own call,
+        watershed.py:151 + _watershed.pyx:278-284): the library replays the reference heap's push / pop mechanics on the
+        host (TF_WS_REFERENCE_ORDER) to get the markers' pop ranks and floods with those: the labels are the reference's
+        bit for bit, at the cost of a sequential host pass when such a tie exists (stats["reference_order"]);
+        "warn" / "raise" / "ignore": labels follow the markers' raster order, and the voxels concerned are reported;
       * ties left by the depth cut-off at `max_chain_depth`: WatershedDepthError (a warning with "ignore").
-    return_ambiguous: also return the (T, H, W) uint8 report (AMB_* bits)."""
+    return_ambiguous: finish() also returns the (T, H, W) uint8 report (AMB_* bits)."""
     if on_ambiguous not in ("warn", "raise", "ignore", "reference"):
         raise ValueError("on_ambiguous must be 'warn', 'raise', 'ignore' or 'reference'")
     t = _lib.torch()
     L = _lib.lib()
     T, H, W = field.shape
-    labels = _lib.empty((T, H, W), t.int32)
-    amb = _lib.empty((T, H, W), t.uint8) if return_ambiguous else None
     nbr = np.ascontiguousarray(nbr, np.int8)
     chain_depth = int(chain_depth)
     max_chain_depth = max(chain_depth, min(int(max_chain_depth), MAX_CHAIN_DEPTH))
@@ -130,54 +231,47 @@ def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN
     # levels beyond chain_depth are rarely needed: the first call gets room for two more, a second one for all
     start, cap = chain_depth, min(max_chain_depth, chain_depth + 2)
     probed = None
-    ws = None
-    while True:
-        nbytes = L.tf_watershed_workspace_bytes(T, H, W, len(nbr), cap, guess)
-        ws = None                                # a retry must not hold the old buffer while the larger one is allocated
-        ws = _lib.workspace(nbytes, "watershed")
-        rc = L.tf_watershed_ex2(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
-                                T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), start, cap, flags, _lib.ptr(labels),
-                                _lib.ptr(amb), _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr())
-        if rc == -2 and st[6] > guess:
-            guess = int(st[6])
-            continue
-        if probed is None and rc in (0, TF_WS_AMBIGUOUS, TF_EDEPTH):
-            probed = int(st[5])
-        if rc == TF_EDEPTH and cap < max_chain_depth:
-            start, cap, flags = cap + 1, max_chain_depth, TF_WS_SKIP_FAST_PATH | (flags & TF_WS_REFERENCE_ORDER)
-            continue
-        break
-    if rc not in (TF_WS_AMBIGUOUS, TF_EDEPTH):
+    slot = _take_slot()
+    handle = ctypes.c_void_p()
+    try:
+        while True:
+            nbytes = L.tf_watershed_workspace_bytes(T, H, W, len(nbr), cap, guess)
+            ws = None                            # a retry must not hold the old buffer while the larger one is allocated
+            ws = _lib.workspace(nbytes, "watershed_job%d" % slot)
+            rc = L.tf_watershed_begin(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
+                                      T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), start, cap, flags,
+                                      _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr(), ctypes.byref(handle))
+            if rc == -2 and st[6] > guess:
+                guess = int(st[6])
+                continue
+            if probed is None and rc == 0:
+                probed = int(st[5])
+            if rc == 0 and st[11] > 0 and cap < max_chain_depth:
+                # ties left by the depth cut-off: all twelve levels (the levels already computed are computed again: rare)
+                L.tf_watershed_abandon(handle)
+                handle = ctypes.c_void_p()
+                start, cap, flags = cap + 1, max_chain_depth, TF_WS_SKIP_FAST_PATH | (flags & TF_WS_REFERENCE_ORDER)
+                continue
+            break
         _lib.check(rc, "tf_watershed")
+    except BaseException:
+        _give_slot(slot)
+        raise
     if probed is not None and probed >= 0:
         memo[0], memo[1] = bool(probed), 0                     # this call probed
     else:
         memo[1] += 1
     with _MEMO_LOCK:
-        if rc in (0, TF_WS_AMBIGUOUS, TF_EDEPTH):
-            _relevant_memo[key] = int(st[6])
+        _relevant_memo[key] = int(st[6])
         _conflict_memo[key] = memo
-    if stats is not None:
-        stats["sweeps"] = st[:8].tolist()
-        stats["chain_depth"] = int(st[8])
-        stats["ambiguous_pixels"] = int(st[9])
-        stats["marker_tie_origins"] = int(st[10])
-        stats["depth_origins"] = int(st[11])
-        stats["reference_order"] = {"replayed_pops": int(st[13]), "seeds": int(st[14]), "microseconds": int(st[15])}
-    if rc == TF_EDEPTH:
-        msg = (f"watershed: {int(st[11])} pixel(s) still tie at chain depth {int(st[8])} (the deepest allowed); "
-               f"{int(st[9])} label(s) may differ from the reference")
-        if on_ambiguous == "ignore":
-            warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=2)
-        else:
-            raise WatershedDepthError(msg)
-    elif rc == TF_WS_AMBIGUOUS and on_ambiguous != "ignore":
-        msg = (f"watershed: the labels of {int(st[9])} pixel(s) depend on the order in which the reference's binary heap "
-               f"pops equal-valued markers ({int(st[10])} tie point(s)); resolved by the markers' raster order")
-        if on_ambiguous == "raise":
-            raise WatershedAmbiguityError(msg)
-        warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=2)
-    return (labels, amb) if return_ambiguous else labels
+    return WatershedJob(handle, slot, ws, (markers,), (T, H, W), on_ambiguous, return_ambiguous, stats, st)
+
+
+def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
+                  expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="reference", return_ambiguous=False):
+    """Device-resident core: torch tensors in, labels out (`watershed_begin(...).finish()`, which see)."""
+    return watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth, stats, expect_conflict, max_chain_depth,
+                           on_ambiguous, return_ambiguous).finish()
 
 
 def watershed(
@@ -190,14 +284,15 @@ def watershed(
     _dev_flows=None,
     chain_depth: int = DEFAULT_CHAIN_DEPTH,
     max_chain_depth: int = MAX_CHAIN_DEPTH,
-    on_ambiguous: str = "warn",
+    on_ambiguous: str = "reference",
     return_ambiguous: bool = False,
 ) -> np.ndarray:
     """Watershed segmentation of a sequence of images in a semi-Lagrangian framework
     (reference: watershed.py:17-168).  Returns int32 labels with the shape of `field`.
 
-    The keyword arguments after `connectivity` are not in the reference: see watershed_dev for the exactness
-    contract they control (`return_ambiguous=True` returns (labels, uint8 report))."""
+    The keyword arguments after `connectivity` are not in the reference: see watershed_begin for the exactness
+    contract they control (`return_ambiguous=True` returns (labels, uint8 report)).  The default, on_ambiguous=
+    "reference", returns the labels of the reference's own call bit for bit, equal-valued markers included."""
     t = _lib.torch()
     on_device = isinstance(field, t.Tensor)
     if hasattr(field, "to_numpy") and not isinstance(field, (np.ndarray, t.Tensor)):
@@ -229,5 +324,5 @@ def watershed(
     return out if on_device else out.cpu().numpy()
 
 
-__all__ = ("watershed", "watershed_dev", "neighbour_offsets", "WatershedAmbiguityWarning", "WatershedAmbiguityError",
+__all__ = ("watershed", "watershed_dev", "watershed_begin", "WatershedJob", "neighbour_offsets", "WatershedAmbiguityWarning", "WatershedAmbiguityError",
            "WatershedDepthError")

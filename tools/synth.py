@@ -53,35 +53,44 @@ def blob_stack(T, H, W, seed=20240601, device="cuda", nan_every=12, t0=0):
 _TORCH_INDEX_LIMIT = 2 ** 31 - 1       # torch's pooling / padding kernels index in 32 bits (a 4e9-voxel call faults the GPU)
 
 
+def _padded_elements(frames, H, W):
+    """elements of the largest tensor _anvil_inputs_block builds for `frames` frames: the background padded by one voxel
+    on every side for the 3 x 3 x 3 pooling"""
+    return (frames + 2) * (H + 2) * (W + 2)
+
+
 def anvil_inputs(bt, lower=270.0, upper=250.0):
     """linearised field, eroded markers (+1) and background seed (-1) as in detect_anvils with
     markers=None (reference detection.py:545-561), computed with torch on the GPU.
     Volumes beyond 2^31 elements are processed in blocks of frames with a one-frame halo (the 3 x 3 x 3 erosion of the
     background reaches one frame): torch's pooling kernels index in 32 bits, and a larger call does not raise, it
-    faults (gpurun_out/config_f_exact.log, round 2)."""
+    faults (the memory fault of round 2's `gpurun_out/config_f_exact.log`: 144 x 5424^2 = 4.2e9 voxels in one
+    max_pool3d call).  A block is sized so that the PADDED tensor that is really built -- block + two halo frames + the
+    padding ring -- stays below the limit, which is also what the guard in _anvil_inputs_block tests (the
+    round-3 sizing left every block two frames over its own guard, so the blocked path could only raise)."""
     import torch
     T = bt.shape[0]
-    per_frame = int(bt[0].numel()) if T else 0
-    if per_frame * 3 > _TORCH_INDEX_LIMIT:
-        raise ValueError("anvil_inputs: a single frame of %d pixels is beyond what torch's 32-bit pooling kernels index" % per_frame)
-    block = max(1, _TORCH_INDEX_LIMIT // max(per_frame, 1) - 2)
-    if T <= block:
-        return _anvil_inputs_block(bt, lower, upper, True, True)
+    H, W = (int(bt.shape[1]), int(bt.shape[2])) if T else (0, 0)
+    if T == 0 or _padded_elements(T, H, W) <= _TORCH_INDEX_LIMIT:
+        return _anvil_inputs_block(bt, lower, upper)
+    block = _TORCH_INDEX_LIMIT // ((H + 2) * (W + 2)) - 4          # + 2 halo frames + 2 padding frames
+    if block < 1:
+        raise ValueError("anvil_inputs: three padded frames of %d x %d pixels are beyond what torch's 32-bit pooling kernels index" % (H, W))
     lin = torch.empty_like(bt)
     markers = torch.empty(bt.shape, dtype=torch.int32, device=bt.device)
     for a in range(0, T, block):
         b = min(a + block, T)
         lo, hi = max(a - 1, 0), min(b + 1, T)
-        l, m = _anvil_inputs_block(bt[lo:hi], lower, upper, lo == 0, hi == T)
+        # the volume's own first / last frame see border_value = 1 beyond them; interior block edges are halo frames whose
+        # own result is discarded
+        l, m = _anvil_inputs_block(bt[lo:hi], lower, upper)
         lin[a:b], markers[a:b] = l[a - lo:b - lo], m[a - lo:b - lo]
     return lin, markers
 
 
-def _anvil_inputs_block(bt, lower, upper, first, last):
-    """`first` / `last`: the block starts / ends the volume (border_value = 1 beyond it; interior block edges are halo
-    frames whose own result is discarded)"""
+def _anvil_inputs_block(bt, lower, upper):
     import torch
-    if bt.numel() + 2 * bt[0].numel() > _TORCH_INDEX_LIMIT:
+    if bt.shape[0] and _padded_elements(int(bt.shape[0]), int(bt.shape[1]), int(bt.shape[2])) > _TORCH_INDEX_LIMIT:
         raise ValueError("anvil_inputs: block beyond torch's 32-bit pooling kernels")
     F = torch.nn.functional
     lo, hi = min(lower, upper), max(lower, upper)
