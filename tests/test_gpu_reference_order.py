@@ -118,23 +118,52 @@ def test_reference_order_costs_nothing_when_no_tie_matters(tf, golden_ws):
 
 
 @pytest.mark.parametrize("seed", range(0, 24, 2))
-def test_sparse_and_dense_replay_agree(tf, seed, monkeypatch):
-    """ws_reference_ranks_sparse (the default: only the heap items at or below the largest tie value are followed, the
-    others are anonymous occupants of their positions) against ws_reference_ranks (every seed pushed;
-    TF_WS_REFERENCE_DENSE=1): same labels, same number of replayed pops, never more seeds."""
+def test_sparse_dense_and_plain_replay_agree(tf, seed, monkeypatch):
+    """The three host replays of csrc/ws_replay.h behind one flood: sparse (the default: only the heap items at or below
+    the largest tie value are followed, the others are anonymous occupants of their positions), dense (every seed in place
+    as an 8-byte entry, runs of equal seeds popped in one scan, the tree of equal seeds walked with a saved path;
+    TF_WS_REFERENCE_DENSE=1) and plain (every item as the reference keeps it; =2): same labels, same number of replayed
+    pops, the sparse form never handed more seeds.  (tools/replay_check compares them on 200 000 random instances on the CPU.)"""
     import torch
     from tobac_flow_amd import _lib
     from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
     fwd, bwd, field, markers, mask, conn = _tie_heavy_case(seed)
     args = (_lib.to_dev(fwd, torch.float32), _lib.to_dev(bwd, torch.float32), _lib.to_dev(field, torch.float32),
             _lib.to_dev(markers, torch.int32), None if mask is None else _lib.to_dev(mask.astype(np.int8), torch.int8), neighbour_offsets(conn))
-    st_sparse, st_dense = {}, {}
+    st_sparse, st_dense, st_plain = {}, {}, {}
     lab_sparse = watershed_dev(*args, stats=st_sparse, on_ambiguous="reference").cpu().numpy()
     monkeypatch.setenv("TF_WS_REFERENCE_DENSE", "1")
     lab_dense = watershed_dev(*args, stats=st_dense, on_ambiguous="reference").cpu().numpy()
-    assert np.array_equal(lab_sparse, lab_dense)
-    a, b = st_sparse["reference_order"], st_dense["reference_order"]
-    assert a["replayed_pops"] == b["replayed_pops"] and a["seeds"] <= b["seeds"]
+    monkeypatch.setenv("TF_WS_REFERENCE_DENSE", "2")
+    lab_plain = watershed_dev(*args, stats=st_plain, on_ambiguous="reference").cpu().numpy()
+    assert np.array_equal(lab_sparse, lab_dense) and np.array_equal(lab_plain, lab_dense)
+    a, b, c = st_sparse["reference_order"], st_dense["reference_order"], st_plain["reference_order"]
+    assert a["replayed_pops"] == b["replayed_pops"] == c["replayed_pops"] and a["seeds"] <= b["seeds"] == c["seeds"]
+    if a["replayed_pops"]:
+        assert st_sparse["reference_order_detail"]["replay_form"] == "sparse" and st_dense["reference_order_detail"]["replay_form"] == "dense"
+
+
+def test_dense_replay_on_full_disk_frames_equals_the_reference_kernel(monkeypatch):
+    """The dense form at the benchmark's frame size (2 x 5424^2: 56 M seeds, most of them the background's at exactly 0, so
+    the runs and the saved path are really exercised) against the C twin of the reference's kernel, every voxel."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from oracle import ws_oracle
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    from tools.synth import anvil_seeds, blob_stack
+    bt = blob_stack(2, 5424, 5424, seed=20240601, t0=30)
+    fl = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    lin, seeds = anvil_seeds(bt)
+    e = get_combined_edge_field(fl, lin, dtype=np.float32)
+    fw, bw = fl._dev_flows()
+    st = {}
+    monkeypatch.setenv("TF_WS_REFERENCE_DENSE", "1")
+    lab = watershed_dev(fw, bw, e, seeds, None, neighbour_offsets(1), stats=st, on_ambiguous="reference")
+    want = ws_oracle.watershed(fw.cpu().numpy(), bw.cpu().numpy(), e.cpu().numpy(), seeds.cpu().numpy(), None, 1, tie_mode=0)
+    print("2 x 5424^2, dense replay:", st["reference_order"], st["reference_order_detail"])
+    assert st["reference_order"]["replayed_pops"] > 0
+    assert np.array_equal(lab.cpu().numpy(), want)
 
 
 def test_config_C_window_with_component_seeds_in_reference_order(tf):

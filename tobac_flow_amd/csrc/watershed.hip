@@ -882,11 +882,12 @@ k_ws_small_list(const uint8_t *__restrict__ cls, const int *__restrict__ cid, co
     const int id = c <= -2 ? -2 - c : -1;
     out_k[slot] = k; out_val[slot] = key; out_id[slot] = (id >= 0 && subid) ? subid[id] : id;
 }
-// dense form: seeds number c0 .. c0 + cap - 1: value key and sub-graph id
+// dense form: seeds number c0 .. c0 + cap - 1 as the 8-byte heap entries of ws_replay.h (value key | seed flag | id + 1; one
+// anonymous LARGE entry for every seed above the tie value): the host sifts them up in place
 __global__ void __launch_bounds__(256)
 k_ws_seed_list(const uint8_t *__restrict__ cls, const int *__restrict__ cid, const float *__restrict__ field, int64_t n,
-               const long long *__restrict__ base_seed, int64_t c0, int64_t cap, const int *__restrict__ subid,
-               unsigned *__restrict__ out_val, int *__restrict__ out_id)
+               const long long *__restrict__ base_seed, int64_t c0, int64_t cap, const int *__restrict__ subid, unsigned vmax,
+               u64 *__restrict__ out_entry)
 {
     __shared__ int part[4];
     const long long b0 = base_seed[blockIdx.x];
@@ -903,9 +904,10 @@ k_ws_seed_list(const uint8_t *__restrict__ cls, const int *__restrict__ cid, con
     k -= c0;
     if (k < 0 || k >= cap) return;
     const int c = cid[i];
-    const int id = c <= -2 ? -2 - c : -1;
-    out_val[k] = ws_ordkey(field[i]);
-    out_id[k] = (id >= 0 && subid) ? subid[id] : id;
+    int id = c <= -2 ? -2 - c : -1;
+    const unsigned v = ws_ordkey(field[i]);
+    if (id >= 0 && subid && v <= vmax) id = subid[id];              // (a seed above the tie value is not in the sub-graph: its entry is anonymous)
+    out_entry[k] = v > vmax ? WS_INF : (((u64)v << 32) | 0x80000000ull | (u64)(unsigned)(id + 1));
 }
 // THE SUB-GRAPH THE REPLAY CAN REACH.  The replay pops an item only while its key is at or below the tie value: P = the
 // relevant markers with a key <= vmax and the floodable pixels with a key < vmax.  It looks at the out-neighbours of what
@@ -968,11 +970,19 @@ typedef hipcub::TransformInputIterator<int, WsU8ToInt, const uint8_t *> WsFlagIt
 // from the total of the chunks before it: volumes beyond 2^31 voxels -- config F's 144 full-disk frames as ONE exact
 // flood -- only need the RELEVANT pixel count to fit the int32 compact ids.
 #define WS_SCAN_CHUNK (1ll << 30)
+struct WsIntToLL { __host__ __device__ __forceinline__ long long operator()(int v) const { return (long long)v; } };
+typedef hipcub::TransformInputIterator<long long, WsIntToLL, const int *> WsCountIter;
 static size_t ws_scan_temp_bytes(int64_t n) {
-    size_t bytes = 0;
+    size_t bytes = 0, b2 = 0, b3 = 0;
     WsFlagIter it((const uint8_t *)nullptr, WsU8ToInt());
-    // size query only (null temp storage): fills `bytes`
+    // size queries only (null temp storage): the flag scan over n positions, and the 64-bit scans of per-block counts
+    // (tile ids; seed numbers of the reference-order export) -- on a small volume the latter need MORE than the former
     (void)hipcub::DeviceScan::ExclusiveScan(nullptr, bytes, it, (int *)nullptr, hipcub::Sum(), 0, (int)(n > WS_SCAN_CHUNK ? WS_SCAN_CHUNK : n));
+    const int64_t nb = (n + 255) / 256 < 0x7fffffffll ? (n + 255) / 256 : 0x7ffffffell;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, (const long long *)nullptr, (long long *)nullptr, (int)nb);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b3, WsCountIter((const int *)nullptr, WsIntToLL()), (long long *)nullptr, (int)nb);
+    if (b2 > bytes) bytes = b2;
+    if (b3 > bytes) bytes = b3;
     return bytes;
 }
 
@@ -1097,31 +1107,15 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
     return TF_OK;
 }
 
-// ---- the reference's pop order of equal-valued markers ------------------------------------------------------------
-// The reference pushes every marker with age 0 (_watershed.pyx:278-284), so markers of equal value compare equal
-// (`smaller`, :161-164) and pop in an order that is a by-product of its binary heap's array mechanics (:67-152): where
-// the sift-up / sift-down loops happen to leave them.  That order depends on EVERY push and pop before it -- a marker
-// of another value pushed in between, or a pixel flooded from a lower marker, moves tied items up and down the array
-// (two tied markers A, B and one smaller item X pushed between them pop X, B, A; without X: A, B) -- so it cannot be
-// derived from the tied markers alone: the mechanics have to be replayed with every item in place.  This routine is
-// that replay, on the host, over the sub-graph of the compact flood graph the device exports (k_ws_sub_*): the same push
-// / pop / sift rules, item for item, with the keys only (no labels are computed here -- the device flood does that, with
-// the pop rank returned here as the last component of its chain comparison).  It stops as soon as every marker whose rank
-// can matter has popped: at the first top item above `vmax`, the largest marker value at which the device found chains
-// that tie down to equal-valued markers of different labels.
-// Ids are sub-graph ids (nQ of them): `val` their value keys, `nbr` the rows of floodable out-neighbours (rows of ids the
-// replay can pop are filled, see k_ws_sub_export), seeds carry -1 when nobody floods from them (ballast the heap needs).
-// rank[id] = pop rank of a marker, -1 if it did not pop; *n_ranked = markers popped.  Returns the pops, -1: out of memory.
-struct WsRefItem { unsigned v; int32_t age; int32_t id; };
-static inline bool ws_ref_smaller(const WsRefItem &a, const WsRefItem &b) { return a.v != b.v ? a.v < b.v : a.age < b.age; }
-
-// host scratch of the replays: plain memory kept between calls (a dense replay touches ~6 GB: as fresh mallocs that is
-// ~1.5 M page faults per call) and pinned memory for the device -> host exports; grow-only, freed by tf_shutdown()
+// ---- the reference's pop order of equal-valued markers: the host replays live in ws_replay.h (pure C++, also built by
+// tools/replay_check for CPU-side checks); here: their scratch, what the device exports for them, and the job around them
+// host scratch of the replays: plain memory kept between calls (a plain-form replay touches ~6 GB: as fresh mallocs that
+// is ~1.5 M page faults per call) and pinned memory for the device -> host exports; grow-only, freed by tf_shutdown()
 #include <vector>
 namespace {
 struct WsHostBuf { void *p; size_t bytes; bool pinned; };
 std::mutex g_ws_host_mu;
-std::vector<WsHostBuf> g_ws_host_free;
+std::vector<WsHostBuf> g_ws_host_free, g_ws_host_lent;
 }
 static WsHostBuf ws_host_take(size_t bytes, bool pinned)
 {
@@ -1148,226 +1142,31 @@ static void ws_host_give(WsHostBuf &b)
     g_ws_host_free.push_back(b);
     b.p = nullptr; b.bytes = 0;
 }
+// malloc / free look-alikes over the pool for ws_replay.h (WSR_ALLOC / WSR_FREE)
+static void *ws_pool_alloc(size_t bytes)
+{
+    WsHostBuf b = ws_host_take(bytes, false);
+    if (!b.p) return nullptr;
+    std::lock_guard<std::mutex> lk(g_ws_host_mu);
+    g_ws_host_lent.push_back(b);
+    return b.p;
+}
+static void ws_pool_free(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_ws_host_mu);
+    for (size_t i = 0; i < g_ws_host_lent.size(); i++)
+        if (g_ws_host_lent[i].p == p) { g_ws_host_free.push_back(g_ws_host_lent[i]); g_ws_host_lent.erase(g_ws_host_lent.begin() + i); return; }
+}
 void tf_ws_host_pool_release()                                      // tf_shutdown()
 {
     std::lock_guard<std::mutex> lk(g_ws_host_mu);
     for (auto &b : g_ws_host_free) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
     g_ws_host_free.clear();
 }
-
-static int64_t ws_reference_ranks(int64_t M, const unsigned *seed_val, const int *seed_id, int64_t nQ, const unsigned *val,
-                                  const int *nbr, int n_nbr, unsigned vmax, int *rank, int *n_ranked_out)
-{
-    WsHostBuf hb = ws_host_take((size_t)(M + nQ + 1) * sizeof(WsRefItem), false);     // every pixel is pushed at most once
-    WsRefItem *h = (WsRefItem *)hb.p;
-    uint8_t *state = (uint8_t *)calloc((size_t)(nQ > 0 ? nQ : 1), 1);                   // 1: already pushed
-    if (!h || !state) { ws_host_give(hb); free(state); return -1; }
-    int64_t items = 0;
-    auto push = [&](const WsRefItem &e) {                                              // _watershed.pyx:120-152
-        int64_t child = items;
-        h[child] = e;
-        items += 1;
-        while (child > 0) {
-            const int64_t parent = (child + 1) / 2 - 1;
-            if (ws_ref_smaller(h[child], h[parent])) { const WsRefItem t = h[parent]; h[parent] = h[child]; h[child] = t; child = parent; }
-            else break;
-        }
-    };
-    for (int64_t i = 0; i < M; i++) push(WsRefItem{seed_val[i], 0, seed_id[i]});      // :278-284, marker_locations order
-    for (int64_t i = 0; i < nQ; i++) rank[i] = -1;
-    int64_t age = 1, popped = 0;
-    int n_ranked = 0;
-    while (items > 0) {
-        const WsRefItem e = h[0];
-        // all markers of value <= vmax pop before the first item that is above vmax or a flooded pixel AT vmax
-        if (e.v > vmax || (e.v == vmax && e.age != 0)) break;
-        items -= 1;                                                                    // :67-111
-        if (items > 0) {
-            h[0] = h[items];
-            int64_t i = 0, smallest = 0;
-            for (;;) {
-                const int64_t l = 2 * i + 1, r = 2 * i + 2;
-                if (l < items) {
-                    if (ws_ref_smaller(h[l], h[i])) smallest = l;
-                    if (r < items && ws_ref_smaller(h[r], h[smallest])) smallest = r;
-                } else break;
-                if (smallest == i) break;
-                const WsRefItem t = h[i]; h[i] = h[smallest]; h[smallest] = t;
-                i = smallest;
-            }
-        }
-        popped++;
-        if (e.id < 0) continue;
-        if (e.age == 0) rank[e.id] = n_ranked++;                                       // a marker: its pop rank
-        const int *np = nbr + (int64_t)e.id * n_nbr;
-        for (int k = 0; k < n_nbr; k++) {                                              // :308-341 (mask / already labelled: not pushed)
-            const int n = np[k];
-            if (n < 0 || state[n]) continue;
-            state[n] = 1;
-            age += 1;
-            push(WsRefItem{val[n], (int32_t)age, n});                                  // Py_ssize_t -> int32 store, :338
-        }
-    }
-    *n_ranked_out = n_ranked;
-    ws_host_give(hb); free(state);
-    return popped;
-}
-
-// THE SAME REPLAY WITHOUT THE LARGE ITEMS (round 3).  Call an item SMALL when the loop above would still pop it --
-// v < vmax, or v == vmax with age 0 -- and LARGE otherwise.  A small item compares smaller than every large one, the heap
-// order keeps every descendant of a large node large, and the loop stops at the first large top: so whatever the large items
-// do among themselves (which of them a sift moves where) never moves a small item, and the trajectory of the small items
-// depends on the large ones only through the POSITIONS they occupy.  The replay therefore keeps the small items alone --
-// an occupancy bitmap over the heap positions plus a position -> item table -- and treats every other position below
-// `items` as an anonymous large item: pushing a large item just lengthens the heap; a small item sifting up walks through
-// unoccupied ancestors without a comparison; a large item sifting down from the root follows the smaller of its small
-// children until both children are large.  With S small seeds out of M (S / M = 0.3 % on detect_anvils fields) the replay
-// costs O(S log M) bit tests instead of M pushes, and only the small seeds cross PCIe.  Same ranks as ws_reference_ranks
-// (tests/test_gpu_reference_order.py compares the two; TF_WS_REFERENCE_DENSE=1 selects the dense form).
-struct WsPosMap {                                                       // open addressing, linear probing, backward-shift deletion
-    int64_t *key = nullptr; WsRefItem *val = nullptr; size_t cap = 0, n = 0;
-    ~WsPosMap() { free(key); free(val); }
-    static size_t hash(int64_t k) { uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull; return (size_t)(x ^ (x >> 29)); }
-    bool init(size_t want) {
-        cap = 1024; while (cap < want) cap <<= 1;
-        key = (int64_t *)malloc(cap * sizeof(int64_t)); val = (WsRefItem *)malloc(cap * sizeof(WsRefItem));
-        if (!key || !val) return false;
-        for (size_t i = 0; i < cap; i++) key[i] = -1;
-        n = 0;
-        return true;
-    }
-    bool grow() {
-        WsPosMap b; if (!b.init(cap * 2)) return false;
-        for (size_t i = 0; i < cap; i++) if (key[i] >= 0) b.put_nogrow(key[i], val[i]);
-        std::swap(key, b.key); std::swap(val, b.val); std::swap(cap, b.cap); std::swap(n, b.n);
-        return true;
-    }
-    void put_nogrow(int64_t k, const WsRefItem &v) {
-        size_t i = hash(k) & (cap - 1);
-        while (key[i] >= 0 && key[i] != k) i = (i + 1) & (cap - 1);
-        if (key[i] < 0) n++;
-        key[i] = k; val[i] = v;
-    }
-    bool put(int64_t k, const WsRefItem &v) { if ((n + 1) * 2 > cap && !grow()) return false; put_nogrow(k, v); return true; }
-    WsRefItem get(int64_t k) const {                                  // the key must be present
-        size_t i = hash(k) & (cap - 1);
-        while (key[i] != k) i = (i + 1) & (cap - 1);
-        return val[i];
-    }
-    void erase(int64_t k) {                                           // the key must be present
-        size_t i = hash(k) & (cap - 1);
-        while (key[i] != k) i = (i + 1) & (cap - 1);
-        size_t j = i;
-        for (;;) {
-            j = (j + 1) & (cap - 1);
-            if (key[j] < 0) break;
-            const size_t h = hash(key[j]) & (cap - 1);
-            // the entry at j may move to the hole at i unless its home slot lies cyclically in (i, j]
-            if ((i <= j) ? (i < h && h <= j) : (i < h || h <= j)) continue;
-            key[i] = key[j]; val[i] = val[j]; i = j;
-        }
-        key[i] = -1; n--;
-    }
-};
-
-static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *sk, const unsigned *sval, const int *sid, int64_t nQ,
-                                         const unsigned *val, const int *nbr, int n_nbr, unsigned vmax, int *rank, int *n_ranked_out)
-{
-    // an item = (key, id) with key = (v << 32) | age: `smaller` (:161-164) is the order of the keys.  LARGE = the all-ones
-    // key: larger than every small item (value keys stop at that of +inf, NaN fields are refused), equal to itself -- a
-    // sift never swaps two of them, which is all the replay needs to know about the large items.
-    struct Item { u64 key; int32_t id; int32_t pad; };
-    const Item LARGE{~0ull, -1, 0};
-    const int64_t max_items = M + nQ + 1;
-    // The small items form an ancestor-closed set (every ancestor of a small item is small): they sit in the top of the
-    // heap.  Positions below `n_top` -- a power of two >= 4 S -- are a plain array initialised to LARGE (the two children
-    // of a node share a cache line: the sift-down of a pop walks through adjacent memory, as in the reference); deeper
-    // positions, which small items only pass through on their way up, are an occupancy bitmap + a hash table.
-    int64_t n_top = 1024;
-    while (n_top < 4 * S && n_top < (1ll << 26)) n_top <<= 1;
-    if (n_top > max_items) n_top = max_items;
-    Item *top = (Item *)malloc((size_t)n_top * sizeof(Item));
-    uint64_t *occ = (uint64_t *)calloc((size_t)((max_items + 63) / 64), sizeof(uint64_t));    // position holds a small item
-    uint8_t *state = (uint8_t *)calloc((size_t)(nQ > 0 ? nQ : 1), 1);                          // 1: already pushed
-    WsPosMap deep;
-    if (!top || !occ || !state || !deep.init(1 << 16)) { free(top); free(occ); free(state); return -1; }
-    memset(top, 0xFF, (size_t)n_top * sizeof(Item));                                            // key = ~0: LARGE everywhere
-    bool oom = false;
-    // the bitmap covers ALL positions: a small item on its way up walks through unoccupied ancestors on bit tests alone
-    // (the top of the bitmap stays in cache; the item array of the top region, 16 B per position, does not)
-    auto has = [&](int64_t p) { return (occ[p >> 6] >> (p & 63)) & 1ull; };
-    auto load = [&](int64_t p) -> Item {
-        if (p < n_top) return top[p];
-        if (!has(p)) return LARGE;
-        const WsRefItem e = deep.get(p);
-        return Item{((u64)e.v << 32) | (uint32_t)e.age, e.id, 0};
-    };
-    auto store = [&](int64_t p, const Item &e) {
-        const bool was = has(p), is = e.key != ~0ull;
-        if (is != was) occ[p >> 6] ^= 1ull << (p & 63);
-        if (p < n_top) { top[p] = e; return; }
-        if (!is) { if (was) deep.erase(p); return; }
-        if (!deep.put(p, WsRefItem{(unsigned)(e.key >> 32), (int32_t)(e.key & 0xffffffffu), e.id})) oom = true;
-    };
-    // _watershed.pyx:120-152 for a small item entering at position `child` (a large one only lengthens the heap)
-    auto push_small = [&](int64_t child, const Item &e) {
-        while (child > 0) {
-            const int64_t parent = (child + 1) / 2 - 1;
-            if (has(parent)) {
-                const Item pe = load(parent);
-                if (!(e.key < pe.key)) break;
-                store(child, pe);
-                store(parent, LARGE);                                    // (rewritten by the next step or by the final store)
-            }
-            child = parent;                                              // a large parent moves down: nothing to record
-        }
-        store(child, e);
-    };
-    for (int64_t j = 0; j < S; j++) push_small((int64_t)sk[j], Item{(u64)sval[j] << 32, sid[j], 0});    // seed k enters at position k, age 0
-    int64_t items = M;
-    for (int64_t i = 0; i < nQ; i++) rank[i] = -1;
-    int64_t age = 1, popped = 0;
-    int n_ranked = 0;
-    while (items > 0 && !oom) {
-        const Item e = load(0);
-        if (e.key == ~0ull) break;                                       // a large top ends the replay
-        items -= 1;                                                      // :67-111
-        if (items > 0) {
-            const Item x = load(items);
-            store(items, LARGE);
-            int64_t i = 0;
-            for (;;) {
-                const int64_t l = 2 * i + 1, r = 2 * i + 2;
-                if (l >= items) break;
-                int64_t smallest = i;
-                Item cur = x;
-                const Item le = load(l);
-                if (le.key < cur.key) { smallest = l; cur = le; }
-                if (r < items) { const Item re = load(r); if (re.key < cur.key) { smallest = r; cur = re; } }
-                if (smallest == i) break;
-                store(i, cur);
-                i = smallest;
-            }
-            store(i, x);
-        } else store(0, LARGE);
-        popped++;
-        if (e.id < 0) continue;
-        if ((e.key & 0xffffffffull) == 0) rank[e.id] = n_ranked++;      // a marker (age 0): its pop rank
-        const int *np = nbr + (int64_t)e.id * n_nbr;
-        for (int k = 0; k < n_nbr; k++) {                                // :308-341
-            const int n = np[k];
-            if (n < 0 || state[n]) continue;
-            state[n] = 1;
-            age += 1;
-            const unsigned v = val[n];
-            if (v < vmax) push_small(items, Item{((u64)v << 32) | (uint32_t)age, n, 0});      // (v == vmax with age != 0 is large)
-            items += 1;
-        }
-    }
-    *n_ranked_out = n_ranked;
-    free(top); free(occ); free(state);
-    return oom ? -1 : popped;
-}
+#define WSR_ALLOC(bytes) ws_pool_alloc(bytes)
+#define WSR_FREE(p) ws_pool_free(p)
+#include "ws_replay.h"
 
 // ---- one flood = a JOB in three parts ---------------------------------------------------------------------------------
 //   begin   (device)  classification / compaction, phase A, chain + root phases at increasing depth until the exactness
@@ -1393,7 +1192,7 @@ struct tf_ws_job {
     unsigned long long h_amb[4];
     int64_t st[TF_WS_NSTATS];
     // reference order
-    bool need_replay, replay_done, applied, sparse, identity;
+    bool need_replay, replay_done, applied, sparse, plain, identity;
     int64_t M, S, nQ; unsigned vmax;
     WsHostBuf hb_val, hb_nbr, hb_rank, hb_sk, hb_sval, hb_sid;
     int64_t popped; int n_ranked; int replay_rc;
@@ -1419,9 +1218,6 @@ static int ws_to_host(void *dst, const void *src, size_t bytes, hipStream_t s)
     return TF_OK;
 }
 
-struct WsIntToLL { __host__ __device__ __forceinline__ long long operator()(int v) const { return (long long)v; } };
-typedef hipcub::TransformInputIterator<long long, WsIntToLL, const int *> WsCountIter;
-
 // begin, part 2: what the host replay needs (see tf_ws_job)
 static int ws_job_export(tf_ws_job *j)
 {
@@ -1432,7 +1228,10 @@ static int ws_job_export(tf_ws_job *j)
     const int nn = j->n_nbr;
     const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
     static const bool ref_debug = ws_env("TF_WS_REF_DEBUG");           // development aid: where the detour's time goes
-    const bool force_dense = ws_env("TF_WS_REFERENCE_DENSE");          // A/B and test aid (read per call: the tests toggle it)
+    // A/B and test aid (read per call: the tests toggle it): TF_WS_REFERENCE_DENSE=1 the dense form whatever the seed counts, =2 the plain form
+    const char *dense_env = getenv("TF_WS_REFERENCE_DENSE");
+    const bool force_dense = dense_env != nullptr;
+    j->plain = dense_env && atoi(dense_env) == 2;
     // the largest marker value at which the order of equal-valued markers decides a label
     unsigned *d_vmax = (unsigned *)(j->d_cnt + 3);
     TF_CHECK_HIP(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), s));
@@ -1484,11 +1283,10 @@ static int ws_job_export(tf_ws_job *j)
     j->hb_val = ws_host_take((size_t)nQ * sizeof(unsigned), true);
     j->hb_nbr = ws_host_take((size_t)nQ * nn * sizeof(int), true);
     j->hb_rank = ws_host_take((size_t)nQ * sizeof(int), true);
-    const int64_t n_list = j->sparse ? j->S : j->M;
-    if (j->sparse) j->hb_sk = ws_host_take((size_t)n_list * sizeof(long long), true);
-    j->hb_sval = ws_host_take((size_t)n_list * sizeof(unsigned), true);
-    j->hb_sid = ws_host_take((size_t)n_list * sizeof(int), true);
-    if (!j->hb_val.p || !j->hb_nbr.p || !j->hb_rank.p || (j->sparse && !j->hb_sk.p) || !j->hb_sval.p || !j->hb_sid.p) {
+    // sparse: heap position, key, id of the small seeds; dense: the heap array itself (one 8-byte entry per seed, room for every push behind them)
+    j->hb_sk = ws_host_take(j->sparse ? (size_t)j->S * sizeof(long long) : (size_t)(j->M + nQ + 1) * sizeof(u64), true);
+    if (j->sparse) { j->hb_sval = ws_host_take((size_t)j->S * sizeof(unsigned), true); j->hb_sid = ws_host_take((size_t)j->S * sizeof(int), true); }
+    if (!j->hb_val.p || !j->hb_nbr.p || !j->hb_rank.p || !j->hb_sk.p || (j->sparse && (!j->hb_sval.p || !j->hb_sid.p))) {
         tf_set_error("tf_watershed: out of host memory for the reference-order replay");
         return TF_ENOMEM;
     }
@@ -1510,20 +1308,21 @@ static int ws_job_export(tf_ws_job *j)
             ws_to_host(j->hb_sid.p, stg_id, (size_t)j->S * sizeof(int), s)) return TF_EHIP;
         TF_CHECK_HIP(hipStreamSynchronize(s));
     } else {
-        // DENSE form: every seed is sent (more small seeds than staging room, or TF_WS_REFERENCE_DENSE); the list travels
-        // through the frontier queues, 2R entries at a time
+        // DENSE form: every seed is sent (more small seeds than staging room, or TF_WS_REFERENCE_DENSE), as the heap entry the
+        // replay keeps; the array travels through the two frontier queues in turn, R entries at a time
         TF_CHECK_HIP(hipStreamSynchronize(s));                          // the sub-graph has left the queues
-        unsigned *stg_val = (unsigned *)j->Q.q[0]; int *stg_id = j->Q.q[1];
-        const int64_t cap = 2 * R;
-        for (int64_t c0 = 0; c0 < j->M; c0 += cap) {
+        const int64_t cap = R + 32;
+        int turn = 0;
+        for (int64_t c0 = 0; c0 < j->M; c0 += cap, turn ^= 1) {
             const int64_t cnt = j->M - c0 < cap ? j->M - c0 : cap;
+            u64 *stg = (u64 *)j->Q.q[turn];
             hipLaunchKernelGGL(k_ws_seed_list, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N,
-                               (const long long *)base_seed, c0, cap, subid_or_null, stg_val, stg_id);
+                               (const long long *)base_seed, c0, cap, subid_or_null, h_vmax, stg);
             TF_CHECK_LAUNCH();
-            if (ws_to_host((unsigned *)j->hb_sval.p + c0, stg_val, (size_t)cnt * sizeof(unsigned), s) ||
-                ws_to_host((int *)j->hb_sid.p + c0, stg_id, (size_t)cnt * sizeof(int), s)) return TF_EHIP;
-            TF_CHECK_HIP(hipStreamSynchronize(s));
+            if (ws_to_host((u64 *)j->hb_sk.p + c0, stg, (size_t)cnt * sizeof(u64), s)) return TF_EHIP;
+            if (turn) TF_CHECK_HIP(hipStreamSynchronize(s));            // (the stream orders kernel k + 2 after copy k anyway; bound the queue of copies)
         }
+        TF_CHECK_HIP(hipStreamSynchronize(s));
     }
     j->need_replay = true;
     j->ms_export = ws_now_ms() - t_enter;
@@ -1759,18 +1558,23 @@ static int ws_job_replay(tf_ws_job *j)
     if (!j->need_replay || j->replay_done) return j->replay_rc;
     const double t0 = ws_now_ms();
     int n_ranked = 0;
+    double phase[2] = {0.0, 0.0};
     if (j->sparse)
         j->popped = ws_reference_ranks_sparse(j->M, j->S, (const long long *)j->hb_sk.p, (const unsigned *)j->hb_sval.p, (const int *)j->hb_sid.p,
                                               j->nQ, (const unsigned *)j->hb_val.p, (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked);
+    else if (j->plain)
+        j->popped = ws_reference_ranks_plain(j->M, (const u64 *)j->hb_sk.p, nullptr, j->nQ, (const unsigned *)j->hb_val.p,
+                                             (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked);
     else
-        j->popped = ws_reference_ranks(j->M, (const unsigned *)j->hb_sval.p, (const int *)j->hb_sid.p, j->nQ, (const unsigned *)j->hb_val.p,
-                                       (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked);
+        j->popped = ws_reference_ranks_dense(j->M, (u64 *)j->hb_sk.p, j->nQ, (const unsigned *)j->hb_val.p,
+                                             (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked, phase);
     j->n_ranked = n_ranked;
     j->replay_done = true;
     j->ms_replay = ws_now_ms() - t0;
     if (j->popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); j->replay_rc = TF_ENOMEM; }
     static const bool ref_debug = ws_env("TF_WS_REF_DEBUG");
-    if (ref_debug) fprintf(stderr, "reference order: replay %.1f ms (%lld pops, %d markers ranked)\n", j->ms_replay, (long long)j->popped, n_ranked);
+    if (ref_debug) fprintf(stderr, "reference order: %s replay %.1f ms (%lld pops, %d markers ranked; heap build %.1f ms, pops %.1f ms)\n",
+                           j->sparse ? "sparse" : (j->plain ? "plain" : "dense"), j->ms_replay, (long long)j->popped, n_ranked, phase[0], phase[1]);
     return j->replay_rc;
 }
 
