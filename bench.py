@@ -224,7 +224,7 @@ def main():
                          "library's default, on_ambiguous='reference': labels bit for bit the reference's; a sequential host replay "
                          "per flood that has such ties, run on worker threads beside the next windows' device work) or raster order "
                          "(such voxels are counted in `watershed`)")
-    ap.add_argument("--inflight", type=int, default=6,
+    ap.add_argument("--inflight", type=int, default=12,
                     help="floods in flight per rank (each owns ~5 GB of scratch at 16 x 5424^2): window k's host replay runs on a "
                          "worker thread while the device floods windows k+1 ...; 1 = strictly one after the other")
     ap.add_argument("--rotate", type=int, default=3,

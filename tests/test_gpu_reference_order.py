@@ -134,9 +134,12 @@ def test_sparse_dense_and_plain_replay_agree(tf, seed, monkeypatch):
     lab_sparse = watershed_dev(*args, stats=st_sparse, on_ambiguous="reference").cpu().numpy()
     monkeypatch.setenv("TF_WS_REFERENCE_DENSE", "1")
     lab_dense = watershed_dev(*args, stats=st_dense, on_ambiguous="reference").cpu().numpy()
+    monkeypatch.setenv("TF_WS_REFERENCE_NO_CODES", "1")                # the dense form's seeds as 8-byte entries instead of 2 bits + exceptions
+    lab_dense8 = watershed_dev(*args, on_ambiguous="reference").cpu().numpy()
+    monkeypatch.delenv("TF_WS_REFERENCE_NO_CODES")
     monkeypatch.setenv("TF_WS_REFERENCE_DENSE", "2")
     lab_plain = watershed_dev(*args, stats=st_plain, on_ambiguous="reference").cpu().numpy()
-    assert np.array_equal(lab_sparse, lab_dense) and np.array_equal(lab_plain, lab_dense)
+    assert np.array_equal(lab_sparse, lab_dense) and np.array_equal(lab_plain, lab_dense) and np.array_equal(lab_dense8, lab_dense)
     a, b, c = st_sparse["reference_order"], st_dense["reference_order"], st_plain["reference_order"]
     assert a["replayed_pops"] == b["replayed_pops"] == c["replayed_pops"] and a["seeds"] <= b["seeds"] == c["seeds"]
     if a["replayed_pops"]:

@@ -909,6 +909,93 @@ k_ws_seed_list(const uint8_t *__restrict__ cls, const int *__restrict__ cid, con
     if (id >= 0 && subid && v <= vmax) id = subid[id];              // (a seed above the tie value is not in the sub-graph: its entry is anonymous)
     out_entry[k] = v > vmax ? WS_INF : (((u64)v << 32) | 0x80000000ull | (u64)(unsigned)(id + 1));
 }
+// THE DENSE FORM IN 2 BITS PER SEED.  When the tie value lies at or above the value most seeds share, every one of those seeds
+// has to be in the replay's heap -- 450 M entries, 3.6 GB over PCIe -- but nearly all of them are one of two things: the
+// MODAL BALLAST entry D (the background's value, not relevant: nobody floods from it) or LARGE.  The device therefore sends
+// two bitmaps over the seed numbers (is D / is LARGE) and the entries of the other seeds in seed order (~ 1 % of them); the
+// host's heap build regenerates seed k's entry as it reaches position k (ws_replay.h, WsSeedCodes).
+// D is the most frequent ballast entry among 256 samples spread over the volume (any choice is correct, a poor one only sends
+// more exceptions).
+__global__ void __launch_bounds__(256)
+k_ws_entry_sample(const uint8_t *__restrict__ cls, const int *__restrict__ cid, const float *__restrict__ field, int64_t n, unsigned vmax,
+                  u64 *__restrict__ out)
+{
+    const int64_t step = n / 256 > 0 ? n / 256 : 1;
+    int64_t i = (int64_t)threadIdx.x * step;
+    u64 e = 0ull;
+    for (int j = 0; j < 512 && i < n; j++, i++) {
+        if (cls[i] != 2 || cid[i] != -1) continue;
+        const unsigned v = ws_ordkey(field[i]);
+        if (v <= vmax) { e = ((u64)v << 32) | 0x80000000ull; break; }
+    }
+    out[threadIdx.x] = e;
+}
+struct WsSeedCode { bool seed, d, l, x; unsigned key; int id; };
+__device__ __forceinline__ WsSeedCode ws_seed_code(const uint8_t *cls, const int *cid, const float *field, int64_t i, int64_t n, unsigned vmax, u64 D) {
+    WsSeedCode r; r.seed = i < n && cls[i] == 2; r.d = r.l = r.x = false; r.key = 0; r.id = -1;
+    if (r.seed) {
+        r.key = ws_ordkey(field[i]);
+        const int c = cid[i];
+        r.id = c <= -2 ? -2 - c : -1;
+        r.l = r.key > vmax;
+        r.d = !r.l && r.id < 0 && D != 0ull && r.key == (unsigned)(D >> 32);
+        r.x = !r.l && !r.d;
+    }
+    return r;
+}
+__global__ void __launch_bounds__(256)
+k_ws_code_counts(const uint8_t *__restrict__ cls, const int *__restrict__ cid, const float *__restrict__ field, int64_t n, unsigned vmax, u64 D,
+                 int *__restrict__ n_exc)
+{
+    __shared__ int part[4];
+    const WsSeedCode r = ws_seed_code(cls, cid, field, (int64_t)blockIdx.x * 256 + threadIdx.x, n, vmax, D);
+    const unsigned long long m = __ballot(r.x);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) n_exc[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// bits_d / bits_l: zeroed by the caller, written when write_bits; exceptions number c0 .. c0 + cap - 1 -> exc[0 .. cap)
+__global__ void __launch_bounds__(256)
+k_ws_seed_codes(const uint8_t *__restrict__ cls, const int *__restrict__ cid, const float *__restrict__ field, int64_t n, unsigned vmax, u64 D,
+                const long long *__restrict__ base_seed, const long long *__restrict__ base_exc, const int *__restrict__ subid,
+                int write_bits, unsigned *__restrict__ bits_d, unsigned *__restrict__ bits_l, int64_t c0, int64_t cap, u64 *__restrict__ exc)
+{
+    __shared__ int part_s[4], part_x[4];
+    __shared__ unsigned lb_d[9], lb_l[9];
+    if (!write_bits) { const long long b0 = base_exc[blockIdx.x]; if (b0 >= c0 + cap || b0 + 256 <= c0) return; }     // (uniform)
+    if (threadIdx.x < 9) { lb_d[threadIdx.x] = 0u; lb_l[threadIdx.x] = 0u; }
+    const WsSeedCode r = ws_seed_code(cls, cid, field, (int64_t)blockIdx.x * 256 + threadIdx.x, n, vmax, D);
+    const unsigned long long ms = __ballot(r.seed), mx = __ballot(r.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { part_s[wave] = __popcll(ms); part_x[wave] = __popcll(mx); }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int sl = __popcll(ms & below), xl = __popcll(mx & below);
+    for (int w = 0; w < wave; w++) { sl += part_s[w]; xl += part_x[w]; }
+    if (write_bits) {
+        if (r.d) atomicOr(&lb_d[sl >> 5], 1u << (sl & 31));
+        if (r.l) atomicOr(&lb_l[sl >> 5], 1u << (sl & 31));
+        __syncthreads();
+        if (threadIdx.x < 18) {                                       // the block's 256-bit strings, shifted to its first seed number
+            const int t = threadIdx.x % 9;
+            const unsigned *lb = threadIdx.x < 9 ? lb_d : lb_l;
+            unsigned *bits = threadIdx.x < 9 ? bits_d : bits_l;
+            const long long kb = base_seed[blockIdx.x];
+            const int sh = (int)(kb & 31);
+            const unsigned lo = t < 8 ? lb[t] : 0u, hi = t > 0 ? lb[t - 1] : 0u;
+            const unsigned word = sh ? ((lo << sh) | (hi >> (32 - sh))) : lo;
+            if (word) atomicOr(&bits[(kb >> 5) + t], word);
+        }
+    }
+    if (r.x) {
+        const long long slot = base_exc[blockIdx.x] + xl - c0;
+        if (slot >= 0 && slot < cap) {
+            int id = r.id;
+            if (id >= 0 && subid) id = subid[id];
+            exc[slot] = ((u64)r.key << 32) | 0x80000000ull | (u64)(unsigned)(id + 1);
+        }
+    }
+}
 // THE SUB-GRAPH THE REPLAY CAN REACH.  The replay pops an item only while its key is at or below the tie value: P = the
 // relevant markers with a key <= vmax and the floodable pixels with a key < vmax.  It looks at the out-neighbours of what
 // it pops (pushed or not yet, small or large): Q = P + the out-neighbours of P.  On a detect_anvils window P is the rim of
@@ -1192,7 +1279,8 @@ struct tf_ws_job {
     unsigned long long h_amb[4];
     int64_t st[TF_WS_NSTATS];
     // reference order
-    bool need_replay, replay_done, applied, sparse, plain, identity;
+    bool need_replay, replay_done, applied, sparse, plain, identity, coded;
+    u64 code_d; int64_t code_words, n_exc;
     int64_t M, S, nQ; unsigned vmax;
     WsHostBuf hb_val, hb_nbr, hb_rank, hb_sk, hb_sval, hb_sid;
     int64_t popped; int n_ranked; int replay_rc;
@@ -1283,10 +1371,12 @@ static int ws_job_export(tf_ws_job *j)
     j->hb_val = ws_host_take((size_t)nQ * sizeof(unsigned), true);
     j->hb_nbr = ws_host_take((size_t)nQ * nn * sizeof(int), true);
     j->hb_rank = ws_host_take((size_t)nQ * sizeof(int), true);
-    // sparse: heap position, key, id of the small seeds; dense: the heap array itself (one 8-byte entry per seed, room for every push behind them)
-    j->hb_sk = ws_host_take(j->sparse ? (size_t)j->S * sizeof(long long) : (size_t)(j->M + nQ + 1) * sizeof(u64), true);
-    if (j->sparse) { j->hb_sval = ws_host_take((size_t)j->S * sizeof(unsigned), true); j->hb_sid = ws_host_take((size_t)j->S * sizeof(int), true); }
-    if (!j->hb_val.p || !j->hb_nbr.p || !j->hb_rank.p || !j->hb_sk.p || (j->sparse && (!j->hb_sval.p || !j->hb_sid.p))) {
+    // sparse: heap position, key, id of the small seeds (the dense form takes its buffers below)
+    if (j->sparse) {
+        j->hb_sk = ws_host_take((size_t)j->S * sizeof(long long), true);
+        j->hb_sval = ws_host_take((size_t)j->S * sizeof(unsigned), true); j->hb_sid = ws_host_take((size_t)j->S * sizeof(int), true);
+    }
+    if (!j->hb_val.p || !j->hb_nbr.p || !j->hb_rank.p || (j->sparse && (!j->hb_sk.p || !j->hb_sval.p || !j->hb_sid.p))) {
         tf_set_error("tf_watershed: out of host memory for the reference-order replay");
         return TF_ENOMEM;
     }
@@ -1308,28 +1398,81 @@ static int ws_job_export(tf_ws_job *j)
             ws_to_host(j->hb_sid.p, stg_id, (size_t)j->S * sizeof(int), s)) return TF_EHIP;
         TF_CHECK_HIP(hipStreamSynchronize(s));
     } else {
-        // DENSE form: every seed is sent (more small seeds than staging room, or TF_WS_REFERENCE_DENSE), as the heap entry the
-        // replay keeps; the array travels through the two frontier queues in turn, R entries at a time
+        // DENSE form: every seed has to be in the replay's heap (more small seeds than staging room, or TF_WS_REFERENCE_DENSE).
         TF_CHECK_HIP(hipStreamSynchronize(s));                          // the sub-graph has left the queues
-        const int64_t cap = R + 32;
-        int turn = 0;
-        for (int64_t c0 = 0; c0 < j->M; c0 += cap, turn ^= 1) {
-            const int64_t cnt = j->M - c0 < cap ? j->M - c0 : cap;
-            u64 *stg = (u64 *)j->Q.q[turn];
-            hipLaunchKernelGGL(k_ws_seed_list, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N,
-                               (const long long *)base_seed, c0, cap, subid_or_null, h_vmax, stg);
+        // 2 bits per seed + the exceptions (k_ws_seed_codes) if the two bitmaps fit a frontier queue ...
+        const int64_t W = (j->M + 31) / 32 + 8;                         // words per bitmap
+        j->coded = 2 * W <= 2 * R + 64 && !ws_env("TF_WS_REFERENCE_NO_CODES");
+        if (j->coded) {
+            u64 *d_sample = (u64 *)j->Q.q[1];
+            hipLaunchKernelGGL(k_ws_entry_sample, dim3(1), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N, h_vmax, d_sample);
             TF_CHECK_LAUNCH();
-            if (ws_to_host((u64 *)j->hb_sk.p + c0, stg, (size_t)cnt * sizeof(u64), s)) return TF_EHIP;
-            if (turn) TF_CHECK_HIP(hipStreamSynchronize(s));            // (the stream orders kernel k + 2 after copy k anyway; bound the queue of copies)
+            u64 h_sample[256];
+            TF_CHECK_HIP(hipMemcpyAsync(h_sample, d_sample, sizeof(h_sample), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            u64 D = 0ull; int best = 0;
+            for (int a = 0; a < 256; a++) {
+                if (!h_sample[a]) continue;
+                int cnt = 0;
+                for (int b = 0; b < 256; b++) cnt += h_sample[b] == h_sample[a];
+                if (cnt > best) { best = cnt; D = h_sample[a]; }
+            }
+            j->code_d = D;
+            int *n_exc = n_small; long long *base_exc = base_small;      // (the small-seed counts have served)
+            hipLaunchKernelGGL(k_ws_code_counts, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N, h_vmax, D, n_exc);
+            TF_CHECK_LAUNCH();
+            tb = j->scan_bytes;
+            TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(j->scan_tmp, tb, WsCountIter(n_exc, WsIntToLL()), base_exc, (int)nb256, s));
+            long long h_e = 0; int h_ec = 0;
+            TF_CHECK_HIP(hipMemcpyAsync(&h_e, base_exc + nb256 - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipMemcpyAsync(&h_ec, n_exc + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            const int64_t E = h_e + h_ec;
+            j->code_words = W; j->n_exc = E;
+            j->hb_sval = ws_host_take((size_t)2 * W * sizeof(unsigned), true);
+            j->hb_sid = ws_host_take((size_t)(E > 0 ? E : 1) * sizeof(u64), true);
+            j->hb_sk = ws_host_take((size_t)(j->M + nQ + 1) * sizeof(u64), false);       // the heap itself: plain memory, filled by the replay
+            if (!j->hb_sval.p || !j->hb_sid.p || !j->hb_sk.p) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); return TF_ENOMEM; }
+            unsigned *d_bits = (unsigned *)j->Q.q[0];
+            TF_CHECK_HIP(hipMemsetAsync(d_bits, 0, (size_t)2 * W * sizeof(unsigned), s));
+            const int64_t cap = R + 32;
+            bool first = true;
+            for (int64_t c0 = 0; first || c0 < E; c0 += cap, first = false) {
+                const int64_t cnt = E - c0 < cap ? E - c0 : cap;
+                u64 *stg = (u64 *)j->Q.q[1];
+                hipLaunchKernelGGL(k_ws_seed_codes, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N, h_vmax, D,
+                                   (const long long *)base_seed, (const long long *)base_exc, subid_or_null, first ? 1 : 0, d_bits, d_bits + W, c0, cap, stg);
+                TF_CHECK_LAUNCH();
+                if (cnt > 0 && ws_to_host((u64 *)j->hb_sid.p + c0, stg, (size_t)cnt * sizeof(u64), s)) return TF_EHIP;
+                if (first && ws_to_host(j->hb_sval.p, d_bits, (size_t)2 * W * sizeof(unsigned), s)) return TF_EHIP;
+                TF_CHECK_HIP(hipStreamSynchronize(s));                  // (the staging queue is written again by the next chunk)
+            }
+        } else {
+            // ... else as the 8-byte heap entries themselves, through the two frontier queues in turn, R entries at a time
+            j->hb_sk = ws_host_take((size_t)(j->M + nQ + 1) * sizeof(u64), true);
+            if (!j->hb_sk.p) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); return TF_ENOMEM; }
+            const int64_t cap = R + 32;
+            int turn = 0;
+            for (int64_t c0 = 0; c0 < j->M; c0 += cap, turn ^= 1) {
+                const int64_t cnt = j->M - c0 < cap ? j->M - c0 : cap;
+                u64 *stg = (u64 *)j->Q.q[turn];
+                hipLaunchKernelGGL(k_ws_seed_list, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N,
+                                   (const long long *)base_seed, c0, cap, subid_or_null, h_vmax, stg);
+                TF_CHECK_LAUNCH();
+                if (ws_to_host((u64 *)j->hb_sk.p + c0, stg, (size_t)cnt * sizeof(u64), s)) return TF_EHIP;
+                if (turn) TF_CHECK_HIP(hipStreamSynchronize(s));        // (the stream orders kernel k + 2 after copy k anyway; bound the queue of copies)
+            }
+            TF_CHECK_HIP(hipStreamSynchronize(s));
         }
-        TF_CHECK_HIP(hipStreamSynchronize(s));
     }
     j->need_replay = true;
     j->ms_export = ws_now_ms() - t_enter;
     if (ref_debug)
         fprintf(stderr, "reference order: %lld seeds, %lld at or below the tie value (key %u), %lld relevant pixels, sub-graph %lld%s, %s form; "
                 "tie value + numbering %.1f ms, export %.1f ms\n", (long long)j->M, (long long)j->S, h_vmax, (long long)R, (long long)nQ,
-                j->identity ? " (whole compact set)" : "", j->sparse ? "sparse" : "dense", t_numbered - t_enter, ws_now_ms() - t_numbered);
+                j->identity ? " (whole compact set)" : "", j->sparse ? "sparse" : (j->coded ? "dense (2 bits per seed + exceptions)" : "dense"), t_numbered - t_enter, ws_now_ms() - t_numbered);
+    if (ref_debug && !j->sparse && j->coded)
+        fprintf(stderr, "reference order: modal ballast entry %016llx, %lld exceptions\n", (unsigned long long)j->code_d, (long long)j->n_exc);
     return TF_OK;
 }
 
@@ -1561,13 +1704,17 @@ static int ws_job_replay(tf_ws_job *j)
     double phase[2] = {0.0, 0.0};
     if (j->sparse)
         j->popped = ws_reference_ranks_sparse(j->M, j->S, (const long long *)j->hb_sk.p, (const unsigned *)j->hb_sval.p, (const int *)j->hb_sid.p,
-                                              j->nQ, (const unsigned *)j->hb_val.p, (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked);
-    else if (j->plain)
-        j->popped = ws_reference_ranks_plain(j->M, (const u64 *)j->hb_sk.p, nullptr, j->nQ, (const unsigned *)j->hb_val.p,
-                                             (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked);
-    else
-        j->popped = ws_reference_ranks_dense(j->M, (u64 *)j->hb_sk.p, j->nQ, (const unsigned *)j->hb_val.p,
-                                             (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked, phase);
+                                              j->nQ, (const unsigned *)j->hb_val.p, (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked, phase);
+    else {
+        const WsSeedCodes codes{(const uint32_t *)j->hb_sval.p, (const uint32_t *)j->hb_sval.p + (j->coded ? j->code_words : 0), j->code_d, (const u64 *)j->hb_sid.p};
+        if (j->plain) {
+            if (j->coded) wsr_expand(j->M, codes, (u64 *)j->hb_sk.p);
+            j->popped = ws_reference_ranks_plain(j->M, (const u64 *)j->hb_sk.p, nullptr, j->nQ, (const unsigned *)j->hb_val.p,
+                                                 (const int *)j->hb_nbr.p, j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked);
+        } else
+            j->popped = ws_reference_ranks_dense(j->M, (u64 *)j->hb_sk.p, j->nQ, (const unsigned *)j->hb_val.p, (const int *)j->hb_nbr.p,
+                                                 j->n_nbr, j->vmax, (int *)j->hb_rank.p, &n_ranked, phase, j->coded ? &codes : nullptr);
+    }
     j->n_ranked = n_ranked;
     j->replay_done = true;
     j->ms_replay = ws_now_ms() - t0;

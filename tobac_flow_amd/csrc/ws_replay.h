@@ -18,6 +18,7 @@
 // rank[id] = pop rank of a marker, -1 if it did not pop; *n_ranked = markers popped.  Return: the pops, -1: out of memory.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -175,8 +176,11 @@ struct WsPosMap {                                                       // open 
 };
 
 static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *sk, const unsigned *sval, const int *sid, int64_t nQ,
-                                         const unsigned *val, const int *nbr, int n_nbr, unsigned vmax, int *rank, int *n_ranked_out)
+                                         const unsigned *val, const int *nbr, int n_nbr, unsigned vmax, int *rank, int *n_ranked_out,
+                                         double *phase_ms = nullptr)
 {
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_start = now_ms();
     // an item = (key, id) with key = (v << 32) | age: `smaller` (:161-164) is the order of the keys.  LARGE = the all-ones
     // key: larger than every small item (value keys stop at that of +inf, NaN fields are refused), equal to itself -- a
     // sift never swaps two of them, which is all the replay needs to know about the large items.
@@ -198,6 +202,8 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
     if (!top || !occ || !state || !deep.init(1 << 16)) { free(top); free(occ); free(state); return -1; }
     memset(top, 0xFF, (size_t)n_top * sizeof(Item));                                            // key = ~0: LARGE everywhere
     bool oom = false;
+    unsigned long long path_key = 0;     // the saved path of the pop loop (below): value class it follows, and whether it still holds
+    bool path_valid = false;
     // the bitmap covers ALL positions: a small item on its way up walks through unoccupied ancestors on bit tests alone
     // (the top of the bitmap stays in cache; the item array of the top region, 16 B per position, does not)
     auto has = [&](int64_t p) { return (occ[p >> 6] >> (p & 63)) & 1ull; };
@@ -216,11 +222,23 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
     };
     // _watershed.pyx:120-152 for a small item entering at position `child` (a large one only lengthens the heap)
     auto push_small = [&](int64_t child, const Item &e) {
+        if (child > 0 && !has((child + 1) / 2 - 1)) {
+            // The small items are an ancestor-closed set, so the unoccupied ancestors of `child` are the LOWER part of its
+            // chain: the item rises through all of them without a comparison.  Find the first unoccupied position of the
+            // chain from the root down -- ~21 tests in the hot top of the bitmap instead of ~8 cold ones from the bottom
+            // (the sparse build was 0.8 us per seed this way round).
+            const uint64_t c1 = (uint64_t)child + 1;
+            const int depth = 63 - __builtin_clzll(c1);
+            int d = 0;
+            while (d < depth && has((int64_t)(c1 >> (depth - d)) - 1)) d++;
+            child = (int64_t)(c1 >> (depth - d)) - 1;
+        }
         while (child > 0) {
             const int64_t parent = (child + 1) / 2 - 1;
             if (has(parent)) {
                 const Item pe = load(parent);
                 if (!(e.key < pe.key)) break;
+                if (pe.key == path_key) path_valid = false;             // a seed of the tracked tree moves down: drop the saved path
                 store(child, pe);
                 store(parent, LARGE);                                    // (rewritten by the next step or by the final store)
             }
@@ -228,11 +246,36 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
         }
         store(child, e);
     };
+    const double t_alloc = now_ms();
     for (int64_t j = 0; j < S; j++) push_small((int64_t)sk[j], Item{(u64)sval[j] << 32, sid[j], 0});    // seed k enters at position k, age 0
+    if (phase_ms) phase_ms[0] = now_ms() - t_start;
+    if (getenv("WSR_DEBUG")) fprintf(stderr, "sparse: scratch %.1f ms, %lld pushes %.1f ms, deep table %zu entries\n", t_alloc - t_start, (long long)S, now_ms() - t_alloc, deep.n);
     int64_t items = M;
     for (int64_t i = 0; i < nQ; i++) rank[i] = -1;
     int64_t age = 1, popped = 0;
     int n_ranked = 0;
+    // The tree of seeds of the root's value (see the dense form below): a larger item taken from the end sinks along the
+    // path "left child if it is such a seed, else the right one if it is" to a leaf of that tree and every seed on the path
+    // moves up one node -- which changes nothing for seeds nobody floods from (one and the same item).  The path is kept
+    // between pops; only the seeds with an id on it are moved.  (Round 4: a pop walked the ~21 levels of 1.9 M equal seeds
+    // through a 128 MB array, 290 ns each.)
+    std::vector<int64_t> path;       // path[0] = 0
+    std::vector<int> rel;            // levels d >= 1 of path items with an id, ascending
+    auto sift_down_from = [&](int64_t i, const Item &x) {                // :67-111 from the hole at i
+        for (;;) {
+            const int64_t l = 2 * i + 1, r = 2 * i + 2;
+            if (l >= items) break;
+            int64_t smallest = i;
+            Item cur = x;
+            const Item le = load(l);
+            if (le.key < cur.key) { smallest = l; cur = le; }
+            if (r < items) { const Item re = load(r); if (re.key < cur.key) { smallest = r; cur = re; } }
+            if (smallest == i) break;
+            store(i, cur);
+            i = smallest;
+        }
+        store(i, x);
+    };
     while (items > 0 && !oom) {
         const Item e = load(0);
         if (e.key == ~0ull) break;                                       // a large top ends the replay
@@ -240,20 +283,35 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
         if (items > 0) {
             const Item x = load(items);
             store(items, LARGE);
-            int64_t i = 0;
-            for (;;) {
-                const int64_t l = 2 * i + 1, r = 2 * i + 2;
-                if (l >= items) break;
-                int64_t smallest = i;
-                Item cur = x;
-                const Item le = load(l);
-                if (le.key < cur.key) { smallest = l; cur = le; }
-                if (r < items) { const Item re = load(r); if (re.key < cur.key) { smallest = r; cur = re; } }
-                if (smallest == i) break;
-                store(i, cur);
-                i = smallest;
-            }
-            store(i, x);
+            const bool seed_root = (e.key & 0xffffffffull) == 0;
+            if (seed_root && x.key == e.key) store(0, x);               // equal to both children at most: stays at the root
+            else if (seed_root) {
+                if (!path_valid || path_key != e.key || path.back() >= items) { path.clear(); path.push_back(0); rel.clear(); path_key = e.key; path_valid = true; }
+                for (;;) {
+                    const int64_t i = path.back(), l = 2 * i + 1, r = l + 1;
+                    int64_t c = -1;
+                    Item ce = LARGE;
+                    if (l < items && has(l)) { ce = load(l); if (ce.key == e.key) c = l; }
+                    if (c < 0 && r < items && has(r)) { ce = load(r); if (ce.key == e.key) c = r; }
+                    if (c < 0) break;
+                    path.push_back(c);
+                    if (ce.id >= 0) rel.push_back((int)path.size() - 1);
+                }
+                const int L = (int)path.size() - 1;
+                if (L >= 1) {
+                    store(0, Item{e.key, -1, 0});
+                    size_t w = 0;
+                    for (size_t q = 0; q < rel.size(); q++) {
+                        const int d = rel[q];
+                        store(path[d - 1], load(path[d]));
+                        store(path[d], Item{e.key, -1, 0});
+                        if (d - 1 >= 1) rel[w++] = d - 1;
+                    }
+                    rel.resize(w);
+                }
+                sift_down_from(path[L], x);
+                if (L >= 1) path.pop_back(); else path_valid = false;
+            } else { path_valid = false; sift_down_from(0, x); }
         } else store(0, LARGE);
         popped++;
         if (e.id < 0) continue;
@@ -269,6 +327,7 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
             items += 1;
         }
     }
+    if (phase_ms) phase_ms[1] = now_ms() - t_start - phase_ms[0];
     *n_ranked_out = n_ranked;
     free(top); free(occ); free(state);
     return oom ? -1 : popped;
@@ -290,8 +349,25 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
 //     it are moved, and the sinking item continues by the general rule from the leaf on.  A pop costs O(1) amortised
 //     instead of the 28 swaps of a 2^28-item heap.
 // Same pushes, pops and sift decisions as the plain form, item for item (tools/replay_check.cpp, test_gpu_reference_order).
+// The seed entries in 2 bits + exceptions (k_ws_seed_codes): most seeds are either the MODAL ballast entry `D` (the
+// background's value, nobody floods from it) or LARGE; bit k of bits_d / bits_l says so for seed k, every other seed's entry
+// follows in `exc`, in seed order.  3.6 GB of entries per 16 x 5424^2 window become 2 x 56 MB + ~30 MB over PCIe.
+struct WsSeedCodes { const uint32_t *bits_d, *bits_l; wsr_u64 d; const wsr_u64 *exc; };
+static inline wsr_u64 wsr_next_entry(const WsSeedCodes &c, int64_t k, int64_t &j) {
+    const uint32_t m = 1u << (k & 31);
+    if (c.bits_d[k >> 5] & m) return c.d;
+    if (c.bits_l[k >> 5] & m) return WSR_LARGE;
+    return c.exc[j++];
+}
+static void wsr_expand(int64_t M, const WsSeedCodes &c, wsr_u64 *h) {
+    int64_t j = 0;
+    for (int64_t k = 0; k < M; k++) h[k] = wsr_next_entry(c, k, j);
+}
+
+// `codes` != nullptr: h[0 .. M) is written here, from the codes, as the build goes (no pass of its own)
 static int64_t ws_reference_ranks_dense(int64_t M, wsr_u64 *h, int64_t nQ, const unsigned *val, const int *nbr, int n_nbr,
-                                        unsigned vmax, int *rank, int *n_ranked_out, double *phase_ms = nullptr)
+                                        unsigned vmax, int *rank, int *n_ranked_out, double *phase_ms = nullptr,
+                                        const WsSeedCodes *codes = nullptr)
 {
     typedef wsr_u64 u64;
     uint8_t *state = (uint8_t *)calloc((size_t)(nQ > 0 ? nQ : 1), 1);                          // 1: already pushed
@@ -300,8 +376,11 @@ static int64_t ws_reference_ranks_dense(int64_t M, wsr_u64 *h, int64_t nQ, const
     auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_start = now_ms();
     // build: _watershed.pyx:120-152 for arrival k = 1 .. M - 1 (position k holds seed k already)
+    int64_t j_exc = 0;
+    if (codes && M > 0) h[0] = wsr_next_entry(*codes, 0, j_exc);
     for (int64_t k = 1; k < M; k++) {
-        const u64 e = h[k];
+        u64 e;
+        if (codes) { e = wsr_next_entry(*codes, k, j_exc); h[k] = e; } else e = h[k];
         int64_t parent = (k - 1) >> 1;
         const u64 pe = h[parent];
         if (e == pe || !wsr_smaller(e, pe)) continue;

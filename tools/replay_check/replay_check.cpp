@@ -29,11 +29,36 @@ static bool run_all(const Inst &I, bool with_plain, bool verbose)
     std::vector<long long> sk; std::vector<unsigned> sv; std::vector<int> sid;
     for (int64_t k = 0; k < M; k++) if (I.seed_val[k] <= I.vmax) { sk.push_back(k); sv.push_back(I.seed_val[k]); sid.push_back(I.seed_id[k]); }
     double t2 = now_ms();
-    p_sparse = ws_reference_ranks_sparse(M, (int64_t)sk.size(), sk.data(), sv.data(), sid.data(), nQ, I.val.data(), I.nbr.data(), I.n_nbr, I.vmax, r_sparse.data(), &n_sparse);
+    double phs[2] = {0, 0};
+    p_sparse = ws_reference_ranks_sparse(M, (int64_t)sk.size(), sk.data(), sv.data(), sid.data(), nQ, I.val.data(), I.nbr.data(), I.n_nbr, I.vmax, r_sparse.data(), &n_sparse, phs);
     double t3 = now_ms();
+    if (verbose) printf("sparse: build %.1f ms, pops %.1f ms\n", phs[0], phs[1]);
+    // the 2-bit codes + exceptions the device sends: modal ballast entry = the most frequent entry with id -1
+    std::vector<uint32_t> bd((M + 31) / 32 + 1, 0), bl((M + 31) / 32 + 1, 0);
+    std::vector<wsr_u64> exc;
+    wsr_u64 D = 0;
+    {
+        std::vector<wsr_u64> sample;
+        for (int64_t k = 0; k < M; k += std::max<int64_t>(1, M / 256)) if (entries[k] != WSR_LARGE && ((unsigned)entries[k] & 0x7fffffffu) == 0) sample.push_back(entries[k]);
+        std::sort(sample.begin(), sample.end());
+        size_t best = 0;
+        for (size_t i = 0; i < sample.size();) { size_t e2 = i; while (e2 < sample.size() && sample[e2] == sample[i]) e2++; if (e2 - i > best) { best = e2 - i; D = sample[i]; } i = e2; }
+        for (int64_t k = 0; k < M; k++) {
+            if (D && entries[k] == D) bd[k >> 5] |= 1u << (k & 31);
+            else if (entries[k] == WSR_LARGE) bl[k >> 5] |= 1u << (k & 31);
+            else exc.push_back(entries[k]);
+        }
+    }
+    WsSeedCodes codes{bd.data(), bl.data(), D, exc.data()};
+    std::vector<wsr_u64> h2(M + nQ + 1);
     double ph[2] = {0, 0};
-    p_dense = ws_reference_ranks_dense(M, entries.data(), nQ, I.val.data(), I.nbr.data(), I.n_nbr, I.vmax, r_dense.data(), &n_dense, ph);
+    p_dense = ws_reference_ranks_dense(M, h2.data(), nQ, I.val.data(), I.nbr.data(), I.n_nbr, I.vmax, r_dense.data(), &n_dense, ph, &codes);
     double t4 = now_ms();
+    {   // and from the expanded array: the same
+        std::vector<int> r2(nQ); int n2 = -1;
+        const int64_t p2 = ws_reference_ranks_dense(M, entries.data(), nQ, I.val.data(), I.nbr.data(), I.n_nbr, I.vmax, r2.data(), &n2);
+        if (p2 != p_dense || n2 != n_dense || r2 != r_dense) { printf("dense from codes != dense from entries\n"); return false; }
+    }
     if (verbose) printf("dense: build %.1f ms, pops %.1f ms\n", ph[0], ph[1]);
     if (verbose) printf("M %lld nQ %lld small seeds %zu: plain %.1f ms (%lld pops), sparse %.1f ms (%lld pops), dense %.1f ms (%lld pops, %d ranked)\n",
                         (long long)M, (long long)nQ, sk.size(), t1 - t0, (long long)p_plain, t3 - t2, (long long)p_sparse, t4 - t3, (long long)p_dense, n_dense);
@@ -129,12 +154,12 @@ int main(int argc, char **argv)
             }
         }
         I.M = (int64_t)I.seed_val.size();
-        I.vmax = key(0.00390625f);
+        I.vmax = (argc >= 5 && atoi(argv[4]) != 0) ? key(-1.0f) : key(0.00390625f);     // 4th argument != 0: the usual case, ties among the cores only
         printf("big: %lld x %lld, M %lld seeds, nQ %lld\n", (long long)W, (long long)H, (long long)I.M, (long long)nQ);
         const bool ok = run_all(I, with_plain, true);
         printf(ok ? "agree\n" : "MISMATCH\n");
         return ok ? 0 : 1;
     }
-    printf("usage: replay_check random N [seed] | big WIDTH [with_plain]\n");
+    printf("usage: replay_check random N [seed] | big WIDTH [with_plain [cores_only]]\n");
     return 2;
 }
