@@ -225,8 +225,9 @@ def main():
                          "per flood that has such ties, run on worker threads beside the next windows' device work) or raster order "
                          "(such voxels are counted in `watershed`)")
     ap.add_argument("--inflight", type=int, default=12,
-                    help="floods in flight per rank (each owns ~5 GB of scratch at 16 x 5424^2): window k's host replay runs on a "
-                         "worker thread while the device floods windows k+1 ...; 1 = strictly one after the other")
+                    help="floods in flight per rank at most (each owns ~8 GB of scratch at 16 x 5424^2; the first step lowers the "
+                         "number to what the free device memory holds): window k's host replay runs on a worker thread while the "
+                         "device floods windows k+1 ...; 1 = strictly one after the other")
     ap.add_argument("--rotate", type=int, default=3,
                     help="the timed steps visit this many different T-frame stacks of the synthetic sequence in turn (offsets "
                          "0, s, 2s, ... frames with s = --rotate-shift), all resident before the timed region: the data-dependent "
@@ -270,7 +271,8 @@ def main():
     from tobac_flow_amd.detection import get_combined_edge_field
     from tobac_flow_amd.parallel import stitch_rank_windows, window_bounds
     from collections import deque
-    from concurrent.futures import ThreadPoolExecutor
+    from concurrent.futures import FIRST_COMPLETED, ThreadPoolExecutor
+    from concurrent.futures import wait as futures_wait
     from tobac_flow_amd.watershed import neighbour_offsets, watershed_begin
     from tools.synth import anvil_seeds, blob_stack
 
@@ -294,9 +296,10 @@ def main():
     ws_stats = []                                            # tf_watershed stats of every window of every step (warmup included)
     ref_order = []                                           # reference order: (detour microseconds, replay form, replay us, export us) per flood that needed it
     tie_mode = {"order": a.tie_order}
+    inflight = {}
     replay_pool = ThreadPoolExecutor(max_workers=max(1, min(a.inflight, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
-    def flood_begin(flow, w, c):
+    def flood_begin(flow, w, c, scratch=None):
         """seeds -> edge field -> device part of the watershed of channel c over the window `w` of the stack (Flow `flow`);
         the host replay of the reference's heap order (if this window needs one) starts on a worker thread"""
         lin, seeds = anvil_seeds(w + CHANNEL_OFFSETS[c] if c else w)
@@ -306,11 +309,12 @@ def main():
         e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
         st = {}
-        job = watershed_begin(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore")
+        job = watershed_begin(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore",
+                              workspace=scratch)
         fut = replay_pool.submit(job.replay) if job.needs_replay else None
-        return job, fut, st
+        return job, fut, st, scratch
 
-    def flood_finish(job, fut, st):
+    def flood_finish(job, fut, st, scratch=None):
         """pop ranks applied, labels written: one label volume"""
         if fut is not None:
             fut.result()
@@ -327,27 +331,56 @@ def main():
         # flow of all T - 1 frame pairs of the stack, ONCE (the frames two windows share are not computed twice), in batches
         # sized by the library (tf_farneback_batch_hint)
         flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic")
+        flow_released = False
         if T * H * W * (1 + 4 + C) * 4 > 0.6 * torch.cuda.mem_get_info()[1]:
             # a stack whose frames + flow vectors + one channel's labels take most of the device (F3: 34 + 136 + 44 GB):
             # the Farneback scratch goes back to the allocator (create_flow would otherwise keep it for the next call)
             _lib.release_workspaces("farneback")
+            flow_released = True
         objects, out = [], None
         for c in range(C):                                   # channels one after the other: one channel's labels resident
             out = None
-            wins = []
             pending = deque()                                # floods in flight, oldest first
-            for lo, hi in bounds:
-                while len(pending) >= max(1, a.inflight):
-                    wins.append(flood_finish(*pending.popleft()))
+            # Every flood in flight owns ~17 B of scratch per window voxel until it is finished.  The Farneback scratch of
+            # create_flow (up to 115 GB) is idle from here to the next step's create_flow: the floods take their scratch from
+            # it, piece by piece, instead of allocating another 50 - 100 GB beside it (which the device does not have).
+            fb = None if flow_released else _lib.borrow_workspace("farneback")
+            per_job = 18 * max(hi - lo for lo, hi in bounds) * H * W
+            if fb is not None and fb.numel() >= per_job:
+                n_fly = int(max(1, min(a.inflight, len(bounds), fb.numel() // per_job)))
+                piece = fb.numel() // n_fly // 256 * 256
+                pieces = [fb[k * piece:(k + 1) * piece] for k in range(n_fly)]
+            else:
+                free = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+                n_fly = int(max(1, min(a.inflight, len(bounds), 0.3 * free // (per_job + 4 * per_job // 18))))
+                pieces = [None] * n_fly
+            inflight["n"] = n_fly
+            wins = [None] * len(bounds)
+
+            def finish_one():
+                """finish a flood whose host replay has ended (the oldest such one); if none has, wait for the first that does:
+                a window whose replay takes long -- the dense form, ~1 s -- does not hold up the others"""
+                ready = [p for p in pending if p[1] is None or p[1].done()]
+                if not ready:
+                    futures_wait([p[1] for p in pending], return_when=FIRST_COMPLETED)
+                    ready = [p for p in pending if p[1] is None or p[1].done()]
+                done = ready[0]
+                pending.remove(done)
+                wins[done[4]] = flood_finish(*done[:4])
+                pieces.append(done[3])
+
+            for iw, (lo, hi) in enumerate(bounds):
+                while len(pending) >= n_fly:
+                    finish_one()
                 # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame
                 # pair does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426);
                 # window_view patches those two frames in the stack's arrays for the duration of the block instead of
                 # copying the window's 7.5 GB of flow vectors (Flow.window).  Only the device part of the flood reads the
                 # flows (its neighbour table has the displacements applied): the job is finished outside the block.
                 with flow_all.window_view(lo, hi) as flow_w:
-                    pending.append(flood_begin(flow_w, bt[lo:hi], c))
+                    pending.append(flood_begin(flow_w, bt[lo:hi], c, pieces.pop()) + (iw,))
             while pending:
-                wins.append(flood_finish(*pending.popleft()))
+                finish_one()
             # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
             out = stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins
             del wins
@@ -484,7 +517,7 @@ def main():
                             "floods_probing": int((timed[:, 5] >= 0).sum()), "floods_skipping_root_phase": int((timed[:, 5] < 0).sum()),
                             "tie_order": a.tie_order,
                             "labels_bit_exact_with_the_reference": a.tie_order == "reference" and int(timed[:, 11].sum()) == 0,
-                            "floods_in_flight": a.inflight}
+                            "floods_in_flight": inflight.get("n", 1)}
         if a.tie_order == "reference":
             ro = ref_order                                                          # warm-up floods included
             out["watershed"]["reference_order"] = {

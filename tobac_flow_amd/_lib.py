@@ -238,6 +238,15 @@ def workspace(nbytes, tag="default"):
     return cur
 
 
+def borrow_workspace(tag):
+    """the scratch buffer this (device, stream) currently holds under `tag`, or None: a caller that knows the owner is idle
+    (the Farneback scratch after create_flow has returned) may lend it to another stage instead of allocating beside it"""
+    t = torch()
+    key = (tag, device().index, t.cuda.current_stream().cuda_stream)
+    with _WS_LOCK:
+        return _WS.get(key)
+
+
 def workspace_bytes(tag):
     """bytes of scratch this (device, stream) holds under `tag` and its sub-tags `tag_*` (0 if none)"""
     t = torch()

@@ -439,6 +439,18 @@ static int64_t ws_reference_ranks_dense(int64_t M, wsr_u64 *h, int64_t nQ, const
         if (seed_root) {
             // runs of ballast seeds of this value at the end of the array: each pops and hands the root to the next
             const u64 ballast = (cls << 31);                           // id + 1 == 0
+            if (e == ballast && items > 1) {
+                // the common case in blocks of eight: entries that ARE the ballast entry (the loop below takes the rest)
+                int64_t n = items;
+                while (n - 8 >= 1) {
+                    const u64 *q = h + n - 8;
+                    const u64 diff = (q[0] ^ ballast) | (q[1] ^ ballast) | (q[2] ^ ballast) | (q[3] ^ ballast) |
+                                     (q[4] ^ ballast) | (q[5] ^ ballast) | (q[6] ^ ballast) | (q[7] ^ ballast);
+                    if (diff) break;
+                    n -= 8;
+                }
+                popped += items - n; items = n;                          // (e stays the ballast entry)
+            }
             while (e == ballast && items > 1 && (h[items - 1] >> 31) == cls) { items -= 1; popped += 1; e = h[items]; }
             h[0] = e;
         }

@@ -187,7 +187,8 @@ class WatershedJob:
 
 
 def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
-                    expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="reference", return_ambiguous=False):
+                    expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="reference", return_ambiguous=False,
+                    workspace=None):
     """Device-resident core, first part: torch tensors in (field f32, markers i32, mask i8 or None) -> WatershedJob.
 
     expect_conflict: True / False force the scheduling hint, None (default) uses the per-shape memo.
@@ -200,7 +201,9 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
         bit for bit, at the cost of a sequential host pass when such a tie exists (stats["reference_order"]);
         "warn" / "raise" / "ignore": labels follow the markers' raster order, and the voxels concerned are reported;
       * ties left by the depth cut-off at `max_chain_depth`: WatershedDepthError (a warning with "ignore").
-    return_ambiguous: finish() also returns the (T, H, W) uint8 report (AMB_* bits)."""
+    return_ambiguous: finish() also returns the (T, H, W) uint8 report (AMB_* bits).
+    workspace: a uint8 device tensor the flood may use as its scratch until the job is finished (e.g. a slice of another
+    stage's idle scratch, _lib.borrow_workspace); too small a one is ignored and the job allocates its own."""
     if on_ambiguous not in ("warn", "raise", "ignore", "reference"):
         raise ValueError("on_ambiguous must be 'warn', 'raise', 'ignore' or 'reference'")
     t = _lib.torch()
@@ -237,7 +240,10 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
         while True:
             nbytes = L.tf_watershed_workspace_bytes(T, H, W, len(nbr), cap, guess)
             ws = None                            # a retry must not hold the old buffer while the larger one is allocated
-            ws = _lib.workspace(nbytes, "watershed_job%d" % slot)
+            if workspace is not None and workspace.numel() >= nbytes:
+                ws = workspace
+            else:
+                ws = _lib.workspace(nbytes, "watershed_job%d" % slot)
             rc = L.tf_watershed_begin(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
                                       T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), start, cap, flags,
                                       _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr(), ctypes.byref(handle))
