@@ -36,8 +36,27 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); the device-
 
 # library profile name -> kernel symbol prefix in the rocprofv3 counter files
 _KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<", "vr_sor": "void k_vr_sor_tile<false>", "vr_system": "void k_vr_system<true, false>",
-                  "sobel": "void k_sobel27<2, double, 2, true>", "fb_polyexp": "k_fb_polyexp"}
-_TRAFFIC_FILE = "profiles/round3_pmc_traffic_bench.json"
+                  "sobel": "void k_sobel27<2, double, 2, true>", "fb_polyexp": "k_fb_polyexp", "vr_prepare": "k_vr_prepare",
+                  "smooth_flow": "void k_smooth<"}
+_TRAFFIC_FILE = "profiles/round4_pmc_traffic_bench.json"
+_VALU_FILE = "profiles/round4_pmc_valu_bench.json"
+_CLOCK_GHZ_DEFAULT = 2.1       # GRBM_GUI_ACTIVE / 8 / duration under k_fb_iter; used when a pass has no timestamps
+
+
+def _valu_floor(profile_name, alg_bytes_total, doc):
+    """VALU ISSUE FLOOR of one kernel over this run, in ms: the wave-level VALU instructions the committed counter pass
+    (`rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE -- python3 bench.py --frames 62 ...`, tools/pmc_valu_json.py)
+    counted per ALGORITHMIC byte of that kernel, times this run's algorithmic bytes, times 4 cycles per wave64 instruction,
+    over 1024 SIMDs at the clock the pass measured under that kernel.  float64 instructions occupy a SIMD for eight cycles,
+    so the real floor of the float64-heavy kernels (Sobel, polynomial expansion) is higher.  None if the pass lacks the kernel."""
+    try:
+        k = next(v for name, v in doc["kernels"].items() if name.startswith(_KERNEL_SYMBOL[profile_name]))
+        rec_bytes = doc["recorded_on"]["algorithmic_bytes_per_launch"][profile_name] * doc["recorded_on"]["launches"][profile_name]
+        instr = k["valu_wave_instructions_per_launch"] * k["launches"]
+        clock = (k.get("clock_ghz_under_this_kernel") or _CLOCK_GHZ_DEFAULT) * 1e9
+        return instr / rec_bytes * alg_bytes_total * doc.get("cycles_per_wave64_instruction", 4) / (doc.get("simds", 1024) * clock) * 1e3
+    except (KeyError, TypeError, StopIteration, ZeroDivisionError):
+        return None
 _TRAFFIC_WORKLOAD = ("F", 144, 5424, 5424, 1)      # (config, frames, height, width, vr_steps) the counter passes were recorded on
 
 
@@ -465,6 +484,27 @@ def main():
                                         "alg_GBps": round(v[2] / (v[1] * 1e-3) / 1e9, 1) if v[2] > 0 else None,
                                         "launches": v[0], "algorithmic_bytes_per_launch": round(v[2] / v[0], 1)}
                                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+            # the right ceiling per kernel: next to the HBM figure, the VALU issue floor from the committed SQ
+            # counter pass; `bound` = whichever floor is larger (frac stays the HBM fraction)
+            try:
+                with open(os.path.join(ROOT, _VALU_FILE)) as fh:
+                    valu_doc = json.load(fh)
+            except (OSError, ValueError):
+                valu_doc = None
+            for k, v in prof.items():
+                e = roof["all_kernels"][k]
+                if v[2] > 0:
+                    e["hbm_floor_ms"] = round(v[2] / a.steps / (HBM_PEAK_GBS * 1e9) * 1e3, 3)
+                    e["frac_hbm"] = round(v[2] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                vf = _valu_floor(k, v[2], valu_doc) if (valu_doc and k in _KERNEL_SYMBOL and v[2] > 0) else None
+                if vf is not None:
+                    e["valu_floor_ms"] = round(vf / a.steps, 3)
+                    e["frac_valu"] = round(vf / v[1], 4)
+                    e["bound"] = "valu" if vf / a.steps > e.get("hbm_floor_ms", 0.0) else "hbm"
+            if valu_doc:
+                roof["valu_floor_source"] = _VALU_FILE + " (instructions per algorithmic byte of a 62-frame run, scaled by this run's algorithmic bytes; 4 cycles per wave64 instruction, 1024 SIMDs)"
+            if "bound" in roof["all_kernels"].get(name, {}):
+                roof["bound_detail"] = roof["all_kernels"][name]["bound"]
             if tr:                                       # what the kernel really moves, at the measured launch time
                 roof["traffic_GBps"] = round(tr["bytes_per_launch"] / (ms * 1e-3 / calls) / 1e9, 1)
                 roof["traffic_frac_of_peak"] = round(roof["traffic_GBps"] / HBM_PEAK_GBS, 4)

@@ -184,3 +184,31 @@ def test_rank_window_lists_stitch_like_one_process(tmp_path, split):
             k += 1
     joined = sum(int(np.unique(w[w > 0]).size) for w in wins) - int(max(w.max() for w in want))
     assert joined > 0                                           # the rule did link objects across boundaries
+
+
+def _bad_input_worker(rank, world, port, out_dir):
+    """rank 1 hands in a window shorter than the overlap: BOTH ranks must raise (a rank that raised on its own
+    left the others waiting in the first collective)"""
+    import torch
+    import torch.distributed as dist
+    from tobac_flow_amd.parallel import stitch_rank_windows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    wins = [torch.ones((6 if rank == 0 else 2, 8, 8), dtype=torch.int32)]
+    try:
+        stitch_rank_windows(wins, overlap=4)
+        msg = "no error"
+    except ValueError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, f"r{rank}.txt"), "w") as fh:
+        fh.write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_bad_window_on_one_rank_raises_on_every_rank(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_bad_input_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(tmp_path / f"r{r}.txt").read() for r in range(2)]
+    assert msgs[0] == msgs[1] and "rank 1" in msgs[0] and "shorter than the overlap" in msgs[0]

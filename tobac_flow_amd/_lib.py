@@ -224,17 +224,21 @@ def workspace(nbytes, tag="default"):
     key = (tag, dev.index, t.cuda.current_stream().cuda_stream)
     with _WS_LOCK:
         cur = _WS.get(key)
-        if cur is None or cur.numel() < nbytes:
-            _WS[key] = None
-            cur = None                           # drop the old buffer BEFORE the new one is allocated (they can be > 100 GB)
-            try:
-                cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
-            except t.OutOfMemoryError:
-                # the scratch is ONE block: free memory that the caching allocator holds in fragments cannot serve it.
-                # Hand the cache back to the driver once and try again (slow -- seconds for > 100 GB -- hence only here)
-                t.cuda.empty_cache()
-                cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
-            _WS[key] = cur
+        if cur is not None and cur.numel() >= nbytes:
+            return cur
+        _WS[key] = None                          # drop the old buffer BEFORE the new one is allocated (they can be > 100 GB)
+    cur = None
+    # allocated OUTSIDE the lock (an allocation of tens of GB, or the empty_cache below, held up every other
+    # thread's scratch lookup); the key is (tag, device, stream): only this stream's caller can be here for it
+    try:
+        cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
+    except t.OutOfMemoryError:
+        # the scratch is ONE block: free memory that the caching allocator holds in fragments cannot serve it.
+        # Hand the cache back to the driver once and try again (slow -- seconds for > 100 GB -- hence only here)
+        t.cuda.empty_cache()
+        cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
+    with _WS_LOCK:
+        _WS[key] = cur
     return cur
 
 
@@ -256,14 +260,15 @@ def workspace_bytes(tag):
                    if v is not None and k[1] == dev and k[2] == stream and (k[0] == tag or k[0].startswith(tag + "_")))
 
 
-def release_workspaces(tag=None):
-    """Hand the scratch buffers (all, or those of one tag and of its sub-tags `tag_*`) back to torch's caching allocator."""
+def release_workspaces(tag=None, stream=None):
+    """Hand the scratch buffers (all, or those of one tag and of its sub-tags `tag_*`; of every stream, or of one
+    `torch.cuda.Stream` / raw stream handle) back to torch's caching allocator.  The buffers are keyed by the calling
+    stream and never dropped on their own: a caller that works on short-lived streams releases theirs when it is done
+    with them."""
+    handle = None if stream is None else int(getattr(stream, "cuda_stream", stream))
     with _WS_LOCK:
-        if tag is None:
-            _WS.clear()
-        else:
-            for key in [k for k in _WS if k[0] == tag or k[0].startswith(tag + "_")]:
-                del _WS[key]
+        for key in [k for k in _WS if (tag is None or k[0] == tag or k[0].startswith(tag + "_")) and (handle is None or k[2] == handle)]:
+            del _WS[key]
 
 
 def profile_enable(on=True):

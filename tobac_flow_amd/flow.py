@@ -324,11 +324,16 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         free = t.cuda.mem_get_info()[0] + (t.cuda.memory_reserved() - t.cuda.memory_allocated())
         budget = int(max(min(budget, held + 0.6 * free), 1))   # (_lib.workspace empties the allocator's cache if fragments are in the way)
         # scratch of the library + the batch's 8-bit frames and raw flow vectors (this function's own buffers)
-        per_pair = max(1, int(L.tf_farneback_workspace_bytes_batch(1, H, W, ctypes.byref(of_model.params))) + H * W * (2 + 16))
+        lib_per_pair = max(1, int(L.tf_farneback_workspace_bytes_batch(1, H, W, ctypes.byref(of_model.params))))
+        per_pair = lib_per_pair + H * W * (2 + 16)
         cap = max(1, budget // per_pair)
+        # the library's hint counts ITS scratch only: hand it the share of the budget that is the library's, so that both
+        # sides price a pair the same way (the hint could return a batch ~25 % over the budget, which then went
+        # through the halving path -- release, empty_cache, half batches for the rest of the call)
+        lib_budget = max(1, int(budget * (lib_per_pair / per_pair)))
         left = n_pairs
         while left > 0:
-            B = left if left <= cap else max(1, int(L.tf_farneback_batch_hint(H, W, ctypes.byref(of_model.params), left, budget)))
+            B = left if left <= cap else min(cap, max(1, int(L.tf_farneback_batch_hint(H, W, ctypes.byref(of_model.params), left, lib_budget))))
             sizes.append(B)
             left -= B
     if os.environ.get("TF_FLOW_DEBUG"):

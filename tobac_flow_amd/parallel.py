@@ -200,17 +200,28 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _force_collectives):
         return stitch_window_list(windows, min_overlap, overlap, atol, rtol, short_overlap_ok)
-    if len(windows) == 0:
-        raise ValueError("every rank must hold at least one window")
-    dev = windows[0].device
-    if dist.get_backend(group) == "gloo" and windows[0].is_cuda:
+    if len(windows) and dist.get_backend(group) == "gloo" and windows[0].is_cuda:
         # gloo has no GPU collectives for these ops: stage the exchanged frames through the host
+        dev = windows[0].device
         out = stitch_rank_windows([w.cpu() for w in windows], group, min_overlap, overlap, atol, rtol, short_overlap_ok, _force_collectives)
         return [w.to(dev) for w in out]
-    atol, rtol, sel = _rule(min_overlap, overlap, atol, rtol, short_overlap_ok)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if any(w.shape[0] < overlap for w in windows):
-        raise ValueError("window shorter than the overlap")
+    if len(windows):
+        dev = windows[0].device
+    else:
+        dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    # A rank with a bad input must not raise on its own: the others would wait for it in the first collective for ever
+    # (ADVICE r3).  The first exchange is therefore a validity code, and every rank raises the same error together.
+    bad = 1 if len(windows) == 0 else (2 if any(w.shape[0] < overlap for w in windows) else
+                                       (3 if any(w.shape[1:] != windows[0].shape[1:] for w in windows) else 0))
+    codes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(codes, torch.tensor([bad], dtype=torch.int64, device=dev), group=group)
+    codes = [int(c.item()) for c in codes]
+    if any(codes):
+        r_bad = next(r for r, c in enumerate(codes) if c)
+        raise ValueError("stitch_rank_windows: rank %d: %s" % (r_bad, {1: "every rank must hold at least one window", 2: "window shorter than the overlap",
+                                                                       3: "windows must share their spatial shape"}[codes[r_bad]]))
+    atol, rtol, sel = _rule(min_overlap, overlap, atol, rtol, short_overlap_ok)
 
     def gather_i64(vec):
         """all_gather of variable-length int64 vectors -> list of 1-D CPU tensors (length exchange, then padded payload)"""
