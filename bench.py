@@ -403,7 +403,12 @@ def main():
             # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
             out = stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins
             del wins
-            objects.append(int(max(int(w.max()) for w in out)))
+            n_obj = int(max(int(w.max()) for w in out))
+            if dist is not None:                             # ids are global after the stitch: the count is the largest id on ANY rank
+                tn = torch.tensor([n_obj], dtype=torch.int64, device="cpu" if a.backend == "gloo" else bt_all.device)
+                dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                n_obj = int(tn.item())
+            objects.append(n_obj)
         del flow_all
         return out, objects
 

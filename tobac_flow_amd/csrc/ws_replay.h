@@ -188,36 +188,42 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
     struct Item { u64 key; int32_t id; int32_t pad; };
     const Item LARGE{~0ull, -1, 0};
     const int64_t max_items = M + nQ + 1;
-    // The small items form an ancestor-closed set (every ancestor of a small item is small): they sit in the top of the
-    // heap.  Positions below `n_top` -- a power of two >= 4 S -- are a plain array initialised to LARGE (the two children
-    // of a node share a cache line: the sift-down of a pop walks through adjacent memory, as in the reference); deeper
-    // positions, which small items only pass through on their way up, are an occupancy bitmap + a hash table.
-    int64_t n_top = 1024;
-    while (n_top < 4 * S && n_top < (1ll << 26)) n_top <<= 1;
-    if (n_top > max_items) n_top = max_items;
-    Item *top = (Item *)malloc((size_t)n_top * sizeof(Item));
+    // WHERE THE SMALL ITEMS LIVE (round 4).  Most of them are one and the same item: the MODAL BALLAST seed -- the value most
+    // small seeds share, age 0, nobody floods from it (the interior of the saturated cores of a detect_anvils field: 95 % of
+    // the small seeds).  A position that holds it is a bit in `occ` and nothing else; every other small item (seeds with an id,
+    // other values, pushed pixels) has its bit in `expl` as well and its item in a hash table keyed by position.  Round 3 kept
+    // a 16-byte item per position for the top 4 S positions (128 MB for 1.9 M seeds, cold) and hashed the rest -- more than half
+    // of the seeds, because seeds come in runs of consecutive numbers whose chains share every ancestor but the last few.
     uint64_t *occ = (uint64_t *)calloc((size_t)((max_items + 63) / 64), sizeof(uint64_t));    // position holds a small item
+    uint64_t *expl = (uint64_t *)calloc((size_t)((max_items + 63) / 64), sizeof(uint64_t));   // ... which is not the modal ballast item
     uint8_t *state = (uint8_t *)calloc((size_t)(nQ > 0 ? nQ : 1), 1);                          // 1: already pushed
     WsPosMap deep;
-    if (!top || !occ || !state || !deep.init(1 << 16)) { free(top); free(occ); free(state); return -1; }
-    memset(top, 0xFF, (size_t)n_top * sizeof(Item));                                            // key = ~0: LARGE everywhere
+    if (!occ || !expl || !state || !deep.init(1 << 16)) { free(occ); free(expl); free(state); return -1; }
+    u64 modal = ~0ull;                                                                          // key of the modal ballast item (none: ~0)
+    {
+        unsigned sample[257]; int ns = 0;
+        const int64_t step = S / 256 > 0 ? S / 256 : 1;
+        for (int64_t j = 0; j < S && ns < 256; j += step) if (sid[j] < 0) sample[ns++] = sval[j];
+        int best = 0;
+        for (int a = 0; a < ns; a++) { int c = 0; for (int b = 0; b < ns; b++) c += sample[b] == sample[a]; if (c > best) { best = c; modal = (u64)sample[a] << 32; } }
+    }
     bool oom = false;
     unsigned long long path_key = 0;     // the saved path of the pop loop (below): value class it follows, and whether it still holds
     bool path_valid = false;
-    // the bitmap covers ALL positions: a small item on its way up walks through unoccupied ancestors on bit tests alone
-    // (the top of the bitmap stays in cache; the item array of the top region, 16 B per position, does not)
+    // the bitmaps cover ALL positions: a small item on its way up walks through unoccupied ancestors on bit tests alone
     auto has = [&](int64_t p) { return (occ[p >> 6] >> (p & 63)) & 1ull; };
     auto load = [&](int64_t p) -> Item {
-        if (p < n_top) return top[p];
         if (!has(p)) return LARGE;
+        if (!((expl[p >> 6] >> (p & 63)) & 1ull)) return Item{modal, -1, 0};
         const WsRefItem e = deep.get(p);
         return Item{((u64)e.v << 32) | (uint32_t)e.age, e.id, 0};
     };
     auto store = [&](int64_t p, const Item &e) {
         const bool was = has(p), is = e.key != ~0ull;
         if (is != was) occ[p >> 6] ^= 1ull << (p & 63);
-        if (p < n_top) { top[p] = e; return; }
-        if (!is) { if (was) deep.erase(p); return; }
+        const bool was_x = (expl[p >> 6] >> (p & 63)) & 1ull, is_x = is && !(e.key == modal && e.id < 0);
+        if (is_x != was_x) expl[p >> 6] ^= 1ull << (p & 63);
+        if (!is_x) { if (was_x) deep.erase(p); return; }
         if (!deep.put(p, WsRefItem{(unsigned)(e.key >> 32), (int32_t)(e.key & 0xffffffffu), e.id})) oom = true;
     };
     // _watershed.pyx:120-152 for a small item entering at position `child` (a large one only lengthens the heap)
@@ -249,7 +255,7 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
     const double t_alloc = now_ms();
     for (int64_t j = 0; j < S; j++) push_small((int64_t)sk[j], Item{(u64)sval[j] << 32, sid[j], 0});    // seed k enters at position k, age 0
     if (phase_ms) phase_ms[0] = now_ms() - t_start;
-    if (getenv("WSR_DEBUG")) fprintf(stderr, "sparse: scratch %.1f ms, %lld pushes %.1f ms, deep table %zu entries\n", t_alloc - t_start, (long long)S, now_ms() - t_alloc, deep.n);
+    if (getenv("WSR_DEBUG")) fprintf(stderr, "sparse: scratch %.1f ms, %lld pushes %.1f ms, table of items with an id / another value: %zu entries\n", t_alloc - t_start, (long long)S, now_ms() - t_alloc, deep.n);
     int64_t items = M;
     for (int64_t i = 0; i < nQ; i++) rank[i] = -1;
     int64_t age = 1, popped = 0;
@@ -329,7 +335,7 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
     }
     if (phase_ms) phase_ms[1] = now_ms() - t_start - phase_ms[0];
     *n_ranked_out = n_ranked;
-    free(top); free(occ); free(state);
+    free(occ); free(expl); free(state);
     return oom ? -1 : popped;
 }
 
