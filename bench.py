@@ -340,7 +340,8 @@ def main():
         lab = job.finish()
         if st.get("reference_order", {}).get("microseconds", 0) > 0:
             d = st["reference_order_detail"]
-            ref_order.append((st["reference_order"]["microseconds"], d["replay_form"], d["replay_us"], d["export_us"]))
+            ref_order.append((st["reference_order"]["microseconds"], d["replay_form"], d["replay_us"], d["export_us"], d["guessed"], d["guess_covered_the_tie"],
+                              st["root_phases"]))
         ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
         return lab
 
@@ -571,6 +572,8 @@ def main():
                 "host_replay_ms_mean": round(float(np.mean([r[2] for r in ro])) / 1e3, 1) if ro else 0.0,
                 "host_replay_ms_max": round(float(np.max([r[2] for r in ro])) / 1e3, 1) if ro else 0.0,
                 "export_ms_mean": round(float(np.mean([r[3] for r in ro])) / 1e3, 1) if ro else 0.0,
+                "exports_on_a_guessed_tie_value": sum(1 for r in ro if r[4]), "guesses_that_covered_the_tie": sum(1 for r in ro if r[5]),
+                "root_phases_per_flood_mean": round(float(np.mean([r[6] for r in ro])), 2) if ro else 0.0,
                 "replay_threads": replay_pool._max_workers,
                 "note": "host replays run on worker threads beside the next windows' device work (tf_watershed_begin / _replay / _finish)"}
             if raster_ms is not None:

@@ -291,28 +291,39 @@ int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *m
 
 /* One flood in three parts (round 4): the replay of TF_WS_REFERENCE_ORDER is host work, so the replays of several time
  * windows can run on worker threads while the device floods the next windows.
- *   tf_watershed_begin   tf_watershed_ex2 up to the exactness check (same arguments, no outputs yet); if the reference
- *                        order is asked for and needed, also the export of what the replay reads.  TF_OK: *job_out is a
- *                        job that MUST be passed to tf_watershed_finish or tf_watershed_abandon; any other code: no job.
- *                        `ws`, `markers` and the job belong together until then: the workspace must not be used by
- *                        another call (one workspace per flood in flight).  stats_host as far as known at this point.
- *   tf_watershed_needs_replay   1 if tf_watershed_replay has work to do
+ *   tf_watershed_begin   set-up, phase A and the chain phases (same arguments as tf_watershed_ex2, no outputs yet).  TF_OK:
+ *                        *job_out is a job that MUST be passed to tf_watershed_finish or tf_watershed_abandon; any other
+ *                        code: no job.  `ws`, `markers`, `field` and the job belong together until then: the workspace must
+ *                        not be used by another call (one workspace per flood in flight).
+ *                        guessed_tie_key: -1, or the ordered key (tf_watershed_job_info [7] of an earlier, similar flood) of
+ *                        a marker value the caller expects the largest tie between equal-valued markers at.  With
+ *                        TF_WS_REFERENCE_ORDER the export of what the replay reads then happens HERE, before the relaxation
+ *                        phases (it needs none of their results), the replay can run beside them, and finish runs ONE root
+ *                        phase, with the pop ranks.  Any guess is safe: finish compares it with the tie value it finds and
+ *                        falls back on export - replay - second root phase when the guess was too low (a guess that is too
+ *                        high only makes the replay longer).
+ *   tf_watershed_needs_replay   1 if tf_watershed_replay has work to do (a guess was given)
  *   tf_watershed_replay  the host replay; no HIP call, any thread, different jobs concurrently.  Optional: finish runs it
- *                        if the caller did not.
- *   tf_watershed_finish  pop ranks to the device, root phase repeated with them, labels (and report) written; frees the
- *                        job; return codes and stats of tf_watershed_ex2.  Synchronises the stream.
+ *                        if the caller did not.  MUST have returned before the job is finished or abandoned.
+ *   tf_watershed_finish  root phase (with the pop ranks if there are any) + exactness check; with TF_WS_REFERENCE_ORDER and
+ *                        labels that hang on the order of equal-valued markers without (sufficient) ranks: export, replay
+ *                        and a second root phase, as tf_watershed_ex2 does; labels (and report) written; frees the job;
+ *                        return codes and stats of tf_watershed_ex2; info_host: NULL or 12 x int64 as tf_watershed_job_info.
+ *                        Synchronises the stream.
  *   tf_watershed_abandon frees a job without finishing it. */
 int tf_watershed_begin(const float *field, const int32_t *markers, const int8_t *mask,
                        const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                        const int8_t *nbr_host, int n_nbr, int chain_depth, int max_depth, int flags,
-                       void *ws, size_t ws_bytes, int64_t *stats_host, void *stream, void **job_out);
+                       int64_t guessed_tie_key, void *ws, size_t ws_bytes, int64_t *stats_host, void *stream, void **job_out);
 int tf_watershed_needs_replay(const void *job);
 int tf_watershed_replay(void *job);
-int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguous, int64_t *stats_host);
+int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguous, int64_t *stats_host, int64_t *info_host);
 void tf_watershed_abandon(void *job);
-/* info (8 x int64): [0] replay form (0 none, 1 sparse, 2 dense), [1] seeds, [2] seeds at or below the tie value,
+/* info (12 x int64): [0] replay form (0 none, 1 sparse, 2 dense), [1] seeds, [2] seeds at or below the tie value,
  * [3] pixels of the exported sub-graph, [4] relevant pixels, [5] microseconds of the export, [6] microseconds of the
- * replay (-1: not run yet), [7] ordered key of the tie value */
+ * replay (-1: not run), [7] ordered key of the largest tie value finish found (-1: no label hangs on such a tie, or not
+ * finished), [8] 1 if the export ran on a guess, [9] 1 if the guess covered the tie value, [10] the tie key the export
+ * used (-1: none), [11] 0 */
 int tf_watershed_job_info(const void *job, int64_t *info);
 
 /* tf_watershed_raveled: the reference's only native seam, argument for argument --

@@ -1042,12 +1042,12 @@ k_ws_scatter_ranks(const uint8_t *__restrict__ in_q, const int *__restrict__ sub
 // largest marker value (ordered key) below which the order of equal-valued markers decides a label: every origin
 // with complete chains ties down to markers of ONE value, the value of its own root
 __global__ void __launch_bounds__(256)
-k_ws_tie_value_max(WsC c, const int *__restrict__ org, const float *__restrict__ field, unsigned *__restrict__ vmax)
+k_ws_tie_value_max(WsC c, const int *__restrict__ org, const float *__restrict__ field, int ranked, unsigned *__restrict__ vmax)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.R || !(org[i] & 1)) return;
-    const u64 r = c.Rt[i];                               // default-mode root key: the raster index of the root marker
-    if (r != WS_INF) atomicMax(vmax, ws_ordkey(field[r]));
+    const u64 r = c.Rt[i];                               // root key: the raster index of the root marker, or (pop rank << 32) | compact id
+    if (r != WS_INF) atomicMax(vmax, ws_ordkey(field[ranked ? (c.pix[r & 0xFFFFFFFFull] & ~WS_MARKER_BIT) : r]));
 }
 
 struct WsU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
@@ -1104,7 +1104,7 @@ static size_t ws_compact_bytes(int64_t R, int n_nbr, int depth) {
     return tf_align_up((size_t)R * 8, 256) + tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 4 * n_nbr, 256)
          + (size_t)(depth + 2) * tf_align_up((size_t)R * 8, 256)          // K2, M1, C_1..C_{d-1}, Rt
          + 2 * tf_align_up((size_t)R * 8 + 256, 256) + tf_align_up((size_t)R * 4, 256)           // two queues (2R ints), inq
-         + 4 * tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 8, 256) + 4096;         // Llo, Lhi, org, rank; edge masks
+         + 5 * tf_align_up((size_t)R * 4, 256) + tf_align_up((size_t)R * 8, 256) + 4096;         // Llo, Lhi, org, rank, sub-graph ids; edge masks
 }
 
 extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, int n_nbr, int chain_depth, int64_t max_relevant)
@@ -1280,6 +1280,10 @@ struct tf_ws_job {
     int64_t st[TF_WS_NSTATS];
     // reference order
     bool need_replay, replay_done, applied, sparse, plain, identity, coded;
+    bool speculative;            // the export ran before the root phase, for a tie value the caller guessed (spec_vmax)
+    bool root_pending;           // finish starts with the root phase (begin has run phase A and the chain levels below `depth`)
+    bool speculate_fast; int levels_done;
+    unsigned true_vmax; bool has_tie, spec_hit; int *subid;
     u64 code_d; int64_t code_words, n_exc;
     int64_t M, S, nQ; unsigned vmax;
     WsHostBuf hb_val, hb_nbr, hb_rank, hb_sk, hb_sval, hb_sid;
@@ -1320,15 +1324,8 @@ static int ws_job_export(tf_ws_job *j)
     const char *dense_env = getenv("TF_WS_REFERENCE_DENSE");
     const bool force_dense = dense_env != nullptr;
     j->plain = dense_env && atoi(dense_env) == 2;
-    // the largest marker value at which the order of equal-valued markers decides a label
-    unsigned *d_vmax = (unsigned *)(j->d_cnt + 3);
-    TF_CHECK_HIP(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_ws_tie_value_max, dim3(nbr_blocks), dim3(256), 0, s, c, (const int *)j->org, j->field, d_vmax);
-    TF_CHECK_LAUNCH();
-    unsigned h_vmax = 0;
-    TF_CHECK_HIP(hipMemcpyAsync(&h_vmax, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    TF_CHECK_HIP(hipStreamSynchronize(s));
-    j->vmax = h_vmax;
+    // the largest marker value at which the order of equal-valued markers decides a label (the caller's: j->vmax)
+    const unsigned h_vmax = j->vmax;
     // seed numbers: per-block counts of seeds / small seeds and their 64-bit scans, in the idle flag array
     const int64_t nb256 = (N + 255) / 256;
     TF_REQUIRE(nb256 < 0x7fffffffll, "tf_watershed: too many voxels for the seed numbering");
@@ -1350,7 +1347,7 @@ static int ws_job_export(tf_ws_job *j)
     TF_CHECK_HIP(hipMemcpyAsync(&h_lastc[1], n_small + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s));
     // the sub-graph: Q = poppable pixels + their out-neighbours (flags in the idle scan array, ids in the idle in-queue flags)
     uint8_t *in_q = (uint8_t *)j->scan;
-    int *subid = j->Q.inq;
+    int *subid = j->subid;
     TF_CHECK_HIP(hipMemsetAsync(in_q, 0, (size_t)R, s));
     hipLaunchKernelGGL(k_ws_sub_mark, dim3(nbr_blocks), dim3(256), 0, s, c, h_vmax, in_q);
     TF_CHECK_LAUNCH();
@@ -1476,13 +1473,54 @@ static int ws_job_export(tf_ws_job *j)
     return TF_OK;
 }
 
+// chain levels C_{levels_done + 1} .. C_{depth - 1} (final once computed)
+static int ws_chain_levels(tf_ws_job *j)
+{
+    const unsigned nbr_blocks = (unsigned)((j->R + 255) / 256);
+    for (int k = j->levels_done + 1; k < j->depth; k++) {
+        hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, j->s, j->c.pix, j->c.C[k], j->R, 0, (const int *)nullptr);
+        TF_CHECK_LAUNCH();
+        int64_t sw = 0;
+        const int rc = ws_run_phase(j->c, k, j->depth_max + 1, j->Q, j->s, j->max_sweeps, &sw);      // k < "depth": a chain level
+        if (rc) return rc;
+        j->st[2 + (k < 3 ? k - 1 : 2)] += sw;
+        j->levels_done = k;
+    }
+    return TF_OK;
+}
+
+// the root phase at the job's depth (root keys: raster indices, or pop ranks from rank_dev) + the exactness check -> h_amb
+static int ws_root_and_check(tf_ws_job *j, bool ranked)
+{
+    hipStream_t s = j->s;
+    const WsC &c = j->c;
+    const int64_t R = j->R;
+    const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
+    hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1, ranked ? (const int *)j->rank_dev : (const int *)nullptr);
+    hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, j->markers, c.Llo, c.Lhi, R);
+    TF_CHECK_LAUNCH();
+    int64_t sw = 0;
+    const int rc = ws_run_phase(c, j->depth, j->depth, j->Q, s, j->max_sweeps, &sw);              // k == depth: the root phase
+    if (rc) return rc;
+    if (j->speculate_fast && j->depth == 1) j->st[1] = sw; else j->st[2 + (j->depth < 3 ? j->depth - 1 : 2)] += sw;
+    j->st[12] += 1;
+    TF_CHECK_HIP(hipMemsetAsync(j->org, 0, (size_t)R * sizeof(int), s));
+    TF_CHECK_HIP(hipMemsetAsync(j->d_cnt, 0, 4 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_ws_origins, dim3(nbr_blocks), dim3(256), 0, s, c, j->depth, j->org);
+    hipLaunchKernelGGL(k_ws_count_ambiguous, dim3(nbr_blocks), dim3(256), 0, s, c, j->org, j->d_cnt);
+    TF_CHECK_LAUNCH();
+    TF_CHECK_HIP(hipMemcpyAsync(j->h_amb, j->d_cnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    return TF_OK;
+}
+
 // `rv` != nullptr: the raveled form (tf_watershed_raveled): `field` = image, `markers` = `labels` = output (in place),
 // seeds = rv_locs; T, H, W, fwd, bwd, nbr_host unused.
 static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers, const int8_t *mask,
                         const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                         const int8_t *nbr_host, int n_nbr, int depth0, int depth_max, int flags,
                         void *ws, size_t ws_bytes, void *stream,
-                        const WsRavel *rv = nullptr, const int64_t *rv_locs = nullptr, int64_t rv_n_locs = 0)
+                        const WsRavel *rv = nullptr, const int64_t *rv_locs = nullptr, int64_t rv_n_locs = 0, int64_t spec_key = -1)
 {
     int64_t *st = j->st;
     for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = 0;
@@ -1609,6 +1647,7 @@ static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers
         WsQueues &Q = j->Q;
         Q.qcap = (int)(2 * R < 0x7fffff00ll ? 2 * R : 0x7fffff00ll);
         Q.q[0] = ar.take<int>(2 * R + 64); Q.q[1] = ar.take<int>(2 * R + 64); Q.inq = ar.take<int>(R);
+        j->subid = ar.take<int>(R);
         Q.cnt = d_flags; Q.h_cnt = j->h_cnt; Q.processed = &st[7];
         if (!ar.ok()) { tf_set_error("tf_watershed: workspace too small"); return TF_ENOMEM; }
         int *d_nan = d_flags + WS_BATCH + 4;
@@ -1639,6 +1678,18 @@ static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers
         // is the number of relevant pixels itself (a snake-shaped mask floods one pixel per sweep)
         const int64_t max_sweeps = rv ? 4096 + 2 * R : 4096 + 512 * (T + H + W);
         j->max_sweeps = max_sweeps;
+        if ((flags & TF_WS_REFERENCE_ORDER) && spec_key >= 0) {
+            // SPECULATIVE EXPORT (round 4).  The replay needs nothing the relaxation phases compute -- seeds, keys and the
+            // neighbour table exist now -- except the tie value, and any value at or above the true one gives the ranks of
+            // every marker that can matter.  With the caller's guess (the previous window's tie value) the export happens
+            // here, the host replay runs beside phase A and the chain phases, and finish runs ONE root phase, with the pop
+            // ranks; it checks the guess against the tie value it then finds and falls back on the export-after-the-root-phase
+            // order if the guess was too low.
+            j->vmax = (unsigned)spec_key;
+            j->speculative = true;
+            const int rc_x = ws_job_export(j);
+            if (rc_x) return rc_x;
+        }
         int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0]);
         if (rc) return rc;
         {
@@ -1649,45 +1700,20 @@ static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers
         // Speculative start: a root phase on K2 alone (depth 1).  If its exactness check finds no origin at all the
         // labelling cannot depend on any tie-break and is final (tie-free fields).  The caller's hint skips it for
         // inputs known to contain exact plateaus: the labels are the same either way, only the work differs.
-        const bool speculate = !((flags & TF_WS_SKIP_FAST_PATH) && depth0 > 1);
-        st[5] = speculate ? 0 : -1;
-        int depth = speculate ? 1 : depth0;
-        int levels_done = 0;                        // C_1 .. C_levels_done are final
-        for (;;) {
-            for (int k = levels_done + 1; k < depth; k++) {
-                hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.C[k], R, 0, (const int *)nullptr);
-                TF_CHECK_LAUNCH();
-                int64_t sw = 0;
-                rc = ws_run_phase(c, k, depth_max + 1, Q, s, max_sweeps, &sw);      // k < "depth": a chain level
-                if (rc) return rc;
-                st[2 + (k < 3 ? k - 1 : 2)] += sw;
-                levels_done = k;
-            }
-            hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1, (const int *)nullptr);
-            hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, markers, c.Llo, c.Lhi, R);
-            TF_CHECK_LAUNCH();
-            int64_t sw = 0;
-            rc = ws_run_phase(c, depth, depth, Q, s, max_sweeps, &sw);              // k == depth: the root phase
+        j->speculate_fast = !((flags & TF_WS_SKIP_FAST_PATH) && depth0 > 1);
+        st[5] = j->speculate_fast ? 0 : -1;
+        j->depth = depth0;
+        j->root_pending = true;
+        if (j->speculate_fast) {
+            j->depth = 1;
+            rc = ws_root_and_check(j, false);
             if (rc) return rc;
-            if (speculate && depth == 1) st[1] = sw; else st[2 + (depth < 3 ? depth - 1 : 2)] += sw;
-            st[12] += 1;
-            TF_CHECK_HIP(hipMemsetAsync(j->org, 0, (size_t)R * sizeof(int), s));
-            TF_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), s));
-            hipLaunchKernelGGL(k_ws_origins, dim3(nbr_blocks), dim3(256), 0, s, c, depth, j->org);
-            hipLaunchKernelGGL(k_ws_count_ambiguous, dim3(nbr_blocks), dim3(256), 0, s, c, j->org, d_cnt);
-            TF_CHECK_LAUNCH();
-            TF_CHECK_HIP(hipMemcpyAsync(j->h_amb, d_cnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            TF_CHECK_HIP(hipStreamSynchronize(s));
-            if (speculate && depth == 1) st[5] = j->h_amb[2] != 0;
-            if (j->h_amb[2] == 0 || depth >= depth_max) break;
-            depth = depth < depth0 ? depth0 : depth + 1;
+            st[5] = j->h_amb[2] != 0;
+            if (j->h_amb[2] == 0 || depth_max <= 1) j->root_pending = false;        // final (at depth 1 every origin counts as cut off)
+            else j->depth = depth0;
         }
-        j->depth = depth;
-        if ((flags & TF_WS_REFERENCE_ORDER) && j->h_amb[1] > 0 && j->h_amb[2] == 0) {
-            // Labels hang on the order of equal-valued markers: the host replay (ws_reference_ranks*) gives the reference's,
-            // and finish repeats the root phase with the pop rank in place of the raster index.  Chain levels, origins and
-            // label sets do not depend on that order, only the choice among tying candidates does.
-            rc = ws_job_export(j);
+        if (j->root_pending) {
+            rc = ws_chain_levels(j);                                                // C_1 .. C_{depth - 1}; the root phase is finish's
             if (rc) return rc;
         }
     }
@@ -1720,9 +1746,23 @@ static int ws_job_replay(tf_ws_job *j)
     j->ms_replay = ws_now_ms() - t0;
     if (j->popped < 0) { tf_set_error("tf_watershed: out of host memory for the reference-order replay"); j->replay_rc = TF_ENOMEM; }
     static const bool ref_debug = ws_env("TF_WS_REF_DEBUG");
-    if (ref_debug) fprintf(stderr, "reference order: %s replay %.1f ms (%lld pops, %d markers ranked; heap build %.1f ms, pops %.1f ms)\n",
+    if (ref_debug) fprintf(stderr, "reference order: %s%s replay %.1f ms (%lld pops, %d markers ranked; heap build %.1f ms, pops %.1f ms)\n", j->speculative ? "speculative " : "",
                            j->sparse ? "sparse" : (j->plain ? "plain" : "dense"), j->ms_replay, (long long)j->popped, n_ranked, phase[0], phase[1]);
     return j->replay_rc;
+}
+
+// pop ranks of the finished replay -> rank_dev (one entry per relevant pixel)
+static int ws_upload_ranks(tf_ws_job *j)
+{
+    hipStream_t s = j->s;
+    const unsigned nbr_blocks = (unsigned)((j->R + 255) / 256);
+    int *stg_rank = j->Q.q[0];
+    TF_CHECK_HIP(hipMemcpyAsync(stg_rank, j->hb_rank.p, (size_t)j->nQ * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ws_scatter_ranks, dim3(nbr_blocks), dim3(256), 0, s, j->identity ? (const uint8_t *)nullptr : (const uint8_t *)j->scan,
+                       (const int *)j->subid, (const int *)stg_rank, j->n_ranked, j->R, j->rank_dev);
+    TF_CHECK_LAUNCH();
+    TF_CHECK_HIP(hipStreamSynchronize(s));                              // (the staging queue is a frontier queue again right after)
+    return TF_OK;
 }
 
 static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
@@ -1733,31 +1773,75 @@ static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
     const WsC &c = j->c;
     const int64_t R = j->R, N = j->N;
     const unsigned nb1 = (unsigned)((N + 255) / 256);
-    if (j->need_replay) {
-        int rc = ws_job_replay(j);                                       // (a no-op if the caller has run it)
-        if (rc) return rc;
-        const double t0 = ws_now_ms();
+    static const bool ref_debug = ws_env("TF_WS_REF_DEBUG");
+    bool ranked = false;                                                 // root keys are (pop rank << 32) | compact id
+    if (R > 0 && j->root_pending) {
         const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
-        int *stg_rank = j->Q.q[0];
-        TF_CHECK_HIP(hipMemcpyAsync(stg_rank, j->hb_rank.p, (size_t)j->nQ * sizeof(int), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_ws_scatter_ranks, dim3(nbr_blocks), dim3(256), 0, s, j->identity ? (const uint8_t *)nullptr : (const uint8_t *)j->scan,
-                           (const int *)j->Q.inq, (const int *)stg_rank, j->n_ranked, R, j->rank_dev);
-        hipLaunchKernelGGL(k_ws_init_level, dim3(nbr_blocks), dim3(256), 0, s, c.pix, c.Rt, R, 1, (const int *)j->rank_dev);
-        hipLaunchKernelGGL(k_ws_init_labelset, dim3(nbr_blocks), dim3(256), 0, s, c.pix, j->markers, c.Llo, c.Lhi, R);
-        TF_CHECK_LAUNCH();
-        int64_t sw = 0;
-        rc = ws_run_phase(c, j->depth, j->depth, j->Q, s, j->max_sweeps, &sw);
-        if (rc) return rc;
-        st[2 + (j->depth < 3 ? j->depth - 1 : 2)] += sw;
-        st[12] += 1;
-        j->applied = true;
-        st[13] = j->popped; st[14] = j->sparse ? j->S : j->M;
-        st[15] = (int64_t)((j->ms_export + j->ms_replay + (ws_now_ms() - t0)) * 1000.0);
+        int rc;
+        double ms_detour = 0.0;
+        if (j->need_replay) {                                            // the speculative export's replay: ranks before the root phase
+            rc = ws_job_replay(j);                                       // (a no-op if the caller has run it)
+            if (rc) return rc;
+            const double t0 = ws_now_ms();
+            rc = ws_upload_ranks(j);
+            if (rc) return rc;
+            ranked = true;
+            ms_detour = j->ms_export + j->ms_replay + (ws_now_ms() - t0);
+        }
+        for (;;) {
+            rc = ws_root_and_check(j, ranked);
+            if (rc) return rc;
+            if (j->h_amb[2] == 0 || j->depth >= j->depth_max) break;
+            j->depth += 1;                                               // ties left by the cut-off: one more chain level
+            rc = ws_chain_levels(j);
+            if (rc) return rc;
+        }
+        if ((j->flags & TF_WS_REFERENCE_ORDER) && j->h_amb[1] > 0 && j->h_amb[2] == 0) {
+            // Labels hang on the order of equal-valued markers.  The largest marker value at which they do:
+            unsigned *d_vmax = (unsigned *)(j->d_cnt + 3);
+            TF_CHECK_HIP(hipMemsetAsync(d_vmax, 0, sizeof(unsigned), s));
+            hipLaunchKernelGGL(k_ws_tie_value_max, dim3(nbr_blocks), dim3(256), 0, s, c, (const int *)j->org, j->field, ranked ? 1 : 0, d_vmax);
+            TF_CHECK_LAUNCH();
+            unsigned h_vmax = 0;
+            TF_CHECK_HIP(hipMemcpyAsync(&h_vmax, d_vmax, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            j->true_vmax = h_vmax; j->has_tie = true;
+            if (ranked && h_vmax <= j->vmax) {
+                j->applied = true;                                       // the guess covered it: these ARE the labels
+                j->spec_hit = true;
+            } else {
+                // the host replay (ws_reference_ranks*) gives the reference's order, and the root phase is repeated with the
+                // pop rank in place of the raster index.  Chain levels, origins and label sets do not depend on that order,
+                // only the choice among tying candidates does.
+                if (ref_debug && ranked) fprintf(stderr, "reference order: the guessed tie value (key %u) was too low (true key %u): export again\n", j->vmax, h_vmax);
+                ws_host_give(j->hb_val); ws_host_give(j->hb_nbr); ws_host_give(j->hb_rank);
+                ws_host_give(j->hb_sk); ws_host_give(j->hb_sval); ws_host_give(j->hb_sid);
+                j->need_replay = false; j->replay_done = false; j->speculative = false; j->replay_rc = TF_OK;
+                j->vmax = h_vmax;
+                rc = ws_job_export(j);
+                if (rc) return rc;
+                rc = ws_job_replay(j);
+                if (rc) return rc;
+                const double t0 = ws_now_ms();
+                rc = ws_upload_ranks(j);
+                if (rc) return rc;
+                ranked = true;
+                rc = ws_root_and_check(j, true);                         // (the check's counts do not depend on the order)
+                if (rc) return rc;
+                j->applied = true;
+                ms_detour += j->ms_export + j->ms_replay + (ws_now_ms() - t0);
+            }
+        }
+        if (j->need_replay && j->replay_done) {
+            st[13] = j->popped; st[14] = j->sparse ? j->S : j->M;
+            st[15] = (int64_t)(ms_detour * 1000.0);
+        }
     }
+    st[8] = j->depth; st[9] = (int64_t)j->h_amb[0]; st[10] = (int64_t)j->h_amb[1]; st[11] = (int64_t)j->h_amb[2];
     {
         TfProfScope ps(TFK_WS_LABELS, 12.0 * (double)N, s);
-        if (j->raveled) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)j->cid, (const u64 *)c.Rt, c.pix, j->applied ? 1 : 0, labels, N); }
-        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, j->markers, j->cid, c.Rt, c.pix, j->applied ? 1 : 0, c.Llo, c.Lhi, j->org, labels,
+        if (j->raveled) { if (R > 0) hipLaunchKernelGGL(k_wsr_labels, dim3(nb1), dim3(256), 0, s, (const int *)j->cid, (const u64 *)c.Rt, c.pix, ranked ? 1 : 0, labels, N); }
+        else hipLaunchKernelGGL(k_ws_labels, dim3(nb1), dim3(256), 0, s, j->markers, j->cid, c.Rt, c.pix, ranked ? 1 : 0, c.Llo, c.Lhi, j->org, labels,
                                 R > 0 ? amb_out : nullptr, N);
     }
     TF_CHECK_LAUNCH();
@@ -1801,13 +1885,15 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
 extern "C" int tf_watershed_begin(const float *field, const int32_t *markers, const int8_t *mask,
                                   const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                                   const int8_t *nbr_host, int n_nbr, int chain_depth, int max_depth, int flags,
-                                  void *ws, size_t ws_bytes, int64_t *stats_host, void *stream, void **job_out)
+                                  int64_t guessed_tie_key, void *ws, size_t ws_bytes, int64_t *stats_host, void *stream, void **job_out)
 {
     TF_REQUIRE(job_out, "tf_watershed_begin: null pointer");
     *job_out = nullptr;
+    TF_REQUIRE(guessed_tie_key >= -1 && guessed_tie_key <= 0xFFFFFFFFll, "tf_watershed_begin: guessed_tie_key must be -1 or a 32-bit ordered key");
     tf_ws_job *j = ws_job_new();
     if (!j) { tf_set_error("tf_watershed: out of host memory"); return TF_ENOMEM; }
-    const int rc = ws_job_begin(j, field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, chain_depth, max_depth, flags, ws, ws_bytes, stream);
+    const int rc = ws_job_begin(j, field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, chain_depth, max_depth, flags, ws, ws_bytes, stream,
+                                nullptr, nullptr, 0, guessed_tie_key);
     if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = j->st[i];
     if (rc != TF_OK) { ws_job_free(j); return rc; }
     *job_out = j;
@@ -1819,12 +1905,14 @@ extern "C" int tf_watershed_replay(void *job)
     TF_REQUIRE(job, "tf_watershed_replay: null job");
     return ws_job_replay((tf_ws_job *)job);
 }
-extern "C" int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguous, int64_t *stats_host)
+extern "C" int tf_watershed_job_info(const void *job, int64_t *info);
+extern "C" int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguous, int64_t *stats_host, int64_t *info_host)
 {
     TF_REQUIRE(job, "tf_watershed_finish: null job");
     tf_ws_job *j = (tf_ws_job *)job;
     const int rc = ws_job_finish(j, labels, ambiguous);
     if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = j->st[i];
+    if (info_host) (void)tf_watershed_job_info(j, info_host);
     ws_job_free(j);
     return rc;
 }
@@ -1836,7 +1924,8 @@ extern "C" int tf_watershed_job_info(const void *job, int64_t *info)
     info[0] = j->need_replay ? (j->sparse ? 1 : 2) : 0;
     info[1] = j->M; info[2] = j->S; info[3] = j->nQ; info[4] = j->R;
     info[5] = (int64_t)(j->ms_export * 1000.0); info[6] = j->replay_done ? (int64_t)(j->ms_replay * 1000.0) : -1;
-    info[7] = (int64_t)j->vmax;
+    info[7] = j->has_tie ? (int64_t)j->true_vmax : -1;
+    info[8] = j->speculative ? 1 : 0; info[9] = j->spec_hit ? 1 : 0; info[10] = j->need_replay ? (int64_t)j->vmax : -1; info[11] = 0;
     return TF_OK;
 }
 

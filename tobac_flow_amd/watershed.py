@@ -104,25 +104,32 @@ def _give_slot(k):
         _slots_busy.discard(k)
 
 
+class _DepthRetry(Exception):
+    """ties left by the chain depth the job was given: the synchronous wrappers start again with all twelve levels"""
+
+
 class WatershedJob:
     """One flood in flight (tf_watershed_begin / _replay / _finish, include/tobac_flow_hip.h): `watershed_begin` has run the
-    device part up to the exactness check; if labels hang on the order of equal-valued markers (and on_ambiguous is
-    "reference") `needs_replay` is True and `replay()` -- pure host work, no GIL, any thread -- computes the reference
-    heap's pop ranks; `finish()` applies them and returns the labels.  Several jobs may be in flight: the replays of earlier
-    windows run on worker threads while the device floods the next ones (bench.py).  `finish()` runs the replay itself
-    if nobody has."""
+    device part up to (not including) the root phase.  If the job was begun with a guessed tie value (on_ambiguous
+    ="reference" and the previous flood of this shape had labels that hang on the order of equal-valued markers),
+    `needs_replay` is True and `replay()` -- pure host work, no GIL, any thread -- computes the reference heap's pop ranks
+    while the device goes on; `finish()` runs the root phase with them and returns the labels (it runs the replay itself
+    if nobody has, and exports / replays after the root phase when there was no guess or the guess was too low).  Several
+    jobs may be in flight: the replays of earlier windows run on worker threads while the device floods the next ones
+    (bench.py)."""
 
-    def __init__(self, handle, slot, ws, keep, shape, on_ambiguous, return_ambiguous, stats, st):
+    def __init__(self, handle, slot, ws, keep, shape, on_ambiguous, return_ambiguous, stats, st, memo_key, can_deepen):
         self._h, self._slot, self._ws, self._keep = handle, slot, ws, keep
         self._shape, self._on_ambiguous, self._return_ambiguous, self._stats, self._st = shape, on_ambiguous, return_ambiguous, stats, st
+        self._memo_key, self._can_deepen = memo_key, can_deepen
         self.needs_replay = bool(_lib.lib().tf_watershed_needs_replay(handle))
-        self.info = self._info()
+        self.info = {}
 
-    def _info(self):
-        a = np.zeros(8, np.int64)
-        _lib.lib().tf_watershed_job_info(self._h, a.ctypes.data_as(_lib._P))
+    @staticmethod
+    def _info_dict(a):
         return {"replay_form": ("none", "sparse", "dense")[int(a[0])], "seeds": int(a[1]), "seeds_at_or_below_tie_value": int(a[2]),
-                "subgraph_pixels": int(a[3]), "relevant_pixels": int(a[4]), "export_us": int(a[5]), "replay_us": int(a[6])}
+                "subgraph_pixels": int(a[3]), "relevant_pixels": int(a[4]), "export_us": int(a[5]), "replay_us": int(a[6]),
+                "tie_key": int(a[7]), "guessed": bool(a[8]), "guess_covered_the_tie": bool(a[9]), "exported_for_key": int(a[10])}
 
     def replay(self):
         if self._h is not None and self.needs_replay:
@@ -142,7 +149,7 @@ class WatershedJob:
         except Exception:                                    # interpreter shutdown
             pass
 
-    def finish(self):
+    def finish(self, _deepen=False):
         if self._h is None:
             raise RuntimeError("WatershedJob.finish: the job has already been finished or abandoned")
         t = _lib.torch()
@@ -150,17 +157,18 @@ class WatershedJob:
         labels = _lib.empty(self._shape, t.int32)
         amb = _lib.empty(self._shape, t.uint8) if self._return_ambiguous else None
         st = self._st
-        if self.needs_replay:
-            self.replay()
-            self.info = self._info()
+        info = np.zeros(12, np.int64)
         h, self._h = self._h, None
         try:
-            rc = L.tf_watershed_finish(h, _lib.ptr(labels), _lib.ptr(amb), st.ctypes.data_as(_lib._P))
+            rc = L.tf_watershed_finish(h, _lib.ptr(labels), _lib.ptr(amb), st.ctypes.data_as(_lib._P), info.ctypes.data_as(_lib._P))
         finally:
             self._ws = self._keep = None
             _give_slot(self._slot)
         if rc not in (TF_WS_AMBIGUOUS, TF_EDEPTH):
             _lib.check(rc, "tf_watershed")
+        self.info = self._info_dict(info)
+        with _MEMO_LOCK:                                     # the next flood of this shape guesses this one's tie value
+            _tie_memo[self._memo_key] = int(info[7])
         stats, on_ambiguous = self._stats, self._on_ambiguous
         if stats is not None:
             stats["sweeps"] = st[:8].tolist()
@@ -168,10 +176,14 @@ class WatershedJob:
             stats["ambiguous_pixels"] = int(st[9])
             stats["marker_tie_origins"] = int(st[10])
             stats["depth_origins"] = int(st[11])
+            stats["root_phases"] = int(st[12])
             stats["reference_order"] = {"replayed_pops": int(st[13]), "seeds": int(st[14]), "microseconds": int(st[15])}
             stats["reference_order_detail"] = self.info
         if rc == TF_EDEPTH:
-            msg = (f"watershed: {int(st[11])} pixel(s) still tie at chain depth {int(st[8])} (the deepest allowed); "
+            if self._can_deepen and _deepen:
+                raise _DepthRetry()
+            msg = (f"watershed: {int(st[11])} pixel(s) still tie at chain depth {int(st[8])} (the deepest "
+                   f"{'this job was given room for: begin it with a larger chain_depth' if self._can_deepen else 'allowed'}); "
                    f"{int(st[9])} label(s) may differ from the reference")
             if on_ambiguous == "ignore":
                 warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=3)
@@ -186,9 +198,12 @@ class WatershedJob:
         return (labels, amb) if self._return_ambiguous else labels
 
 
+_tie_memo = {}           # (T, H, W, neighbours, depth, stream) -> ordered key of the largest tie value of the last flood (-1: none)
+
+
 def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
                     expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="reference", return_ambiguous=False,
-                    workspace=None):
+                    workspace=None, guess_tie_value=True, _all_levels=False):
     """Device-resident core, first part: torch tensors in (field f32, markers i32, mask i8 or None) -> WatershedJob.
 
     expect_conflict: True / False force the scheduling hint, None (default) uses the per-shape memo.
@@ -200,10 +215,13 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
         host (TF_WS_REFERENCE_ORDER) to get the markers' pop ranks and floods with those: the labels are the reference's
         bit for bit, at the cost of a sequential host pass when such a tie exists (stats["reference_order"]);
         "warn" / "raise" / "ignore": labels follow the markers' raster order, and the voxels concerned are reported;
-      * ties left by the depth cut-off at `max_chain_depth`: WatershedDepthError (a warning with "ignore").
+      * ties left by the depth cut-off: finish() raises WatershedDepthError (a warning with "ignore"); watershed_dev /
+        watershed start again with all twelve levels first.
     return_ambiguous: finish() also returns the (T, H, W) uint8 report (AMB_* bits).
     workspace: a uint8 device tensor the flood may use as its scratch until the job is finished (e.g. a slice of another
-    stage's idle scratch, _lib.borrow_workspace); too small a one is ignored and the job allocates its own."""
+    stage's idle scratch, _lib.borrow_workspace); too small a one is ignored and the job allocates its own.
+    guess_tie_value: with on_ambiguous="reference", begin the export for the tie value of the previous flood of this shape
+    and stream (scheduling only: finish verifies the guess; see tf_watershed_begin)."""
     if on_ambiguous not in ("warn", "raise", "ignore", "reference"):
         raise ValueError("on_ambiguous must be 'warn', 'raise', 'ignore' or 'reference'")
     t = _lib.torch()
@@ -221,6 +239,7 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
     with _MEMO_LOCK:
         known = _relevant_memo.get(key)
         memo = list(_conflict_memo.get(key, (False, 0)))      # [last probe conflicted, calls since that probe]
+        tie_key = _tie_memo.get(key, -1)
     if known is not None:
         guess = min(T * H * W, int(known * 1.25) + 4096)
     else:
@@ -231,9 +250,11 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
     flags = TF_WS_SKIP_FAST_PATH if (skip and chain_depth > 1) else 0
     if on_ambiguous == "reference":
         flags |= TF_WS_REFERENCE_ORDER
-    # levels beyond chain_depth are rarely needed: the first call gets room for two more, a second one for all
+    spec = tie_key if (on_ambiguous == "reference" and guess_tie_value) else -1
+    # levels beyond chain_depth are rarely needed: the first job gets room for two more, a second one for all
     start, cap = chain_depth, min(max_chain_depth, chain_depth + 2)
-    probed = None
+    if _all_levels:
+        start, cap, flags = min(max_chain_depth, chain_depth + 3), max_chain_depth, flags | TF_WS_SKIP_FAST_PATH
     slot = _take_slot()
     handle = ctypes.c_void_p()
     try:
@@ -245,39 +266,37 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
             else:
                 ws = _lib.workspace(nbytes, "watershed_job%d" % slot)
             rc = L.tf_watershed_begin(_lib.ptr(field), _lib.ptr(markers), _lib.ptr(mask), _lib.ptr(fwd), _lib.ptr(bwd),
-                                      T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), start, cap, flags,
+                                      T, H, W, nbr.ctypes.data_as(_lib._P), len(nbr), start, cap, flags, spec,
                                       _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), _lib.stream_ptr(), ctypes.byref(handle))
             if rc == -2 and st[6] > guess:
                 guess = int(st[6])
-                continue
-            if probed is None and rc == 0:
-                probed = int(st[5])
-            if rc == 0 and st[11] > 0 and cap < max_chain_depth:
-                # ties left by the depth cut-off: all twelve levels (the levels already computed are computed again: rare)
-                L.tf_watershed_abandon(handle)
-                handle = ctypes.c_void_p()
-                start, cap, flags = cap + 1, max_chain_depth, TF_WS_SKIP_FAST_PATH | (flags & TF_WS_REFERENCE_ORDER)
                 continue
             break
         _lib.check(rc, "tf_watershed")
     except BaseException:
         _give_slot(slot)
         raise
-    if probed is not None and probed >= 0:
+    probed = int(st[5])
+    if probed >= 0:
         memo[0], memo[1] = bool(probed), 0                     # this call probed
     else:
         memo[1] += 1
     with _MEMO_LOCK:
         _relevant_memo[key] = int(st[6])
         _conflict_memo[key] = memo
-    return WatershedJob(handle, slot, ws, (markers,), (T, H, W), on_ambiguous, return_ambiguous, stats, st)
+    return WatershedJob(handle, slot, ws, (field, markers, mask), (T, H, W), on_ambiguous, return_ambiguous, stats, st, key,
+                        can_deepen=cap < max_chain_depth)
 
 
 def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
                   expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="reference", return_ambiguous=False):
     """Device-resident core: torch tensors in, labels out (`watershed_begin(...).finish()`, which see)."""
-    return watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth, stats, expect_conflict, max_chain_depth,
-                           on_ambiguous, return_ambiguous).finish()
+    try:
+        return watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth, stats, expect_conflict, max_chain_depth,
+                               on_ambiguous, return_ambiguous).finish(_deepen=True)
+    except _DepthRetry:
+        return watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth, stats, expect_conflict, max_chain_depth,
+                               on_ambiguous, return_ambiguous, _all_levels=True).finish()
 
 
 def watershed(
