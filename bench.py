@@ -334,10 +334,13 @@ def main():
         return job, fut, st, scratch
 
     def flood_finish(job, fut, st, scratch=None):
-        """pop ranks applied, labels written: one label volume"""
+        """root phase (with the pop ranks), labels written: one label volume -- or None if the library had to export for a host
+        replay after the root phase (no guessed tie value, or one that was too low): the caller queues the job again"""
         if fut is not None:
             fut.result()
-        lab = job.finish()
+        done, lab = job.step()
+        if not done:
+            return None
         if st.get("reference_order", {}).get("microseconds", 0) > 0:
             d = st["reference_order_detail"]
             ref_order.append((st["reference_order"]["microseconds"], d["replay_form"], d["replay_us"], d["export_us"], d["guessed"], d["guess_covered_the_tie"],
@@ -386,7 +389,11 @@ def main():
                     ready = [p for p in pending if p[1] is None or p[1].done()]
                 done = ready[0]
                 pending.remove(done)
-                wins[done[4]] = flood_finish(*done[:4])
+                lab = flood_finish(*done[:4])
+                if lab is None:                              # exported after its root phase: the replay goes to a worker, the job comes back
+                    pending.append((done[0], replay_pool.submit(done[0].replay)) + done[2:])
+                    return
+                wins[done[4]] = lab
                 pieces.append(done[3])
 
             for iw, (lo, hi) in enumerate(bounds):

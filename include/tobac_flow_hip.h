@@ -233,6 +233,7 @@ int tf_sobel_edge_field(const float *field, int64_t T, int64_t H, int64_t W, con
  *     of the marker = the reference's own marker_locations order) and returns TF_WS_AMBIGUOUS (> 0, not an error)
  *     when at least one pixel's LABEL depends on that; tf_watershed_ex2 reports which pixels.
  *   Return TF_OK therefore means: bit-identical to the reference's output for this input, whatever the tie-breaks. */
+#define TF_WS_REPLAY_PENDING 2 /* tf_watershed_finish only: exported for a host replay, call tf_watershed_finish again (see there) */
 #define TF_WS_AMBIGUOUS 1      /* success; stats[9] pixels carry a label that depends on the order of equal-valued markers */
 #define TF_WS_MAX_DEPTH 12     /* largest chain depth (levels of the pop-order key) */
 #define TF_WS_NSTATS 16
@@ -305,11 +306,14 @@ int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *m
  *   tf_watershed_needs_replay   1 if tf_watershed_replay has work to do (a guess was given)
  *   tf_watershed_replay  the host replay; no HIP call, any thread, different jobs concurrently.  Optional: finish runs it
  *                        if the caller did not.  MUST have returned before the job is finished or abandoned.
- *   tf_watershed_finish  root phase (with the pop ranks if there are any) + exactness check; with TF_WS_REFERENCE_ORDER and
- *                        labels that hang on the order of equal-valued markers without (sufficient) ranks: export, replay
- *                        and a second root phase, as tf_watershed_ex2 does; labels (and report) written; frees the job;
- *                        return codes and stats of tf_watershed_ex2; info_host: NULL or 12 x int64 as tf_watershed_job_info.
- *                        Synchronises the stream.
+ *   tf_watershed_finish  root phase (with the pop ranks if there are any) + exactness check, labels (and report) written;
+ *                        frees the job; return codes and stats of tf_watershed_ex2; info_host: NULL or 12 x int64 as
+ *                        tf_watershed_job_info.  Synchronises the stream.
+ *                        With TF_WS_REFERENCE_ORDER and labels that hang on the order of equal-valued markers without
+ *                        (sufficient) ranks it exports for the tie value it found and returns TF_WS_REPLAY_PENDING (2):
+ *                        the job is NOT freed, nothing is written; the caller runs tf_watershed_replay (again: any thread)
+ *                        and calls tf_watershed_finish a second time, which uploads the ranks, repeats the root phase and
+ *                        completes (it runs the replay itself if the caller did not).
  *   tf_watershed_abandon frees a job without finishing it. */
 int tf_watershed_begin(const float *field, const int32_t *markers, const int8_t *mask,
                        const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,

@@ -1284,6 +1284,7 @@ struct tf_ws_job {
     bool root_pending;           // finish starts with the root phase (begin has run phase A and the chain levels below `depth`)
     bool speculate_fast; int levels_done;
     unsigned true_vmax; bool has_tie, spec_hit; int *subid;
+    bool ranked, late_export; double ms_detour;
     u64 code_d; int64_t code_words, n_exc;
     int64_t M, S, nQ; unsigned vmax;
     WsHostBuf hb_val, hb_nbr, hb_rank, hb_sk, hb_sval, hb_sid;
@@ -1774,18 +1775,34 @@ static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
     const int64_t R = j->R, N = j->N;
     const unsigned nb1 = (unsigned)((N + 255) / 256);
     static const bool ref_debug = ws_env("TF_WS_REF_DEBUG");
-    bool ranked = false;                                                 // root keys are (pop rank << 32) | compact id
-    if (R > 0 && j->root_pending) {
+    bool ranked = j->ranked;                                             // root keys are (pop rank << 32) | compact id
+    if (R > 0 && j->late_export) {
+        // second entry: the replay of the export that followed the root phase has run (or runs here): ranks up, root phase again
+        j->late_export = false;
+        int rc = ws_job_replay(j);
+        if (rc) return rc;
+        const double t0 = ws_now_ms();
+        rc = ws_upload_ranks(j);
+        if (rc) return rc;
+        ranked = j->ranked = true;
+        rc = ws_root_and_check(j, true);                                 // (the check's counts do not depend on the order)
+        if (rc) return rc;
+        j->applied = true;
+        j->ms_detour += j->ms_export + j->ms_replay + (ws_now_ms() - t0);
+        st[13] = j->popped; st[14] = j->sparse ? j->S : j->M;
+        st[15] = (int64_t)(j->ms_detour * 1000.0);
+    } else if (R > 0 && j->root_pending) {
+        j->root_pending = false;
         const unsigned nbr_blocks = (unsigned)((R + 255) / 256);
         int rc;
-        double ms_detour = 0.0;
+        double &ms_detour = j->ms_detour;
         if (j->need_replay) {                                            // the speculative export's replay: ranks before the root phase
             rc = ws_job_replay(j);                                       // (a no-op if the caller has run it)
             if (rc) return rc;
             const double t0 = ws_now_ms();
             rc = ws_upload_ranks(j);
             if (rc) return rc;
-            ranked = true;
+            ranked = j->ranked = true;
             ms_detour = j->ms_export + j->ms_replay + (ws_now_ms() - t0);
         }
         for (;;) {
@@ -1820,16 +1837,10 @@ static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
                 j->vmax = h_vmax;
                 rc = ws_job_export(j);
                 if (rc) return rc;
-                rc = ws_job_replay(j);
-                if (rc) return rc;
-                const double t0 = ws_now_ms();
-                rc = ws_upload_ranks(j);
-                if (rc) return rc;
-                ranked = true;
-                rc = ws_root_and_check(j, true);                         // (the check's counts do not depend on the order)
-                if (rc) return rc;
-                j->applied = true;
-                ms_detour += j->ms_export + j->ms_replay + (ws_now_ms() - t0);
+                // the replay is the caller's to run (any thread); finish is entered again afterwards
+                j->late_export = true;
+                st[8] = j->depth; st[9] = (int64_t)j->h_amb[0]; st[10] = (int64_t)j->h_amb[1]; st[11] = (int64_t)j->h_amb[2];
+                return TF_WS_REPLAY_PENDING;
             }
         }
         if (j->need_replay && j->replay_done) {
@@ -1876,7 +1887,10 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
     tf_ws_job *j = ws_job_new();
     if (!j) { tf_set_error("tf_watershed: out of host memory"); return TF_ENOMEM; }
     int rc = ws_job_begin(j, field, markers, mask, fwd, bwd, T, H, W, nbr_host, n_nbr, depth0, depth_max, flags, ws, ws_bytes, stream, rv, rv_locs, rv_n_locs);
-    if (rc == TF_OK) rc = ws_job_finish(j, labels, amb_out);
+    if (rc == TF_OK) {
+        rc = ws_job_finish(j, labels, amb_out);
+        if (rc == TF_WS_REPLAY_PENDING) rc = ws_job_finish(j, labels, amb_out);     // (runs the replay itself)
+    }
     for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = j->st[i];
     ws_job_free(j);
     return rc;
@@ -1913,6 +1927,7 @@ extern "C" int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguou
     const int rc = ws_job_finish(j, labels, ambiguous);
     if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = j->st[i];
     if (info_host) (void)tf_watershed_job_info(j, info_host);
+    if (rc == TF_WS_REPLAY_PENDING) return rc;                            // the job lives on: replay, then finish again
     ws_job_free(j);
     return rc;
 }

@@ -31,7 +31,7 @@ _NEIGHBOUR_ORDER = {
 
 DEFAULT_CHAIN_DEPTH = 3
 MAX_CHAIN_DEPTH = 12              # TF_WS_MAX_DEPTH
-TF_WS_AMBIGUOUS, TF_EDEPTH = 1, -5
+TF_WS_AMBIGUOUS, TF_WS_REPLAY_PENDING, TF_EDEPTH = 1, 2, -5
 AMB_DEPENDS, AMB_MARKER_TIE, AMB_DEPTH = 1, 2, 4
 
 
@@ -124,6 +124,7 @@ class WatershedJob:
         self._memo_key, self._can_deepen = memo_key, can_deepen
         self.needs_replay = bool(_lib.lib().tf_watershed_needs_replay(handle))
         self.info = {}
+        self._out = None
 
     @staticmethod
     def _info_dict(a):
@@ -149,21 +150,32 @@ class WatershedJob:
         except Exception:                                    # interpreter shutdown
             pass
 
-    def finish(self, _deepen=False):
+    def step(self, _deepen=False):
+        """One entry of tf_watershed_finish.  Returns (True, labels [, report]) when the flood is complete, or (False, None)
+        when the library has exported for a host replay AFTER the root phase (no guess, or a guess that was too low):
+        `needs_replay` is True again, run `replay()` (any thread) and call step() once more."""
         if self._h is None:
-            raise RuntimeError("WatershedJob.finish: the job has already been finished or abandoned")
+            raise RuntimeError("WatershedJob: the job has already been finished or abandoned")
         t = _lib.torch()
         L = _lib.lib()
-        labels = _lib.empty(self._shape, t.int32)
-        amb = _lib.empty(self._shape, t.uint8) if self._return_ambiguous else None
+        if self._out is None:
+            self._out = (_lib.empty(self._shape, t.int32), _lib.empty(self._shape, t.uint8) if self._return_ambiguous else None)
+        labels, amb = self._out
         st = self._st
         info = np.zeros(12, np.int64)
-        h, self._h = self._h, None
+        rc = TF_WS_REPLAY_PENDING
         try:
-            rc = L.tf_watershed_finish(h, _lib.ptr(labels), _lib.ptr(amb), st.ctypes.data_as(_lib._P), info.ctypes.data_as(_lib._P))
+            rc = L.tf_watershed_finish(self._h, _lib.ptr(labels), _lib.ptr(amb), st.ctypes.data_as(_lib._P), info.ctypes.data_as(_lib._P))
         finally:
-            self._ws = self._keep = None
-            _give_slot(self._slot)
+            if rc != TF_WS_REPLAY_PENDING:                   # the library has freed the job
+                self._h = None
+                self._ws = self._keep = self._out = None
+                _give_slot(self._slot)
+        if rc == TF_WS_REPLAY_PENDING:
+            self.needs_replay = True
+            self.info = self._info_dict(info)
+            return False, None
+        self.needs_replay = False
         if rc not in (TF_WS_AMBIGUOUS, TF_EDEPTH):
             _lib.check(rc, "tf_watershed")
         self.info = self._info_dict(info)
@@ -186,7 +198,7 @@ class WatershedJob:
                    f"{'this job was given room for: begin it with a larger chain_depth' if self._can_deepen else 'allowed'}); "
                    f"{int(st[9])} label(s) may differ from the reference")
             if on_ambiguous == "ignore":
-                warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=3)
+                warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=4)
             else:
                 raise WatershedDepthError(msg)
         elif rc == TF_WS_AMBIGUOUS and on_ambiguous != "ignore":
@@ -194,8 +206,16 @@ class WatershedJob:
                    f"pops equal-valued markers ({int(st[10])} tie point(s)); resolved by the markers' raster order")
             if on_ambiguous == "raise":
                 raise WatershedAmbiguityError(msg)
-            warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=3)
-        return (labels, amb) if self._return_ambiguous else labels
+            warnings.warn(msg, WatershedAmbiguityWarning, stacklevel=4)
+        return True, ((labels, amb) if self._return_ambiguous else labels)
+
+    def finish(self, _deepen=False):
+        """Complete the flood on this thread (replays included) and return the labels."""
+        while True:
+            done, out = self.step(_deepen)
+            if done:
+                return out
+            self.replay()
 
 
 _tie_memo = {}           # (T, H, W, neighbours, depth, stream) -> ordered key of the largest tie value of the last flood (-1: none)
