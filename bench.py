@@ -247,6 +247,9 @@ def main():
                     help="floods in flight per rank at most (each owns ~8 GB of scratch at 16 x 5424^2; the first step lowers the "
                          "number to what the free device memory holds): window k's host replay runs on a worker thread while the "
                          "device floods windows k+1 ...; 1 = strictly one after the other")
+    ap.add_argument("--no-stream-windows", dest="stream_windows", action="store_false",
+                    help="begin the windows only after the whole stack's flow (default: a window is begun as soon as the flow batch "
+                         "with its last frame pair is enqueued, so that its host replay overlaps the later batches' flow; one channel only)")
     ap.add_argument("--rotate", type=int, default=3,
                     help="the timed steps visit this many different T-frame stacks of the synthetic sequence in turn (offsets "
                          "0, s, 2s, ... frames with s = --rotate-shift), all resident before the timed region: the data-dependent "
@@ -263,6 +266,9 @@ def main():
                     help="diagnostic: do not record HIP events around the library's launches in the timed region "
                          "(roofline = null); the difference to a default run is what the instrumentation costs")
     a = ap.parse_args()
+    if a.stream_windows and CONFIGS[a.config][4] == 1:
+        # floods in flight beside the flow need ~12 GB each: leave room (21 pairs per Farneback batch at 5424^2 instead of 42: +3 % flow time)
+        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", "60")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
 
@@ -318,6 +324,13 @@ def main():
     inflight = {}
     replay_pool = ThreadPoolExecutor(max_workers=max(1, min(a.inflight, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
+    timeline = os.environ.get("TF_BENCH_TIMELINE") is not None      # development aid: when each part of a step starts and ends
+    t_step = [0.0]
+
+    def mark(what):
+        if timeline:
+            print("  t+%7.1f ms  %s" % ((time.perf_counter() - t_step[0]) * 1e3, what), file=sys.stderr, flush=True)
+
     def flood_begin(flow, w, c, scratch=None):
         """seeds -> edge field -> device part of the watershed of channel c over the window `w` of the stack (Flow `flow`);
         the host replay of the reference's heap order (if this window needs one) starts on a worker thread"""
@@ -328,8 +341,10 @@ def main():
         e = get_combined_edge_field(flow, lin, dtype=np.float32)
         fw, bw = flow._dev_flows()
         st = {}
+        mark("begin: seeds + edge field enqueued")
         job = watershed_begin(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore",
                               workspace=scratch)
+        mark("begin: done (replay %s)" % ("submitted" if job.needs_replay else "none"))
         fut = replay_pool.submit(job.replay) if job.needs_replay else None
         return job, fut, st, scratch
 
@@ -338,7 +353,9 @@ def main():
         replay after the root phase (no guessed tie value, or one that was too low): the caller queues the job again"""
         if fut is not None:
             fut.result()
+        mark("finish: enter")
         done, lab = job.step()
+        mark("finish: %s" % ("done" if done else "exported again, replay pending"))
         if not done:
             return None
         if st.get("reference_order", {}).get("microseconds", 0) > 0:
@@ -348,12 +365,82 @@ def main():
         ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
         return lab
 
+    class Windows:
+        """the floods of one channel of one step: begun window by window (each with its seeds and edge field), their host
+        replays on the worker threads, finished -- out of order -- as soon as their replay has ended"""
+
+        def __init__(self, bt, c, pieces, n_fly):
+            self.bt, self.c, self.pieces, self.n_fly = bt, c, pieces, n_fly
+            self.pending = deque()                           # floods in flight: (job, future, stats, scratch, window index)
+            self.wins = [None] * len(bounds)
+            self.next = 0                                    # next window to begin
+
+        def finish_one(self, block=True):
+            """finish a flood whose host replay has ended (the oldest such one); if none has, wait for the first that does:
+            a window whose replay takes long -- the dense form, ~1 s -- does not hold up the others.  block=False: only if
+            one is ready now (called after every begin: a flood whose guessed tie value turns out too low gets its
+            second export -- and with it the start of its long replay -- as early as possible)"""
+            pending = self.pending
+            ready = [p for p in pending if p[1] is None or p[1].done()]
+            if not ready and not block:
+                return False
+            if not ready:
+                futures_wait([p[1] for p in pending], return_when=FIRST_COMPLETED)
+                ready = [p for p in pending if p[1] is None or p[1].done()]
+            done = ready[0]
+            pending.remove(done)
+            lab = flood_finish(*done[:4])
+            if lab is None:                                  # exported after its root phase: the replay goes to a worker, the job comes back
+                pending.append((done[0], replay_pool.submit(done[0].replay)) + done[2:])
+                return True
+            self.wins[done[4]] = lab
+            self.pieces.append(done[3])
+            return True
+
+        def begin_up_to(self, flow, n_frames):
+            """begin every window that ends within the first n_frames frames of the stack (their flow is final)"""
+            while self.next < len(bounds) and bounds[self.next][1] <= n_frames:
+                lo, hi = bounds[self.next]
+                while len(self.pending) >= self.n_fly:
+                    self.finish_one()
+                # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame
+                # pair does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426);
+                # window_view patches those two frames in the stack's arrays for the duration of the block instead of
+                # copying the window's 7.5 GB of flow vectors (Flow.window).  Only the device part of the flood reads the
+                # flows (its neighbour table has the displacements applied): the job is finished outside the block.
+                with flow.window_view(lo, hi) as flow_w:
+                    self.pending.append(flood_begin(flow_w, self.bt[lo:hi], self.c, self.pieces.pop()) + (self.next,))
+                self.next += 1
+                while self.finish_one(block=False):
+                    pass
+
+        def finish_all(self):
+            while self.pending:
+                self.finish_one()
+            return self.wins
+
     def step(bt, vr_steps=None):
         """one pass over the stack `bt`; returns (stitched windows of the LAST channel, objects per channel)"""
         vr = a.vr_steps if vr_steps is None else vr_steps
+        t_step[0] = time.perf_counter()
+        mark("step starts")
+        per_job = 18 * max(hi - lo for lo, hi in bounds) * H * W
+        stream = a.stream_windows and C == 1 and n_windows > 1
         # flow of all T - 1 frame pairs of the stack, ONCE (the frames two windows share are not computed twice), in batches
-        # sized by the library (tf_farneback_batch_hint)
-        flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic")
+        # sized by the library (tf_farneback_batch_hint).  --stream-windows (default): a window is begun as soon as the batch
+        # that holds its last frame pair is enqueued (create_flow(on_frames_ready=...)): its host replay then runs beside the
+        # NEXT batches' flow, not after the whole stack's.  The floods in flight then need scratch of their own (the Farneback
+        # scratch is busy): TF_FLOW_WORKSPACE_GB is lowered to make room (set below, before the first create_flow).
+        first = None
+        if stream:
+            n_fly = int(max(1, min(a.inflight, len(bounds), 6)))
+            first = Windows(bt, 0, [None] * n_fly, n_fly)
+            inflight["n"] = n_fly
+            flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic",
+                                      on_frames_ready=lambda fl, n: (mark("flow final for %d frames" % n), first.begin_up_to(fl, n)))
+        else:
+            flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic")
+        mark("create_flow returned (device still working)")
         flow_released = False
         if T * H * W * (1 + 4 + C) * 4 > 0.6 * torch.cuda.mem_get_info()[1]:
             # a stack whose frames + flow vectors + one channel's labels take most of the device (F3: 34 + 136 + 44 GB):
@@ -363,53 +450,30 @@ def main():
         objects, out = [], None
         for c in range(C):                                   # channels one after the other: one channel's labels resident
             out = None
-            pending = deque()                                # floods in flight, oldest first
-            # Every flood in flight owns ~17 B of scratch per window voxel until it is finished.  The Farneback scratch of
-            # create_flow (up to 115 GB) is idle from here to the next step's create_flow: the floods take their scratch from
-            # it, piece by piece, instead of allocating another 50 - 100 GB beside it (which the device does not have).
-            fb = None if flow_released else _lib.borrow_workspace("farneback")
-            per_job = 18 * max(hi - lo for lo, hi in bounds) * H * W
-            if fb is not None and fb.numel() >= per_job:
-                n_fly = int(max(1, min(a.inflight, len(bounds), fb.numel() // per_job)))
-                piece = fb.numel() // n_fly // 256 * 256
-                pieces = [fb[k * piece:(k + 1) * piece] for k in range(n_fly)]
+            if first is not None:
+                wq = first
             else:
-                free = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
-                n_fly = int(max(1, min(a.inflight, len(bounds), 0.3 * free // (per_job + 4 * per_job // 18))))
-                pieces = [None] * n_fly
-            inflight["n"] = n_fly
-            wins = [None] * len(bounds)
-
-            def finish_one():
-                """finish a flood whose host replay has ended (the oldest such one); if none has, wait for the first that does:
-                a window whose replay takes long -- the dense form, ~1 s -- does not hold up the others"""
-                ready = [p for p in pending if p[1] is None or p[1].done()]
-                if not ready:
-                    futures_wait([p[1] for p in pending], return_when=FIRST_COMPLETED)
-                    ready = [p for p in pending if p[1] is None or p[1].done()]
-                done = ready[0]
-                pending.remove(done)
-                lab = flood_finish(*done[:4])
-                if lab is None:                              # exported after its root phase: the replay goes to a worker, the job comes back
-                    pending.append((done[0], replay_pool.submit(done[0].replay)) + done[2:])
-                    return
-                wins[done[4]] = lab
-                pieces.append(done[3])
-
-            for iw, (lo, hi) in enumerate(bounds):
-                while len(pending) >= n_fly:
-                    finish_one()
-                # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame
-                # pair does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426);
-                # window_view patches those two frames in the stack's arrays for the duration of the block instead of
-                # copying the window's 7.5 GB of flow vectors (Flow.window).  Only the device part of the flood reads the
-                # flows (its neighbour table has the displacements applied): the job is finished outside the block.
-                with flow_all.window_view(lo, hi) as flow_w:
-                    pending.append(flood_begin(flow_w, bt[lo:hi], c, pieces.pop()) + (iw,))
-            while pending:
-                finish_one()
+                # Every flood in flight owns ~17 B of scratch per window voxel until it is finished.  The Farneback scratch of
+                # create_flow (up to 115 GB) is idle from here to the next step's create_flow: the floods take their scratch from
+                # it, piece by piece, instead of allocating another 50 - 100 GB beside it (which the device does not have).
+                fb = None if flow_released else _lib.borrow_workspace("farneback")
+                if fb is not None and fb.numel() >= per_job:
+                    n_fly = int(max(1, min(a.inflight, len(bounds), fb.numel() // per_job)))
+                    piece = fb.numel() // n_fly // 256 * 256
+                    pieces = [fb[k * piece:(k + 1) * piece] for k in range(n_fly)]
+                else:
+                    free = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+                    n_fly = int(max(1, min(a.inflight, len(bounds), 0.3 * free // (per_job + 4 * per_job // 18))))
+                    pieces = [None] * n_fly
+                inflight["n"] = n_fly
+                wq = Windows(bt, c, pieces, n_fly)
+            wq.begin_up_to(flow_all, T)
+            wins = wq.finish_all()
+            first = None
             # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
+            mark("all windows finished")
             out = stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins
+            mark("stitched")
             del wins
             n_obj = int(max(int(w.max()) for w in out))
             if dist is not None:                             # ids are global after the stitch: the count is the largest id on ANY rank
@@ -570,7 +634,8 @@ def main():
                             "floods_probing": int((timed[:, 5] >= 0).sum()), "floods_skipping_root_phase": int((timed[:, 5] < 0).sum()),
                             "tie_order": a.tie_order,
                             "labels_bit_exact_with_the_reference": a.tie_order == "reference" and int(timed[:, 11].sum()) == 0,
-                            "floods_in_flight": inflight.get("n", 1)}
+                            "floods_in_flight": inflight.get("n", 1),
+                            "windows_begun_during_the_flow": bool(a.stream_windows and C == 1 and n_windows > 1)}
         if a.tie_order == "reference":
             ro = ref_order                                                          # warm-up floods included
             out["watershed"]["reference_order"] = {

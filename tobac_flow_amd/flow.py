@@ -34,14 +34,32 @@ def _is_dataarray(x):
 
 
 def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
-                interp_method: str = "linear", max_value=20) -> "Flow":
+                interp_method: str = "linear", max_value=20, on_frames_ready=None) -> "Flow":
     """Forward and backward optical flow along the leading dimension of `data`, clipped to
-    +-`max_value` pixels, wrapped in a Flow object (reference: flow.py:23-65)."""
+    +-`max_value` pixels, wrapped in a Flow object (reference: flow.py:23-65).
+
+    on_frames_ready (not in the reference; device-resident input only): `f(flow, n)` is called after every batch of frame
+    pairs with the Flow object under construction and the number n of leading frames whose windows are complete:
+    `flow.window_view(a, b)` / `flow.window(a, b)` with b <= n equal those of the finished object, bit for bit (the flow of
+    a frame pair does not depend on the rest of the stack).  A long stack processed as overlapping time windows can so
+    start on its first windows -- Sobel, seeds, flood, host work -- while the device computes the flow of the later frames
+    (bench.py).  The calls are made on the calling thread, in order; n == len(data) in the last one."""
     # the clip of flow.py:60-61 is applied by the same kernel that mirrors the end frames (tf_flow_finalize);
     # clipping commutes with the sign-flipped mirror
+    extra = {}
+    if on_frames_ready is not None:
+        holder = {}
+
+        def on_batch(forward, backward, pairs_done, n_pairs):
+            if "flow" not in holder:
+                holder["flow"] = Flow(forward, backward)
+            on_frames_ready(holder["flow"], pairs_done + 1 if pairs_done < n_pairs else n_pairs + 1)
+        extra["_on_batch"] = on_batch
     forward_flow, backward_flow = calculate_flow(data, model=model, vr_steps=vr_steps,
                                                  smoothing_passes=smoothing_passes, interp_method=interp_method,
-                                                 _max_value=float(max_value))
+                                                 _max_value=float(max_value), **extra)
+    if on_frames_ready is not None and "flow" in holder:
+        return holder["flow"]
     return Flow(forward_flow, backward_flow)
 
 
@@ -289,7 +307,7 @@ def _side_stream(main):
 
 
 def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_passes, interp_method,
-                         norm_name, norm_method, normalisation_kwargs, on_device, max_value=float("inf")):
+                         norm_name, norm_method, normalisation_kwargs, on_device, max_value=float("inf"), on_batch=None):
     t = _lib.torch()
     L = _lib.lib()
     H, W = shape
@@ -427,11 +445,28 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                 refine_and_smooth()
     # a batch that does not fit (the budget above is an estimate; a caching allocator's free memory can be fragmented) is
     # halved and tried again, and so are the batches after it
+    def finalize_ends():
+        # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping.  With smoothing the interior is already
+        # clipped (run_batch): only the two end frames are left to write
+        if smoothing_passes > 0 or max_value == float("inf"):
+            _lib.check(L.tf_flow_finalize_ends(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
+                       "tf_flow_finalize_ends")
+        else:
+            _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
+                       "tf_flow_finalize")
+
+    if on_batch is not None and (side is not None or not on_device or not (smoothing_passes > 0 or max_value == float("inf"))):
+        raise ValueError("on_frames_ready needs device-resident input, the default single-stream schedule and either smoothing or no clipping")
     pending = [(a_, b_ - a_) for a_, b_ in zip(starts[:-1], starts[1:])]
     while pending:
         i0, B = pending.pop(0)
         try:
             run_batch(i0, B)
+            if on_batch is not None and i0 + B < n_pairs:
+                # the first i0 + B + 1 frames are final but for the stack's own first frame, whose backward vectors are the
+                # mirror of its forward ones: written now (and, with the still unknown other end, once more at the end)
+                finalize_ends()
+                on_batch(forward, backward, i0 + B, n_pairs)
         except t.OutOfMemoryError:
             if os.environ.get("TF_FLOW_DEBUG"):
                 print("flow: batch of %d pairs does not fit (free %.1f GB, cached %.1f GB): halving" % (
@@ -458,14 +493,9 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         free_now, total = t.cuda.mem_get_info()
         if free_now + (t.cuda.memory_reserved() - t.cuda.memory_allocated()) < 0.2 * total:
             _lib.release_workspaces("farneback")
-    # flow.py:425-426 (mirror the end frames); max_value = inf -> no clipping.  With smoothing the interior is already
-    # clipped (above): only the two end frames are left to write
-    if smoothing_passes > 0 or max_value == float("inf"):
-        _lib.check(L.tf_flow_finalize_ends(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
-                   "tf_flow_finalize_ends")
-    else:
-        _lib.check(L.tf_flow_finalize(_lib.ptr(forward), _lib.ptr(backward), T, H, W, max_value, _lib.stream_ptr()),
-                   "tf_flow_finalize")
+    finalize_ends()
+    if on_batch is not None:
+        on_batch(forward, backward, n_pairs, n_pairs)
     if on_device:
         return forward, backward
     return forward.cpu().numpy(), backward.cpu().numpy()
@@ -476,6 +506,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     """Forward / backward flow for every consecutive frame pair of `data` (reference: flow.py:362-428).
     forward[i] = flow i -> i+1, backward[i+1] = flow i+1 -> i; the end frames are mirrored."""
     max_value = normalisation_kwargs.pop("_max_value", float("inf"))
+    on_batch = normalisation_kwargs.pop("_on_batch", None)
     of_model = select_of_model(model)
     norm_method = select_normalisation_method(normalisation_method)
     t = _lib.torch()
@@ -488,7 +519,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     T = d.shape[0]
     return _calculate_flow_impl(lambda i: (d[i], d[i + 1]), T, tuple(d.shape[1:]), of_model, vr_steps,
                                 smoothing_passes, interp_method, normalisation_method, norm_method,
-                                normalisation_kwargs, on_device, max_value)
+                                normalisation_kwargs, on_device, max_value, on_batch)
 
 
 def calculate_flow_2(a, b, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,

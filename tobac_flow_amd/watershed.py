@@ -179,8 +179,10 @@ class WatershedJob:
         if rc not in (TF_WS_AMBIGUOUS, TF_EDEPTH):
             _lib.check(rc, "tf_watershed")
         self.info = self._info_dict(info)
-        with _MEMO_LOCK:                                     # the next flood of this shape guesses this one's tie value
-            _tie_memo[self._memo_key] = int(info[7])
+        with _MEMO_LOCK:                                     # the next floods of this shape guess from the tie values seen
+            hist = _tie_memo.setdefault(self._memo_key, [])
+            hist.append(int(info[7]))
+            del hist[:-_TIE_HISTORY]
         stats, on_ambiguous = self._stats, self._on_ambiguous
         if stats is not None:
             stats["sweeps"] = st[:8].tolist()
@@ -218,7 +220,12 @@ class WatershedJob:
             self.replay()
 
 
-_tie_memo = {}           # (T, H, W, neighbours, depth, stream) -> ordered key of the largest tie value of the last flood (-1: none)
+# (T, H, W, neighbours, depth, stream) -> ordered keys of the largest tie value of the last floods (-1: no tie).  The guess
+# handed to tf_watershed_begin is the SMALLEST of them: a guess that is too low costs what no guess costs (export after the
+# root phase, second root phase), one that is too high makes the replay long -- with the background's value as the guess it
+# is the dense form, ~1 s instead of 0.2 s, for every flood until the next one finishes.
+_tie_memo = {}
+_TIE_HISTORY = 32
 
 
 def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
@@ -259,7 +266,8 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
     with _MEMO_LOCK:
         known = _relevant_memo.get(key)
         memo = list(_conflict_memo.get(key, (False, 0)))      # [last probe conflicted, calls since that probe]
-        tie_key = _tie_memo.get(key, -1)
+        ties = [k for k in _tie_memo.get(key, ()) if k >= 0]
+        tie_key = min(ties) if ties else -1
     if known is not None:
         guess = min(T * H * W, int(known * 1.25) + 4096)
     else:
