@@ -324,6 +324,7 @@ def main():
     inflight = {}
     replay_pool = ThreadPoolExecutor(max_workers=max(1, min(a.inflight, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
 
+    side_stream = [None]            # streaming windows: the floods are FINISHED on a second stream (the main one is busy with the flow)
     timeline = os.environ.get("TF_BENCH_TIMELINE") is not None      # development aid: when each part of a step starts and ends
     t_step = [0.0]
 
@@ -354,10 +355,12 @@ def main():
         if fut is not None:
             fut.result()
         mark("finish: enter")
-        done, lab = job.step()
+        done, lab = job.step(stream=side_stream[0])
         mark("finish: %s" % ("done" if done else "exported again, replay pending"))
         if not done:
             return None
+        if side_stream[0] is not None:
+            lab.record_stream(torch.cuda.current_stream())   # allocated on the second stream, used (stitch) on the main one
         if st.get("reference_order", {}).get("microseconds", 0) > 0:
             d = st["reference_order_detail"]
             ref_order.append((st["reference_order"]["microseconds"], d["replay_form"], d["replay_us"], d["export_us"], d["guessed"], d["guess_covered_the_tie"],
@@ -397,8 +400,13 @@ def main():
             self.pieces.append(done[3])
             return True
 
-        def begin_up_to(self, flow, n_frames):
-            """begin every window that ends within the first n_frames frames of the stack (their flow is final)"""
+        def begin_up_to(self, flow, n_frames, wait_for=None):
+            """begin every window that ends within the first n_frames frames of the stack (their flow is final).
+            wait_for: an event on the main stream behind the flow these windows need: until it has passed, floods whose replay
+            has ended are finished (on the second stream) instead of blocking in the first synchronisation of a begin"""
+            while wait_for is not None and self.next < len(bounds) and bounds[self.next][1] <= n_frames and not wait_for.query():
+                if not self.finish_one(block=False):
+                    time.sleep(0.0005)
             while self.next < len(bounds) and bounds[self.next][1] <= n_frames:
                 lo, hi = bounds[self.next]
                 while len(self.pending) >= self.n_fly:
@@ -436,8 +444,15 @@ def main():
             n_fly = int(max(1, min(a.inflight, len(bounds), 6)))
             first = Windows(bt, 0, [None] * n_fly, n_fly)
             inflight["n"] = n_fly
-            flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic",
-                                      on_frames_ready=lambda fl, n: (mark("flow final for %d frames" % n), first.begin_up_to(fl, n)))
+            if side_stream[0] is None:
+                side_stream[0] = torch.cuda.Stream()
+
+            def frames_ready(fl, n):
+                mark("flow enqueued for %d frames" % n)
+                ev = torch.cuda.Event()
+                ev.record()
+                first.begin_up_to(fl, n, wait_for=ev)
+            flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic", on_frames_ready=frames_ready)
         else:
             flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic")
         mark("create_flow returned (device still working)")

@@ -323,6 +323,10 @@ int tf_watershed_needs_replay(const void *job);
 int tf_watershed_replay(void *job);
 int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguous, int64_t *stats_host, int64_t *info_host);
 void tf_watershed_abandon(void *job);
+/* the stream tf_watershed_finish works on (default: the one the job was begun on; everything begin enqueued has completed
+ * when begin returns, so any stream is safe): a caller that keeps its main stream busy with other work -- the flow of the
+ * next frames -- finishes its floods on a second one instead of queueing the root phase behind that work */
+int tf_watershed_set_stream(void *job, void *stream);
 /* info (12 x int64): [0] replay form (0 none, 1 sparse, 2 dense), [1] seeds, [2] seeds at or below the tie value,
  * [3] pixels of the exported sub-graph, [4] relevant pixels, [5] microseconds of the export, [6] microseconds of the
  * replay (-1: not run), [7] ordered key of the largest tie value finish found (-1: no label hangs on such a tie, or not

@@ -71,6 +71,7 @@ _PROTOS = {
     "tf_watershed_replay": (_c.c_int, [_P]),
     "tf_watershed_finish": (_c.c_int, [_P, _P, _P, _P, _P]),
     "tf_watershed_abandon": (None, [_P]),
+    "tf_watershed_set_stream": (_c.c_int, [_P, _P]),
     "tf_watershed_job_info": (_c.c_int, [_P, _P]),
     "tf_watershed_raveled_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int, _c.c_int, _c.c_int64]),
     "tf_watershed_raveled": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _P, _c.c_int, _P, _P, _P, _P, _P, _P, _c.c_int,

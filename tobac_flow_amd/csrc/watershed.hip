@@ -1932,6 +1932,12 @@ extern "C" int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguou
     return rc;
 }
 extern "C" void tf_watershed_abandon(void *job) { ws_job_free((tf_ws_job *)job); }
+extern "C" int tf_watershed_set_stream(void *job, void *stream)
+{
+    TF_REQUIRE(job, "tf_watershed_set_stream: null job");
+    ((tf_ws_job *)job)->s = (hipStream_t)stream;
+    return TF_OK;
+}
 extern "C" int tf_watershed_job_info(const void *job, int64_t *info)
 {
     TF_REQUIRE(job && info, "tf_watershed_job_info: null pointer");

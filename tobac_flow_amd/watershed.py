@@ -150,12 +150,22 @@ class WatershedJob:
         except Exception:                                    # interpreter shutdown
             pass
 
-    def step(self, _deepen=False):
+    def step(self, _deepen=False, stream=None):
         """One entry of tf_watershed_finish.  Returns (True, labels [, report]) when the flood is complete, or (False, None)
         when the library has exported for a host replay AFTER the root phase (no guess, or a guess that was too low):
-        `needs_replay` is True again, run `replay()` (any thread) and call step() once more."""
+        `needs_replay` is True again, run `replay()` (any thread) and call step() once more.
+        stream: a torch.cuda.Stream to do this on instead of the stream the job was begun on (tf_watershed_set_stream): the
+        root phase then does not queue behind whatever the main stream is busy with.  The call returns with that stream idle."""
         if self._h is None:
             raise RuntimeError("WatershedJob: the job has already been finished or abandoned")
+        t = _lib.torch()
+        if stream is not None:
+            _lib.check(_lib.lib().tf_watershed_set_stream(self._h, ctypes.c_void_p(stream.cuda_stream)), "tf_watershed_set_stream")
+            with t.cuda.stream(stream):
+                return self._step(_deepen)
+        return self._step(_deepen)
+
+    def _step(self, _deepen):
         t = _lib.torch()
         L = _lib.lib()
         if self._out is None:
