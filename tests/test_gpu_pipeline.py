@@ -250,3 +250,78 @@ def test_stitch_collectives_over_rccl_in_a_one_rank_group(tmp_path):
     mp.spawn(_rccl_one_rank_worker, args=(port, wins, overlap, str(tmp_path)), nprocs=1, join=True)
     for j in range(n_windows):
         assert np.array_equal(np.load(tmp_path / f"w{j}.npy"), want[j]), j
+
+
+def test_create_flow_on_frames_ready_hands_out_final_windows():
+    """create_flow(on_frames_ready=f) (round 4): f(flow, n) is called after every batch of frame pairs, and every window
+    that ends within the first n frames is then already the window of the finished Flow, bit for bit -- which is what lets
+    bench.py begin a window's Sobel / seeds / flood (and its host replay) while the device computes the flow of the later
+    frames.  Checked: the windows copied out inside the callbacks equal create_flow(window) of a fresh call."""
+    import os
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tools.synth import blob_stack
+    bt = blob_stack(11, 96, 128, seed=5, t0=3)
+    bounds = [(0, 4), (2, 7), (5, 9), (7, 11)]
+    got, seen = {}, []
+
+    def ready(flow, n):
+        seen.append(n)
+        for a, b in bounds:
+            if b <= n and (a, b) not in got:
+                with flow.window_view(a, b) as w:
+                    got[(a, b)] = (w.forward_flow.clone(), w.backward_flow.clone())
+    old = os.environ.get("TF_FLOW_BATCH")
+    os.environ["TF_FLOW_BATCH"] = "3"                                  # four batches of 3 / 3 / 2 / 2 pairs
+    try:
+        full = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic", on_frames_ready=ready)
+    finally:
+        if old is None:
+            del os.environ["TF_FLOW_BATCH"]
+        else:
+            os.environ["TF_FLOW_BATCH"] = old
+    assert seen == sorted(seen) and seen[-1] == 11 and len(seen) >= 3
+    assert set(got) == set(bounds)
+    plain = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    assert torch.equal(full.forward_flow, plain.forward_flow) and torch.equal(full.backward_flow, plain.backward_flow)
+    for (a, b), (fw, bw) in got.items():
+        want = tf.create_flow(bt[a:b], vr_steps=1, smoothing_passes=1, interp_method="cubic")
+        assert torch.equal(fw, want.forward_flow) and torch.equal(bw, want.backward_flow), (a, b)
+
+
+def test_watershed_job_in_parts_on_a_second_stream_equals_the_one_call(golden_ws):
+    """tf_watershed_begin / _replay / _finish (WatershedJob): begin, the host replay on a worker thread, step() on a second
+    stream -- with and without a guessed tie value, and with a guess that is too low (re-entrant finish) -- give the labels
+    of the one-call form (which are the reference's, tests/test_gpu_reference_order.py)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd import watershed as W
+    c = golden_ws["E_const_plateau_c1"]
+    args = (_lib.to_dev(c["fwd"], torch.float32), _lib.to_dev(c["bwd"], torch.float32), _lib.to_dev(c["field"], torch.float32),
+            _lib.to_dev(c["markers"], torch.int32), None, W.neighbour_offsets(int(c["conn"])))
+    side = torch.cuda.Stream()
+    pool = ThreadPoolExecutor(2)
+    key = next(iter(()), None)
+    for guess in ("none", "memo", "too_low"):
+        with W._MEMO_LOCK:
+            k = (*c["field"].shape, len(args[5]), W.DEFAULT_CHAIN_DEPTH, torch.cuda.current_stream().cuda_stream)
+            if guess == "none":
+                W._tie_memo.pop(k, None)
+            elif guess == "too_low":
+                W._tie_memo[k] = [0]                              # the smallest ordered key: below every marker value
+        st = {}
+        job = W.watershed_begin(*args, stats=st, expect_conflict=True)
+        assert job.needs_replay == (guess != "none")
+        rounds = 0
+        while True:
+            if job.needs_replay:
+                pool.submit(job.replay).result()
+            done, lab = job.step(stream=side)
+            rounds += 1
+            if done:
+                break
+        assert rounds == (1 if guess == "memo" else 2), (guess, rounds)
+        assert np.array_equal(lab.cpu().numpy(), c["labels"]), guess
+        assert st["reference_order_detail"]["guess_covered_the_tie"] == (guess == "memo")
+        assert st["root_phases"] == (1 if guess == "memo" else 2)
