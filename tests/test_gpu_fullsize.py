@@ -234,8 +234,13 @@ def test_watershed_beyond_2_to_31_voxels_equals_its_halves():
     labels of frames 0..37 and 39..75 must be exactly those of flooding each half alone (1.12e9 voxels each, the size
     range every other test covers)."""
     import torch
+    from tobac_flow_amd import _lib
     from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
     T, H, W, cut = 76, 5424, 5424, 38
+    # this test needs most of the device (64 GB of inputs, ~108 GB of scratch in ONE block): the caching allocator must not
+    # carve its inputs out of the huge blocks earlier tests left in the cache (a split block cannot go back to the driver)
+    _lib.release_workspaces()
+    torch.cuda.empty_cache()
     g = torch.Generator(device="cuda").manual_seed(7)
     # a smooth field with plateaus (quantised) and sparse markers; smooth sub-pixel .. 2-pixel flows
     base = torch.nn.functional.avg_pool2d(torch.randn((1, 1, H // 8 + 2, W // 8 + 2), device="cuda", generator=g), 3, 1, 1)
@@ -262,7 +267,6 @@ def test_watershed_beyond_2_to_31_voxels_equals_its_halves():
     del base, fl
     nbr = neighbour_offsets(1)
     st = {}
-    from tobac_flow_amd import _lib
     try:
         whole = watershed_dev(fwd, bwd, field, markers, mask, nbr, stats=st, on_ambiguous="ignore")
         assert T * H * W > 2 ** 31 and st["sweeps"][6] > 10 ** 8          # relevant pixels: a real flood

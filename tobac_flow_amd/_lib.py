@@ -237,7 +237,16 @@ def workspace(nbytes, tag="default"):
         # the scratch is ONE block: free memory that the caching allocator holds in fragments cannot serve it.
         # Hand the cache back to the driver once and try again (slow -- seconds for > 100 GB -- hence only here)
         t.cuda.empty_cache()
-        cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
+        try:
+            cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
+        except t.OutOfMemoryError:
+            # last resort: the scratch of the OTHER stages of this (device, stream) -- tens of GB that sit idle between their
+            # calls (the Farneback workspace of an earlier create_flow) -- goes back as well; they grow again on their next use
+            with _WS_LOCK:
+                for k in [k for k in _WS if k[1] == key[1] and k[2] == key[2] and k != key]:
+                    del _WS[k]
+            t.cuda.empty_cache()
+            cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
     with _WS_LOCK:
         _WS[key] = cur
     return cur
