@@ -267,8 +267,11 @@ def main():
                          "(roofline = null); the difference to a default run is what the instrumentation costs")
     a = ap.parse_args()
     if a.stream_windows and CONFIGS[a.config][4] == 1:
-        # floods in flight beside the flow need ~12 GB each: leave room (21 pairs per Farneback batch at 5424^2 instead of 42: +3 % flow time)
-        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", "60")
+        # floods in flight beside the flow need ~12 GB each: leave room.  82 GB hold the full-size Farneback scratch of 21 pairs
+        # at 5424^2 (+ the batch's frames and raw vectors); with TF_FLOW_SPLIT=2 a batch still has 42 pairs at the coarse
+        # pyramid levels, where 21 would leave the iteration kernel's launches half empty (tf_farneback_batch_split)
+        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", "82")
+        os.environ.setdefault("TF_FLOW_SPLIT", "2")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
 
@@ -441,7 +444,7 @@ def main():
         # scratch is busy): TF_FLOW_WORKSPACE_GB is lowered to make room (set below, before the first create_flow).
         first = None
         if stream:
-            n_fly = int(max(1, min(a.inflight, len(bounds), 6)))
+            n_fly = int(max(1, min(a.inflight, len(bounds), 5)))
             first = Windows(bt, 0, [None] * n_fly, n_fly)
             inflight["n"] = n_fly
             if side_stream[0] is None:
@@ -487,7 +490,7 @@ def main():
             first = None
             # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
             mark("all windows finished")
-            out = stitch_rank_windows(wins, overlap=a.overlap) if (len(wins) > 1 or world > 1) else wins
+            out = stitch_rank_windows(wins, overlap=a.overlap, inplace=True) if (len(wins) > 1 or world > 1) else wins
             mark("stitched")
             del wins
             n_obj = int(max(int(w.max()) for w in out))
@@ -636,6 +639,7 @@ def main():
                           "objects_after_stitch": n_objects[0] if len(n_objects) == 1 else n_objects,
                           "objects_after_stitch_per_step": objects_per_step},
                "rate_over_computed_window_frames_Mpix_s": round(world * a.steps * frames_computed * H * W / dt / 1e6, 2),
+               "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
                "roofline": roof}
         # which watershed schedule the timed windows ran: stats[5] = 1 / 0 probe (speculative root phase + conflict test,
         # conflict found / not found), -1 = root phase skipped on the conflict memo of watershed.py (identical labels)

@@ -108,6 +108,16 @@ int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B, int6
                        int64_t H, int64_t W, const tf_farneback_params *p,
                        float *flow_fwd, float *flow_bwd, int64_t flow_stride,
                        void *ws, size_t ws_bytes, void *stream);
+/* tf_farneback_batch_split (round 4): the same batch with the pyramid levels >= 2 run for all B pairs at once and the two
+ * finest levels in `parts` parts of ceil(B / parts) pairs -- full-size scratch for one part only
+ * (tf_farneback_workspace_bytes_split), so a scratch budget that holds 21 full-size pairs still fills the coarse levels'
+ * launches with 42.  Same kernels on the same data: results identical to tf_farneback_batch (parts = 1 is that call).
+ * Needs pyr_scale = 0.5 (otherwise, and with fewer than three levels, it runs unsplit). */
+size_t tf_farneback_workspace_bytes_split(int64_t B, int64_t parts, int64_t H, int64_t W, const tf_farneback_params *p);
+int tf_farneback_batch_split(const uint8_t *prev, const uint8_t *next, int64_t B, int64_t parts, int64_t img_stride,
+                             int64_t H, int64_t W, const tf_farneback_params *p,
+                             float *flow_fwd, float *flow_bwd, int64_t flow_stride,
+                             void *ws, size_t ws_bytes, void *stream);
 
 /* ---- a5 tail / section 8f-1: variational refinement of one flow field -------------------------------------
  * replaces cv2.VariationalRefinement.create().calc(I0, I1, flow) as tobac_flow/flow.py:359 creates it and
@@ -133,6 +143,10 @@ int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const 
  *   arithmetic of OpenCV's variational_refinement.cpp as restated in oracle/c/varref.c, but stays within the 1e-4 px the
  *   flow is specified to (given the same input flow).  The default (flags = 0) evaluates every expression as written. */
 #define TF_VR_FAST_DIVIDE 1
+/* TF_VR_FAST_SOR (round 4): the reciprocal-multiply form in the SOR sweeps only (one hardware reciprocal of A11 / A22 per
+ * pixel and fixed-point iteration, a multiplication per update instead of a correctly rounded division); the system
+ * assembly keeps its correctly rounded divisions and square roots. */
+#define TF_VR_FAST_SOR 2
 int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
                  float *flow, int flags, void *ws, size_t ws_bytes, void *stream);
 

@@ -403,3 +403,24 @@ def test_two_host_threads_on_two_streams_do_not_disturb_each_other():
     for k in range(2):
         for got, want in zip(results[k], alone[k]):
             assert torch.equal(torch.nan_to_num(got.float(), nan=-7.0), torch.nan_to_num(want.float(), nan=-7.0)), k
+
+
+@pytest.mark.parametrize("B,parts", [(6, 2), (7, 3), (2, 2)])
+def test_farneback_split_batch_equals_the_unsplit_one(B, parts):
+    """tf_farneback_batch_split (round 4): the pyramid levels >= 2 for all B pairs at once, the two finest levels in parts --
+    the same kernels on the same data, so the flows are those of tf_farneback_batch bit for bit (uneven last part,
+    part of one pair, and an odd frame size whose levels do not halve exactly)."""
+    import torch
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow
+    rng = np.random.default_rng(31 + B)
+    H, W = 203, 331
+    frames = torch.from_numpy((rng.random((B + 1, H, W)) * 255).astype(np.uint8)).cuda()
+    frames[1:] = (frames[:-1].float() * 0.7 + frames[1:].float() * 0.3).to(torch.uint8)        # some frame-to-frame coherence
+    prev, nxt = frames[:-1].contiguous(), frames[1:].contiguous()
+    m = FarnebackFlow()
+    f0, b0 = torch.empty((B, H, W, 2), device="cuda"), torch.empty((B, H, W, 2), device="cuda")
+    f1, b1 = torch.empty_like(f0), torch.empty_like(b0)
+    m.calc_batch_dev(prev, nxt, f0, b0)
+    m.calc_batch_dev(prev, nxt, f1, b1, parts=parts)
+    assert torch.equal(f0, f1) and torch.equal(b0, b1)
+    assert float(f0.abs().max()) > 0

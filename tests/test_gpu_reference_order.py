@@ -103,8 +103,11 @@ def test_reference_order_costs_nothing_when_no_tie_matters(tf, golden_ws):
     import torch
     from tobac_flow_amd import _lib
     from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    from tobac_flow_amd import watershed as W
     c = golden_ws["A_cont_c1"]
     st = {}
+    with W._MEMO_LOCK:
+        W._tie_memo.clear()       # no guessed tie value left by an earlier flood of this shape (a guess starts the export, and a replay, regardless)
     lab = watershed_dev(_lib.to_dev(c["fwd"], torch.float32), _lib.to_dev(c["bwd"], torch.float32), _lib.to_dev(c["field"], torch.float32),
                         _lib.to_dev(c["markers"], torch.int32), None, neighbour_offsets(int(c["conn"])), stats=st, on_ambiguous="reference")
     assert st["reference_order"] == {"replayed_pops": 0, "seeds": 0, "microseconds": 0}

@@ -1178,48 +1178,58 @@ extern "C" size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_fa
     return tf_farneback_workspace_bytes_batch(1, H, W, p);
 }
 
-extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B64, int64_t img_stride,
-                                  int64_t H64, int64_t W64, const tf_farneback_params *p,
-                                  float *flow_fwd, float *flow_bwd, int64_t flow_stride,
-                                  void *ws, size_t ws_bytes, void *stream)
-{
-    TF_REQUIRE(prev && next && p && ws, "tf_farneback: null pointer");
-    TF_REQUIRE(flow_fwd || flow_bwd, "tf_farneback: both outputs are NULL");
-    TF_REQUIRE(B64 >= 1 && B64 <= 1024, "tf_farneback: bad batch size");
-    TF_REQUIRE(H64 > 0 && W64 > 0 && H64 < (1 << 15) && W64 < (1 << 15), "tf_farneback: bad shape");
-    TF_REQUIRE(img_stride >= H64 * W64 && flow_stride >= H64 * W64 * 2, "tf_farneback: strides smaller than one frame");
-    TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= FB_MAX_POLY_N, "tf_farneback: poly_n out of range");
-    TF_REQUIRE(p->win_size >= 1 && p->win_size / 2 <= FB_MAX_M, "tf_farneback: win_size out of range");
-    TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback: bad params");
-    if (ws_bytes < tf_farneback_workspace_bytes_batch(B64, H64, W64, p)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
-    const int H = (int)H64, W = (int)W64, B = (int)B64;
-    hipStream_t s = (hipStream_t)stream;
-    const size_t n = (size_t)H * W;
-    // every scratch array holds B items back to back; bs_* = items' stride in floats
-    TfArena ar(ws, ws_bytes);
-    const int64_t bs_tmp = (int64_t)tf_align_up(n + 2 * (size_t)H + 64, 64), bs_n = (int64_t)tf_align_up(n, 64);
-    const int64_t bs_R = 5 * bs_n, bs_f = (int64_t)tf_align_up(2 * n, 64);
-    float *tmp = ar.take<float>(bs_tmp * B), *blur = ar.take<float>(bs_n * B), *I = ar.take<float>(bs_n * B);
-    float *R[2] = {ar.take<float>(bs_R * B), ar.take<float>(bs_R * B)};
-    float *M = p->win_size == FBI_WIN ? nullptr : ar.take<float>(bs_R * B);      // unfused fallback only
-    float *fbuf[2] = {ar.take<float>(bs_f * B), ar.take<float>(bs_f * B)};
-    if (!ar.ok()) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+// scratch of one phase: every array holds B items back to back; bs_* = the items' stride in floats
+struct FbScratch { float *tmp, *blur, *I, *R[2], *M, *fbuf[2]; int64_t bs_tmp, bs_n, bs_R, bs_f; };
+static size_t fb_scratch_floats(size_t tmp_floats, size_t plane, bool fused) {
+    return tf_align_up(tmp_floats, 64) + 2 * tf_align_up(plane, 64) + (fused ? 10 : 15) * tf_align_up(plane, 64) + 2 * tf_align_up(2 * plane, 64);
+}
+static bool fb_carve(TfArena &ar, int B, size_t tmp_floats, size_t plane, bool fused, FbScratch *S) {
+    S->bs_tmp = (int64_t)tf_align_up(tmp_floats, 64); S->bs_n = (int64_t)tf_align_up(plane, 64);
+    S->bs_R = 5 * S->bs_n; S->bs_f = (int64_t)tf_align_up(2 * plane, 64);
+    S->tmp = ar.take<float>(S->bs_tmp * B); S->blur = ar.take<float>(S->bs_n * B); S->I = ar.take<float>(S->bs_n * B);
+    S->R[0] = ar.take<float>(S->bs_R * B); S->R[1] = ar.take<float>(S->bs_R * B);
+    S->M = fused ? nullptr : ar.take<float>(S->bs_R * B);          // unfused fallback only
+    S->fbuf[0] = ar.take<float>(S->bs_f * B); S->fbuf[1] = ar.take<float>(S->bs_f * B);
+    return ar.ok();
+}
+// level k's image size and the largest plane / row-blur scratch among the levels k_lo .. k_hi
+static void fb_level_size(int H, int W, const tf_farneback_params *p, int k, int *h, int *w) {
+    double scale = 1; for (int i = 0; i < k; i++) scale *= p->pyr_scale;
+    *w = (int)lrint(W * scale); *h = (int)lrint(H * scale);
+}
+static void fb_phase_sizes(int H, int W, const tf_farneback_params *p, int k_hi, int k_lo, size_t *tmp_floats, size_t *plane) {
+    size_t t = 0, pl = 0;
+    for (int k = k_lo; k <= k_hi; k++) {
+        int h, w; fb_level_size(H, W, p, k, &h, &w);
+        pl = std::max(pl, (size_t)h * w);
+        // the two-pass blur of a full-size level keeps a whole image (+ rows), the sampled blur H rows of w float2
+        t = std::max(t, k == 0 ? (size_t)H * W + 2 * (size_t)H + 64 : std::max((size_t)H * W / 4 + 2 * (size_t)H + 64, 2 * (size_t)H * w + 64));
+    }
+    if (k_lo == 0) t = std::max(t, (size_t)H * W + 2 * (size_t)H + 64);
+    *tmp_floats = t; *plane = pl;
+}
 
-    FbPoly pp; fb_prepare_poly(p->poly_n, p->poly_sigma, &pp);
-    const int levels = fb_levels(H, W, p);
+// pyramid levels k_hi .. k_lo for B pairs (pointers at the first pair of the range); cur / pw / ph carry the state of the
+// levels above over to the next call
+static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_t img_stride, int H, int W, const tf_farneback_params *p,
+                         float *const out[2], int64_t flow_stride, const FbScratch &S, int k_hi, int k_lo, int cur[2], int *pw_io, int *ph_io,
+                         const FbPoly &pp, hipStream_t s)
+{
+    const size_t n = (size_t)H * W;
+    float *tmp = S.tmp, *blur = S.blur, *I = S.I, *M = S.M;
+    float *const R[2] = {S.R[0], S.R[1]};
+    const int64_t bs_tmp = S.bs_tmp, bs_n = S.bs_n, bs_R = S.bs_R;
     const uint8_t *img[2] = {prev, next};
-    float *out[2] = {flow_fwd, flow_bwd};
     int nd = 0, dirs[2];
     for (int d = 0; d < 2; d++) if (out[d]) dirs[nd++] = d;
     // per direction two ping-pong slots: slot 0 = the caller's output (stride flow_stride), slot 1 = scratch
     float *slot[2][2]; int64_t slot_bs[2][2];
-    for (int d = 0; d < 2; d++) { slot[d][0] = out[d]; slot_bs[d][0] = flow_stride; slot[d][1] = fbuf[d]; slot_bs[d][1] = bs_f; }
-    int cur[2] = {-1, -1};                       // slot index that holds the current flow of direction d
-    int pw = 0, ph = 0;
+    for (int d = 0; d < 2; d++) { slot[d][0] = out[d]; slot_bs[d][0] = flow_stride; slot[d][1] = S.fbuf[d]; slot_bs[d][1] = S.bs_f; }
+    int pw = *pw_io, ph = *ph_io;
     const dim3 block(64, 4);
     const dim3 gfull((W + 63) / 64, (H + 3) / 4, B);
     const bool fused = p->win_size == FBI_WIN;
-    for (int k = levels; k >= 0; k--) {
+    for (int k = k_hi; k >= k_lo; k--) {
         double scale = 1; for (int i = 0; i < k; i++) scale *= p->pyr_scale;
         const double sigma = (1. / scale - 1) * 0.5;
         int smooth_sz = (int)lrint(sigma * 5) | 1; if (smooth_sz < 3) smooth_sz = 3;
@@ -1361,9 +1371,99 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
         }
         pw = w; ph = h;
     }
-    for (int q = 0; q < nd; q++)
-        if (cur[dirs[q]] != 0) { tf_set_error("tf_farneback: internal slot parity error"); return TF_EINVAL; }
+    *pw_io = pw; *ph_io = ph;
     return TF_OK;
+}
+
+// levels >= FB_SPLIT_LEVEL of a split batch run for all its pairs at once, the finer ones in parts
+#define FB_SPLIT_LEVEL 2
+extern "C" size_t tf_farneback_workspace_bytes_split(int64_t B, int64_t parts, int64_t H, int64_t W, const tf_farneback_params *p)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || !p) return 0;
+    const int levels = fb_levels(H, W, p);
+    const bool fused = p->win_size == FBI_WIN;
+    if (parts <= 1 || levels < FB_SPLIT_LEVEL || B < 2 || p->pyr_scale != 0.5) return tf_farneback_workspace_bytes_batch(B, H, W, p);
+    if (parts > B) parts = B;
+    size_t t = 0, pl = 0;
+    fb_phase_sizes((int)H, (int)W, p, levels, FB_SPLIT_LEVEL, &t, &pl);
+    const size_t coarse = (size_t)B * fb_scratch_floats(t, pl, fused) * sizeof(float) + 8192;
+    const size_t fine = tf_farneback_workspace_bytes_batch((B + parts - 1) / parts, H, W, p);
+    return coarse > fine ? coarse : fine;
+}
+
+extern "C" int tf_farneback_batch_split(const uint8_t *prev, const uint8_t *next, int64_t B64, int64_t parts64, int64_t img_stride,
+                                        int64_t H64, int64_t W64, const tf_farneback_params *p,
+                                        float *flow_fwd, float *flow_bwd, int64_t flow_stride,
+                                        void *ws, size_t ws_bytes, void *stream)
+{
+    TF_REQUIRE(prev && next && p && ws, "tf_farneback: null pointer");
+    TF_REQUIRE(flow_fwd || flow_bwd, "tf_farneback: both outputs are NULL");
+    TF_REQUIRE(B64 >= 1 && B64 <= 1024 && parts64 >= 1, "tf_farneback: bad batch size");
+    TF_REQUIRE(H64 > 0 && W64 > 0 && H64 < (1 << 15) && W64 < (1 << 15), "tf_farneback: bad shape");
+    TF_REQUIRE(img_stride >= H64 * W64 && flow_stride >= H64 * W64 * 2, "tf_farneback: strides smaller than one frame");
+    TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= FB_MAX_POLY_N, "tf_farneback: poly_n out of range");
+    TF_REQUIRE(p->win_size >= 1 && p->win_size / 2 <= FB_MAX_M, "tf_farneback: win_size out of range");
+    TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback: bad params");
+    if (ws_bytes < tf_farneback_workspace_bytes_split(B64, parts64, H64, W64, p)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+    const int H = (int)H64, W = (int)W64, B = (int)B64;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = p->win_size == FBI_WIN;
+    FbPoly pp; fb_prepare_poly(p->poly_n, p->poly_sigma, &pp);
+    const int levels = fb_levels(H, W, p);
+    float *const out[2] = {flow_fwd, flow_bwd};
+    int cur[2] = {-1, -1};                       // slot index that holds the current flow of direction d
+    int pw = 0, ph = 0;
+    int parts = (int)(parts64 > B ? B : parts64);
+    if (levels < FB_SPLIT_LEVEL || B < 2 || p->pyr_scale != 0.5) parts = 1;     // (only then is every coarse level a sampled blur: no full-size plane)
+    if (parts == 1) {
+        TfArena ar(ws, ws_bytes);
+        FbScratch S;
+        if (!fb_carve(ar, B, (size_t)H * W + 2 * (size_t)H + 64, (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+        const int rc = fb_run_levels(prev, next, B, img_stride, H, W, p, out, flow_stride, S, levels, 0, cur, &pw, &ph, pp, s);
+        if (rc) return rc;
+    } else {
+        // SPLIT BATCH (round 4).  A launch of the iteration kernel costs whole rounds of resident workgroups; at the coarse
+        // levels a round holds the strips of ~40 pairs, at full resolution those of ~10 -- but the scratch of a pair is sized by
+        // its full-resolution planes.  So the levels >= 2 run for ALL pairs of the batch at once, with scratch strides of the
+        // level-2 plane (1 / 16 of a full one), and leave their flow in the caller's output frames; the two finest levels then
+        // run part by part on full-size scratch for B / parts pairs.  Same kernels on the same data: the results are those
+        // of the unsplit batch.  (Every level flips the ping-pong slot num_iters + 1 times, and two levels remain: the flow
+        // of level 2 is in slot 0, the caller's buffer, whatever the parity of num_iters.)
+        {
+            size_t t = 0, pl = 0;
+            fb_phase_sizes(H, W, p, levels, FB_SPLIT_LEVEL, &t, &pl);
+            TfArena ar(ws, ws_bytes);
+            FbScratch S;
+            if (!fb_carve(ar, B, t, pl, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+            const int rc = fb_run_levels(prev, next, B, img_stride, H, W, p, out, flow_stride, S, levels, FB_SPLIT_LEVEL, cur, &pw, &ph, pp, s);
+            if (rc) return rc;
+            for (int d = 0; d < 2; d++) if (out[d] && cur[d] != 0) { tf_set_error("tf_farneback: internal slot parity error (split)"); return TF_EINVAL; }
+        }
+        const int per = (B + parts - 1) / parts;
+        for (int b0 = 0; b0 < B; b0 += per) {
+            const int Bp = B - b0 < per ? B - b0 : per;
+            TfArena ar(ws, ws_bytes);                                 // (the coarse phase's scratch is dead: stream order)
+            FbScratch S;
+            if (!fb_carve(ar, Bp, (size_t)H * W + 2 * (size_t)H + 64, (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+            float *const outp[2] = {flow_fwd ? flow_fwd + (int64_t)b0 * flow_stride : nullptr, flow_bwd ? flow_bwd + (int64_t)b0 * flow_stride : nullptr};
+            int curp[2] = {cur[0], cur[1]}, pwp = pw, php = ph;
+            const int rc = fb_run_levels(prev + (int64_t)b0 * img_stride, next + (int64_t)b0 * img_stride, Bp, img_stride, H, W, p, outp, flow_stride, S,
+                                         FB_SPLIT_LEVEL - 1, 0, curp, &pwp, &php, pp, s);
+            if (rc) return rc;
+            if (b0 + per >= B) { cur[0] = curp[0]; cur[1] = curp[1]; }
+        }
+    }
+    for (int d = 0; d < 2; d++)
+        if (out[d] && cur[d] != 0) { tf_set_error("tf_farneback: internal slot parity error"); return TF_EINVAL; }
+    return TF_OK;
+}
+
+extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B64, int64_t img_stride,
+                                  int64_t H64, int64_t W64, const tf_farneback_params *p,
+                                  float *flow_fwd, float *flow_bwd, int64_t flow_stride,
+                                  void *ws, size_t ws_bytes, void *stream)
+{
+    return tf_farneback_batch_split(prev, next, B64, 1, img_stride, H64, W64, p, flow_fwd, flow_bwd, flow_stride, ws, ws_bytes, stream);
 }
 
 extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H, int64_t W,

@@ -497,8 +497,9 @@ extern "C" size_t tf_varref_workspace_bytes(int64_t H, int64_t W)
 extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
                             float *flow, int flags, void *ws, size_t ws_bytes, void *stream)
 {
-    TF_REQUIRE((flags & ~TF_VR_FAST_DIVIDE) == 0, "tf_varref_ex: unknown flag");
-    const bool fast = (flags & TF_VR_FAST_DIVIDE) != 0;
+    TF_REQUIRE((flags & ~(TF_VR_FAST_DIVIDE | TF_VR_FAST_SOR)) == 0, "tf_varref_ex: unknown flag");
+    const bool fast = (flags & TF_VR_FAST_DIVIDE) != 0;                  // system assembly AND the sweeps
+    const bool fast_sor = fast || (flags & TF_VR_FAST_SOR) != 0;        // the sweeps only
     TF_REQUIRE(I0 && I1 && flow && ws, "tf_varref: null pointer");
     TF_REQUIRE(H > 0 && W > 0 && H < 32768 && W < 32768, "tf_varref: bad shape");
     tf_varref_params dp;
@@ -566,7 +567,7 @@ extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int
             const bool last = it == params->fixed_point_iterations - 1;
             TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + (dW_cur ? 8.0 : 0.0) + (last ? 8.0 : 0.0) + 8.0) * (double)n, s);
             float2 *dst = last ? (float2 *)flow : (dW_cur == dW ? dW2 : dW);
-            if (fast)
+            if (fast_sor)
                 hipLaunchKernelGGL(k_vr_sor_tile<true>, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
                                    VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
                                    2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);

@@ -214,6 +214,8 @@ class VariationalRefinement:
         # not in OpenCV: True = hardware reciprocals instead of correctly rounded divisions / square roots
         # (TF_VR_FAST_DIVIDE, include/tobac_flow_hip.h: within 1e-4 px of the default, ~25 % faster); default False
         self.fastDivide = os.environ.get("TF_VR_FAST_DIVIDE", "0") == "1"
+        # ... in the SOR sweeps only (TF_VR_FAST_SOR: the system assembly keeps its correctly rounded divisions)
+        self.fastSor = os.environ.get("TF_VR_FAST_SOR", "0") == "1"
 
     @classmethod
     def create(cls):
@@ -231,7 +233,7 @@ class VariationalRefinement:
         assert flow.is_contiguous() and tuple(flow.shape) == (H, W, 2)
         ws = _lib.workspace(L.tf_varref_workspace_bytes(H, W), "varref")
         p = self._params()
-        _lib.check(L.tf_varref_ex(_lib.ptr(i0), _lib.ptr(i1), H, W, ctypes.byref(p), _lib.ptr(flow), 1 if self.fastDivide else 0,
+        _lib.check(L.tf_varref_ex(_lib.ptr(i0), _lib.ptr(i1), H, W, ctypes.byref(p), _lib.ptr(flow), (1 if self.fastDivide else 0) | (2 if self.fastSor else 0),
                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "tf_varref")
         return flow
 
@@ -343,15 +345,23 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         budget = int(max(min(budget, held + 0.6 * free), 1))   # (_lib.workspace empties the allocator's cache if fragments are in the way)
         # scratch of the library + the batch's 8-bit frames and raw flow vectors (this function's own buffers)
         lib_per_pair = max(1, int(L.tf_farneback_workspace_bytes_batch(1, H, W, ctypes.byref(of_model.params))))
-        per_pair = lib_per_pair + H * W * (2 + 16)
+        # TF_FLOW_SPLIT=<parts> (default 1): a batch of B pairs runs its pyramid levels >= 2 for all pairs at once and the two
+        # finest levels in `parts` parts (tf_farneback_batch_split): full-size library scratch for B / parts pairs only, so a
+        # budget that holds the full-size scratch of 21 pairs still fills the coarse levels' launches with 42
+        split_parts = max(1, int(os.environ.get("TF_FLOW_SPLIT", "1")))
+        per_pair = lib_per_pair // split_parts + H * W * (2 + 16)
         cap = max(1, budget // per_pair)
         # the library's hint counts ITS scratch only: hand it the share of the budget that is the library's, so that both
         # sides price a pair the same way (the hint could return a batch ~25 % over the budget, which then went
         # through the halving path -- release, empty_cache, half batches for the rest of the call)
-        lib_budget = max(1, int(budget * (lib_per_pair / per_pair)))
+        lib_budget = max(1, int(budget * ((lib_per_pair // split_parts) / per_pair)))
         left = n_pairs
         while left > 0:
-            B = left if left <= cap else min(cap, max(1, int(L.tf_farneback_batch_hint(H, W, ctypes.byref(of_model.params), left, lib_budget))))
+            if left <= cap:
+                B = left
+            else:       # the hint sizes the FULL-resolution launches: B / parts pairs of them
+                b_fine = max(1, int(L.tf_farneback_batch_hint(H, W, ctypes.byref(of_model.params), -(-left // split_parts), lib_budget)))
+                B = min(cap, left, b_fine * split_parts)
             sizes.append(B)
             left -= B
     if os.environ.get("TF_FLOW_DEBUG"):
@@ -395,6 +405,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
             f, bk = _lib.empty((B, H, W, 2), t.float32), _lib.empty((B, H, W, 2), t.float32)
         return prev8, next8, f, bk
 
+    def split_parts_used(B):
+        parts = max(1, int(os.environ.get("TF_FLOW_SPLIT", "1")))
+        return parts if (hasattr(of_model, "params") and "TF_FLOW_BATCH" not in os.environ and B >= 2 * parts) else 1
+
     def run_batch(i0, B):
         if B <= 0:
             return
@@ -410,7 +424,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                 next8[b].copy_(_lib.to_dev(p8[1]))
         if smoothing_passes == 0:
             f, bk = forward[i0:i0 + B], backward[i0 + 1:i0 + 1 + B]
-        of_model.calc_batch_dev(prev8, next8, f, bk)
+        of_model.calc_batch_dev(prev8, next8, f, bk, parts=split_parts_used(B))
         if vr_steps == 0 and smoothing_passes == 0:
             return
 

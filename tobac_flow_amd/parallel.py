@@ -167,7 +167,7 @@ def _count(w):
 
 
 def stitch_window_list(windows, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=LINK_ATOL, rtol=LINK_RTOL,
-                       short_overlap_ok=False):
+                       short_overlap_ok=False, inplace=False):
     """Single-process form of stitch_labels: `windows` is a list of (T_w, H, W) int32 label tensors (CPU or GPU), the
     first `overlap` frames of window w + 1 being the last `overlap` frames of window w (e.g. a 144-frame stack processed
     as twelve windows on one GPU, window_bounds).  Returns the relabelled windows: positive ids made globally consistent
@@ -177,11 +177,11 @@ def stitch_window_list(windows, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=
         return []
     atol, rtol, sel = _rule(min_overlap, overlap, atol, rtol, short_overlap_ok)
     luts = stitch_lut([_count(w) for w in windows], _local_pairs(windows, overlap, sel, atol, rtol))
-    return [apply_global_lut(w, lut) for w, lut in zip(windows, luts)]
+    return [apply_global_lut(w, lut, inplace) for w, lut in zip(windows, luts)]
 
 
 def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=LINK_ATOL, rtol=LINK_RTOL,
-                        short_overlap_ok=False, _force_collectives=False):
+                        short_overlap_ok=False, _force_collectives=False, inplace=False):
     """Make the positive label IDs of ALL windows of ALL ranks globally consistent.
 
     windows: this rank's list of (T_w, H, W) int32 label tensors, consecutive windows sharing `overlap` frames; the
@@ -199,7 +199,7 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _force_collectives):
-        return stitch_window_list(windows, min_overlap, overlap, atol, rtol, short_overlap_ok)
+        return stitch_window_list(windows, min_overlap, overlap, atol, rtol, short_overlap_ok, inplace)
     if len(windows) and dist.get_backend(group) == "gloo" and windows[0].is_cuda:
         # gloo has no GPU collectives for these ops: stage the exchanged frames through the host
         dev = windows[0].device
@@ -264,7 +264,7 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
     pairs = [p.reshape(-1, 2) for p in np.split(triples_all[:, 1:], cuts)] if n_total > 1 else []
     all_counts = [int(v) for c in counts for v in c.tolist()]
     luts = stitch_lut(all_counts, pairs)
-    return [apply_global_lut(w, luts[first_window[rank] + k]) for k, w in enumerate(windows)]
+    return [apply_global_lut(w, luts[first_window[rank] + k], inplace) for k, w in enumerate(windows)]
 
 
 def stitch_labels(labels, group=None, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=LINK_ATOL, rtol=LINK_RTOL,
@@ -279,10 +279,12 @@ def stitch_labels(labels, group=None, min_overlap=None, overlap=DEFAULT_OVERLAP,
     return stitch_rank_windows([labels], group, min_overlap, overlap, atol, rtol, short_overlap_ok)[0]
 
 
-def apply_global_lut(labels, lut):
+def apply_global_lut(labels, lut, inplace=False):
     """labels -> lut[labels] for the positive ids, zero and negative ids kept.  GPU tensors go through the library's
     one-pass gather (tf_apply_lut: 4 B read + 4 B written per voxel; a boolean-mask update in torch would compact and
-    scatter several GB of int64 temporaries for a 12 x 5424^2 window); CPU tensors (gloo rehearsals) use torch."""
+    scatter several GB of int64 temporaries for a 12 x 5424^2 window); CPU tensors (gloo rehearsals) use torch.
+    inplace: rewrite `labels` itself (an int32 contiguous GPU tensor) instead of returning a new volume -- the twelve windows
+    of a 144 x 5424^2 stack are 23 GB, which a caller that is done with the window-local ids need not hold twice."""
     import torch
     lut = np.asarray(lut)
     if not labels.is_cuda:
@@ -294,7 +296,7 @@ def apply_global_lut(labels, lut):
     from tobac_flow_amd import _lib
     lab = labels.to(torch.int32).contiguous()
     lut_t = torch.from_numpy(np.ascontiguousarray(lut, np.int32)).to(lab.device)
-    out = torch.empty_like(lab)
+    out = lab if (inplace and lab is labels) else torch.empty_like(lab)        # (elementwise: output may alias input)
     # ids <= 0 (background seeds -1, unlabelled 0) pass through in the same pass
     _lib.check(_lib.lib().tf_apply_lut_keep_nonpositive(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut_t.numel(), _lib.ptr(out),
                                                         _lib.stream_ptr()), "tf_apply_lut_keep_nonpositive")

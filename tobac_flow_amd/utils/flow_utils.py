@@ -45,22 +45,24 @@ class FarnebackFlow:
         _lib.check(rc, "tf_farneback_pair")
         return fwd, bwd
 
-    def calc_batch_dev(self, prev, nxt, fwd_out, bwd_out, tag="farneback"):
+    def calc_batch_dev(self, prev, nxt, fwd_out, bwd_out, tag="farneback", parts=1):
         """B independent pairs at once: prev / nxt (B, H, W) uint8 device tensors; fwd_out / bwd_out are
         (B, H, W, 2) float32 device tensors (views into the big flow arrays are fine: only the batch stride
-        may differ from H*W*2)."""
+        may differ from H*W*2).  parts > 1: the pyramid levels >= 2 run for all B pairs at once, the two finest ones in
+        `parts` parts (tf_farneback_batch_split: full-size scratch for B / parts pairs only; same results)."""
         import ctypes
         L = _lib.lib()
         B, H, W = prev.shape
         assert prev.is_contiguous() and nxt.is_contiguous()
         for o in (fwd_out, bwd_out):
             assert o.shape == (B, H, W, 2) and o[0].is_contiguous() and (B == 1 or o.stride(0) >= H * W * 2)
-        nbytes = L.tf_farneback_workspace_bytes_batch(B, H, W, ctypes.byref(self.params))
+        parts = max(1, int(parts))
+        nbytes = L.tf_farneback_workspace_bytes_split(B, parts, H, W, ctypes.byref(self.params))
         ws = _lib.workspace(nbytes, tag)
         stride = fwd_out.stride(0) if B > 1 else H * W * 2
         assert B == 1 or bwd_out.stride(0) == stride
-        rc = L.tf_farneback_batch(_lib.ptr(prev), _lib.ptr(nxt), B, H * W, H, W, ctypes.byref(self.params),
-                                  _lib.ptr(fwd_out), _lib.ptr(bwd_out), stride, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        rc = L.tf_farneback_batch_split(_lib.ptr(prev), _lib.ptr(nxt), B, parts, H * W, H, W, ctypes.byref(self.params),
+                                        _lib.ptr(fwd_out), _lib.ptr(bwd_out), stride, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "tf_farneback_batch")
 
     def calc(self, prev, nxt, flow=None):
