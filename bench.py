@@ -267,11 +267,11 @@ def main():
                          "(roofline = null); the difference to a default run is what the instrumentation costs")
     a = ap.parse_args()
     if a.stream_windows and CONFIGS[a.config][4] == 1:
-        # floods in flight beside the flow need ~12 GB each: leave room.  82 GB hold the full-size Farneback scratch of 21 pairs
-        # at 5424^2 (+ the batch's frames and raw vectors); with TF_FLOW_SPLIT=2 a batch still has 42 pairs at the coarse
-        # pyramid levels, where 21 would leave the iteration kernel's launches half empty (tf_farneback_batch_split)
-        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", "82")
-        os.environ.setdefault("TF_FLOW_SPLIT", "2")
+        # floods in flight beside the flow need ~12 GB each: leave room (21 pairs per Farneback batch at 5424^2 instead of 42:
+        # +3 % flow time -- the iteration kernel's launches are half as long and pay their ramp-down twice as often; measured
+        # and not adopted: TF_FLOW_SPLIT=2 with 82 GB, 42 pairs at the coarse pyramid levels and 2 x 21 at the two finest:
+        # the same iteration time as plain 21-pair batches, and half as many points at which windows can begin)
+        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", "60")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
 
