@@ -250,6 +250,8 @@ def main():
     ap.add_argument("--no-stream-windows", dest="stream_windows", action="store_false",
                     help="begin the windows only after the whole stack's flow (default: a window is begun as soon as the flow batch "
                          "with its last frame pair is enqueued, so that its host replay overlaps the later batches' flow; one channel only)")
+    ap.add_argument("--chain-depth", type=int, default=3,
+                    help="tie-break levels the floods start with (the library deepens on its own where ties remain; scheduling only)")
     ap.add_argument("--rotate", type=int, default=3,
                     help="the timed steps visit this many different T-frame stacks of the synthetic sequence in turn (offsets "
                          "0, s, 2s, ... frames with s = --rotate-shift), all resident before the timed region: the data-dependent "
@@ -346,8 +348,8 @@ def main():
         fw, bw = flow._dev_flows()
         st = {}
         mark("begin: seeds + edge field enqueued")
-        job = watershed_begin(fw, bw, e, seeds, None, nbr, stats=st, on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore",
-                              workspace=scratch)
+        job = watershed_begin(fw, bw, e, seeds, None, nbr, a.chain_depth, stats=st,
+                              on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore", workspace=scratch)
         mark("begin: done (replay %s)" % ("submitted" if job.needs_replay else "none"))
         fut = replay_pool.submit(job.replay) if job.needs_replay else None
         return job, fut, st, scratch
