@@ -227,7 +227,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="F", help="BASELINE.json configuration (default F = the metric's)")
     ap.add_argument("--frames", type=int, default=None, help="frames of the stack per GPU per step (default: the config's)")
     ap.add_argument("--n-windows", type=int, default=None, help="time windows the stack is processed in (default: the config's)")
