@@ -445,6 +445,11 @@ def main():
         # NEXT batches' flow, not after the whole stack's.  The floods in flight then need scratch of their own (the Farneback
         # scratch is busy): TF_FLOW_WORKSPACE_GB is lowered to make room (set below, before the first create_flow).
         first = None
+        if not stream and T * H * W * (1 + 4 + C) * 4 > 0.6 * torch.cuda.mem_get_info()[1]:
+            # a stack that takes most of the device: the flood slots of the previous step go back to the allocator's cache before
+            # the flow is sized (held, they cost the Farneback batches a third of their pairs); the floods take them again afterwards
+            for k in range(64):
+                _lib.release_workspaces("watershed_job%d" % k)
         if stream:
             n_fly = int(max(1, min(a.inflight, len(bounds), 5)))
             first = Windows(bt, 0, [None] * n_fly, n_fly)
@@ -468,8 +473,9 @@ def main():
             _lib.release_workspaces("farneback")
             flow_released = True
         objects, out = [], None
+        wq = None
         for c in range(C):                                   # channels one after the other: one channel's labels resident
-            out = None
+            out = wq = None                                  # (the previous channel's windows go before this one's floods are sized)
             if first is not None:
                 wq = first
             else:
@@ -482,8 +488,14 @@ def main():
                     piece = fb.numel() // n_fly // 256 * 256
                     pieces = [fb[k * piece:(k + 1) * piece] for k in range(n_fly)]
                 else:
+                    # no scratch to borrow (released above): every flood in flight allocates ~8 GB + its field and seeds; the
+                    # labels of the channel (4 B per window voxel, rewritten in place by the stitch) still have to fit beside them
                     free = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
-                    n_fly = int(max(1, min(a.inflight, len(bounds), 0.3 * free // (per_job + 4 * per_job // 18))))
+                    held = sum(int(v.numel()) for k, v in list(_lib._WS.items()) if v is not None and k[0].startswith("watershed_job"))
+                    # (a flood in flight: scratch + field + seeds ~ 1.5 x the scratch; one window's transients: ~1.5 x more)
+                    room = 0.85 * (free + held - 4 * sum(hi - lo for lo, hi in bounds) * H * W - 3 * per_job // 2)
+                    n_fly = int(max(1, min(a.inflight, len(bounds), room // (3 * per_job // 2))))
+                    mark("floods in flight: %d (free %.1f GB, flood slots held %.1f GB)" % (n_fly, free / 1e9, held / 1e9))
                     pieces = [None] * n_fly
                 inflight["n"] = n_fly
                 wq = Windows(bt, c, pieces, n_fly)
