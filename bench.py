@@ -493,7 +493,7 @@ def main():
                     free = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
                     held = sum(int(v.numel()) for k, v in list(_lib._WS.items()) if v is not None and k[0].startswith("watershed_job"))
                     # (a flood in flight: scratch + field + seeds ~ 1.5 x the scratch; one window's transients: ~1.5 x more)
-                    room = 0.85 * (free + held - 4 * sum(hi - lo for lo, hi in bounds) * H * W - 3 * per_job // 2)
+                    room = 0.75 * (free + held - 4 * sum(hi - lo for lo, hi in bounds) * H * W - 3 * per_job // 2)
                     n_fly = int(max(1, min(a.inflight, len(bounds), room // (3 * per_job // 2))))
                     mark("floods in flight: %d (free %.1f GB, flood slots held %.1f GB)" % (n_fly, free / 1e9, held / 1e9))
                     pieces = [None] * n_fly
