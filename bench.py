@@ -150,14 +150,14 @@ def cpu_baseline(seed, vr_steps=1):
 
 
 def cv2_parity(seed=20240601):
-    """SURVEY.md section 7 hard part 2 / section 8d: Farneback and remap values are pinned only where OpenCV exists.  If
-    this box has cv2 with the optflow module, compare the library with it on one synthetic frame pair and report the
-    largest differences; otherwise say so."""
+    """SURVEY.md section 7 hard part 2 / section 8d: Farneback, refinement and remap values are pinned only where OpenCV exists.
+    Whatever part of it this box has is compared with the library on one synthetic frame pair: cv2.optflow (contrib) for
+    Farneback, cv2.VariationalRefinement (the main `video` module: checked independently of optflow, ADVICE r3) and cv2.remap;
+    otherwise the status says so."""
     try:
         import cv2
-        cv2.optflow.createOptFlow_Farneback
-    except Exception as e:                                   # ImportError, or a cv2 build without contrib modules
-        return {"status": "parity unpinned", "reason": f"cv2.optflow unavailable on this box ({type(e).__name__})"}
+    except Exception as e:                                   # ImportError on this image
+        return {"status": "parity unpinned", "reason": f"cv2 unavailable on this box ({type(e).__name__})"}
     import numpy as np
     from tobac_flow_amd.utils.flow_utils import FarnebackFlow, warp_flow
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -166,9 +166,16 @@ def cv2_parity(seed=20240601):
     bt = blob_sequence(rng, 2, 768, 1024, n_blobs=24)
     lo, hi = np.nanmin(bt), np.nanmax(bt)
     p8 = np.clip((bt - lo) / (hi - lo) * 255, 0, 255).astype(np.uint8)
-    ref = cv2.optflow.createOptFlow_Farneback().calc(p8[0], p8[1], None)
     got = FarnebackFlow().calc(p8[0], p8[1], None)
-    out = {"status": "pinned", "cv2": cv2.__version__, "farneback_max_abs_diff": float(np.abs(ref - got).max())}
+    out = {"status": "pinned", "cv2": cv2.__version__}
+    try:
+        ref = cv2.optflow.createOptFlow_Farneback().calc(p8[0], p8[1], None)
+        out["farneback_max_abs_diff"] = float(np.abs(ref - got).max())
+    except Exception as e:                                   # a cv2 build without the contrib modules
+        ref = got                                            # the other comparisons take the library's own vectors as their input
+        out["status"] = "partly pinned"
+        out["farneback_max_abs_diff"] = None
+        out["farneback_reason"] = f"cv2.optflow unavailable ({type(e).__name__})"
     img = bt[0].astype(np.float32)
     locs = ref.copy()                                        # the map as utils/flow_utils.py:84-87 builds it
     locs[:, :, 0] += np.arange(img.shape[1])
@@ -180,15 +187,20 @@ def cv2_parity(seed=20240601):
         both = np.isfinite(want) & np.isfinite(have)
         out[f"remap_{name}_max_abs_diff"] = float(np.abs(want - have)[both].max())
         out[f"remap_{name}_nan_mask_equal"] = bool(np.array_equal(np.isnan(want), np.isnan(have)))
-    # cv2.VariationalRefinement (flow.py:359, 513-519; ADVICE r2): the same refinement of the same input flow
-    if hasattr(cv2, "VariationalRefinement"):
+    # cv2.VariationalRefinement (flow.py:359, 513-519): the same refinement of the same input flow
+    vr = getattr(cv2, "VariationalRefinement", None) or getattr(getattr(cv2, "optflow", None), "VariationalRefinement", None)
+    if vr is not None:
         from tobac_flow_amd.flow import VariationalRefinement
-        want = cv2.VariationalRefinement.create().calc(p8[0], p8[1], ref.copy())
+        want = (vr.create() if hasattr(vr, "create") else vr_create(cv2)).calc(p8[0], p8[1], ref.copy())
         have = VariationalRefinement.create().calc(p8[0], p8[1], ref.copy())
         out["varref_max_abs_diff"] = float(np.abs(np.asarray(want) - np.asarray(have)).max())
     else:
         out["varref_max_abs_diff"] = None
     return out
+
+
+def vr_create(cv2):
+    return cv2.VariationalRefinement_create()
 
 
 def launch_ranks(a):
