@@ -191,11 +191,11 @@ def test_a_batch_that_does_not_fit_is_halved_and_the_flow_is_the_same(monkeypatc
     refused = []
     real = FarnebackFlow.calc_batch_dev
 
-    def picky(self, prev, nxt, fwd_out, bwd_out, tag="farneback"):
+    def picky(self, prev, nxt, fwd_out, bwd_out, tag="farneback", parts=1):
         if prev.shape[0] > 2:
             refused.append(int(prev.shape[0]))
             raise torch.OutOfMemoryError("simulated: scratch for %d pairs does not fit" % prev.shape[0])
-        return real(self, prev, nxt, fwd_out, bwd_out, tag)
+        return real(self, prev, nxt, fwd_out, bwd_out, tag, parts)
 
     monkeypatch.setattr(FarnebackFlow, "calc_batch_dev", picky)
     got = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
