@@ -639,3 +639,20 @@ def test_anvil_inputs_blocked_path_equals_the_single_block(monkeypatch):
     monkeypatch.setattr(synth, "_TORCH_INDEX_LIMIT", 4 * 22 * 26)                   # not even one frame + halo + padding
     with pytest.raises(ValueError):
         synth.anvil_inputs(bt)
+
+
+def test_the_three_host_replays_of_the_reference_heap_agree(tmp_path):
+    """csrc/ws_replay.h is pure C++ (the host half of TF_WS_REFERENCE_ORDER): tools/replay_check builds it with g++ and runs
+    the plain form (every item as the reference keeps it, _watershed.pyx:67-152), the sparse form and the dense form (from
+    8-byte entries and from the device's 2-bit codes) on random instances with few distinct values -- equal-valued seeds,
+    floods from below and inside the tie value, runs of ballast seeds, small items at the end of the array -- and compares
+    pop counts and every marker's rank.  (On the GPU the same three run behind one flood: tests/test_gpu_reference_order.py.)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "replay_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-o", str(exe), os.path.join(ROOT, "tools", "replay_check", "replay_check.cpp")])
+    for seed in ("101", "202"):
+        out = subprocess.run([str(exe), "random", "4000", seed], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "plain == sparse == dense" in out.stdout, out.stdout + out.stderr
