@@ -39,3 +39,32 @@ def test_two_ranks_on_one_device_equal_the_one_process_run():
     assert two["config"]["objects_after_stitch"] == one["config"]["objects_after_stitch"] > 10
     # whole-job value: both ranks' frames over the slower rank's time
     assert two["value"] > 0 and abs(two["value"] - 2 * 24 * 1500 * 2500 / (two["ms_per_step"] * 1e-3) / 1e6) < 0.02 * two["value"]
+
+
+def test_bench_pipeline_equals_the_plain_calls():
+    """bench.py's step -- windows begun from create_flow's callback while the later frames' flow is computed, floods in parts
+    with their replays on worker threads, finished on a second stream, stitched in place -- against the same stack processed
+    with the plain calls one after the other (create_flow, Flow.window, seeds, edge field, Flow.watershed, stitch_window_list):
+    the same number of objects after the stitch, for the streaming and the non-streaming schedule."""
+    import numpy as np
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.parallel import stitch_window_list, window_bounds
+    from tools.synth import anvil_seeds, blob_stack
+    T, H, W, n_win, overlap = 44, 1500, 2500, 4, 4
+    bt = blob_stack(T, H, W, seed=20240601, t0=0)
+    flow = tf.create_flow(bt, model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    labs = []
+    for a, b in window_bounds(T, n_win, overlap):
+        fl = flow.window(a, b)
+        lin, seeds = anvil_seeds(bt[a:b])
+        e = get_combined_edge_field(fl, lin, dtype=np.float32)
+        labs.append(fl.watershed(e, seeds, connectivity=1))
+    want = int(max(int(w.max()) for w in stitch_window_list(labs, overlap=overlap)))
+    del flow, labs
+    torch.cuda.empty_cache()
+    streamed = _bench("--frames", "44", "--n-windows", "4")
+    plain = _bench("--frames", "44", "--n-windows", "4", "--no-stream-windows")
+    assert streamed["watershed"]["windows_begun_during_the_flow"] and not plain["watershed"]["windows_begun_during_the_flow"]
+    assert streamed["config"]["objects_after_stitch"] == plain["config"]["objects_after_stitch"] == want > 10
