@@ -285,7 +285,7 @@ def main():
         # +3 % flow time -- the iteration kernel's launches are half as long and pay their ramp-down twice as often; measured
         # and not adopted: TF_FLOW_SPLIT=2 with 82 GB, 42 pairs at the coarse pyramid levels and 2 x 21 at the two finest:
         # the same iteration time as plain 21-pair batches, and half as many points at which windows can begin)
-        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", "60")
+        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", os.environ.get("TF_BENCH_FLOW_GB", "60"))
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
 

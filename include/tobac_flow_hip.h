@@ -118,6 +118,17 @@ int tf_farneback_batch_split(const uint8_t *prev, const uint8_t *next, int64_t B
                              int64_t H, int64_t W, const tf_farneback_params *p,
                              float *flow_fwd, float *flow_bwd, int64_t flow_stride,
                              void *ws, size_t ws_bytes, void *stream);
+/* The two halves of a split batch as calls of their own (tf_farneback_can_split says whether the geometry allows it):
+ * phase 1 = pyramid levels >= 2 for B pairs, their flow left in the output frames; phase 2 = levels 1 and 0 for B pairs
+ * whose output frames hold that flow (any part of the pairs of phase 1).  create_flow runs phase 1 for a whole batch, then
+ * per part: phase 2, refinement, smoothing, on_frames_ready -- the coarse launches hold twice the pairs, the caller still
+ * gets its frames part by part. */
+int tf_farneback_can_split(int64_t H, int64_t W, const tf_farneback_params *p);
+size_t tf_farneback_workspace_bytes_phase(int64_t B, int64_t H, int64_t W, const tf_farneback_params *p, int phase);
+int tf_farneback_batch_phase(const uint8_t *prev, const uint8_t *next, int64_t B, int64_t img_stride,
+                             int64_t H, int64_t W, const tf_farneback_params *p,
+                             float *flow_fwd, float *flow_bwd, int64_t flow_stride,
+                             void *ws, size_t ws_bytes, void *stream, int phase);
 
 /* ---- a5 tail / section 8f-1: variational refinement of one flow field -------------------------------------
  * replaces cv2.VariationalRefinement.create().calc(I0, I1, flow) as tobac_flow/flow.py:359 creates it and

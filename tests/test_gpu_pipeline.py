@@ -325,3 +325,24 @@ def test_watershed_job_in_parts_on_a_second_stream_equals_the_one_call(golden_ws
         assert np.array_equal(lab.cpu().numpy(), c["labels"]), guess
         assert st["reference_order_detail"]["guess_covered_the_tie"] == (guess == "memo")
         assert st["root_phases"] == (1 if guess == "memo" else 2)
+
+
+def test_create_flow_with_split_batches_is_bit_identical_and_hands_out_parts(monkeypatch):
+    """TF_FLOW_SPLIT=2: a batch runs its coarse pyramid levels for all pairs at once and its two finest levels, refinement and
+    smoothing part by part (tf_farneback_batch_phase); the flows are those of the unsplit schedule bit for bit, and
+    on_frames_ready fires after every PART."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tools.synth import blob_stack
+    bt = blob_stack(11, 203, 331, seed=9, t0=1)
+    want = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    monkeypatch.setenv("TF_FLOW_SPLIT", "2")
+    seen = []
+    got = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic", on_frames_ready=lambda fl, n: seen.append(n))
+    assert seen == [6, 11]                                            # ten pairs: two parts of five
+    assert torch.equal(torch.nan_to_num(got.forward_flow, nan=-7.0), torch.nan_to_num(want.forward_flow, nan=-7.0))
+    assert torch.equal(torch.nan_to_num(got.backward_flow, nan=-7.0), torch.nan_to_num(want.backward_flow, nan=-7.0))
+    raw = tf.calculate_flow(bt, "Farneback")                          # no refinement, no smoothing: written straight into the arrays
+    monkeypatch.delenv("TF_FLOW_SPLIT")
+    raw0 = tf.calculate_flow(bt, "Farneback")
+    assert torch.equal(torch.nan_to_num(raw[0], nan=-7.0), torch.nan_to_num(raw0[0], nan=-7.0))

@@ -45,6 +45,10 @@ _PROTOS = {
     "tf_farneback_workspace_bytes_split": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams)]),
     "tf_farneback_batch_split": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                             _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),
+    "tf_farneback_can_split": (_c.c_int, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams)]),
+    "tf_farneback_workspace_bytes_phase": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int]),
+    "tf_farneback_batch_phase": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
+                                            _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _c.c_int]),
     "tf_farneback_batch_hint": (_c.c_int64, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int64, _c.c_size_t]),
     "tf_farneback_batch": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                       _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),

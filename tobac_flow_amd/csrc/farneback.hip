@@ -1466,6 +1466,64 @@ extern "C" int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int6
     return tf_farneback_batch_split(prev, next, B64, 1, img_stride, H64, W64, p, flow_fwd, flow_bwd, flow_stride, ws, ws_bytes, stream);
 }
 
+// The two halves of a split batch as calls of their own, for a caller that does something between the parts (create_flow
+// refines and smooths a part and hands its frames out before the next part's finest levels run):
+//   phase 1  pyramid levels >= 2 for B pairs; their flow is left in the output frames
+//   phase 2  levels 1 and 0 for B pairs whose output frames hold the flow of level 2 (a part of the pairs of phase 1)
+extern "C" int tf_farneback_can_split(int64_t H, int64_t W, const tf_farneback_params *p)
+{
+    return (p && H > 0 && W > 0 && fb_levels(H, W, p) >= FB_SPLIT_LEVEL && p->pyr_scale == 0.5) ? 1 : 0;
+}
+extern "C" size_t tf_farneback_workspace_bytes_phase(int64_t B, int64_t H, int64_t W, const tf_farneback_params *p, int phase)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || !p || !tf_farneback_can_split(H, W, p)) return 0;
+    if (phase == 2) return tf_farneback_workspace_bytes_batch(B, H, W, p);
+    size_t t = 0, pl = 0;
+    fb_phase_sizes((int)H, (int)W, p, fb_levels(H, W, p), FB_SPLIT_LEVEL, &t, &pl);
+    return (size_t)B * fb_scratch_floats(t, pl, p->win_size == FBI_WIN) * sizeof(float) + 8192;
+}
+extern "C" int tf_farneback_batch_phase(const uint8_t *prev, const uint8_t *next, int64_t B64, int64_t img_stride,
+                                        int64_t H64, int64_t W64, const tf_farneback_params *p,
+                                        float *flow_fwd, float *flow_bwd, int64_t flow_stride,
+                                        void *ws, size_t ws_bytes, void *stream, int phase)
+{
+    TF_REQUIRE(prev && next && p && ws, "tf_farneback: null pointer");
+    TF_REQUIRE(flow_fwd || flow_bwd, "tf_farneback: both outputs are NULL");
+    TF_REQUIRE(B64 >= 1 && B64 <= 1024 && (phase == 1 || phase == 2), "tf_farneback: bad batch size / phase");
+    TF_REQUIRE(H64 > 0 && W64 > 0 && H64 < (1 << 15) && W64 < (1 << 15), "tf_farneback: bad shape");
+    TF_REQUIRE(img_stride >= H64 * W64 && flow_stride >= H64 * W64 * 2, "tf_farneback: strides smaller than one frame");
+    TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= FB_MAX_POLY_N, "tf_farneback: poly_n out of range");
+    TF_REQUIRE(p->win_size >= 1 && p->win_size / 2 <= FB_MAX_M, "tf_farneback: win_size out of range");
+    TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback: bad params");
+    TF_REQUIRE(tf_farneback_can_split(H64, W64, p), "tf_farneback_batch_phase: this geometry does not split (tf_farneback_can_split)");
+    if (ws_bytes < tf_farneback_workspace_bytes_phase(B64, H64, W64, p, phase)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+    const int H = (int)H64, W = (int)W64, B = (int)B64;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = p->win_size == FBI_WIN;
+    FbPoly pp; fb_prepare_poly(p->poly_n, p->poly_sigma, &pp);
+    const int levels = fb_levels(H, W, p);
+    float *const out[2] = {flow_fwd, flow_bwd};
+    TfArena ar(ws, ws_bytes);
+    FbScratch S;
+    if (phase == 1) {
+        size_t t = 0, pl = 0;
+        fb_phase_sizes(H, W, p, levels, FB_SPLIT_LEVEL, &t, &pl);
+        if (!fb_carve(ar, B, t, pl, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+        int cur[2] = {-1, -1}, pw = 0, ph = 0;
+        const int rc = fb_run_levels(prev, next, B, img_stride, H, W, p, out, flow_stride, S, levels, FB_SPLIT_LEVEL, cur, &pw, &ph, pp, s);
+        if (rc) return rc;
+        for (int d = 0; d < 2; d++) if (out[d] && cur[d] != 0) { tf_set_error("tf_farneback: internal slot parity error (phase 1)"); return TF_EINVAL; }
+        return TF_OK;
+    }
+    if (!fb_carve(ar, B, (size_t)H * W + 2 * (size_t)H + 64, (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+    int cur[2] = {0, 0}, pw = 0, ph = 0;                              // the flow of level FB_SPLIT_LEVEL sits in slot 0 = the output frames
+    fb_level_size(H, W, p, FB_SPLIT_LEVEL, &ph, &pw);
+    const int rc = fb_run_levels(prev, next, B, img_stride, H, W, p, out, flow_stride, S, FB_SPLIT_LEVEL - 1, 0, cur, &pw, &ph, pp, s);
+    if (rc) return rc;
+    for (int d = 0; d < 2; d++) if (out[d] && cur[d] != 0) { tf_set_error("tf_farneback: internal slot parity error (phase 2)"); return TF_EINVAL; }
+    return TF_OK;
+}
+
 extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H, int64_t W,
                                  const tf_farneback_params *p, float *flow_fwd, float *flow_bwd,
                                  void *ws, size_t ws_bytes, void *stream)

@@ -409,7 +409,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         parts = max(1, int(os.environ.get("TF_FLOW_SPLIT", "1")))
         return parts if (hasattr(of_model, "params") and "TF_FLOW_BATCH" not in os.environ and B >= 2 * parts) else 1
 
-    def run_batch(i0, B):
+    def run_batch(i0, B, after_part=None):
         if B <= 0:
             return
         prev8, next8, f, bk = batch_buffers(B)
@@ -424,8 +424,17 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                 next8[b].copy_(_lib.to_dev(p8[1]))
         if smoothing_passes == 0:
             f, bk = forward[i0:i0 + B], backward[i0 + 1:i0 + 1 + B]
-        of_model.calc_batch_dev(prev8, next8, f, bk, parts=split_parts_used(B))
-        if vr_steps == 0 and smoothing_passes == 0:
+        parts = split_parts_used(B)
+        by_part = parts > 1 and side is None and of_model.can_split(H, W)
+        if by_part:
+            # SPLIT BATCH, part by part: the coarse pyramid levels for all B pairs at once (their launches are half empty with
+            # B / parts pairs), then per part the two finest levels, the refinement, the smoothing -- and the caller's callback:
+            # the frames are handed out with the granularity of a part
+            per = -(-B // parts)
+            of_model.calc_phase_dev(prev8, next8, f, bk, 1, (B, per))
+        else:
+            of_model.calc_batch_dev(prev8, next8, f, bk, parts=parts)
+        if vr_steps == 0 and smoothing_passes == 0 and not by_part:
             return
 
         def refine_and_smooth(i0=i0, B=B, prev8=prev8, next8=next8, f=f, bk=bk):
@@ -445,7 +454,15 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                                                           max_value if last else float("inf"), _lib.stream_ptr()), "tf_smooth_flow_step")
                     fi, bi = fo, bo
 
-        if side is None:
+        if by_part:
+            for b0 in range(0, B, per):
+                b1 = min(B, b0 + per)
+                of_model.calc_phase_dev(prev8[b0:b1], next8[b0:b1], f[b0:b1], bk[b0:b1], 2, (B, per))
+                if vr_steps > 0 or smoothing_passes > 0:
+                    refine_and_smooth(i0 + b0, b1 - b0, prev8[b0:b1], next8[b0:b1], f[b0:b1], bk[b0:b1])
+                if after_part is not None and b1 < B:
+                    after_part(i0 + b1)
+        elif side is None:
             refine_and_smooth()
         else:
             # The refinement / smoothing of this batch runs on a second stream while the main stream goes on with the
@@ -474,8 +491,12 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     pending = [(a_, b_ - a_) for a_, b_ in zip(starts[:-1], starts[1:])]
     while pending:
         i0, B = pending.pop(0)
+        def part_done(pairs_done):                            # (a part of a split batch: same hand-over as after a batch)
+            if on_batch is not None and pairs_done < n_pairs:
+                finalize_ends()
+                on_batch(forward, backward, pairs_done, n_pairs)
         try:
-            run_batch(i0, B)
+            run_batch(i0, B, part_done)
             if on_batch is not None and i0 + B < n_pairs:
                 # the first i0 + B + 1 frames are final but for the stack's own first frame, whose backward vectors are the
                 # mirror of its forward ones: written now (and, with the still unknown other end, once more at the end)

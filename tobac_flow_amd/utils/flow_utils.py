@@ -65,6 +65,25 @@ class FarnebackFlow:
                                         _lib.ptr(fwd_out), _lib.ptr(bwd_out), stride, _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "tf_farneback_batch")
 
+    def can_split(self, H, W):
+        import ctypes
+        return bool(_lib.lib().tf_farneback_can_split(H, W, ctypes.byref(self.params)))
+
+    def calc_phase_dev(self, prev, nxt, fwd_out, bwd_out, phase, ws_pairs, tag="farneback"):
+        """phase 1 / 2 of a split batch (tf_farneback_batch_phase) on the pairs handed in; the scratch is sized for the larger
+        of phase 1 with `ws_pairs[0]` pairs and phase 2 with `ws_pairs[1]` pairs, so that both phases of a batch share it."""
+        import ctypes
+        L = _lib.lib()
+        B, H, W = prev.shape
+        nbytes = max(L.tf_farneback_workspace_bytes_phase(ws_pairs[0], H, W, ctypes.byref(self.params), 1),
+                     L.tf_farneback_workspace_bytes_phase(ws_pairs[1], H, W, ctypes.byref(self.params), 2))
+        ws = _lib.workspace(nbytes, tag)
+        stride = fwd_out.stride(0) if B > 1 else H * W * 2
+        assert B == 1 or bwd_out.stride(0) == stride
+        rc = L.tf_farneback_batch_phase(_lib.ptr(prev), _lib.ptr(nxt), B, H * W, H, W, ctypes.byref(self.params), _lib.ptr(fwd_out),
+                                        _lib.ptr(bwd_out), stride, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(), phase)
+        _lib.check(rc, "tf_farneback_batch_phase")
+
     def calc(self, prev, nxt, flow=None):
         t = _lib.torch()
         on_device = isinstance(prev, t.Tensor)
