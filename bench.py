@@ -281,11 +281,14 @@ def main():
                          "(roofline = null); the difference to a default run is what the instrumentation costs")
     a = ap.parse_args()
     if a.stream_windows and CONFIGS[a.config][4] == 1:
-        # floods in flight beside the flow need ~12 GB each: leave room (21 pairs per Farneback batch at 5424^2 instead of 42:
-        # +3 % flow time -- the iteration kernel's launches are half as long and pay their ramp-down twice as often; measured
-        # and not adopted: TF_FLOW_SPLIT=2 with 82 GB, 42 pairs at the coarse pyramid levels and 2 x 21 at the two finest:
-        # the same iteration time as plain 21-pair batches, and half as many points at which windows can begin)
-        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", os.environ.get("TF_BENCH_FLOW_GB", "60"))
+        # floods in flight beside the flow need ~12 GB each: leave room.  84 GB hold the full-size Farneback scratch of 21 pairs
+        # at 5424^2 and the 8-bit frames / raw vectors of 42.  TF_FLOW_SPLIT=2: a batch has 42 pairs at the pyramid levels >= 2
+        # (with 21 their launches are one half-empty round of workgroups: +4 % iteration time,
+        # profiles/round4_fb_levels_21_vs_42_pairs.txt) and is finished -- finest levels, refinement, smoothing, hand-over
+        # of its frames -- in two parts of 21 (tf_farneback_batch_phase): same step time as plain 21-pair batches within
+        # the run-to-run spread (4.45 - 4.50 s either way), the iteration kernel 3 % faster (frac 0.481 vs 0.467)
+        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", os.environ.get("TF_BENCH_FLOW_GB", "84"))
+        os.environ.setdefault("TF_FLOW_SPLIT", "2")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
 
