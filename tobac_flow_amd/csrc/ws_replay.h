@@ -227,6 +227,8 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
         if (!deep.put(p, WsRefItem{(unsigned)(e.key >> 32), (int32_t)(e.key & 0xffffffffu), e.id})) oom = true;
     };
     // _watershed.pyx:120-152 for a small item entering at position `child` (a large one only lengthens the heap)
+    bool hint_on = true;                 // (the build only)
+    uint64_t hint_c1 = 0; int hint_depth = -1, hint_d = 0;
     auto push_small = [&](int64_t child, const Item &e) {
         if (child > 0 && !has((child + 1) / 2 - 1)) {
             // The small items are an ancestor-closed set, so the unoccupied ancestors of `child` are the LOWER part of its
@@ -236,9 +238,18 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
             const uint64_t c1 = (uint64_t)child + 1;
             const int depth = 63 - __builtin_clzll(c1);
             int d = 0;
+            if (hint_on && hint_depth == depth) {
+                // during the build (no pop in between) the chain of the previous seed is occupied down to the level it
+                // reached, and seeds come in runs of consecutive numbers: the levels this chain shares with that one need no test
+                const uint64_t x = c1 ^ hint_c1;
+                const int shared = x ? depth - (63 - __builtin_clzll(x)) : depth + 1;      // levels 0 .. shared - 1 coincide
+                d = shared < hint_d + 1 ? shared : hint_d + 1;
+                if (d > depth) d = depth;
+            }
             while (d < depth && has((int64_t)(c1 >> (depth - d)) - 1)) d++;
             child = (int64_t)(c1 >> (depth - d)) - 1;
-        }
+            hint_c1 = c1; hint_depth = depth; hint_d = d;
+        } else hint_depth = -1;
         while (child > 0) {
             const int64_t parent = (child + 1) / 2 - 1;
             if (has(parent)) {
@@ -254,6 +265,7 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
     };
     const double t_alloc = now_ms();
     for (int64_t j = 0; j < S; j++) push_small((int64_t)sk[j], Item{(u64)sval[j] << 32, sid[j], 0});    // seed k enters at position k, age 0
+    hint_on = false;
     if (phase_ms) phase_ms[0] = now_ms() - t_start;
     if (getenv("WSR_DEBUG")) fprintf(stderr, "sparse: scratch %.1f ms, %lld pushes %.1f ms, table of items with an id / another value: %zu entries\n", t_alloc - t_start, (long long)S, now_ms() - t_alloc, deep.n);
     int64_t items = M;
