@@ -294,6 +294,11 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
  *   host memory the library keeps between calls.  Cost: sequential, O(small items x log n) bit tests on one host core;
  *   nothing extra when no such tie exists.  (With more small seeds than relevant pixels -- no staging room -- or
  *   TF_WS_REFERENCE_DENSE=1 in the environment: the dense form, every seed sent and pushed.)
+ *   No host pass at all in the commonest case (round 4): when every item at or below that value is a SEED OF THAT ONE
+ *   VALUE (no smaller seed, no floodable pixel below it, none of those seeds among the last S heap positions), equal keys
+ *   never swap and the reference's build and pops have a closed form -- seed k settles at the first node of its
+ *   root-to-k chain no earlier such seed holds, and the seeds leave in the pre-order of the tree they form -- which the
+ *   device evaluates itself (k_ws_tie_*: one launch per tree level); TF_WS_REFERENCE_HOST=1 keeps the host replay.
  *   stats[13] = items the replay popped, [14] = seeds the replay was given, [15] = microseconds the detour took on the
  *   host clock (export + replay + repeated root phase; 0 if not needed). */
 #define TF_WS_REFERENCE_ORDER 2
@@ -352,11 +357,12 @@ void tf_watershed_abandon(void *job);
  * when begin returns, so any stream is safe): a caller that keeps its main stream busy with other work -- the flow of the
  * next frames -- finishes its floods on a second one instead of queueing the root phase behind that work */
 int tf_watershed_set_stream(void *job, void *stream);
-/* info (12 x int64): [0] replay form (0 none, 1 sparse, 2 dense), [1] seeds, [2] seeds at or below the tie value,
+/* info (12 x int64): [0] replay form (0 none, 1 sparse, 2 dense, 3 none needed: pop ranks computed on the device in closed
+ * form -- every heap item at or below the tie value was a seed of that one value), [1] seeds, [2] seeds at or below the tie value,
  * [3] pixels of the exported sub-graph, [4] relevant pixels, [5] microseconds of the export, [6] microseconds of the
  * replay (-1: not run), [7] ordered key of the largest tie value finish found (-1: no label hangs on such a tie, or not
  * finished), [8] 1 if the export ran on a guess, [9] 1 if the guess covered the tie value, [10] the tie key the export
- * used (-1: none), [11] 0 */
+ * used (-1: none), [11] 1 if the pop ranks came from the device's closed form */
 int tf_watershed_job_info(const void *job, int64_t *info);
 
 /* tf_watershed_raveled: the reference's only native seam, argument for argument --

@@ -149,6 +149,76 @@ def test_sparse_dense_and_plain_replay_agree(tf, seed, monkeypatch):
         assert st_sparse["reference_order_detail"]["replay_form"] == "sparse" and st_dense["reference_order_detail"]["replay_form"] == "dense"
 
 
+def _one_value_class_case(seed):
+    """The detect_anvils shape of a tie: a plateau at the SMALLEST value of the field carrying seeds of many different
+    labels (striped, with floodable plateau pixels between them), every other seed larger and (float noise) distinct, and
+    the plateau early in raster order -- so every heap item at or below the tie value is a seed of that one value and none
+    of them sits among the last S heap positions: the case the device evaluates in closed form (k_ws_tie_*)."""
+    rng = np.random.default_rng(9100 + seed)
+    T, H, W = int(rng.integers(2, 5)), int(rng.integers(40, 90)), int(rng.integers(48, 120))
+    field = (0.1 + ndi.gaussian_filter(rng.random((T, H, W)), (0.5, 2, 2)) + 1e-3 * rng.random((T, H, W))).astype(np.float32)
+    markers = np.zeros((T, H, W), np.int32)
+    y0, y1 = 3, 3 + int(rng.integers(8, 18))
+    field[0, y0:y1, 2:W - 2] = -1.0                                     # the plateau
+    step = int(rng.integers(2, 5))
+    lab = 1
+    for y in range(y0, y1, 2 if seed % 2 else 1):
+        for x in range(2 + int(rng.integers(0, step)), W - 2, step):
+            if rng.random() < 0.8:
+                markers[0, y, x] = lab if seed % 3 else (lab % 7) + 1
+                lab += 1
+    if seed % 4 == 1:                                                  # a second plateau frame, still early
+        field[1, y0:y1, 2:W // 2] = -1.0
+        markers[1, y0:y1:2, 3:W // 2:step] = np.arange(lab, lab + len(range(3, W // 2, step)), dtype=np.int32)[None, :]
+    # the larger seeds: the last frame's border band as background (-1) + scattered ones, all at values > -1
+    markers[T - 1, H - 12:, :] = -1
+    for k in range(int(rng.integers(5, 20))):
+        t, y, x = int(rng.integers(1, T)), int(rng.integers(y1 + 2, H - 14)), int(rng.integers(0, W - 3))
+        markers[t, y:y + 2, x:x + 3] = 1000 + k
+    amp = [0.0, 1.0, 2.5][seed % 3]
+    fwd = (rng.normal(size=(T, H, W, 2)) * amp).astype(np.float32)
+    bwd = (rng.normal(size=(T, H, W, 2)) * amp).astype(np.float32)
+    mask = None if seed % 2 == 0 else rng.random((T, H, W)) > 0.03
+    return fwd, bwd, field, markers, mask, [1, 2, 3][(seed // 2) % 3]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_pop_ranks_in_closed_form_on_the_device_equal_the_host_replay_and_the_reference_kernel(tf, seed, monkeypatch):
+    """Round 4: when every heap item at or below the tie value is a seed of that one value, the pop ranks are computed on
+    the device (no export, no host pass).  Same labels as the host replay (TF_WS_REFERENCE_HOST=1) and as the C twin of the
+    reference's kernel (tie_mode 0); run twice, so that both the export after the root phase (first flood of a shape: no
+    guess) and the export on a guessed tie value (second) take the device form."""
+    import torch
+    from oracle import ws_oracle
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd import watershed as Wm
+    from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
+    fwd, bwd, field, markers, mask, conn = _one_value_class_case(seed)
+    want = ws_oracle.watershed(fwd, bwd, field, markers, mask, conn, tie_mode=0)
+    args = (_lib.to_dev(fwd, torch.float32), _lib.to_dev(bwd, torch.float32), _lib.to_dev(field, torch.float32),
+            _lib.to_dev(markers, torch.int32), None if mask is None else _lib.to_dev(mask.astype(np.int8), torch.int8), neighbour_offsets(conn))
+    with Wm._MEMO_LOCK:
+        Wm._tie_memo.clear()
+    st1, st2, sth, st0 = {}, {}, {}, {}
+    raster = watershed_dev(*args, stats=st0, on_ambiguous="ignore").cpu().numpy()
+    with Wm._MEMO_LOCK:
+        Wm._tie_memo.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        lab1 = watershed_dev(*args, stats=st1, on_ambiguous="reference").cpu().numpy()
+        lab2 = watershed_dev(*args, stats=st2, on_ambiguous="reference").cpu().numpy()
+        monkeypatch.setenv("TF_WS_REFERENCE_HOST", "1")
+        labh = watershed_dev(*args, stats=sth, on_ambiguous="reference").cpu().numpy()
+    assert st0["ambiguous_pixels"] > 0, "the case has no label that hangs on the order of equal-valued markers"
+    d1, d2, dh = st1["reference_order_detail"], st2["reference_order_detail"], sth["reference_order_detail"]
+    assert d1["replay_form"] == "device" and not d1["guessed"], d1
+    assert d2["replay_form"] == "device" and d2["guessed"] and d2["guess_covered_the_tie"], d2
+    assert dh["replay_form"] == "sparse", dh
+    assert st2["root_phases"] < st1["root_phases"]                      # the guess saves the second root phase
+    assert np.array_equal(lab1, labh) and np.array_equal(lab2, labh)
+    assert np.array_equal(lab1, want), f"{int((lab1 != want).sum())} px differ from the reference kernel ({int((raster != want).sum())} in raster order)"
+
+
 def test_dense_replay_on_full_disk_frames_equals_the_reference_kernel(monkeypatch):
     """The dense form at the benchmark's frame size (2 x 5424^2: 56 M seeds, most of them the background's at exactly 0, so
     the runs and the saved path are really exercised) against the C twin of the reference's kernel, every voxel."""
@@ -242,7 +312,7 @@ def test_full_disk_frames_with_component_seeds_in_reference_order():
     lab = watershed_dev(fw, bw, e, seeds, None, neighbour_offsets(1), stats=st, on_ambiguous="reference")
     want = ws_oracle.watershed(fw.cpu().numpy(), bw.cpu().numpy(), e.cpu().numpy(), seeds.cpu().numpy(), None, 1, tie_mode=0)
     got = lab.cpu().numpy()
-    print("3 x 5424^2, component seeds: ambiguous voxels %d, reference order %s" % (st["ambiguous_pixels"], st["reference_order"]))
+    print("3 x 5424^2, component seeds: ambiguous voxels %d, reference order %s, %s" % (st["ambiguous_pixels"], st["reference_order"], st["reference_order_detail"]))
     assert np.array_equal(got, want), f"{int((got != want).sum())} px differ from the reference kernel"
 
 

@@ -844,12 +844,14 @@ k_ws_labels(const int32_t *__restrict__ markers, const int *__restrict__ cid, co
 // voxel: 2.4 GB written and read back per 16 x 5424^2 window).
 __global__ void __launch_bounds__(256)
 k_ws_seed_counts(const uint8_t *__restrict__ cls, const float *__restrict__ field, int64_t n, unsigned vmax,
-                 int *__restrict__ n_seed, int *__restrict__ n_small)
+                 int *__restrict__ n_seed, int *__restrict__ n_small, int *__restrict__ any_below)
 {
     __shared__ int part[2][4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool sd = i < n && cls[i] == 2;
-    const bool sm = sd && ws_ordkey(field[i]) <= vmax;
+    const unsigned key = sd ? ws_ordkey(field[i]) : 0u;
+    const bool sm = sd && key <= vmax;
+    if (sm && key < vmax) *any_below = 1;                              // (every writer stores 1) a seed BELOW the tie value: not one value class
     const unsigned long long ms = __ballot(sd), mm = __ballot(sm);
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = __popcll(ms); part[1][threadIdx.x >> 6] = __popcll(mm); }
     __syncthreads();
@@ -1006,11 +1008,12 @@ __device__ __forceinline__ bool ws_poppable(const WsC &c, int64_t i, unsigned vm
     return (c.pix[i] & WS_MARKER_BIT) ? v <= vmax : v < vmax;
 }
 __global__ void __launch_bounds__(256)
-k_ws_sub_mark(WsC c, unsigned vmax, uint8_t *__restrict__ in_q)       // in_q zeroed by the caller
+k_ws_sub_mark(WsC c, unsigned vmax, uint8_t *__restrict__ in_q, int *__restrict__ any_flooded_small)       // in_q zeroed by the caller
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.R || !ws_poppable(c, i, vmax)) return;
     in_q[i] = 1;
+    if (!(c.pix[i] & WS_MARKER_BIT)) *any_flooded_small = 1;          // a floodable pixel below the tie value: pushed, it is a small item of another key
     const int *np = c.nbr + i * c.n_nbr;
     for (int j = 0; j < c.n_nbr; j++) { const int n = np[j]; if (n >= 0) in_q[n] = 1; }     // (every writer stores 1)
 }
@@ -1026,6 +1029,86 @@ k_ws_sub_export(WsC c, unsigned vmax, const uint8_t *__restrict__ in_q, const in
     const int *np = c.nbr + i * c.n_nbr;
     for (int j = 0; j < c.n_nbr; j++) { const int n = pop ? np[j] : -1; out_nbr[q * c.n_nbr + j] = n >= 0 ? subid[n] : -1; }
 }
+// ---- THE REPLAY IN CLOSED FORM, ON THE DEVICE, WHEN THE SMALL ITEMS ARE ONE VALUE CLASS (round 4) ----------------------------
+// The usual case on a detect_anvils field: the tie value is the SMALLEST marker value (-1: the saturated cores), so every
+// small item is a seed of that one value (age 0) and no flooded pixel can be small.  Equal keys never swap, and then the
+// reference heap's mechanics have a closed form:
+//   BUILD.  Seed k enters at position k and rises through its large ancestors until its parent is a small seed: it ends at
+//     the FIRST position of its root-to-k chain that no earlier small seed holds (the small seeds are an ancestor-closed set).
+//     So node v is taken by the first small seed inside subtree(v) that arrives after the seed that took v's parent --
+//     t(v) = min { j in subtree(v) : j > t(parent v) } -- which is one binary search in the sorted list of small seed numbers
+//     per tree level of the subtree (the positions of subtree(v) at level L are one contiguous range).
+//   POPS.  A popped root is replaced by the last item of the array -- a large one, as long as no small seed sits in the last S
+//     positions -- which sinks along "left child if small, else right child if small" and moves every seed on that path up
+//     one node: the seeds leave the heap in the PRE-ORDER of the tree they form (ws_replay.h, "the tree of equal seeds").
+//     Pushes are all large (a flooded pixel is at or above the tie value) and only lengthen the array.
+// The tree is built level by level (one launch per level, <= 30), subtree sizes bottom-up, pre-order indices top-down; the
+// pre-order index IS the pop rank.  ~2 ms per 16 x 5424^2 window instead of a 0.2 s host pass, no export at all.  The host
+// replay remains for every other case (several small values, flooded pixels below the tie value, small seeds at the very
+// end of the array) and as the cross-check (TF_WS_REFERENCE_HOST=1; tests/test_gpu_reference_order.py).
+struct WsTie { const long long *k; const int *sid; int S; long long M; long long *pos; int *tj, *c0, *c1, *size, *pre; int *n_nodes; };
+__device__ __forceinline__ int ws_tie_lower_bound(const long long *k, int lo, int hi, long long a) {
+    while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (k[mid] < a) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ void __launch_bounds__(256)
+k_ws_tie_level(WsTie t, int lo, int hi)
+{
+    const int n = lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (n >= hi) return;
+    const long long p = t.pos[n];
+    const int j = t.tj[n];
+    const long long kprev = t.k[j];
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const long long v = 2 * p + 1 + side;
+        int jj = -1;
+        for (int sh = 0; sh < 62; sh++) {                              // the positions of subtree(v), level by level
+            const long long lo_l = ((v + 1) << sh) - 1;
+            if (lo_l >= t.M) break;
+            const long long hi_l = lo_l + (1ll << sh) - 1;
+            if (hi_l <= kprev) continue;                               // seeds there arrived before the parent's
+            const long long a = lo_l > kprev + 1 ? lo_l : kprev + 1;
+            const int idx = ws_tie_lower_bound(t.k, j + 1, t.S, a);
+            if (idx < t.S && t.k[idx] <= hi_l) { jj = idx; break; }    // (ranges and seed numbers both ascend: the first hit is the earliest arrival)
+        }
+        int m = -1;
+        if (jj >= 0) { m = atomicAdd(t.n_nodes, 1); if (m < t.S) { t.pos[m] = v; t.tj[m] = jj; } else m = -1; }
+        if (side == 0) t.c0[n] = m; else t.c1[n] = m;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_ws_tie_sizes(WsTie t, int lo, int hi)
+{
+    const int n = lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (n >= hi) return;
+    const int a = t.c0[n], b = t.c1[n];
+    t.size[n] = 1 + (a >= 0 ? t.size[a] : 0) + (b >= 0 ? t.size[b] : 0);
+}
+__global__ void __launch_bounds__(256)
+k_ws_tie_pre(WsTie t, int lo, int hi)
+{
+    const int n = lo + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (n >= hi) return;
+    const int a = t.c0[n], b = t.c1[n], p = t.pre[n];
+    if (a >= 0) t.pre[a] = p + 1;
+    if (b >= 0) t.pre[b] = p + 1 + (a >= 0 ? t.size[a] : 0);
+}
+__global__ void __launch_bounds__(256)
+k_ws_tie_default_ranks(int64_t R, int S, int *__restrict__ rank)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R) rank[i] = (int)(S + i);                                // markers that do not pop: after all that do (no label depends on their order)
+}
+__global__ void __launch_bounds__(256)
+k_ws_tie_scatter(WsTie t, int *__restrict__ rank)
+{
+    const int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (n >= t.S) return;
+    const int id = t.sid[t.tj[n]];
+    if (id >= 0) rank[id] = t.pre[n];
+}
+
 // pop ranks back on the compact set: a marker the replay popped gets its rank, every other one keeps its place after all
 // of those (no label depends on their order)
 __global__ void __launch_bounds__(256)
@@ -1285,6 +1368,7 @@ struct tf_ws_job {
     bool speculate_fast; int levels_done;
     unsigned true_vmax; bool has_tie, spec_hit; int *subid;
     bool ranked, late_export; double ms_detour;
+    bool device_ranks;           // the small items were one value class: rank_dev filled on the device (k_ws_tie_*), no host replay
     u64 code_d; int64_t code_words, n_exc;
     int64_t M, S, nQ; unsigned vmax;
     WsHostBuf hb_val, hb_nbr, hb_rank, hb_sk, hb_sval, hb_sid;
@@ -1315,6 +1399,7 @@ static int ws_to_host(void *dst, const void *src, size_t bytes, hipStream_t s)
 static int ws_job_export(tf_ws_job *j)
 {
     const double t_enter = ws_now_ms();
+    j->device_ranks = false;
     hipStream_t s = j->s;
     const WsC &c = j->c;
     const int64_t R = j->R, N = j->N;
@@ -1335,7 +1420,9 @@ static int ws_job_export(tf_ws_job *j)
     size_t need = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need, WsCountIter((const int *)nullptr, WsIntToLL()), (long long *)nullptr, (int)nb256);
     TF_REQUIRE(need <= j->scan_bytes, "tf_watershed: scan scratch too small for the seed numbering");
-    hipLaunchKernelGGL(k_ws_seed_counts, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, j->field, N, h_vmax, n_seed, n_small);
+    int *d_any = j->d_flags + WS_BATCH + 6;                             // [0] a seed below the tie value, [1] a floodable pixel below it
+    TF_CHECK_HIP(hipMemsetAsync(d_any, 0, 2 * sizeof(int), s));
+    hipLaunchKernelGGL(k_ws_seed_counts, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, j->field, N, h_vmax, n_seed, n_small, d_any);
     TF_CHECK_LAUNCH();
     size_t tb = j->scan_bytes;
     TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(j->scan_tmp, tb, WsCountIter(n_seed, WsIntToLL()), base_seed, (int)nb256, s));
@@ -1350,14 +1437,81 @@ static int ws_job_export(tf_ws_job *j)
     uint8_t *in_q = (uint8_t *)j->scan;
     int *subid = j->subid;
     TF_CHECK_HIP(hipMemsetAsync(in_q, 0, (size_t)R, s));
-    hipLaunchKernelGGL(k_ws_sub_mark, dim3(nbr_blocks), dim3(256), 0, s, c, h_vmax, in_q);
+    hipLaunchKernelGGL(k_ws_sub_mark, dim3(nbr_blocks), dim3(256), 0, s, c, h_vmax, in_q, d_any + 1);
     TF_CHECK_LAUNCH();
+    int h_any[2] = {0, 0};
+    TF_CHECK_HIP(hipMemcpyAsync(h_any, d_any, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     int64_t nQ = 0;
     {
         const int rc = ws_scan_flags(in_q, subid, R, j->scan_tmp, j->scan_bytes, s, &nQ);       // synchronises
         if (rc) return rc;
     }
     j->M = h_last[0] + h_lastc[0]; j->S = h_last[1] + h_lastc[1];
+    {
+        // ONE VALUE CLASS?  Then the pop ranks have a closed form and are computed here, on the device (k_ws_tie_*).
+        const bool force_host = ws_env("TF_WS_REFERENCE_HOST");                          // A/B and test aid (read per call: the tests toggle it)
+        const int64_t S = j->S;
+        char *tie_base = (char *)j->scan + tf_align_up((size_t)R, 256);
+        const size_t tie_room = (size_t)j->NV * 4 > tf_align_up((size_t)R, 256) ? (size_t)j->NV * 4 - tf_align_up((size_t)R, 256) : 0;
+        const size_t tie_need = tf_align_up((size_t)S * 8, 256) + 5 * tf_align_up((size_t)S * 4, 256) + 256;
+        if (ref_debug)
+            fprintf(stderr, "reference order: closed form? seed below the tie value %d, floodable pixel below it %d, S %lld, R %lld, room %zu of %zu\n",
+                    h_any[0], h_any[1], (long long)S, (long long)R, tie_room, tie_need);
+        if (!force_host && !force_dense && !h_any[0] && !h_any[1] && S > 0 && S <= R && S < 0x3fffffffll && tie_need <= tie_room) {
+            long long *stg_k = (long long *)c.Rt; unsigned *stg_val = (unsigned *)c.Llo; int *stg_id = c.Lhi;
+            hipLaunchKernelGGL(k_ws_small_list, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N, h_vmax,
+                               (const long long *)base_seed, (const long long *)base_small, (const int *)nullptr, stg_k, stg_val, stg_id);
+            TF_CHECK_LAUNCH();
+            long long k_max = 0;
+            TF_CHECK_HIP(hipMemcpyAsync(&k_max, stg_k + S - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
+            TF_CHECK_HIP(hipStreamSynchronize(s));
+            if (ref_debug && k_max >= j->M - S) fprintf(stderr, "reference order: closed form refused: small seed at heap position %lld of %lld\n", k_max, (long long)j->M);
+            if (k_max < j->M - S) {                                     // no small seed among the last S positions: every replacement item is large
+                TfArena ta(tie_base, tie_room);
+                WsTie t;
+                t.k = stg_k; t.sid = stg_id; t.S = (int)S; t.M = j->M;
+                t.pos = ta.take<long long>(S); t.tj = ta.take<int>(S); t.c0 = ta.take<int>(S); t.c1 = ta.take<int>(S);
+                t.size = ta.take<int>(S); t.pre = ta.take<int>(S); t.n_nodes = ta.take<int>(4);
+                if (ta.ok()) {
+                    const long long h_pos0 = 0; const int h_init[2] = {1, 0};      // node 0 = the root, taken by the first small seed; pre-order index 0
+                    TF_CHECK_HIP(hipMemcpyAsync(t.pos, &h_pos0, sizeof(long long), hipMemcpyHostToDevice, s));
+                    TF_CHECK_HIP(hipMemsetAsync(t.tj, 0, sizeof(int), s));
+                    TF_CHECK_HIP(hipMemsetAsync(t.pre, 0, sizeof(int), s));
+                    TF_CHECK_HIP(hipMemcpyAsync(t.n_nodes, h_init, sizeof(int), hipMemcpyHostToDevice, s));
+                    int offs[80]; int n_lev = 0, lo = 0, hi = 1;
+                    offs[0] = 0;
+                    while (hi > lo && n_lev < 78) {
+                        hipLaunchKernelGGL(k_ws_tie_level, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, s, t, lo, hi);
+                        TF_CHECK_LAUNCH();
+                        int h_n = 0;
+                        TF_CHECK_HIP(hipMemcpyAsync(&h_n, t.n_nodes, sizeof(int), hipMemcpyDeviceToHost, s));
+                        TF_CHECK_HIP(hipStreamSynchronize(s));
+                        offs[++n_lev] = hi;
+                        lo = hi; hi = h_n < (int)S ? h_n : (int)S;
+                        if (h_n > (int)S) { lo = hi = -1; break; }      // (cannot happen: every seed takes exactly one node)
+                    }
+                    if (hi == (int)S && lo == hi) {                     // every small seed has its node
+                        for (int l = n_lev - 1; l >= 0; l--)
+                            hipLaunchKernelGGL(k_ws_tie_sizes, dim3((unsigned)((offs[l + 1] - offs[l] + 255) / 256)), dim3(256), 0, s, t, offs[l], offs[l + 1]);
+                        for (int l = 0; l < n_lev; l++)
+                            hipLaunchKernelGGL(k_ws_tie_pre, dim3((unsigned)((offs[l + 1] - offs[l] + 255) / 256)), dim3(256), 0, s, t, offs[l], offs[l + 1]);
+                        hipLaunchKernelGGL(k_ws_tie_default_ranks, dim3(nbr_blocks), dim3(256), 0, s, R, (int)S, j->rank_dev);
+                        hipLaunchKernelGGL(k_ws_tie_scatter, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, s, t, j->rank_dev);
+                        TF_CHECK_LAUNCH();
+                        TF_CHECK_HIP(hipStreamSynchronize(s));
+                        j->device_ranks = true;
+                        j->need_replay = false;
+                        j->popped = S; j->n_ranked = (int)S;
+                        j->ms_export = ws_now_ms() - t_enter;
+                        if (ref_debug)
+                            fprintf(stderr, "reference order: %lld seeds, %lld at the tie value (key %u) and nothing below it: pop ranks on the device "
+                                    "(tree of %d levels), %.1f ms\n", (long long)j->M, (long long)S, h_vmax, n_lev, j->ms_export);
+                        return TF_OK;
+                    }
+                }
+            }
+        }
+    }
     // compact export if the translated rows fit the staging room (the two idle frontier queues), else the whole compact
     // set with its own ids
     j->identity = nQ * nn > 2 * R + 64;
@@ -1804,6 +1958,9 @@ static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
             if (rc) return rc;
             ranked = j->ranked = true;
             ms_detour = j->ms_export + j->ms_replay + (ws_now_ms() - t0);
+        } else if (j->device_ranks) {                                    // the speculative export found one value class: rank_dev is filled
+            ranked = j->ranked = true;
+            ms_detour = j->ms_export;
         }
         for (;;) {
             rc = ws_root_and_check(j, ranked);
@@ -1837,6 +1994,15 @@ static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
                 j->vmax = h_vmax;
                 rc = ws_job_export(j);
                 if (rc) return rc;
+                if (j->device_ranks) {                                   // closed form on the device: no host pass, root phase again at once
+                    ranked = j->ranked = true;
+                    rc = ws_root_and_check(j, true);                     // (the check's counts do not depend on the order)
+                    if (rc) return rc;
+                    j->applied = true;
+                    ms_detour += j->ms_export;
+                    st[13] = j->popped; st[14] = j->S; st[15] = (int64_t)(ms_detour * 1000.0);
+                    goto labels_out;
+                }
                 // the replay is the caller's to run (any thread); finish is entered again afterwards
                 j->late_export = true;
                 st[8] = j->depth; st[9] = (int64_t)j->h_amb[0]; st[10] = (int64_t)j->h_amb[1]; st[11] = (int64_t)j->h_amb[2];
@@ -1846,8 +2012,11 @@ static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
         if (j->need_replay && j->replay_done) {
             st[13] = j->popped; st[14] = j->sparse ? j->S : j->M;
             st[15] = (int64_t)(ms_detour * 1000.0);
+        } else if (j->device_ranks) {
+            st[13] = j->popped; st[14] = j->S; st[15] = (int64_t)(ms_detour * 1000.0);
         }
     }
+labels_out:
     st[8] = j->depth; st[9] = (int64_t)j->h_amb[0]; st[10] = (int64_t)j->h_amb[1]; st[11] = (int64_t)j->h_amb[2];
     {
         TfProfScope ps(TFK_WS_LABELS, 12.0 * (double)N, s);
@@ -1942,11 +2111,11 @@ extern "C" int tf_watershed_job_info(const void *job, int64_t *info)
 {
     TF_REQUIRE(job && info, "tf_watershed_job_info: null pointer");
     const tf_ws_job *j = (const tf_ws_job *)job;
-    info[0] = j->need_replay ? (j->sparse ? 1 : 2) : 0;
+    info[0] = j->need_replay ? (j->sparse ? 1 : 2) : (j->device_ranks ? 3 : 0);
     info[1] = j->M; info[2] = j->S; info[3] = j->nQ; info[4] = j->R;
     info[5] = (int64_t)(j->ms_export * 1000.0); info[6] = j->replay_done ? (int64_t)(j->ms_replay * 1000.0) : -1;
     info[7] = j->has_tie ? (int64_t)j->true_vmax : -1;
-    info[8] = j->speculative ? 1 : 0; info[9] = j->spec_hit ? 1 : 0; info[10] = j->need_replay ? (int64_t)j->vmax : -1; info[11] = 0;
+    info[8] = j->speculative ? 1 : 0; info[9] = j->spec_hit ? 1 : 0; info[10] = (j->need_replay || j->device_ranks) ? (int64_t)j->vmax : -1; info[11] = j->device_ranks ? 1 : 0;
     return TF_OK;
 }
 

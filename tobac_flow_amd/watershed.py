@@ -128,7 +128,7 @@ class WatershedJob:
 
     @staticmethod
     def _info_dict(a):
-        return {"replay_form": ("none", "sparse", "dense")[int(a[0])], "seeds": int(a[1]), "seeds_at_or_below_tie_value": int(a[2]),
+        return {"replay_form": ("none", "sparse", "dense", "device")[int(a[0])], "seeds": int(a[1]), "seeds_at_or_below_tie_value": int(a[2]),
                 "subgraph_pixels": int(a[3]), "relevant_pixels": int(a[4]), "export_us": int(a[5]), "replay_us": int(a[6]),
                 "tie_key": int(a[7]), "guessed": bool(a[8]), "guess_covered_the_tie": bool(a[9]), "exported_for_key": int(a[10])}
 
