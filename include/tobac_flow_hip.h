@@ -91,6 +91,12 @@ size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_par
 int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H, int64_t W,
                       const tf_farneback_params *p, float *flow_fwd, float *flow_bwd,
                       void *ws, size_t ws_bytes, void *stream);
+/* Diagnostic / test entry: the 3 x 3 Gaussian of a uint8 frame and its polynomial expansion exactly as the full-resolution
+ * pyramid level computes them (cv2's FarnebackPolyExp on the blurred frame), for stage-by-stage comparison with the oracle.
+ * blur_out: H * W floats or NULL; R_out: 5 * H * W floats = H * W float4 {r0, r1, r2, r3} + one plane r4 (OpenCV's five
+ * interleaved channels, in its order). */
+int tf_farneback_expansion(const uint8_t *img, int64_t H, int64_t W, const tf_farneback_params *p,
+                           float *blur_out, float *R_out, void *stream);
 /* The same for B independent frame pairs in one set of launches (the loop of tobac_flow/flow.py:411-423):
  * pair b reads prev + b*img_stride / next + b*img_stride (bytes = pixels, uint8) and writes
  * flow_fwd + b*flow_stride / flow_bwd + b*flow_stride (strides in floats), so the results can land

@@ -41,6 +41,7 @@ _PROTOS = {
     "tf_farneback_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams)]),
     "tf_farneback_pair": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _P, _P, _P,
                                      _c.c_size_t, _P]),
+    "tf_farneback_expansion": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _P, _P, _P]),
     "tf_farneback_workspace_bytes_batch": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams)]),
     "tf_farneback_workspace_bytes_split": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams)]),
     "tf_farneback_batch_split": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),

@@ -699,7 +699,11 @@ k_fb_update_matrices(const float *__restrict__ R0, const float *__restrict__ R1,
 #endif
 #define FBI_OW (FBI_T - 2 * FBI_M)
 // R[img] / fin[q] / fout[q] are the pointers of batch item 0; item b adds b * the matching stride
-struct FbIterArgs { const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2]; };
+struct FbIterArgs {
+    const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2];
+    // sequential row sums (k_fb_iter): hand-over words of batch item 0 (item b adds b * bs_hand words), this launch's tag, its ticket counter
+    unsigned long long *hand; int64_t bs_hand; unsigned epoch; int *ticket;
+};
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
 #ifndef FBI_NB
 #define FBI_NB 2                    // rows whose gathers are in flight together.  Round 3, four-wave workgroups: 2 / 3 / 4 / 5 rows ->
@@ -717,6 +721,9 @@ struct FbIterCtx {
     // +1 row, both) is folded into four wave-uniform base pointers
     const char *R1c[4], *R1ec[4];
     int H, W; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale; bool xborder;
+    // sequential row sums: strip index / count, the (row of the group, channel) this lane scans, hand-over slots of the left
+    // neighbour (read) and of this strip (written), the launch's tag
+    int sx, nx, sr, sch; const unsigned long long *hin; unsigned long long *hout; unsigned epoch;
 };
 
 struct FbTaps { float4 q0, c00, c01, c10, c11; float2 e0, e1; float q04, dx, dy; };
@@ -914,7 +921,7 @@ __device__ __forceinline__ void fb_iter_group(const FbIterCtx &c, int s0, float 
 // (tf_farneback_batch_hint: 21 pairs = 1974 chains = 96 % of two rounds at 5424^2), which a stack of frames allows.
 template <int NB, int ABL>
 __global__ void __launch_bounds__(2 * FBI_T, 2)
-k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
+k_fb_iter_tree(FbIterArgs a, int H, int W, int64_t plane)
 {
     // BOTH directions of a strip in ONE workgroup: waves 0 - 1 walk the column strip for direction dir[0], waves 2 - 3 for
     // dir[1], in step (they share the barriers).  Each direction reads its own expansion row by row and gathers from the
@@ -1002,6 +1009,235 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
         fb_iter_group<0, 4, 4, NB, ABL>(c, base, ring, S, fl, vrow);
         fb_iter_group<4, 4, 5, NB, ABL>(c, base + 4, ring, S, fl, vrow);
         fb_iter_group<8, 5, 4, NB, ABL>(c, base + 8, ring, S, fl, vrow);
+    }
+}
+
+// ---- the same iteration with OpenCV's ROW sums too (round 4): bit-identical flow ---------------------------------------------
+// FarnebackUpdateFlow_Blur forms the 13-wide window sums of a row as a RUNNING sum in double, left to right over the
+// whole row (oracle/c/farneback.c:282-292):
+//   g  = vsum[0] * (m + 2) + vsum[1] + ... + vsum[m - 1];     x = 0 .. W-1:   g += vsum[x + m] - vsum[x - m - 1]
+// (columns left / right of the image replicate the border).  Every rounding of that chain stays in g for the rest of the
+// row, so no other order of the additions reproduces it (k_fb_iter_tree above: max 7e-5 px away at 5424^2, which the
+// refinement's 1/32-px remap bins amplify to 0.02 px in the composed flow).  A floating-point chain is sequential by
+// definition; what is parallel is the number of chains -- rows x 5 channels x strips x directions x pairs:
+//   * a workgroup still owns a strip of FBI_OW columns over all rows and forms OpenCV's column sums as before;
+//   * per row group, lane (row r, channel ch) of each direction's first wave walks the strip's 116 columns:
+//     g += V[x + 6] - V[x - 7] out of LDS, and leaves g in the slot whose column sum is no longer needed (25 chains side by
+//     side; the other lanes have nothing to do for ~1 us: the price of the order);
+//   * the chain ENTERS the strip with the g and the V[x_strip - 7] its left neighbour left at the same row: strips hand
+//     10 doubles per row to the right through global memory -- a skewed pipeline, strip k one row group behind strip
+//     k - 1.  Every double travels as two 64-bit words (launch tag << 32 | half): a word is valid iff its tag is this
+//     launch's, so there is no flag to order against the data and no fence -- relaxed agent-scope atomics only.  The words
+//     live in the (idle) blur scratch of the pair, zeroed once per pyramid level; tags count the level's iterations;
+//   * workgroups take their (pair, strip) from a TICKET counter in arrival order, strips of a pair consecutively: a
+//     workgroup only ever waits for a lower ticket, which is running or done -- no deadlock whatever the dispatch order;
+//   * the 2 x 2 solve is OpenCV's expression on the window MEANS, with a true division (k_fb_iter_tree: scaled
+//     regulariser, reciprocal + Newton step).
+#define FBI_VS2 137                 // LDS row stride in doubles: lanes (r, ch) of a scan hit different banks (137 * 2 mod 64 = 18)
+#define FBI_HW 20                   // hand-over words per row: (g, V[next strip's x - 7]) x 5 channels x two halves
+
+__device__ __forceinline__ unsigned long long fb_hand_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fb_hand_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one chain: row `row` (LDS, slot i = column x_strip + i - 6) of output row yo, channel ch
+__device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch, double *row)
+{
+    const int n_out = min(FBI_OW, c.W - c.x_strip);                    // (wave-uniform)
+    double g, sub;
+    if (c.sx == 0) {
+        const double v0 = row[FBI_M];                                  // column 0
+        g = v0 * (double)(FBI_M + 2);
+#pragma unroll
+        for (int x = 1; x < FBI_M; x++) g += row[FBI_M + x];           // (columns past W - 1 hold the clamped column: OpenCV's replicated border)
+        sub = v0;                                                      // vsum[-m - 1] = vsum[0]
+    } else {
+        const unsigned long long *pg = c.hin + (int64_t)yo * FBI_HW + 2 * ch, *ps = pg + 10;
+        unsigned long long w0, w1, w2, w3;
+        bool ok = false;
+        // (the left neighbour holds a lower ticket: it is running or done.  The poll count is bounded all the same -- several
+        // seconds -- so that the grid drains whatever happens; a chain that gives up continues with NaN, which no test misses)
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            w0 = fb_hand_ld(pg); w1 = fb_hand_ld(pg + 1); w2 = fb_hand_ld(ps); w3 = fb_hand_ld(ps + 1);
+            ok = (unsigned)(w0 >> 32) == c.epoch && (unsigned)(w1 >> 32) == c.epoch && (unsigned)(w2 >> 32) == c.epoch && (unsigned)(w3 >> 32) == c.epoch;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        g = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
+        sub = __longlong_as_double((long long)((w3 << 32) | (w2 & 0xffffffffull)));
+        if (!ok) g = __longlong_as_double(0x7ff8000000000000ll);
+    }
+    for (int i0 = 0; i0 < n_out; i0 += 8) {
+        double mn[8], nx[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {                                  // slots up to 115 + 12 = 127 are column sums; the over-run of the last chunk stays inside the padded row
+            const int i = min(i0 + k, FBI_OW - 1);
+            mn[k] = row[i + 2 * FBI_M]; nx[k] = row[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (i0 + k < n_out) {
+                g += mn[k] - sub;
+                row[i0 + k] = g;                                       // window sum of column x_strip + i, in the slot of V[x - 6] (read above)
+                sub = nx[k];
+            }
+    }
+    if (c.sx < c.nx - 1) {
+        unsigned long long *pg = c.hout + (int64_t)yo * FBI_HW + 2 * ch, *ps = pg + 10;
+        const unsigned long long tag = (unsigned long long)c.epoch << 32;
+        const unsigned long long ug = (unsigned long long)__double_as_longlong(g), us = (unsigned long long)__double_as_longlong(sub);
+        fb_hand_st(pg, tag | (ug & 0xffffffffull)); fb_hand_st(pg + 1, tag | (ug >> 32));
+        fb_hand_st(ps, tag | (us & 0xffffffffull)); fb_hand_st(ps + 1, tag | (us >> 32));
+    }
+}
+
+// OpenCV's solve for output pixel (yo, x_strip + j) from the five window sums in LDS
+__device__ __forceinline__ void fb_iter_solve(const FbIterCtx &c, int yo, const double *rows5)
+{
+    typedef fb_off_t off_t;
+    const double scale = 1. / (double)(FBI_WIN * FBI_WIN);
+    const double g11 = rows5[c.j] * scale, g12 = rows5[FBI_VS2 + c.j] * scale, g22 = rows5[2 * FBI_VS2 + c.j] * scale;
+    const double h1 = rows5[3 * FBI_VS2 + c.j] * scale, h2 = rows5[4 * FBI_VS2 + c.j] * scale;
+    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+    float2 f;
+    f.x = (float)((g11 * h2 - g12 * h1) * idet);
+    f.y = (float)((g22 * h1 - g12 * h2) * idet);
+    *(float2 *)(c.fout + ((off_t)yo * (off_t)c.W + (off_t)(c.x_strip + c.j)) * 8) = f;
+}
+
+template <int K0, int G, int GN, int NB, int ABL>
+__device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
+                                                  float2 (&fl)[FBI_G], double *vrow)
+{
+#pragma unroll
+    for (int g0 = 0; g0 < G; g0 += NB) {
+        FbTaps t[NB];
+        float m[NB][5];
+#pragma unroll
+        for (int r = 0; r < NB; r++)
+            if (g0 + r < G && ABL != 1) fb_taps_load<ABL>(c, s0 + g0 + r, fl[g0 + r], t[r]);
+#pragma unroll
+        for (int r = 0; r < NB; r++)
+            if (g0 + r < G) {
+                const int g = g0 + r, s = s0 + g;
+                if (ABL == 1) { m[r][0] = (float)s; m[r][1] = (float)c.xc; m[r][2] = 1.f; m[r][3] = 2.f; m[r][4] = (float)(s + c.xc); }
+                else fb_taps_eval(c, s, t[r], m[r]);
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    S[ch] += (double)(m[r][ch] - ring[K0 + g][ch]); ring[K0 + g][ch] = m[r][ch];
+                    vrow[(g * 5 + ch) * FBI_VS2 + c.j] = S[ch];
+                }
+            }
+    }
+    if (ABL != 1) {
+#pragma unroll
+        for (int g = 0; g < GN; g++) fl[g] = fb_iter_flow_at(c, s0 + G + g);
+    }
+    __syncthreads();
+    if (c.j < G * 5) {                                                 // 20 or 25 chains, lanes of the direction's first wave
+        const int yo = s0 + c.sr - FBI_M;
+        if (yo < c.H) fb_iter_scan(c, yo, c.sch, vrow + c.j * FBI_VS2);    // (row r, channel ch) = LDS row r * 5 + ch = j
+    }
+    __syncthreads();
+    if (c.j < FBI_OW && c.x_strip + c.j < c.W) {
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            const int yo = s0 + r - FBI_M;
+            if (yo < c.H) fb_iter_solve(c, yo, vrow + (r * 5) * FBI_VS2);
+        }
+    }
+    __syncthreads();
+}
+
+template <int NB, int ABL>
+__global__ void __launch_bounds__(2 * FBI_T, 2)
+k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
+{
+    __shared__ double vrow_all[2][FBI_G * 5 * FBI_VS2];
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x / FBI_T); // wave-uniform: 0 / 1 (one direction only: 128 threads, q = 0)
+    double *vrow = vrow_all[q];
+    const int b = ticket / a.nx, sx = ticket - b * a.nx;               // strips of a pair hold consecutive tickets
+    const int d = a.dir[q];                                            // 0: prev -> next, 1: next -> prev
+    FbIterCtx c;
+    const float *R0 = a.R[d] + b * a.bs_R, *R1 = a.R[1 - d] + b * a.bs_R;
+    c.R0 = (const char *)R0; c.R0e = (const char *)(R0 + 4 * plane);
+    {
+        const bool patch = W >= 2 && H >= 2;
+        const int64_t dcorner[4] = {0, patch ? 1 : 0, patch ? W : 0, patch ? (int64_t)W + 1 : 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c.R1c[k] = (const char *)R1 + dcorner[k] * 16;
+            c.R1ec[k] = (const char *)(R1 + 4 * plane) + dcorner[k] * 4;
+        }
+    }
+    c.fin = (const char *)(a.fin[q] + b * a.bs_fin[q]); c.fout = (char *)(a.fout[q] + b * a.bs_fout[q]);
+    c.H = H; c.W = W;
+    c.j = threadIdx.x - q * FBI_T;
+    c.dj = c.j; c.tg = 0; c.tq = 0;
+    c.sr = c.j / 5; c.sch = c.j - c.sr * 5;
+    c.sx = sx; c.nx = a.nx; c.epoch = a.epoch;
+    {
+        // hand-over slots of (pair b, direction q, strip): [q][strip 0 .. nx - 2][row][FBI_HW words]
+        unsigned long long *hb = a.hand + b * a.bs_hand + (int64_t)q * (a.nx - 1) * H * FBI_HW;
+        c.hout = hb + (int64_t)sx * H * FBI_HW;
+        c.hin = hb + (int64_t)(sx > 0 ? sx - 1 : 0) * H * FBI_HW;
+    }
+    c.x_strip = sx * FBI_OW;
+    c.xc = tf_clampi(c.x_strip + c.j - FBI_M, 0, W - 1);              // column this thread evaluates M for (replicate border)
+    c.y0 = 0;
+    c.y1 = H;
+    {
+        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        const int xb = W - 1 - c.xc;
+        float lo = 1.f, hi = 1.f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { lo = c.xc == k ? border[k] : lo; hi = xb == k ? border[k] : hi; }
+        c.xscale = lo * hi;
+        c.xborder = (unsigned)(c.xc - 5) >= (unsigned)(W - 10);
+    }
+    float ring[FBI_WIN][5];
+    double S[5];
+    float2 fl[FBI_G];
+    {
+        // rows 0 .. m-1 -> ring slots m+1 .. 2m; slots 0 .. m+1 hold row 0 (as in k_fb_iter_tree)
+#pragma unroll
+        for (int r0 = 0; r0 < FBI_M; r0 += 3) {
+            float2 f0[3];
+            FbTaps t[3];
+            float mm[3][5];
+#pragma unroll
+            for (int r = 0; r < 3; r++) f0[r] = (ABL != 1) ? fb_iter_flow_at(c, r0 + r) : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 3; r++) if (ABL != 1) fb_taps_load<ABL>(c, r0 + r, f0[r], t[r]);
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int row = r0 + r;
+                if (ABL == 1) { mm[r][0] = (float)row; mm[r][1] = (float)c.xc; mm[r][2] = 1.f; mm[r][3] = 2.f; mm[r][4] = (float)(row + c.xc); }
+                else fb_taps_eval(c, row, t[r], mm[r]);
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    if (row == 0) {
+                        S[ch] = (double)(mm[r][ch] * (float)(FBI_M + 2));
+#pragma unroll
+                        for (int k = 0; k <= FBI_M + 1; k++) ring[k][ch] = mm[r][ch];       // rows -(m+1) .. 0
+                    } else {
+                        S[ch] += (double)mm[r][ch];
+                        ring[FBI_M + 1 + row][ch] = mm[r][ch];
+                    }
+                }
+            }
+        }
+    }
+    const int s_last = H - 1 + FBI_M;
+#pragma unroll
+    for (int g = 0; g < FBI_G; g++) fl[g] = (ABL != 1) ? fb_iter_flow_at(c, FBI_M + g) : make_float2(0.f, 0.f);
+    for (int base = FBI_M; base <= s_last; base += FBI_WIN) {
+        fb_iter_group_seq<0, 4, 4, NB, ABL>(c, base, ring, S, fl, vrow);
+        fb_iter_group_seq<4, 4, 5, NB, ABL>(c, base + 4, ring, S, fl, vrow);
+        fb_iter_group_seq<8, 5, 4, NB, ABL>(c, base + 8, ring, S, fl, vrow);
     }
 }
 
@@ -1106,15 +1342,28 @@ static void fb_prepare_poly(int n, double sigma, FbPoly *pp) {
             G00 += g[y] * g[x]; G11 += g[y] * g[x] * x * x;
             G33 += g[y] * g[x] * x * x * x * x; G55 += g[y] * g[x] * x * x * y * y;
         }
-    // G = [[G00,0,0,G11,G11,0],[0,G11,..],[..,G11,..],[G11,0,0,G33,G55,0],[G11,0,0,G55,G33,0],[..G55]]
-    // inverse by blocks: indices {1},{2},{5} are decoupled; {0,3,4} form a 3x3 symmetric block.
-    const double a = G00, b = G11, c = G33, d = G55;
-    // 3x3 block B = [[a,b,b],[b,c,d],[b,d,c]]; cofactors
-    const double det = a * (c * c - d * d) - b * (b * c - b * d) + b * (b * d - b * c);
-    pp->ig11 = 1. / G11;
-    pp->ig03 = -(b * c - d * b) / det;          // inv[0][1] of the block = -(b*c - b*d)/det
-    pp->ig33 = (a * c - b * b) / det;           // inv[1][1] of the block
-    pp->ig55 = 1. / G55;
+    // inv(G) by Gauss-Jordan elimination with partial pivoting in double, operation for operation as the oracle does it
+    // (oracle/c/farneback.c inv6): the four entries are used as double factors of every expansion coefficient, and a
+    // closed-form block inverse (rounds 1 - 3) differs from the elimination in the last digits -- enough to flip the float
+    // rounding of one coefficient in ~10^5, which the sequential box sums then carry down a whole column.
+    double m[6][12];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 12; j++) m[i][j] = 0.;
+    m[0][0] = G00; m[1][1] = m[2][2] = m[0][3] = m[0][4] = m[3][0] = m[4][0] = G11;
+    m[3][3] = m[4][4] = G33; m[3][4] = m[4][3] = m[5][5] = G55;
+    for (int i = 0; i < 6; i++) m[i][i + 6] = 1.;
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++) if (fabs(m[r][c]) > fabs(m[piv][c])) piv = r;
+        if (piv != c) for (int j = 0; j < 12; j++) std::swap(m[c][j], m[piv][j]);
+        const double d = 1. / m[c][c];
+        for (int j = 0; j < 12; j++) m[c][j] *= d;
+        for (int r = 0; r < 6; r++) {
+            if (r == c) continue;
+            const double f = m[r][c];
+            if (f != 0) for (int j = 0; j < 12; j++) m[r][j] -= f * m[c][j];
+        }
+    }
+    pp->ig11 = m[1][7]; pp->ig03 = m[0][9]; pp->ig33 = m[3][9]; pp->ig55 = m[5][11];
 }
 
 static int fb_levels(int64_t H, int64_t W, const tf_farneback_params *p) {
@@ -1325,6 +1574,18 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             const dim3 gi((unsigned)(nx * B), 1, 1), bi(FBI_T * nd);
             FbIterArgs ia;
             ia.R[0] = R[0]; ia.R[1] = R[1]; ia.bs_R = bs_R; ia.nd = nd; ia.nx = nx;
+            // development switch: TF_FB_ROW_SUMS_TREE=1 -> the round-3 kernel (window sums as a tree: within 1e-4 px of OpenCV's order, not identical)
+            static const bool tree = getenv("TF_FB_ROW_SUMS_TREE") != nullptr;
+            // sequential row sums: the strips' hand-over words and the launches' ticket counters live in the blur scratch,
+            // idle from the polynomial expansion of this level to the blur of the next: [1 KB of counters][words] per pair
+            const size_t hand_words = (size_t)nd * (size_t)(nx - 1) * (size_t)h * FBI_HW;
+            ia.hand = (unsigned long long *)((char *)tmp + 1024); ia.bs_hand = bs_tmp / 2; ia.ticket = (int *)tmp; ia.epoch = 0;
+            if (!tree) {
+                TF_REQUIRE(1024 + hand_words * 8 <= (size_t)bs_tmp * sizeof(float), "tf_farneback: blur scratch too small for the strips' hand-over words");
+                TF_REQUIRE(p->num_iters <= 255, "tf_farneback: more than 255 iterations per level");
+                TF_CHECK_HIP(hipMemsetAsync(tmp, 0, 1024, s));
+                for (int b = 0; b < B && hand_words > 0; b++) TF_CHECK_HIP(hipMemsetAsync((char *)(tmp + (int64_t)b * bs_tmp) + 1024, 0, hand_words * 8, s));
+            }
             for (int it = 0; it < p->num_iters; it++) {
                 for (int q = 0; q < nd; q++) {
                     const int d = dirs[q];
@@ -1335,7 +1596,12 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                 {
                     TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd * B, s);
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
-                    if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1>), gi, bi, 0, s, ia, h, w, plane);
+                    ia.epoch = (unsigned)(it + 1); ia.ticket = (int *)tmp + it;
+                    if (tree) {
+                        if (abl == 1) hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 1>), gi, bi, 0, s, ia, h, w, plane);
+                        else if (abl == 2) hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 2>), gi, bi, 0, s, ia, h, w, plane);
+                        else hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 0>), gi, bi, 0, s, ia, h, w, plane);
+                    } else if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1>), gi, bi, 0, s, ia, h, w, plane);
                     else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2>), gi, bi, 0, s, ia, h, w, plane);
                     else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0>), gi, bi, 0, s, ia, h, w, plane);
                 }
@@ -1529,4 +1795,29 @@ extern "C" int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64
                                  void *ws, size_t ws_bytes, void *stream)
 {
     return tf_farneback_batch(prev, next, 1, H * W, H, W, p, flow_fwd, flow_bwd, H * W * 2, ws, ws_bytes, stream);
+}
+
+// Diagnostic / test entry: the full-resolution level's image (3 x 3 Gaussian of the uint8 frame) and its polynomial
+// expansion, as the pyramid loop computes them -- so that the stages below the iteration can be compared with the oracle
+// one by one (tests/test_gpu_parity.py).  blur_out: H * W floats or NULL; R_out: 5 * H * W floats, the library's layout
+// (H * W float4 {r0, r1, r2, r3} followed by one plane r4; OpenCV's 5 interleaved channels in the same order).
+extern "C" int tf_farneback_expansion(const uint8_t *img, int64_t H64, int64_t W64, const tf_farneback_params *p,
+                                      float *blur_out, float *R_out, void *stream)
+{
+    TF_REQUIRE(img && p && R_out, "tf_farneback_expansion: null pointer");
+    TF_REQUIRE(H64 > 0 && W64 > 0 && H64 < (1 << 15) && W64 < (1 << 15), "tf_farneback_expansion: bad shape");
+    TF_REQUIRE(p->poly_n >= 1 && p->poly_n <= FB_MAX_POLY_N, "tf_farneback_expansion: poly_n out of range");
+    const int H = (int)H64, W = (int)W64;
+    hipStream_t s = (hipStream_t)stream;
+    FbPoly pp; fb_prepare_poly(p->poly_n, p->poly_sigma, &pp);
+    FbKernel hk; fb_gaussian_kernel(3, 0.0, &hk);
+    float *blur = blur_out;
+    if (!blur) TF_CHECK_HIP(hipMallocAsync((void **)&blur, (size_t)H * W * sizeof(float), s));
+    const dim3 block(64, 4);
+    hipLaunchKernelGGL(k_fb_blur3_fused<uint8_t>, dim3((W + 255) / 256, (H + 3) / 4, 1), block, 0, s, img, H, W, hk, blur, (int64_t)H * W, (int64_t)H * W);
+    hipLaunchKernelGGL(pp.n == 5 && !fb_polyexp_generic() ? k_fb_polyexp5 : k_fb_polyexp, dim3((W + FBP_W - 1) / FBP_W, (H + FBP_H - 1) / FBP_H, 1), block, 0, s,
+                       (const float *)blur, H, W, pp, R_out, (int64_t)H * W, (int64_t)H * W, (int64_t)5 * H * W);
+    TF_CHECK_LAUNCH();
+    if (!blur_out) TF_CHECK_HIP(hipFreeAsync(blur, s));
+    return TF_OK;
 }
