@@ -67,12 +67,12 @@ def _anvil_markers(field):
 def test_config_S_whole_pipeline_matches_the_oracle():
     """Config S: 16 x 512 x 512 translating blobs, the settings of scripts/dcc_detect_goes.py:164-166
     (vr_steps=1, smoothing_passes=1, cubic).
-    Flow: the raw Farneback vectors are within the north star's 1e-4 of the oracle's; the refinement and the smoothing
-    are bit-exact GIVEN their input (checked here by running the oracle's stages on the GPU's own raw vectors).  The
-    composed pipelines cannot agree to 1e-4 everywhere, by the algorithm itself: cv2's remap quantises sampling
-    coordinates to 1/32 px, so a 1e-5 difference in a vector that sits on a bin edge moves the warped grey value by a
-    finite step (up to gradient / 32) and the refined vector by ~1e-2 -- that happens at a handful of pixels and is
-    asserted as such (maximum <= 0.05 px, and at most 2e-5 of the components beyond 1e-4).
+    Flow (round 4): BIT FOR BIT the oracle's, raw and composed.  Rounds 1 - 3 accepted a maximum of 0.05 px with up to 2e-5
+    of the components beyond 1e-4 for the composed flow: the raw vectors were ~1e-7 away (window sums in another order
+    than OpenCV's running sum along the row, a reciprocal with a Newton step in the solve, inv(G) in closed form), and
+    cv2's remap quantises sampling coordinates to 1/32 px, so a vector on a bin edge moved the refined one by ~1e-2.
+    With the sequential row sums (k_fb_iter), OpenCV's solve and the oracle's inverse every stage is bit-identical, and so
+    is the composition.
     Everything downstream is integer / bit-exact work and is compared bit for bit on the GPU's own flows."""
     import tobac_flow_amd.flow as tf
     from oracle import np_label, np_ops, ws_oracle
@@ -87,16 +87,11 @@ def test_config_S_whole_pipeline_matches_the_oracle():
         assert got.shape == (16, 512, 512, 2) and got.dtype == np.float32
         assert np.array_equal(np.isnan(got), np.isnan(want))
         d = np.abs(np.nan_to_num(got) - np.nan_to_num(want))
-        n_off = int((d > 1e-4).sum())
-        print("config S composed flow vs oracle: 99.9th percentile %.3g, max %.3g, %d of %d components beyond 1e-4"
-              % (np.percentile(d, 99.9), d.max(), n_off, d.size))
-        # a MAX and a COUNT: the raw vectors differ by ~1e-7 (asserted below at <= 1e-4, and bit-exact stages on top of
-        # them), so a sampling coordinate crosses one of remap's 1/32-px bins at a few dozen of the 8 million vectors;
-        # there the refined vector moves by up to (grey-value step) / (local gradient), a few hundredths of a pixel
-        assert d.max() <= 0.05 and n_off <= 2e-5 * d.size, (np.percentile(d, 99.9), d.max(), n_off)
+        print("config S composed flow vs oracle: max %.3g, %d of %d components differ" % (d.max(), int((d != 0).sum()), d.size))
+        assert np.array_equal(got, want, equal_nan=True), (d.max(), int((d != 0).sum()))
     raw_f, raw_b = tf.calculate_flow(bt, "Farneback")           # no refinement, no smoothing
     want_rf, want_rb = _oracle_flow(bt, 0, 0, "linear", max_value=np.inf)
-    assert np.abs(raw_f - want_rf).max() <= 1e-4 and np.abs(raw_b - want_rb).max() <= 1e-4
+    assert np.array_equal(raw_f, want_rf, equal_nan=True) and np.array_equal(raw_b, want_rb, equal_nan=True)
     for i in (0, 5, 14):                                        # oracle stages on the GPU's raw vectors: bit-exact
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")

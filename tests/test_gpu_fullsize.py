@@ -77,13 +77,12 @@ def test_farneback_full_frame_recovers_translation(size):
 
 
 def test_farneback_full_frame_matches_oracle_without_strip_seams():
-    """One full-disk-sized pair (5424 x 5424: 47 column strips of the fused iteration kernel, all six pyramid
-    resolutions) against the CPU oracle, forward direction (the oracle needs ~15 - 30 s): EVERY vector within the north
-    star's 1e-4.  (Round 2 accepted a 1.5e-4 tail at the 99.99th percentile: the iteration kernel restarted OpenCV's
-    running column sums at every row strip, and the float rounding those sums carry down a whole column -- oracle/c/
-    farneback.c:280, `vsum += srow1 - srow0` with the difference in float -- moved low-texture pixels by more than 1e-4.
-    The kernel now walks whole columns with that recurrence.)  The difference must not depend on the position inside a
-    116-column strip (FBI_OW, farneback.hip): that is what a tiling seam would look like; there are no row strips."""
+    """One full-disk-sized pair (5424 x 5424: 47 column strips of the fused iteration kernel handing their running row
+    sums to each other, all six pyramid resolutions) against the CPU oracle, forward direction (the oracle needs ~15 - 30 s):
+    EVERY vector BIT FOR BIT (round 4).  History: round 2 accepted a 1.5e-4 tail (running column sums restarted at every
+    row strip); round 3 walked whole columns with OpenCV's recurrence (oracle/c/farneback.c:280) and was within 7.3e-5;
+    round 4 carries OpenCV's running sum along the row from strip to strip too (farneback.c:282-292), solves on the window
+    means with a true division and inverts G as the oracle does: nothing is left."""
     import torch
     import tobac_flow_amd.flow as tf
     from test_gpu_parity import _oracle_farneback
@@ -100,20 +99,7 @@ def test_farneback_full_frame_matches_oracle_without_strip_seams():
     assert abs(float(np.median(want[..., 0])) + 3) < 0.1 and abs(float(np.median(want[..., 1])) - 2) < 0.1
     d = np.abs(got - want)
     print("farneback 5424^2 vs oracle: mean %.3g, 99.99th percentile %.3g, max %.3g" % (d.mean(), np.percentile(d, 99.99), d.max()))
-    assert d.max() <= 1e-4, (d.mean(), np.percentile(d, 99.99), d.max())
-    STRIP = 116                                                                   # FBI_OW = FBI_T - 2 * FBI_M output columns per workgroup
-    per_col = d.sum(-1).mean(0)
-    xl = np.arange(W) % STRIP
-    overall = per_col.mean()
-    for lo in (0, 6, STRIP - 12):                                                 # strip edges and their halo overlap
-        assert per_col[(xl >= lo) & (xl < lo + 12)].mean() <= 1.5 * overall + 1e-9
-    # what is left grows slowly DOWN the image: a one-ulp difference anywhere (the horizontal window sums and the division
-    # are evaluated in double in another order than OpenCV's sequential running sum along the row, which no parallel
-    # evaluation can reproduce to the last bit) changes M there, with it the float rounding of OpenCV's vertical
-    # differences, and through the running column sum every row below: bounded here, and far below the tolerance
-    per_row = d.sum(-1).mean(1)
-    print("per-row mean difference: top half %.3g, bottom half %.3g" % (per_row[:H // 2].mean(), per_row[H // 2:].mean()))
-    assert per_row.max() <= 2e-5
+    assert np.array_equal(got, want), (int((got != want).sum()), d.max())
 
 
 def test_sobel_full_frame_power_of_two_linearity(full):

@@ -703,6 +703,9 @@ struct FbIterArgs {
     const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2];
     // sequential row sums (k_fb_iter): hand-over words of batch item 0 (item b adds b * bs_hand words), this launch's tag, its ticket counter
     unsigned long long *hand; int64_t bs_hand; unsigned epoch; int *ticket;
+    int abl;                        // timing aid (TF_FBI_SEQ_ABLATE, wrong flows): 1 no wait for the left neighbour, 2 no chain, 4 no solve
+    int nq;                         // 1: a workgroup holds all directions of its strip; 2: one direction per workgroup, directions take tickets
+    int nb, nxg, slack_rows;        // pairs in the launch; strips per column group (ticket order); rows a strip lets its left neighbour get ahead before it starts
 };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
 #ifndef FBI_NB
@@ -723,7 +726,7 @@ struct FbIterCtx {
     int H, W; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale; bool xborder;
     // sequential row sums: strip index / count, the (row of the group, channel) this lane scans, hand-over slots of the left
     // neighbour (read) and of this strip (written), the launch's tag
-    int sx, nx, sr, sch; const unsigned long long *hin; unsigned long long *hout; unsigned epoch;
+    int sx, nx, sr, sch; const unsigned long long *hin; unsigned long long *hout; unsigned epoch; int abl; int *spins;
 };
 
 struct FbTaps { float4 q0, c00, c01, c10, c11; float2 e0, e1; float q04, dx, dy; };
@@ -1039,47 +1042,87 @@ k_fb_iter_tree(FbIterArgs a, int H, int W, int64_t plane)
 __device__ __forceinline__ unsigned long long fb_hand_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fb_hand_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// one chain: row `row` (LDS, slot i = column x_strip + i - 6) of output row yo, channel ch
-__device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch, double *row)
+// the hand-over words of one chain (row yo, channel ch), as loaded: valid iff all four tags are this launch's
+struct FbHand { unsigned long long w0, w1, w2, w3; };
+__device__ __forceinline__ void fb_hand_load(const FbIterCtx &c, int yo, int ch, FbHand &h)
+{
+    const unsigned long long *pg = c.hin + (int64_t)yo * FBI_HW + 2 * ch;
+    h.w0 = fb_hand_ld(pg); h.w1 = fb_hand_ld(pg + 1); h.w2 = fb_hand_ld(pg + 10); h.w3 = fb_hand_ld(pg + 11);
+}
+__device__ __forceinline__ bool fb_hand_valid(const FbIterCtx &c, const FbHand &h)
+{
+    return (unsigned)(h.w0 >> 32) == c.epoch && (unsigned)(h.w1 >> 32) == c.epoch && (unsigned)(h.w2 >> 32) == c.epoch && (unsigned)(h.w3 >> 32) == c.epoch;
+}
+
+// one chain: row `row` (LDS, slot i = column x_strip + i - 6) of output row yo, channel ch; `h`: the left neighbour's words
+// as fetched at the top of the row group (it is normally a group ahead: they are there), polled here if they were not
+__device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch, double *row, FbHand h)
 {
     const int n_out = min(FBI_OW, c.W - c.x_strip);                    // (wave-uniform)
     double g, sub;
-    if (c.sx == 0) {
+    if (c.sx == 0 || (c.abl & 1)) {
         const double v0 = row[FBI_M];                                  // column 0
         g = v0 * (double)(FBI_M + 2);
 #pragma unroll
         for (int x = 1; x < FBI_M; x++) g += row[FBI_M + x];           // (columns past W - 1 hold the clamped column: OpenCV's replicated border)
         sub = v0;                                                      // vsum[-m - 1] = vsum[0]
     } else {
-        const unsigned long long *pg = c.hin + (int64_t)yo * FBI_HW + 2 * ch, *ps = pg + 10;
-        unsigned long long w0, w1, w2, w3;
-        bool ok = false;
+        bool ok = fb_hand_valid(c, h);
         // (the left neighbour holds a lower ticket: it is running or done.  The poll count is bounded all the same -- several
         // seconds -- so that the grid drains whatever happens; a chain that gives up continues with NaN, which no test misses)
-        for (int spin = 0; spin < (1 << 22); spin++) {
-            w0 = fb_hand_ld(pg); w1 = fb_hand_ld(pg + 1); w2 = fb_hand_ld(ps); w3 = fb_hand_ld(ps + 1);
-            ok = (unsigned)(w0 >> 32) == c.epoch && (unsigned)(w1 >> 32) == c.epoch && (unsigned)(w2 >> 32) == c.epoch && (unsigned)(w3 >> 32) == c.epoch;
-            if (ok) break;
+        if (!ok && c.spins) atomicAdd(c.spins, 1);                     // (development aid: chains that found their words missing at scan time)
+        for (int spin = 0; !ok && spin < (1 << 22); spin++) {
+            if (c.spins) atomicAdd(c.spins + 1, 1);
             __builtin_amdgcn_s_sleep(1);
+            fb_hand_load(c, yo, ch, h);
+            ok = fb_hand_valid(c, h);
         }
-        g = __longlong_as_double((long long)((w1 << 32) | (w0 & 0xffffffffull)));
-        sub = __longlong_as_double((long long)((w3 << 32) | (w2 & 0xffffffffull)));
+        g = __longlong_as_double((long long)((h.w1 << 32) | (h.w0 & 0xffffffffull)));
+        sub = __longlong_as_double((long long)((h.w3 << 32) | (h.w2 & 0xffffffffull)));
         if (!ok) g = __longlong_as_double(0x7ff8000000000000ll);
     }
-    for (int i0 = 0; i0 < n_out; i0 += 8) {
-        double mn[8], nx[8];
+    if (n_out == FBI_OW) {
+        // a full strip, straight-line.  A column sum is the minuend of step i and the subtrahend of step i + 13: chunks of
+        // WIN = 13 steps keep the last 13 minuends in registers, so every LDS slot is read ONCE (a lone wave pays ~4 ns per
+        // instruction whatever it is -- tools/microbench/chain_lds.hip: dependent add 5, subtraction 4, LDS read of two
+        // values 8, LDS write of two 5 ns -- so the chain is bound by its instruction count, not by the adds).  The reads of
+        // chunk c + 1 (slots 13c + 25 .. 13c + 37) are issued before the chain of chunk c, which writes slots 13c .. 13c + 12.
+        constexpr int CH = FBI_WIN, NFULL = FBI_OW / CH, TAIL = FBI_OW - NFULL * CH;
+        static_assert(TAIL == 12 && NFULL * CH + TAIL + 2 * FBI_M == FBI_T, "chain chunks");
+        double prev[CH], mn[CH];
+        prev[0] = sub;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {                                  // slots up to 115 + 12 = 127 are column sums; the over-run of the last chunk stays inside the padded row
-            const int i = min(i0 + k, FBI_OW - 1);
-            mn[k] = row[i + 2 * FBI_M]; nx[k] = row[i];
+        for (int k = 1; k < CH; k++) prev[k] = row[k - 1];             // slots 0 .. 11: the subtrahends of steps 1 .. 12
+#pragma unroll
+        for (int k = 0; k < CH; k++) mn[k] = row[2 * FBI_M + k];       // slots 12 .. 24
+#pragma unroll 1
+        for (int i0 = 0; i0 < NFULL * CH; i0 += CH) {
+            double nxt[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) nxt[k] = row[min(i0 + CH + 2 * FBI_M + k, FBI_T - 1)];   // (the chunk after the last full one has 12 steps: slots up to 127)
+            double d[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) d[k] = mn[k] - prev[k];
+#pragma unroll
+            for (int k = 0; k < CH; k++) { g += d[k]; row[i0 + k] = g; }
+#pragma unroll
+            for (int k = 0; k < CH; k++) { prev[k] = mn[k]; mn[k] = nxt[k]; }
         }
+        {
+            double d[TAIL];
 #pragma unroll
-        for (int k = 0; k < 8; k++)
-            if (i0 + k < n_out) {
-                g += mn[k] - sub;
-                row[i0 + k] = g;                                       // window sum of column x_strip + i, in the slot of V[x - 6] (read above)
-                sub = nx[k];
-            }
+            for (int k = 0; k < TAIL; k++) d[k] = mn[k] - prev[k];
+#pragma unroll
+            for (int k = 0; k < TAIL; k++) { g += d[k]; row[NFULL * CH + k] = g; }
+            sub = prev[TAIL];                                          // slot 115 = column x_strip + 109: the next strip's first subtrahend
+        }
+    } else {
+        for (int i = 0; i < n_out; i++) {                              // the ragged last strip
+            const double mnv = row[i + 2 * FBI_M], nxv = row[i];
+            g += mnv - sub;
+            row[i] = g;                                                // window sum of column x_strip + i, in the slot of V[x - 6] (read above)
+            sub = nxv;
+        }
     }
     if (c.sx < c.nx - 1) {
         unsigned long long *pg = c.hout + (int64_t)yo * FBI_HW + 2 * ch, *ps = pg + 10;
@@ -1108,6 +1151,10 @@ template <int K0, int G, int GN, int NB, int ABL>
 __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
                                                   float2 (&fl)[FBI_G], double *vrow)
 {
+    // the chain lanes ask for their left neighbour's hand-over words now: the answer arrives during the column phase
+    FbHand hand = {0ull, 0ull, 0ull, 0ull};
+    const bool chain_lane = c.j < G * 5 && s0 + c.sr - FBI_M < c.H;
+    if (chain_lane && c.sx > 0) fb_hand_load(c, s0 + c.sr - FBI_M, c.sch, hand);
 #pragma unroll
     for (int g0 = 0; g0 < G; g0 += NB) {
         FbTaps t[NB];
@@ -1133,12 +1180,10 @@ __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, fl
         for (int g = 0; g < GN; g++) fl[g] = fb_iter_flow_at(c, s0 + G + g);
     }
     __syncthreads();
-    if (c.j < G * 5) {                                                 // 20 or 25 chains, lanes of the direction's first wave
-        const int yo = s0 + c.sr - FBI_M;
-        if (yo < c.H) fb_iter_scan(c, yo, c.sch, vrow + c.j * FBI_VS2);    // (row r, channel ch) = LDS row r * 5 + ch = j
-    }
+    if (chain_lane && !(c.abl & 2))                                    // 20 or 25 chains, lanes of the direction's first wave
+        fb_iter_scan(c, s0 + c.sr - FBI_M, c.sch, vrow + c.j * FBI_VS2, hand);             // (row r, channel ch) = LDS row r * 5 + ch = j
     __syncthreads();
-    if (c.j < FBI_OW && c.x_strip + c.j < c.W) {
+    if (c.j < FBI_OW && c.x_strip + c.j < c.W && !(c.abl & 4)) {
 #pragma unroll
         for (int r = 0; r < G; r++) {
             const int yo = s0 + r - FBI_M;
@@ -1148,18 +1193,27 @@ __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, fl
     __syncthreads();
 }
 
-template <int NB, int ABL>
-__global__ void __launch_bounds__(2 * FBI_T, 2)
+// NDW = directions per workgroup: 2 = both directions of a strip share a workgroup (and the R rows they read), 1 = every
+// (strip, direction) is a two-wave workgroup of its own, four per CU (a.nq = 2 then: directions take tickets of their own)
+template <int NB, int ABL, int NDW>
+__global__ void __launch_bounds__(NDW * FBI_T, 2)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
 {
-    __shared__ double vrow_all[2][FBI_G * 5 * FBI_VS2];
+    __shared__ double vrow_all[NDW][FBI_G * 5 * FBI_VS2];
     __shared__ int s_ticket;
     if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1);
     __syncthreads();
     const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x / FBI_T); // wave-uniform: 0 / 1 (one direction only: 128 threads, q = 0)
-    double *vrow = vrow_all[q];
-    const int b = ticket / a.nx, sx = ticket - b * a.nx;               // strips of a pair hold consecutive tickets
+    const int qw = __builtin_amdgcn_readfirstlane(threadIdx.x / FBI_T); // wave-uniform: which half of the workgroup (0 when it has one direction)
+    double *vrow = vrow_all[qw];
+    // ticket -> (pair, strip): column groups of nxg strips, group by group; inside a group pair by pair, strips left to right
+    // (a strip's left neighbour always holds a lower ticket).  A launch that needs several rounds of resident workgroups
+    // runs one column group per round: the start delays below then add up over nxg strips, not over all of them.
+    const int per_group = a.nb * a.nxg * a.nq;
+    const int cg = ticket / per_group, tr = ticket - cg * per_group, n_cg = min(a.nxg, a.nx - cg * a.nxg);
+    const int b = tr / (n_cg * a.nq), tr2 = tr - b * n_cg * a.nq, sxl = tr2 / a.nq;
+    const int sx = cg * a.nxg + sxl;
+    const int q = NDW == 2 ? qw : tr2 - sxl * a.nq;                    // index into the launch's directions
     const int d = a.dir[q];                                            // 0: prev -> next, 1: next -> prev
     FbIterCtx c;
     const float *R0 = a.R[d] + b * a.bs_R, *R1 = a.R[1 - d] + b * a.bs_R;
@@ -1175,10 +1229,10 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
     }
     c.fin = (const char *)(a.fin[q] + b * a.bs_fin[q]); c.fout = (char *)(a.fout[q] + b * a.bs_fout[q]);
     c.H = H; c.W = W;
-    c.j = threadIdx.x - q * FBI_T;
+    c.j = threadIdx.x - qw * FBI_T;
     c.dj = c.j; c.tg = 0; c.tq = 0;
     c.sr = c.j / 5; c.sch = c.j - c.sr * 5;
-    c.sx = sx; c.nx = a.nx; c.epoch = a.epoch;
+    c.sx = sx; c.nx = a.nx; c.epoch = a.epoch; c.abl = a.abl; c.spins = (a.abl & 8) ? a.ticket - (a.epoch - 1) + 256 - 4 : nullptr;
     {
         // hand-over slots of (pair b, direction q, strip): [q][strip 0 .. nx - 2][row][FBI_HW words]
         unsigned long long *hb = a.hand + b * a.bs_hand + (int64_t)q * (a.nx - 1) * H * FBI_HW;
@@ -1234,6 +1288,17 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
     const int s_last = H - 1 + FBI_M;
 #pragma unroll
     for (int g = 0; g < FBI_G; g++) fl[g] = (ABL != 1) ? fb_iter_flow_at(c, FBI_M + g) : make_float2(0.f, 0.f);
+    if (sx > 0 && a.slack_rows > 0 && !(a.abl & 1)) {
+        // SLACK.  Strips that start together run in lockstep: each finds its left neighbour's words missing at every row
+        // group, polls, and passes every hiccup on to all strips right of it (measured: 55 % of the chains waited, the launch
+        // took 1.5 x the time of its parts).  So a strip starts only when its left neighbour is slack_rows ahead: the
+        // words are then there when the row group asks for them, and a neighbour's hiccup is absorbed by the lead.
+        if (threadIdx.x == 0) {
+            const unsigned long long *p = c.hin + (int64_t)min(a.slack_rows, H - 1) * FBI_HW;
+            for (int spin = 0; spin < (1 << 22) && (unsigned)(fb_hand_ld(p) >> 32) != a.epoch; spin++) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    }
     for (int base = FBI_M; base <= s_last; base += FBI_WIN) {
         fb_iter_group_seq<0, 4, 4, NB, ABL>(c, base, ring, S, fl, vrow);
         fb_iter_group_seq<4, 4, 5, NB, ABL>(c, base + 4, ring, S, fl, vrow);
@@ -1579,10 +1644,32 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             // sequential row sums: the strips' hand-over words and the launches' ticket counters live in the blur scratch,
             // idle from the polynomial expansion of this level to the blur of the next: [1 KB of counters][words] per pair
             const size_t hand_words = (size_t)nd * (size_t)(nx - 1) * (size_t)h * FBI_HW;
+            static const int seq_abl = getenv("TF_FBI_SEQ_ABLATE") ? atoi(getenv("TF_FBI_SEQ_ABLATE")) : 0;
+            ia.abl = seq_abl;
+            {
+                // column groups: one per round of resident workgroups (two 4-wave workgroups per CU)
+                static int slots = 0;
+                if (slots == 0) {
+                    int dev = 0, n_cu = 256;
+                    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+                    slots = 2 * n_cu;
+                }
+                // one direction per workgroup (four two-wave workgroups per CU) unless TF_FBI_JOIN_DIRECTIONS=1: the chains make a
+                // workgroup latency-bound for a third of its time, and four independent workgroups per CU overlap those
+                // stretches better than two (config F: 2.05 s of k_fb_iter per step against 2.25 s), at the price of reading the
+                // R rows once per direction again (round 3 joined the directions for that: -23 % HBM bytes, same time)
+                static const bool join_env = getenv("TF_FBI_JOIN_DIRECTIONS") != nullptr;
+                ia.nq = (!join_env && nd == 2) ? 2 : 1;
+                const int rounds = (int)(((int64_t)nx * B + slots - 1) / slots);
+                static const int slack_env = getenv("TF_FBI_SLACK_ROWS") ? atoi(getenv("TF_FBI_SLACK_ROWS")) : -1;
+                static const int groups_env = getenv("TF_FBI_COLUMN_GROUPS") ? atoi(getenv("TF_FBI_COLUMN_GROUPS")) : 0;
+                const int n_groups = groups_env > 0 ? std::min(groups_env, nx) : std::min(rounds, nx);
+                ia.nb = B; ia.nxg = (nx + n_groups - 1) / n_groups; ia.slack_rows = slack_env >= 0 ? slack_env : 0;
+            }
             ia.hand = (unsigned long long *)((char *)tmp + 1024); ia.bs_hand = bs_tmp / 2; ia.ticket = (int *)tmp; ia.epoch = 0;
             if (!tree) {
                 TF_REQUIRE(1024 + hand_words * 8 <= (size_t)bs_tmp * sizeof(float), "tf_farneback: blur scratch too small for the strips' hand-over words");
-                TF_REQUIRE(p->num_iters <= 255, "tf_farneback: more than 255 iterations per level");
+                TF_REQUIRE(p->num_iters <= 250, "tf_farneback: more than 250 iterations per level");
                 TF_CHECK_HIP(hipMemsetAsync(tmp, 0, 1024, s));
                 for (int b = 0; b < B && hand_words > 0; b++) TF_CHECK_HIP(hipMemsetAsync((char *)(tmp + (int64_t)b * bs_tmp) + 1024, 0, hand_words * 8, s));
             }
@@ -1601,13 +1688,22 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                         if (abl == 1) hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 1>), gi, bi, 0, s, ia, h, w, plane);
                         else if (abl == 2) hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 2>), gi, bi, 0, s, ia, h, w, plane);
                         else hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 0>), gi, bi, 0, s, ia, h, w, plane);
-                    } else if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1>), gi, bi, 0, s, ia, h, w, plane);
-                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2>), gi, bi, 0, s, ia, h, w, plane);
-                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0>), gi, bi, 0, s, ia, h, w, plane);
+                    } else if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1, 2>), gi, bi, 0, s, ia, h, w, plane);
+                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2, 2>), gi, bi, 0, s, ia, h, w, plane);
+                    else if (ia.nq == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 1>), dim3(gi.x * 2), dim3(FBI_T), 0, s, ia, h, w, plane);
+                    else if (nd == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 1>), gi, bi, 0, s, ia, h, w, plane);
+                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 2>), gi, bi, 0, s, ia, h, w, plane);
                 }
                 for (int q = 0; q < nd; q++) cur[dirs[q]] = 1 - cur[dirs[q]];
             }
             TF_CHECK_LAUNCH();
+            if (!tree && (seq_abl & 8)) {                               // development aid: how often did a chain have to wait?
+                int h_sp[2] = {0, 0};
+                TF_CHECK_HIP(hipMemcpyAsync(h_sp, (int *)tmp + 252, sizeof(h_sp), hipMemcpyDeviceToHost, s));
+                TF_CHECK_HIP(hipStreamSynchronize(s));
+                fprintf(stderr, "k_fb_iter %d x %d, %d pairs, %d launches: %d chains waited (of %lld), %d polls\n", h, w, B, p->num_iters, h_sp[0],
+                        (long long)B * nd * (nx - 1) * h * 5 * p->num_iters, h_sp[1]);
+            }
         } else {
             // generic window size: separate UpdateMatrices / box-filter+solve kernels, one pair at a time, in place
             const dim3 glev1((w + 63) / 64, (h + 3) / 4, 1);
