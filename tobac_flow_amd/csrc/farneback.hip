@@ -1437,11 +1437,17 @@ static int fb_levels(int64_t H, int64_t W, const tf_farneback_params *p) {
     return k;
 }
 
+// floats of blur scratch the iteration kernel borrows per pair at a level of h x w: 1 KB of ticket counters + the strips'
+// hand-over words (both directions)
+static size_t fb_hand_floats(int64_t h, int64_t w) {
+    const int64_t nx = (w + FBI_OW - 1) / FBI_OW;
+    return 256 + 2 * (size_t)(2 * (nx - 1) * h * FBI_HW);
+}
 static size_t fb_pair_floats(int64_t H, int64_t W, bool fused) {
     // per pair: tmp (n + 2H + 64), blur, I, R[2] (5n each), 2 flow scratch (2n each); the 5-plane matrix M (5n) only for the
     // unfused fallback (window sizes other than 13): the fused iteration never stores it
     const size_t n = (size_t)H * W;
-    return tf_align_up(n + 2 * (size_t)H + 64, 64) + 2 * tf_align_up(n, 64) + (fused ? 10 : 15) * tf_align_up(n, 64) + 2 * tf_align_up(2 * n, 64);
+    return tf_align_up(std::max(n + 2 * (size_t)H + 64, fb_hand_floats(H, W)), 64) + 2 * tf_align_up(n, 64) + (fused ? 10 : 15) * tf_align_up(n, 64) + 2 * tf_align_up(2 * n, 64);
 }
 
 extern "C" size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const tf_farneback_params *p)
@@ -1518,8 +1524,9 @@ static void fb_phase_sizes(int H, int W, const tf_farneback_params *p, int k_hi,
         pl = std::max(pl, (size_t)h * w);
         // the two-pass blur of a full-size level keeps a whole image (+ rows), the sampled blur H rows of w float2
         t = std::max(t, k == 0 ? (size_t)H * W + 2 * (size_t)H + 64 : std::max((size_t)H * W / 4 + 2 * (size_t)H + 64, 2 * (size_t)H * w + 64));
+        t = std::max(t, fb_hand_floats(h, w));
     }
-    if (k_lo == 0) t = std::max(t, (size_t)H * W + 2 * (size_t)H + 64);
+    if (k_lo == 0) t = std::max(t, std::max((size_t)H * W + 2 * (size_t)H + 64, fb_hand_floats(H, W)));
     *tmp_floats = t; *plane = pl;
 }
 
@@ -1780,7 +1787,7 @@ extern "C" int tf_farneback_batch_split(const uint8_t *prev, const uint8_t *next
     if (parts == 1) {
         TfArena ar(ws, ws_bytes);
         FbScratch S;
-        if (!fb_carve(ar, B, (size_t)H * W + 2 * (size_t)H + 64, (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+        if (!fb_carve(ar, B, std::max((size_t)H * W + 2 * (size_t)H + 64, fb_hand_floats(H, W)), (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
         const int rc = fb_run_levels(prev, next, B, img_stride, H, W, p, out, flow_stride, S, levels, 0, cur, &pw, &ph, pp, s);
         if (rc) return rc;
     } else {
@@ -1806,7 +1813,7 @@ extern "C" int tf_farneback_batch_split(const uint8_t *prev, const uint8_t *next
             const int Bp = B - b0 < per ? B - b0 : per;
             TfArena ar(ws, ws_bytes);                                 // (the coarse phase's scratch is dead: stream order)
             FbScratch S;
-            if (!fb_carve(ar, Bp, (size_t)H * W + 2 * (size_t)H + 64, (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+            if (!fb_carve(ar, Bp, std::max((size_t)H * W + 2 * (size_t)H + 64, fb_hand_floats(H, W)), (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
             float *const outp[2] = {flow_fwd ? flow_fwd + (int64_t)b0 * flow_stride : nullptr, flow_bwd ? flow_bwd + (int64_t)b0 * flow_stride : nullptr};
             int curp[2] = {cur[0], cur[1]}, pwp = pw, php = ph;
             const int rc = fb_run_levels(prev + (int64_t)b0 * img_stride, next + (int64_t)b0 * img_stride, Bp, img_stride, H, W, p, outp, flow_stride, S,
@@ -1877,7 +1884,7 @@ extern "C" int tf_farneback_batch_phase(const uint8_t *prev, const uint8_t *next
         for (int d = 0; d < 2; d++) if (out[d] && cur[d] != 0) { tf_set_error("tf_farneback: internal slot parity error (phase 1)"); return TF_EINVAL; }
         return TF_OK;
     }
-    if (!fb_carve(ar, B, (size_t)H * W + 2 * (size_t)H + 64, (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+    if (!fb_carve(ar, B, std::max((size_t)H * W + 2 * (size_t)H + 64, fb_hand_floats(H, W)), (size_t)H * W, fused, &S)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
     int cur[2] = {0, 0}, pw = 0, ph = 0;                              // the flow of level FB_SPLIT_LEVEL sits in slot 0 = the output frames
     fb_level_size(H, W, p, FB_SPLIT_LEVEL, &ph, &pw);
     const int rc = fb_run_levels(prev, next, B, img_stride, H, W, p, out, flow_stride, S, FB_SPLIT_LEVEL - 1, 0, cur, &pw, &ph, pp, s);
