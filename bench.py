@@ -141,9 +141,22 @@ def cpu_baseline(seed, vr_steps=1):
         s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, None, None].astype(bool)
         markers = ndi.label(ndi.binary_erosion(lin >= 1, structure=s))[0].astype(np.int32)   # component-labelled seeds
         markers[ndi.binary_erosion(lin <= 0, structure=np.ones([3, 3, 3]), border_value=1)] = -1
-        ws_oracle.watershed(fw, bw, edges, markers.astype(np.int32), None, 1)
+        want_labels = ws_oracle.watershed(fw, bw, edges, markers.astype(np.int32), None, 1)
     dt = time.perf_counter() - t0
-    return {"value": round(T * H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": threads, "kind": "port",
+    # the oracle as the checker (outside its timed window): the library on the same sample, stage by stage, bit for bit
+    check = None
+    try:
+        import tobac_flow_amd.flow as tf
+        from tobac_flow_amd.detection import get_combined_edge_field
+        flow = tf.create_flow(bt, model="Farneback", vr_steps=vr_steps, smoothing_passes=1, interp_method="cubic")
+        got_e = get_combined_edge_field(flow, lin)
+        got_l = flow.watershed(got_e, markers.astype(np.int32), connectivity=ndi.generate_binary_structure(3, 1))
+        check = {"flow_bit_identical": bool(np.array_equal(flow.forward_flow, fw, equal_nan=True) and np.array_equal(flow.backward_flow, bw, equal_nan=True)),
+                 "edge_field_bit_identical": bool(np.array_equal(np.asarray(got_e), edges, equal_nan=True)),
+                 "labels_bit_identical": bool(np.array_equal(np.asarray(got_l), want_labels))}
+    except Exception as e:                                   # the baseline figure stands on its own
+        check = {"error": f"{type(e).__name__}: {e}"}
+    return {"value": round(T * H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": threads, "kind": "port", "library_vs_oracle_on_the_sample": check,
             "sample": f"{T}x{H}x{W} synthetic stack, same stage sequence, oracle (C/numpy restatement of the "
                       f"cv2+scipy+Cython path{', with the refinement' if vr_steps > 0 else ''}): flow {t_flow:.1f} s and Sobel {t_sobel:.1f} s on {threads} threads, flood "
                       f"{dt - t_flow - t_sobel:.1f} s on one (sequential heap), {dt:.1f} s in all; host has {os.cpu_count()} cores"}

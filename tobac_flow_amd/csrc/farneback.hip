@@ -1081,7 +1081,8 @@ __device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch,
         sub = __longlong_as_double((long long)((h.w3 << 32) | (h.w2 & 0xffffffffull)));
         if (!ok) g = __longlong_as_double(0x7ff8000000000000ll);
     }
-    if (n_out == FBI_OW) {
+    if (c.abl & 16) {                                                  // timing aid: hand-over without the chain (wrong flows)
+    } else if (n_out == FBI_OW) {
         // a full strip, straight-line.  A column sum is the minuend of step i and the subtrahend of step i + 13: chunks of
         // WIN = 13 steps keep the last 13 minuends in registers, so every LDS slot is read ONCE (a lone wave pays ~4 ns per
         // instruction whatever it is -- tools/microbench/chain_lds.hip: dependent add 5, subtraction 4, LDS read of two
