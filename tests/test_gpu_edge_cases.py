@@ -87,7 +87,10 @@ def test_farneback_reference_test_blob(tf):
     assert np.array_equal(z, _oracle_farneback(blob, blob)) and np.allclose(z, 0, atol=0.05)
 
 
-@pytest.mark.parametrize("shape", [(33, 47), (64, 31), (100, 333)])
+@pytest.mark.parametrize("shape", [(33, 47), (64, 31), (100, 333),
+                                   # the iteration kernel's strip geometry (116 output columns per strip, farneback.hip FBI_OW): exactly
+                                   # one / two strips, a last strip of one column, of 115, three strips with a short one
+                                   (70, 116), (70, 117), (45, 232), (45, 233), (40, 347), (260, 349)])
 def test_farneback_odd_sizes_match_oracle(tf, shape):
     from test_gpu_parity import _oracle_farneback
     rng = np.random.default_rng(shape[1])
@@ -415,6 +418,28 @@ def test_two_host_threads_on_two_streams_do_not_disturb_each_other():
     for k in range(2):
         for got, want in zip(results[k], alone[k]):
             assert torch.equal(torch.nan_to_num(got.float(), nan=-7.0), torch.nan_to_num(want.float(), nan=-7.0)), k
+
+
+def test_farneback_launch_of_several_rounds_and_column_groups_equals_the_oracle(tf):
+    """A batch whose iteration launches need more workgroups than the GPU holds at once (96 pairs x 7 strips x 2 directions =
+    1344 two-wave workgroups on 1024 slots at the full resolution): the tickets are then dealt by column groups, strips of
+    the second group find their left neighbours' hand-over words complete, and every pair must still be the oracle's bit
+    for bit -- checked on five pairs of the batch (first, last, three in between), both directions."""
+    import torch
+    from test_gpu_parity import _oracle_farneback
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow
+    rng = np.random.default_rng(77)
+    B, H, W = 96, 96, 760
+    base = ndi.gaussian_filter(rng.normal(size=(H + B + 2, W + B + 2)), 2.5)
+    base = ((base - base.min()) / np.ptp(base) * 255).astype(np.uint8)
+    frames = np.stack([base[i:i + H, B - i:B - i + W] for i in range(B + 1)])              # drifting content
+    fr = torch.from_numpy(frames).cuda()
+    fwd = torch.empty((B, H, W, 2), dtype=torch.float32, device="cuda")
+    bwd = torch.empty_like(fwd)
+    FarnebackFlow().calc_batch_dev(fr[:-1].contiguous(), fr[1:].contiguous(), fwd, bwd)
+    for i in (0, 17, 48, 80, B - 1):
+        assert np.array_equal(fwd[i].cpu().numpy(), _oracle_farneback(frames[i], frames[i + 1])), i
+        assert np.array_equal(bwd[i].cpu().numpy(), _oracle_farneback(frames[i + 1], frames[i])), i
 
 
 @pytest.mark.parametrize("B,parts", [(6, 2), (7, 3), (2, 2)])
