@@ -1037,7 +1037,7 @@ k_fb_iter_tree(FbIterArgs a, int H, int W, int64_t plane)
 //   * the 2 x 2 solve is OpenCV's expression on the window MEANS, with a true division (k_fb_iter_tree: scaled
 //     regulariser, reciprocal + Newton step).
 #define FBI_VS2 137                 // LDS row stride in doubles: lanes (r, ch) of a scan hit different banks (137 * 2 mod 64 = 18)
-#define FBI_HW 20                   // hand-over words per row: (g, V[next strip's x - 7]) x 5 channels x two halves
+#define FBI_HW 20                   // hand-over words per row and strip: (g, V[next strip's x - 7]) x 5 channels x two halves, stored as four planes of H x 5
 
 __device__ __forceinline__ unsigned long long fb_hand_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fb_hand_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1046,8 +1046,11 @@ __device__ __forceinline__ void fb_hand_st(unsigned long long *p, unsigned long 
 struct FbHand { unsigned long long w0, w1, w2, w3; };
 __device__ __forceinline__ void fb_hand_load(const FbIterCtx &c, int yo, int ch, FbHand &h)
 {
-    const unsigned long long *pg = c.hin + (int64_t)yo * FBI_HW + 2 * ch;
-    h.w0 = fb_hand_ld(pg); h.w1 = fb_hand_ld(pg + 1); h.w2 = fb_hand_ld(pg + 10); h.w3 = fb_hand_ld(pg + 11);
+    // four planes of H x 5 words (g low / high half, subtrahend low / high half): the 25 lanes of a row group read 25
+    // CONSECUTIVE words per instruction (four cache lines instead of thirteen)
+    const unsigned long long *pg = c.hin + (int64_t)yo * 5 + ch;
+    const int64_t pl = (int64_t)c.H * 5;
+    h.w0 = fb_hand_ld(pg); h.w1 = fb_hand_ld(pg + pl); h.w2 = fb_hand_ld(pg + 2 * pl); h.w3 = fb_hand_ld(pg + 3 * pl);
 }
 __device__ __forceinline__ bool fb_hand_valid(const FbIterCtx &c, const FbHand &h)
 {
@@ -1126,11 +1129,12 @@ __device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch,
         }
     }
     if (c.sx < c.nx - 1) {
-        unsigned long long *pg = c.hout + (int64_t)yo * FBI_HW + 2 * ch, *ps = pg + 10;
+        unsigned long long *pg = c.hout + (int64_t)yo * 5 + ch;
+        const int64_t pl = (int64_t)c.H * 5;
         const unsigned long long tag = (unsigned long long)c.epoch << 32;
         const unsigned long long ug = (unsigned long long)__double_as_longlong(g), us = (unsigned long long)__double_as_longlong(sub);
-        fb_hand_st(pg, tag | (ug & 0xffffffffull)); fb_hand_st(pg + 1, tag | (ug >> 32));
-        fb_hand_st(ps, tag | (us & 0xffffffffull)); fb_hand_st(ps + 1, tag | (us >> 32));
+        fb_hand_st(pg, tag | (ug & 0xffffffffull)); fb_hand_st(pg + pl, tag | (ug >> 32));
+        fb_hand_st(pg + 2 * pl, tag | (us & 0xffffffffull)); fb_hand_st(pg + 3 * pl, tag | (us >> 32));
     }
 }
 
@@ -1295,7 +1299,7 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
         // took 1.5 x the time of its parts).  So a strip starts only when its left neighbour is slack_rows ahead: the
         // words are then there when the row group asks for them, and a neighbour's hiccup is absorbed by the lead.
         if (threadIdx.x == 0) {
-            const unsigned long long *p = c.hin + (int64_t)min(a.slack_rows, H - 1) * FBI_HW;
+            const unsigned long long *p = c.hin + (int64_t)min(a.slack_rows, H - 1) * 5;
             for (int spin = 0; spin < (1 << 22) && (unsigned)(fb_hand_ld(p) >> 32) != a.epoch; spin++) __builtin_amdgcn_s_sleep(8);
         }
         __syncthreads();
