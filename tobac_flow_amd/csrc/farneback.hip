@@ -1036,7 +1036,7 @@ k_fb_iter_tree(FbIterArgs a, int H, int W, int64_t plane)
 //     workgroup only ever waits for a lower ticket, which is running or done -- no deadlock whatever the dispatch order;
 //   * the 2 x 2 solve is OpenCV's expression on the window MEANS, with a true division (k_fb_iter_tree: scaled
 //     regulariser, reciprocal + Newton step).
-#define FBI_VS2 137                 // LDS row stride in doubles: lanes (r, ch) of a scan hit different banks (137 * 2 mod 64 = 18)
+#define FBI_VS2 (FBI_T + 9)         // LDS row stride in doubles, odd: lanes (r, ch) of a scan hit different banks (137 * 2 mod 64 = 18)
 #define FBI_HW 20                   // hand-over words per row and strip: (g, V[next strip's x - 7]) x 5 channels x two halves, stored as four planes of H x 5
 
 __device__ __forceinline__ unsigned long long fb_hand_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1092,7 +1092,7 @@ __device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch,
         // values 8, LDS write of two 5 ns -- so the chain is bound by its instruction count, not by the adds).  The reads of
         // chunk c + 1 (slots 13c + 25 .. 13c + 37) are issued before the chain of chunk c, which writes slots 13c .. 13c + 12.
         constexpr int CH = FBI_WIN, NFULL = FBI_OW / CH, TAIL = FBI_OW - NFULL * CH;
-        static_assert(TAIL == 12 && NFULL * CH + TAIL + 2 * FBI_M == FBI_T, "chain chunks");
+        static_assert(NFULL * CH + TAIL + 2 * FBI_M == FBI_T && NFULL >= 1, "chain chunks");
         double prev[CH], mn[CH];
         prev[0] = sub;
 #pragma unroll
@@ -1112,14 +1112,14 @@ __device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch,
 #pragma unroll
             for (int k = 0; k < CH; k++) { prev[k] = mn[k]; mn[k] = nxt[k]; }
         }
-        {
-            double d[TAIL];
+        if (TAIL > 0) {
+            double d[TAIL > 0 ? TAIL : 1];
 #pragma unroll
             for (int k = 0; k < TAIL; k++) d[k] = mn[k] - prev[k];
 #pragma unroll
             for (int k = 0; k < TAIL; k++) { g += d[k]; row[NFULL * CH + k] = g; }
-            sub = prev[TAIL];                                          // slot 115 = column x_strip + 109: the next strip's first subtrahend
         }
+        sub = prev[TAIL];                                              // slot FBI_OW - 1 = column x_strip + FBI_OW - 7: the next strip's first subtrahend
     } else {
         for (int i = 0; i < n_out; i++) {                              // the ragged last strip
             const double mnv = row[i + 2 * FBI_M], nxv = row[i];
@@ -1470,7 +1470,7 @@ extern "C" int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneb
     if (H <= 0 || W <= 0 || !p || max_pairs < 1) return 0;
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    const int64_t slots = 2ll * n_cu;                                           // both directions in one 4-wave workgroup, two per CU
+    const int64_t slots = (int64_t)n_cu * 8 / (FBI_T / 64);                     // two waves per SIMD; one (strip, direction) per workgroup of FBI_T threads
     const size_t per_pair_bytes = fb_pair_floats(H, W, p->win_size == FBI_WIN) * sizeof(float);
     int64_t cap = max_pairs;
     if (max_bytes > 0 && (int64_t)(max_bytes / per_pair_bytes) < cap) cap = (int64_t)(max_bytes / per_pair_bytes);
@@ -1485,7 +1485,7 @@ extern "C" int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneb
         double cost = 0, work = 0, scale = 1;
         for (int k = 0; k <= levels; k++) {
             const int64_t w = (int64_t)lrint(W * scale), h = (int64_t)lrint(H * scale);
-            const int64_t chains = B * ((w + FBI_OW - 1) / FBI_OW), rounds = (chains + slots - 1) / slots;
+            const int64_t chains = 2 * B * ((w + FBI_OW - 1) / FBI_OW), rounds = (chains + slots - 1) / slots;
             cost += (double)rounds * (double)h; work += (double)chains / (double)slots * (double)h;
             scale *= p->pyr_scale;
         }
@@ -1664,7 +1664,7 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                 if (slots == 0) {
                     int dev = 0, n_cu = 256;
                     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-                    slots = 2 * n_cu;
+                    slots = n_cu * 8 / (FBI_T / 64);                         // resident two-wave workgroups (one direction each)
                 }
                 // one direction per workgroup (four two-wave workgroups per CU) unless TF_FBI_JOIN_DIRECTIONS=1: the chains make a
                 // workgroup latency-bound for a third of its time, and four independent workgroups per CU overlap those
@@ -1672,7 +1672,7 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                 // R rows once per direction again (round 3 joined the directions for that: -23 % HBM bytes, same time)
                 static const bool join_env = getenv("TF_FBI_JOIN_DIRECTIONS") != nullptr;
                 ia.nq = (!join_env && nd == 2) ? 2 : 1;
-                const int rounds = (int)(((int64_t)nx * B + slots - 1) / slots);
+                const int rounds = (int)(((int64_t)nx * B * 2 + slots - 1) / slots);   // (a joined workgroup counts as two)
                 static const int slack_env = getenv("TF_FBI_SLACK_ROWS") ? atoi(getenv("TF_FBI_SLACK_ROWS")) : -1;
                 static const int groups_env = getenv("TF_FBI_COLUMN_GROUPS") ? atoi(getenv("TF_FBI_COLUMN_GROUPS")) : 0;
                 const int n_groups = groups_env > 0 ? std::min(groups_env, nx) : std::min(rounds, nx);
