@@ -17,9 +17,12 @@
 //   * the polynomial expansion R is stored as float4 {y, x, yy, xx} + a float plane {xy}: a bilinear gather is five wide
 //     loads per corner pair instead of twenty scalar ones (k_fb_polyexp / k_fb_polyexp5, LDS tiles);
 //   * ONE kernel per iteration (k_fb_iter): UpdateMatrices -> 13 x 13 box sums in double -> 2 x 2 solve; each thread walks
-//     down a column with the last 13 rows of M in a register ring, column sums parked in a padded LDS row, four window
-//     sums per thread in the horizontal phase.  The 5-channel M of OpenCV never exists in HBM.  The unfused pair
-//     k_fb_update_matrices + k_fb_blur_solve (LDS tiles, one channel at a time) serves window sizes other than 13;
+//     down a column with the last 13 rows of M in a register ring and OpenCV's running column sum, the column sums of a row
+//     group go to LDS, and (round 4) OpenCV's running ROW sum is carried through them by 25 chain lanes and from column strip
+//     to column strip through tagged words in global memory: the flow is bit-identical to the oracle's.  The 5-channel M of
+//     OpenCV never exists in HBM.  (k_fb_iter_tree, round 3: window sums as a tree, within 7e-5 px; TF_FB_ROW_SUMS_TREE=1.)
+//     The unfused pair k_fb_update_matrices + k_fb_blur_solve (LDS tiles, one channel at a time) serves window sizes other
+//     than 13;
 //   * all of these are HBM / L2- or latency-bound stencils: no MFMA.
 #include "tf_common.h"
 #include <math.h>
@@ -1032,8 +1035,9 @@ k_fb_iter_tree(FbIterArgs a, int H, int W, int64_t plane)
 //     k - 1.  Every double travels as two 64-bit words (launch tag << 32 | half): a word is valid iff its tag is this
 //     launch's, so there is no flag to order against the data and no fence -- relaxed agent-scope atomics only.  The words
 //     live in the (idle) blur scratch of the pair, zeroed once per pyramid level; tags count the level's iterations;
-//   * workgroups take their (pair, strip) from a TICKET counter in arrival order, strips of a pair consecutively: a
-//     workgroup only ever waits for a lower ticket, which is running or done -- no deadlock whatever the dispatch order;
+//   * workgroups take their (pair, strip, direction) from a TICKET counter in arrival order, strips of a pair left to right
+//     (column group by column group when the launch needs several rounds of resident workgroups): a workgroup only ever
+//     waits for a lower ticket, which is running or done -- no deadlock whatever the dispatch order;
 //   * the 2 x 2 solve is OpenCV's expression on the window MEANS, with a true division (k_fb_iter_tree: scaled
 //     regulariser, reciprocal + Newton step).
 #define FBI_VS2 (FBI_T + 9)         // LDS row stride in doubles, odd: lanes (r, ch) of a scan hit different banks (137 * 2 mod 64 = 18)
