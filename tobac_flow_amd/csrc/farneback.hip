@@ -707,6 +707,7 @@ struct FbIterArgs {
     // sequential row sums (k_fb_iter): hand-over words of batch item 0 (item b adds b * bs_hand words), this launch's tag, its ticket counter
     unsigned long long *hand; int64_t bs_hand; unsigned epoch; int *ticket;
     int abl;                        // timing aid (TF_FBI_SEQ_ABLATE, wrong flows): 1 no wait for the left neighbour, 2 no chain, 4 no solve
+    int xcd_lists;                  // 1: one ticket list per XCD (pairs dealt round robin), 0: one list
     int nq;                         // 1: a workgroup holds all directions of its strip; 2: one direction per workgroup, directions take tickets
     int nb, nxg, slack_rows;        // pairs in the launch; strips per column group (ticket order); rows a strip lets its left neighbour get ahead before it starts
 };
@@ -1041,6 +1042,7 @@ k_fb_iter_tree(FbIterArgs a, int H, int W, int64_t plane)
 //   * the 2 x 2 solve is OpenCV's expression on the window MEANS, with a true division (k_fb_iter_tree: scaled
 //     regulariser, reciprocal + Newton step).
 #define FBI_VS2 (FBI_T + 9)         // LDS row stride in doubles, odd: lanes (r, ch) of a scan hit different banks (137 * 2 mod 64 = 18)
+#define FBI_HDR 16384               // bytes of ticket counters in front of a batch's hand-over words: 16 ints per launch of a level (8 used: one per XCD)
 #define FBI_HW 20                   // hand-over words per row and strip: (g, V[next strip's x - 7]) x 5 channels x two halves, stored as four planes of H x 5
 
 __device__ __forceinline__ unsigned long long fb_hand_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1209,18 +1211,41 @@ __global__ void __launch_bounds__(NDW * FBI_T, 2)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
 {
     __shared__ double vrow_all[NDW][FBI_G * 5 * FBI_VS2];
-    __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(a.ticket, 1);
+    // TICKETS, ONE LIST PER XCD.  Pair b belongs to the list of XCD b mod 8 -- with all its strips, both directions and all
+    // column groups -- and a workgroup takes the next item of ITS XCD's list (s_getreg XCC_ID): the two directions of a
+    // strip, which read each other's expansion rows, then run on the same XCD within microseconds and share them in its
+    // L2 (one workgroup per direction otherwise fetches every R row from HBM twice), and the strips of a pair hand their
+    // words to a neighbour on the same XCD.  A workgroup whose own list is exhausted takes from the next XCD's (21 pairs
+    // on 8 XCDs: three of them own two pairs, five own three).  Inside a list tickets run column group by column group,
+    // pair by pair, strips left to right: a workgroup only ever waits for a lower ticket of the same list, whose owner
+    // is running or done whichever XCD it came from -- no deadlock whatever the dispatch order.
+    __shared__ int s_ticket[2];
+    if (threadIdx.x == 0) {
+        const int xcc = a.xcd_lists ? (int)(__builtin_amdgcn_s_getreg(6164) & 7u) : 0;      // HW_REG_XCC_ID (id 20), bits 3:0
+        const int n_lists = a.xcd_lists ? 8 : 1;
+        int found = -1, y = 0;
+        for (int k = 0; k < n_lists && found < 0; k++) {
+            y = (xcc + k) & (n_lists - 1);
+            const int n_pairs = a.nb > y ? (a.nb - y + n_lists - 1) / n_lists : 0;
+            if (n_pairs == 0) continue;
+            const int t = atomicAdd(a.ticket + y, 1);
+            if (t < n_pairs * a.nx * a.nq) found = t;                  // (the grid has exactly one workgroup per item: some list has one left)
+        }
+        s_ticket[0] = found; s_ticket[1] = y;
+    }
     __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket[0]), list = __builtin_amdgcn_readfirstlane(s_ticket[1]);
+    if (ticket < 0) return;                                            // (cannot happen: more workgroups than items)
+    const int n_lists = a.xcd_lists ? 8 : 1, list_pairs = (a.nb - list + n_lists - 1) / n_lists;
     const int qw = __builtin_amdgcn_readfirstlane(threadIdx.x / FBI_T); // wave-uniform: which half of the workgroup (0 when it has one direction)
     double *vrow = vrow_all[qw];
     // ticket -> (pair, strip): column groups of nxg strips, group by group; inside a group pair by pair, strips left to right
     // (a strip's left neighbour always holds a lower ticket).  A launch that needs several rounds of resident workgroups
     // runs one column group per round: the start delays below then add up over nxg strips, not over all of them.
-    const int per_group = a.nb * a.nxg * a.nq;
+    const int per_group = list_pairs * a.nxg * a.nq;
     const int cg = ticket / per_group, tr = ticket - cg * per_group, n_cg = min(a.nxg, a.nx - cg * a.nxg);
-    const int b = tr / (n_cg * a.nq), tr2 = tr - b * n_cg * a.nq, sxl = tr2 / a.nq;
+    const int bi = tr / (n_cg * a.nq), tr2 = tr - bi * n_cg * a.nq, sxl = tr2 / a.nq;
+    const int b = list + n_lists * bi;
     const int sx = cg * a.nxg + sxl;
     const int q = NDW == 2 ? qw : tr2 - sxl * a.nq;                    // index into the launch's directions
     const int d = a.dir[q];                                            // 0: prev -> next, 1: next -> prev
@@ -1241,7 +1266,7 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
     c.j = threadIdx.x - qw * FBI_T;
     c.dj = c.j; c.tg = 0; c.tq = 0;
     c.sr = c.j / 5; c.sch = c.j - c.sr * 5;
-    c.sx = sx; c.nx = a.nx; c.epoch = a.epoch; c.abl = a.abl; c.spins = (a.abl & 8) ? a.ticket - (a.epoch - 1) + 256 - 4 : nullptr;
+    c.sx = sx; c.nx = a.nx; c.epoch = a.epoch; c.abl = a.abl; c.spins = (a.abl & 8) ? a.ticket - 16 * (a.epoch - 1) + FBI_HDR / 4 - 4 : nullptr;
     {
         // hand-over slots of (pair b, direction q, strip): [q][strip 0 .. nx - 2][row][FBI_HW words]
         unsigned long long *hb = a.hand + b * a.bs_hand + (int64_t)q * (a.nx - 1) * H * FBI_HW;
@@ -1450,7 +1475,7 @@ static int fb_levels(int64_t H, int64_t W, const tf_farneback_params *p) {
 // hand-over words (both directions)
 static size_t fb_hand_floats(int64_t h, int64_t w) {
     const int64_t nx = (w + FBI_OW - 1) / FBI_OW;
-    return 256 + 2 * (size_t)(2 * (nx - 1) * h * FBI_HW);
+    return FBI_HDR / 4 + 2 * (size_t)(2 * (nx - 1) * h * FBI_HW);
 }
 static size_t fb_pair_floats(int64_t H, int64_t W, bool fused) {
     // per pair: tmp (n + 2H + 64), blur, I, R[2] (5n each), 2 flow scratch (2n each); the 5-plane matrix M (5n) only for the
@@ -1676,18 +1701,20 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                 // R rows once per direction again (round 3 joined the directions for that: -23 % HBM bytes, same time)
                 static const bool join_env = getenv("TF_FBI_JOIN_DIRECTIONS") != nullptr;
                 ia.nq = (!join_env && nd == 2) ? 2 : 1;
+                static const bool one_list_env = getenv("TF_FBI_ONE_TICKET_LIST") != nullptr;
+                ia.xcd_lists = one_list_env ? 0 : 1;
                 const int rounds = (int)(((int64_t)nx * B * 2 + slots - 1) / slots);   // (a joined workgroup counts as two)
                 static const int slack_env = getenv("TF_FBI_SLACK_ROWS") ? atoi(getenv("TF_FBI_SLACK_ROWS")) : -1;
                 static const int groups_env = getenv("TF_FBI_COLUMN_GROUPS") ? atoi(getenv("TF_FBI_COLUMN_GROUPS")) : 0;
                 const int n_groups = groups_env > 0 ? std::min(groups_env, nx) : std::min(rounds, nx);
                 ia.nb = B; ia.nxg = (nx + n_groups - 1) / n_groups; ia.slack_rows = slack_env >= 0 ? slack_env : 0;
             }
-            ia.hand = (unsigned long long *)((char *)tmp + 1024); ia.bs_hand = bs_tmp / 2; ia.ticket = (int *)tmp; ia.epoch = 0;
+            ia.hand = (unsigned long long *)((char *)tmp + FBI_HDR); ia.bs_hand = bs_tmp / 2; ia.ticket = (int *)tmp; ia.epoch = 0;
             if (!tree) {
-                TF_REQUIRE(1024 + hand_words * 8 <= (size_t)bs_tmp * sizeof(float), "tf_farneback: blur scratch too small for the strips' hand-over words");
+                TF_REQUIRE(FBI_HDR + hand_words * 8 <= (size_t)bs_tmp * sizeof(float), "tf_farneback: blur scratch too small for the strips' hand-over words");
                 TF_REQUIRE(p->num_iters <= 250, "tf_farneback: more than 250 iterations per level");
-                TF_CHECK_HIP(hipMemsetAsync(tmp, 0, 1024, s));
-                for (int b = 0; b < B && hand_words > 0; b++) TF_CHECK_HIP(hipMemsetAsync((char *)(tmp + (int64_t)b * bs_tmp) + 1024, 0, hand_words * 8, s));
+                TF_CHECK_HIP(hipMemsetAsync(tmp, 0, FBI_HDR, s));
+                for (int b = 0; b < B && hand_words > 0; b++) TF_CHECK_HIP(hipMemsetAsync((char *)(tmp + (int64_t)b * bs_tmp) + FBI_HDR, 0, hand_words * 8, s));
             }
             for (int it = 0; it < p->num_iters; it++) {
                 for (int q = 0; q < nd; q++) {
@@ -1699,7 +1726,7 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                 {
                     TfProfScope ps(TFK_FB_ITER, 56.0 * plane * nd * B, s);
                     static const int abl = getenv("TF_FBI_ABLATE") ? atoi(getenv("TF_FBI_ABLATE")) : 0;
-                    ia.epoch = (unsigned)(it + 1); ia.ticket = (int *)tmp + it;
+                    ia.epoch = (unsigned)(it + 1); ia.ticket = (int *)tmp + 16 * it;
                     if (tree) {
                         if (abl == 1) hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 1>), gi, bi, 0, s, ia, h, w, plane);
                         else if (abl == 2) hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 2>), gi, bi, 0, s, ia, h, w, plane);
@@ -1715,7 +1742,7 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             TF_CHECK_LAUNCH();
             if (!tree && (seq_abl & 8)) {                               // development aid: how often did a chain have to wait?
                 int h_sp[2] = {0, 0};
-                TF_CHECK_HIP(hipMemcpyAsync(h_sp, (int *)tmp + 252, sizeof(h_sp), hipMemcpyDeviceToHost, s));
+                TF_CHECK_HIP(hipMemcpyAsync(h_sp, (int *)tmp + FBI_HDR / 4 - 4, sizeof(h_sp), hipMemcpyDeviceToHost, s));
                 TF_CHECK_HIP(hipStreamSynchronize(s));
                 fprintf(stderr, "k_fb_iter %d x %d, %d pairs, %d launches: %d chains waited (of %lld), %d polls\n", h, w, B, p->num_iters, h_sp[0],
                         (long long)B * nd * (nx - 1) * h * 5 * p->num_iters, h_sp[1]);
