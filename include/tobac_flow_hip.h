@@ -110,6 +110,10 @@ size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const
  * <= max_pairs whose workspace fits max_bytes (0 = no limit) with the best ratio of work to rounds x rows summed over
  * the levels -- the largest one within 1 % of the best (42 pairs at 5424 x 5424 on 256 CUs: full rounds at levels 0, 1, 2). */
 int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneback_params *p, int64_t max_pairs, size_t max_bytes);
+/* Workgroups of the iteration kernel's full-resolution launch for B pairs, and (resident_out, may be NULL) how many the
+ * device holds at once.  A launch costs whole rounds of resident workgroups: cut a batch into parts
+ * (tf_farneback_batch_phase) only while a part still fills a round. */
+int64_t tf_farneback_iteration_workgroups(int64_t H, int64_t W, const tf_farneback_params *p, int64_t B, int64_t *resident_out);
 int tf_farneback_batch(const uint8_t *prev, const uint8_t *next, int64_t B, int64_t img_stride,
                        int64_t H, int64_t W, const tf_farneback_params *p,
                        float *flow_fwd, float *flow_bwd, int64_t flow_stride,

@@ -339,10 +339,15 @@ def test_create_flow_with_split_batches_is_bit_identical_and_hands_out_parts(mon
     monkeypatch.setenv("TF_FLOW_SPLIT", "2")
     seen = []
     got = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic", on_frames_ready=lambda fl, n: seen.append(n))
+    assert seen == [11]                                               # parts of five pairs of 203 x 331 would not fill the GPU: not split
+    monkeypatch.setenv("TF_FLOW_SPLIT_FORCE", "1")                    # (split whatever the size)
+    seen = []
+    got = tf.create_flow(bt, vr_steps=1, smoothing_passes=1, interp_method="cubic", on_frames_ready=lambda fl, n: seen.append(n))
     assert seen == [6, 11]                                            # ten pairs: two parts of five
     assert torch.equal(torch.nan_to_num(got.forward_flow, nan=-7.0), torch.nan_to_num(want.forward_flow, nan=-7.0))
     assert torch.equal(torch.nan_to_num(got.backward_flow, nan=-7.0), torch.nan_to_num(want.backward_flow, nan=-7.0))
     raw = tf.calculate_flow(bt, "Farneback")                          # no refinement, no smoothing: written straight into the arrays
     monkeypatch.delenv("TF_FLOW_SPLIT")
+    monkeypatch.delenv("TF_FLOW_SPLIT_FORCE")
     raw0 = tf.calculate_flow(bt, "Farneback")
     assert torch.equal(torch.nan_to_num(raw[0], nan=-7.0), torch.nan_to_num(raw0[0], nan=-7.0))

@@ -1527,6 +1527,18 @@ extern "C" int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneb
     return pick;
 }
 
+// Workgroups of the iteration kernel's full-resolution launch for B pairs (both directions), and how many of them the
+// device holds at once: a launch costs whole rounds of resident workgroups, so a caller that may cut a batch into parts
+// (tf_farneback_batch_phase) does so only while a part still fills a round.
+extern "C" int64_t tf_farneback_iteration_workgroups(int64_t H, int64_t W, const tf_farneback_params *p, int64_t B, int64_t *resident_out)
+{
+    if (H <= 0 || W <= 0 || !p || B < 1) return 0;
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    if (resident_out) *resident_out = (int64_t)n_cu * 8 / (FBI_T / 64);
+    return 2 * B * ((W + FBI_OW - 1) / FBI_OW);
+}
+
 extern "C" size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_params *p)
 {
     return tf_farneback_workspace_bytes_batch(1, H, W, p);

@@ -407,7 +407,16 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
 
     def split_parts_used(B):
         parts = max(1, int(os.environ.get("TF_FLOW_SPLIT", "1")))
-        return parts if (hasattr(of_model, "params") and "TF_FLOW_BATCH" not in os.environ and B >= 2 * parts) else 1
+        if parts == 1 or not hasattr(of_model, "params") or "TF_FLOW_BATCH" in os.environ or B < 2 * parts:
+            return 1
+        # a launch of the iteration kernel costs whole rounds of resident workgroups: parts that no longer fill a round at
+        # the full resolution each cost what the whole batch costs (config C, 23 pairs of 1500 x 2500 = one round:
+        # two parts took 2 x 2.3 ms per iteration instead of 2.6)
+        if os.environ.get("TF_FLOW_SPLIT_FORCE"):            # (tests: split whatever the size)
+            return parts
+        resident = ctypes.c_int64(0)
+        wgs = int(L.tf_farneback_iteration_workgroups(H, W, ctypes.byref(of_model.params), -(-B // parts), ctypes.byref(resident)))
+        return parts if wgs >= 0.9 * max(1, resident.value) else 1
 
     def run_batch(i0, B, after_part=None):
         if B <= 0:
