@@ -190,6 +190,43 @@ def _oracle_farneback(a, b):
     return out
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (7, 5), (16, 64), (17, 65), (96, 128), (150, 250), (333, 517), (700, 1100)])
+def test_farneback_blur_and_polynomial_expansion_are_bit_identical_to_the_oracle(tf, shape):
+    """Stage level (tf_farneback_expansion, round 4): the 3 x 3 Gaussian of the uint8 frame and its polynomial expansion
+    (cv2 FarnebackPolyExp, n = 5, sigma = 1.1) as the full-resolution pyramid level computes them, against the oracle's
+    restatement, every coefficient bit for bit.  (The expansion multiplies by four entries of inv(G): the library inverts G
+    by the oracle's elimination -- a closed-form block inverse differed in the last digits and flipped the float rounding of
+    one coefficient in ~10^5, which the running column sums of the iteration then carried down the image.)"""
+    import ctypes
+    import torch
+    from oracle import _lib as ol
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow
+    Lo, L = ol.lib(), _lib.lib()
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    img = ndi.gaussian_filter(rng.normal(size=(shape[0] + 8, shape[1] + 8)), 2.0)[4:-4, 4:-4]
+    img = np.ascontiguousarray(((img - img.min()) / (np.ptp(img) + 1e-9) * 255).astype(np.uint8))
+    h, w = img.shape
+    f = img.astype(np.float32)
+    want_blur = np.zeros_like(f)
+    Lo.oracle_gaussian_blur(ol.ptr(f, ctypes.c_float), h, w, 3, ctypes.c_double(0.0), ol.ptr(want_blur, ctypes.c_float))
+    want = np.zeros((h, w, 5), np.float32)
+    Lo.oracle_poly_exp(ol.ptr(want_blur, ctypes.c_float), h, w, ol.ptr(want, ctypes.c_float), 5, ctypes.c_double(1.1))
+    d_img = torch.from_numpy(img).cuda()
+    d_blur = torch.empty((h, w), dtype=torch.float32, device="cuda")
+    d_R = torch.empty(5 * h * w, dtype=torch.float32, device="cuda")
+    m = FarnebackFlow()
+    _lib.check(L.tf_farneback_expansion(_lib.ptr(d_img), h, w, ctypes.byref(m.params), _lib.ptr(d_blur), _lib.ptr(d_R), _lib.stream_ptr()), "tf_farneback_expansion")
+    torch.cuda.synchronize()
+    R = d_R.cpu().numpy()
+    got = np.concatenate([R[:4 * h * w].reshape(h, w, 4), R[4 * h * w:].reshape(h, w, 1)], -1)
+    assert np.array_equal(d_blur.cpu().numpy(), want_blur)
+    assert np.array_equal(got, want), int((got != want).sum())
+    d_R2 = torch.empty_like(d_R)                                        # blur_out = NULL: the library's own temporary
+    _lib.check(L.tf_farneback_expansion(_lib.ptr(d_img), h, w, ctypes.byref(m.params), None, _lib.ptr(d_R2), _lib.stream_ptr()), "tf_farneback_expansion")
+    assert torch.equal(d_R, d_R2)
+
+
 @pytest.mark.parametrize("shape", [(96, 128), (150, 250), (333, 517)])
 def test_farneback_matches_oracle(tf, shape):
     from oracle import np_ops
