@@ -706,7 +706,7 @@ struct FbIterArgs {
     const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2];
     // sequential row sums (k_fb_iter): hand-over words of batch item 0 (item b adds b * bs_hand words), this launch's tag, its ticket counter
     unsigned long long *hand; int64_t bs_hand; unsigned epoch; int *ticket;
-    int abl;                        // timing aid (TF_FBI_SEQ_ABLATE, wrong flows): 1 no wait for the left neighbour, 2 no chain, 4 no solve
+    int abl;                        // timing aid (TF_FBI_SEQ_ABLATE): 1 no wait for the left neighbour, 2 no chain, 4 no solve, 16 hand-over without the chain (all wrong flows); 8 count waiting chains, 128 no priority for the chain wave, 256 priority 1 instead of 3 (right flows)
     int xcd_lists;                  // 1: one ticket list per XCD (pairs dealt round robin), 0: one list
     int nq;                         // 1: a workgroup holds all directions of its strip; 2: one direction per workgroup, directions take tickets
     int nb, nxg, slack_rows;        // pairs in the launch; strips per column group (ticket order); rows a strip lets its left neighbour get ahead before it starts
@@ -1191,8 +1191,14 @@ __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, fl
         for (int g = 0; g < GN; g++) fl[g] = fb_iter_flow_at(c, s0 + G + g);
     }
     __syncthreads();
-    if (chain_lane && !(c.abl & 2))                                    // 20 or 25 chains, lanes of the direction's first wave
+    if (chain_lane && !(c.abl & 2)) {                                  // 20 or 25 chains, lanes of the direction's first wave
+        // the chain is the serial stretch of the workgroup -- one wave, bound by its instruction count, everybody else at the
+        // barrier -- while the SIMD's other wave (another workgroup's column phase) has work for both issue slots: the
+        // chain wave takes priority in the arbitration for its duration (level-0 launch of 21 pairs: 19.7 -> 18.3 ms)
+        if (!(c.abl & 128)) { if (c.abl & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3); }
         fb_iter_scan(c, s0 + c.sr - FBI_M, c.sch, vrow + c.j * FBI_VS2, hand);             // (row r, channel ch) = LDS row r * 5 + ch = j
+        if (!(c.abl & 128)) __builtin_amdgcn_s_setprio(0);
+    }
     __syncthreads();
     if (c.j < FBI_OW && c.x_strip + c.j < c.W && !(c.abl & 4)) {
 #pragma unroll
