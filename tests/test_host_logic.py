@@ -26,6 +26,28 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().tf_version() >= 100
 
 
+def test_farneback_launch_arithmetic_of_the_host_side():
+    """Host-only arithmetic of the C ABI (no device work): workspace sizes grow with the batch, hold the strips' hand-over
+    words of the iteration kernel at every size (1 x 1 included), and the workgroup count the batching decisions rest on
+    is two directions x pairs x strips of 116 columns (farneback.hip FBI_OW)."""
+    import ctypes
+    from tobac_flow_amd import _lib
+    L = _lib.lib()
+    p = _lib.FarnebackParams(5, 0.5, 13, 10, 5, 1.1)
+    resident = ctypes.c_int64(0)
+    assert L.tf_farneback_iteration_workgroups(5424, 5424, ctypes.byref(p), 21, ctypes.byref(resident)) == 2 * 21 * 47
+    assert resident.value > 0 and resident.value % 4 == 0                       # four two-wave workgroups per CU
+    assert L.tf_farneback_iteration_workgroups(1500, 2500, ctypes.byref(p), 23, None) == 2 * 23 * 22
+    assert L.tf_farneback_iteration_workgroups(0, 10, ctypes.byref(p), 1, None) == 0
+    one = L.tf_farneback_workspace_bytes_batch(1, 5424, 5424, ctypes.byref(p))
+    assert L.tf_farneback_workspace_bytes_batch(21, 5424, 5424, ctypes.byref(p)) > 20 * one
+    # hand-over words of a pair at the full resolution: 2 directions x 46 strip boundaries x 5424 rows x 20 words of 8 bytes
+    assert one > 2 * 46 * 5424 * 20 * 8
+    tiny = L.tf_farneback_workspace_bytes(1, 1, ctypes.byref(p))
+    assert tiny >= 16384                                                        # the ticket counters alone
+    assert L.tf_farneback_can_split(5424, 5424, ctypes.byref(p)) == 1 and L.tf_farneback_can_split(40, 40, ctypes.byref(p)) == 0
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
