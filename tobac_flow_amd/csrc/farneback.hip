@@ -1063,12 +1063,11 @@ __device__ __forceinline__ bool fb_hand_valid(const FbIterCtx &c, const FbHand &
     return (unsigned)(h.w0 >> 32) == c.epoch && (unsigned)(h.w1 >> 32) == c.epoch && (unsigned)(h.w2 >> 32) == c.epoch && (unsigned)(h.w3 >> 32) == c.epoch;
 }
 
-// one chain: row `row` (LDS, slot i = column x_strip + i - 6) of output row yo, channel ch; `h`: the left neighbour's words
-// as fetched at the top of the row group (it is normally a group ahead: they are there), polled here if they were not
-__device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch, double *row, FbHand h)
+// how a chain enters its strip: the running sum g left of column x_strip and the first subtrahend V[x_strip - 7] -- OpenCV's
+// start of a row for strip 0 (row: LDS, slot i = column x_strip + i - 6), the left neighbour's hand-over words otherwise
+// (`h`: as fetched at the top of the row group -- the neighbour is normally ahead: they are there -- polled here if not)
+__device__ __forceinline__ void fb_chain_enter(const FbIterCtx &c, int yo, int ch, const double *row, FbHand h, double &g, double &sub)
 {
-    const int n_out = min(FBI_OW, c.W - c.x_strip);                    // (wave-uniform)
-    double g, sub;
     if (c.sx == 0 || (c.abl & 1)) {
         const double v0 = row[FBI_M];                                  // column 0
         g = v0 * (double)(FBI_M + 2);
@@ -1090,43 +1089,69 @@ __device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch,
         sub = __longlong_as_double((long long)((h.w3 << 32) | (h.w2 & 0xffffffffull)));
         if (!ok) g = __longlong_as_double(0x7ff8000000000000ll);
     }
-    if (c.abl & 16) {                                                  // timing aid: hand-over without the chain (wrong flows)
-    } else if (n_out == FBI_OW) {
-        // a full strip, straight-line.  A column sum is the minuend of step i and the subtrahend of step i + 13: chunks of
-        // WIN = 13 steps keep the last 13 minuends in registers, so every LDS slot is read ONCE (a lone wave pays ~4 ns per
-        // instruction whatever it is -- tools/microbench/chain_lds.hip: dependent add 5, subtraction 4, LDS read of two
-        // values 8, LDS write of two 5 ns -- so the chain is bound by its instruction count, not by the adds).  The reads of
-        // chunk c + 1 (slots 13c + 25 .. 13c + 37) are issued before the chain of chunk c, which writes slots 13c .. 13c + 12.
-        constexpr int CH = FBI_WIN, NFULL = FBI_OW / CH, TAIL = FBI_OW - NFULL * CH;
-        static_assert(NFULL * CH + TAIL + 2 * FBI_M == FBI_T && NFULL >= 1, "chain chunks");
-        double prev[CH], mn[CH];
-        prev[0] = sub;
+}
+// (g, V[next strip's x - 7]) for the strip to the right
+__device__ __forceinline__ void fb_hand_store(const FbIterCtx &c, int yo, int ch, double g, double sub)
+{
+    if (c.sx >= c.nx - 1) return;
+    unsigned long long *pg = c.hout + (int64_t)yo * 5 + ch;
+    const int64_t pl = (int64_t)c.H * 5;
+    const unsigned long long tag = (unsigned long long)c.epoch << 32;
+    const unsigned long long ug = (unsigned long long)__double_as_longlong(g), us = (unsigned long long)__double_as_longlong(sub);
+    fb_hand_st(pg, tag | (ug & 0xffffffffull)); fb_hand_st(pg + pl, tag | (ug >> 32));
+    fb_hand_st(pg + 2 * pl, tag | (us & 0xffffffffull)); fb_hand_st(pg + 3 * pl, tag | (us >> 32));
+}
+
+// NSTEP steps of a chain, straight-line: step s adds base[s + 12] - base[s - 1] (base[-1] = `sub` on entry) and leaves g in
+// base[s].  A column sum is the minuend of step s and the subtrahend of step s + 13: chunks of WIN = 13 steps keep the last
+// 13 minuends in registers, so every LDS slot is read ONCE (a lone wave pays 4 - 8 ns per instruction whatever it is --
+// tools/microbench/chain_lds.hip: dependent add 5, subtraction 4, LDS read of two values 8, LDS write of two 5 ns -- so the
+// chain is bound by its instruction count, not by the adds).  The reads of chunk c + 1 are issued before the chain of chunk
+// c, whose writes go to slots below them.  Returns in `sub` the column sum base[NSTEP - 1] held on entry: the first
+// subtrahend of whoever continues the chain.
+template <int NSTEP>
+__device__ __forceinline__ void fb_chain_run(double *base, double &g, double &sub)
+{
+    constexpr int CH = FBI_WIN, NFULL = NSTEP / CH, TAIL = NSTEP - NFULL * CH, LAST = NSTEP + 2 * FBI_M - 1;
+    static_assert(NFULL >= 1, "chain chunks");
+    double prev[CH], mn[CH];
+    prev[0] = sub;
 #pragma unroll
-        for (int k = 1; k < CH; k++) prev[k] = row[k - 1];             // slots 0 .. 11: the subtrahends of steps 1 .. 12
+    for (int k = 1; k < CH; k++) prev[k] = base[k - 1];
 #pragma unroll
-        for (int k = 0; k < CH; k++) mn[k] = row[2 * FBI_M + k];       // slots 12 .. 24
+    for (int k = 0; k < CH; k++) mn[k] = base[2 * FBI_M + k];
 #pragma unroll 1
-        for (int i0 = 0; i0 < NFULL * CH; i0 += CH) {
-            double nxt[CH];
+    for (int i0 = 0; i0 < NFULL * CH; i0 += CH) {
+        double nxt[CH];
 #pragma unroll
-            for (int k = 0; k < CH; k++) nxt[k] = row[min(i0 + CH + 2 * FBI_M + k, FBI_T - 1)];   // (the chunk after the last full one has 12 steps: slots up to 127)
-            double d[CH];
+        for (int k = 0; k < CH; k++) nxt[k] = base[min(i0 + CH + 2 * FBI_M + k, LAST)];       // (the last chunk may be shorter: clamped, unused)
+        double d[CH];
 #pragma unroll
-            for (int k = 0; k < CH; k++) d[k] = mn[k] - prev[k];
+        for (int k = 0; k < CH; k++) d[k] = mn[k] - prev[k];
 #pragma unroll
-            for (int k = 0; k < CH; k++) { g += d[k]; row[i0 + k] = g; }
+        for (int k = 0; k < CH; k++) { g += d[k]; base[i0 + k] = g; }
 #pragma unroll
-            for (int k = 0; k < CH; k++) { prev[k] = mn[k]; mn[k] = nxt[k]; }
-        }
-        if (TAIL > 0) {
-            double d[TAIL > 0 ? TAIL : 1];
+        for (int k = 0; k < CH; k++) { prev[k] = mn[k]; mn[k] = nxt[k]; }
+    }
+    if (TAIL > 0) {
+        double d[TAIL > 0 ? TAIL : 1];
 #pragma unroll
-            for (int k = 0; k < TAIL; k++) d[k] = mn[k] - prev[k];
+        for (int k = 0; k < TAIL; k++) d[k] = mn[k] - prev[k];
 #pragma unroll
-            for (int k = 0; k < TAIL; k++) { g += d[k]; row[NFULL * CH + k] = g; }
-        }
-        sub = prev[TAIL];                                              // slot FBI_OW - 1 = column x_strip + FBI_OW - 7: the next strip's first subtrahend
-    } else {
+        for (int k = 0; k < TAIL; k++) { g += d[k]; base[NFULL * CH + k] = g; }
+    }
+    sub = prev[TAIL];
+}
+
+// one whole chain by one lane: row `row` of output row yo, channel ch
+__device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch, double *row, FbHand h)
+{
+    const int n_out = min(FBI_OW, c.W - c.x_strip);                    // (wave-uniform)
+    double g, sub;
+    fb_chain_enter(c, yo, ch, row, h, g, sub);
+    if (c.abl & 16) {                                                  // timing aid: hand-over without the chain (wrong flows)
+    } else if (n_out == FBI_OW) fb_chain_run<FBI_OW>(row, g, sub);
+    else {
         for (int i = 0; i < n_out; i++) {                              // the ragged last strip
             const double mnv = row[i + 2 * FBI_M], nxv = row[i];
             g += mnv - sub;
@@ -1134,14 +1159,7 @@ __device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch,
             sub = nxv;
         }
     }
-    if (c.sx < c.nx - 1) {
-        unsigned long long *pg = c.hout + (int64_t)yo * 5 + ch;
-        const int64_t pl = (int64_t)c.H * 5;
-        const unsigned long long tag = (unsigned long long)c.epoch << 32;
-        const unsigned long long ug = (unsigned long long)__double_as_longlong(g), us = (unsigned long long)__double_as_longlong(sub);
-        fb_hand_st(pg, tag | (ug & 0xffffffffull)); fb_hand_st(pg + pl, tag | (ug >> 32));
-        fb_hand_st(pg + 2 * pl, tag | (us & 0xffffffffull)); fb_hand_st(pg + 3 * pl, tag | (us >> 32));
-    }
+    fb_hand_store(c, yo, ch, g, sub);
 }
 
 // OpenCV's solve for output pixel (yo, x_strip + j) from the five window sums in LDS
