@@ -731,6 +731,7 @@ struct FbIterCtx {
     // sequential row sums: strip index / count, the (row of the group, channel) this lane scans, hand-over slots of the left
     // neighbour (read) and of this strip (written), the launch's tag
     int sx, nx, sr, sch; const unsigned long long *hin; unsigned long long *hout; unsigned epoch; int abl; int *spins;
+    int rsr, rsch; bool full;       // (row, channel) of a right-half chain lane (j - 32); a full strip of FBI_OW output columns
 };
 
 struct FbTaps { float4 q0, c00, c01, c10, c11; float2 e0, e1; float q04, dx, dy; };
@@ -1163,12 +1164,14 @@ __device__ __forceinline__ void fb_iter_scan(const FbIterCtx &c, int yo, int ch,
 }
 
 // OpenCV's solve for output pixel (yo, x_strip + j) from the five window sums in LDS
-__device__ __forceinline__ void fb_iter_solve(const FbIterCtx &c, int yo, const double *rows5)
+// (rows5: the five channels' LDS rows, `stride` doubles apart; col: the pixel's slot in them)
+__device__ __forceinline__ void fb_iter_solve(const FbIterCtx &c, int yo, const double *rows5, int stride = FBI_VS2, int col = -1)
 {
     typedef fb_off_t off_t;
+    if (col < 0) col = c.j;
     const double scale = 1. / (double)(FBI_WIN * FBI_WIN);
-    const double g11 = rows5[c.j] * scale, g12 = rows5[FBI_VS2 + c.j] * scale, g22 = rows5[2 * FBI_VS2 + c.j] * scale;
-    const double h1 = rows5[3 * FBI_VS2 + c.j] * scale, h2 = rows5[4 * FBI_VS2 + c.j] * scale;
+    const double g11 = rows5[col] * scale, g12 = rows5[stride + col] * scale, g22 = rows5[2 * stride + col] * scale;
+    const double h1 = rows5[3 * stride + col] * scale, h2 = rows5[4 * stride + col] * scale;
     const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
     float2 f;
     f.x = (float)((g11 * h2 - g12 * h1) * idet);
@@ -1176,7 +1179,7 @@ __device__ __forceinline__ void fb_iter_solve(const FbIterCtx &c, int yo, const 
     *(float2 *)(c.fout + ((off_t)yo * (off_t)c.W + (off_t)(c.x_strip + c.j)) * 8) = f;
 }
 
-template <int K0, int G, int GN, int NB, int ABL>
+template <int K0, int G, int GN, int NB, int ABL, int VS = FBI_VS2>
 __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
                                                   float2 (&fl)[FBI_G], double *vrow)
 {
@@ -1200,7 +1203,7 @@ __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, fl
 #pragma unroll
                 for (int ch = 0; ch < 5; ch++) {
                     S[ch] += (double)(m[r][ch] - ring[K0 + g][ch]); ring[K0 + g][ch] = m[r][ch];
-                    vrow[(g * 5 + ch) * FBI_VS2 + c.j] = S[ch];
+                    vrow[(g * 5 + ch) * VS + c.j] = S[ch];
                 }
             }
     }
@@ -1214,7 +1217,7 @@ __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, fl
         // barrier -- while the SIMD's other wave (another workgroup's column phase) has work for both issue slots: the
         // chain wave takes priority in the arbitration for its duration (level-0 launch of 21 pairs: 19.7 -> 18.3 ms)
         if (!(c.abl & 128)) { if (c.abl & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3); }
-        fb_iter_scan(c, s0 + c.sr - FBI_M, c.sch, vrow + c.j * FBI_VS2, hand);             // (row r, channel ch) = LDS row r * 5 + ch = j
+        fb_iter_scan(c, s0 + c.sr - FBI_M, c.sch, vrow + c.j * VS, hand);             // (row r, channel ch) = LDS row r * 5 + ch = j
         if (!(c.abl & 128)) __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
@@ -1222,7 +1225,148 @@ __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, fl
 #pragma unroll
         for (int r = 0; r < G; r++) {
             const int yo = s0 + r - FBI_M;
-            if (yo < c.H) fb_iter_solve(c, yo, vrow + (r * 5) * FBI_VS2);
+            if (yo < c.H) fb_iter_solve(c, yo, vrow + (r * 5) * VS, VS);
+        }
+    }
+    __syncthreads();
+}
+
+// ---- THE CHAIN IN TWO PARTS, ONE ROW GROUP APART (HP form of the kernel) --------------------------------------------------------
+// A chain uses 20 - 25 of its wave's 64 lanes for 116 steps, and a lone wave pays for instructions, not for lanes.  So the
+// wave chains TWO parts at once: lanes 0 .. 24 the LEFT part (steps 0 .. 63) of the current row group, lanes 32 .. 56 the
+// RIGHT part (steps 64 .. 115) of the PREVIOUS one, which starts from the g the left part reached a group earlier -- 64 steps
+// per row group instead of 116, the same additions in the same order.  (64 + 52, not 58 + 58: the pixels of the left part are
+// then solved by the workgroup's first wave, those of the right part by its second, without divergence.)  What the right
+// part needs of its group outlives the group's LDS rows in a side buffer: the column sums of slots 63 .. 127 (65 per row and
+// channel: slot 63 written by the left chain itself, which replaces it by its last sum; slots 64 .. 127 copied by the thread
+// that has just solved the pixel whose entry it overwrites) and the left part's g (gmid).  The right-part pixels are solved
+// one group late; the strip's hand-over words leave one group late too (a lag, not a cost).  LDS: 25 x (129 + 65 + 1)
+// doubles = 39 000 B per direction -- four workgroups still fit a CU's 160 KB.  After the last group one more chain phase
+// flushes the right part.
+#define FBI_HS (FBI_T + 1)           // row stride of the column sums (129)
+#define FBI_HL 64                    // steps of the left part
+#define FBI_HRN (FBI_OW - FBI_HL)    // steps of the right part (52)
+#define FBI_HR (FBI_T - FBI_HL + 1)  // side-buffer row: slots 63 .. 127 (65)
+#define FBI_HP_DOUBLES (FBI_G * 5 * (FBI_HS + FBI_HR + 1))
+static_assert(FBI_T == 128 && FBI_HRN == 4 * FBI_WIN && FBI_HL == FBI_HRN + FBI_WIN - 1 && FBI_G * 5 <= 32, "two parts of a strip in one wave");
+
+// FBI_HRN steps by every active lane, FBI_HL - FBI_HRN more by the lanes with `left` (fb_chain_run for two lengths in one
+// instruction stream); base[-1] = `sub` on entry; `sub` returns the column sum the last step's slot held
+__device__ __forceinline__ void fb_chain_run_lr(double *base, double &g, double &sub, bool left)
+{
+    constexpr int CH = FBI_WIN, NFULL = FBI_HRN / CH, TAIL = FBI_HL - FBI_HRN;
+    const int last = (left ? FBI_HL : FBI_HRN) + 2 * FBI_M - 1;
+    double prev[CH], mn[CH];
+    prev[0] = sub;
+#pragma unroll
+    for (int k = 1; k < CH; k++) prev[k] = base[k - 1];
+#pragma unroll
+    for (int k = 0; k < CH; k++) mn[k] = base[2 * FBI_M + k];
+#pragma unroll 1
+    for (int i0 = 0; i0 < NFULL * CH; i0 += CH) {
+        double nxt[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) nxt[k] = base[min(i0 + CH + 2 * FBI_M + k, last)];
+        double d[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) d[k] = mn[k] - prev[k];
+#pragma unroll
+        for (int k = 0; k < CH; k++) { g += d[k]; base[i0 + k] = g; }
+#pragma unroll
+        for (int k = 0; k < CH; k++) { prev[k] = mn[k]; mn[k] = nxt[k]; }
+    }
+    sub = prev[0];                                                     // right part: slot 115, the next strip's first subtrahend
+    if (left) {
+        double d[TAIL];
+#pragma unroll
+        for (int k = 0; k < TAIL; k++) d[k] = mn[k] - prev[k];
+#pragma unroll
+        for (int k = 0; k < TAIL; k++) { g += d[k]; base[NFULL * CH + k] = g; }
+        sub = prev[TAIL];                                              // left part: slot 63, the right part's first subtrahend
+    }
+}
+
+// the right part of row group (s0p, PG rows) by lanes 32 .. 56, the left part of (s0, G rows) by lanes 0 .. 24; G = 0: flush
+template <int G, int PG>
+__device__ __forceinline__ void fb_iter_chain_parts(const FbIterCtx &c, int s0, int s0p, bool has_prev, FbHand hand, double *lds)
+{
+    double *M = lds, *Rb = lds + FBI_G * 5 * FBI_HS, *gmid = Rb + FBI_G * 5 * FBI_HR;
+    const int jr = c.j - 32;
+    const bool chainL = G > 0 && c.j < G * 5 && s0 + c.sr - FBI_M < c.H;
+    const bool chainR = PG > 0 && has_prev && jr >= 0 && jr < PG * 5 && s0p + c.rsr - FBI_M < c.H;
+    if ((chainL || chainR) && !(c.abl & 2)) {
+        if (!(c.abl & 128)) __builtin_amdgcn_s_setprio(3);             // (the serial stretch of the workgroup: see fb_iter_group_seq)
+        double g, sub, *base;
+        if (chainR) { base = Rb + jr * FBI_HR + 1; g = gmid[jr]; sub = base[-1]; }
+        else { base = M + c.j * FBI_HS; fb_chain_enter(c, s0 + c.sr - FBI_M, c.sch, base, hand, g, sub); }
+        fb_chain_run_lr(base, g, sub, !chainR);
+        if (chainR) fb_hand_store(c, s0p + c.rsr - FBI_M, c.rsch, g, sub);
+        else { gmid[c.j] = g; Rb[c.j * FBI_HR] = sub; }                // (the right lanes have read both entries: same wave, program order)
+        if (!(c.abl & 128)) __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+template <int K0, int G, int GN, int NB, int ABL, int PG>
+__device__ __forceinline__ void fb_iter_group_half(const FbIterCtx &c, int s0, float (&ring)[FBI_WIN][5], double (&S)[5],
+                                                   float2 (&fl)[FBI_G], double *lds, bool has_prev)
+{
+    double *M = lds, *Rb = lds + FBI_G * 5 * FBI_HS;
+    FbHand hand = {0ull, 0ull, 0ull, 0ull};
+    if (c.j < G * 5 && s0 + c.sr - FBI_M < c.H && c.sx > 0) fb_hand_load(c, s0 + c.sr - FBI_M, c.sch, hand);
+#pragma unroll
+    for (int g0 = 0; g0 < G; g0 += NB) {
+        FbTaps t[NB];
+        float m[NB][5];
+#pragma unroll
+        for (int r = 0; r < NB; r++)
+            if (g0 + r < G && ABL != 1) fb_taps_load<ABL>(c, s0 + g0 + r, fl[g0 + r], t[r]);
+#pragma unroll
+        for (int r = 0; r < NB; r++)
+            if (g0 + r < G) {
+                const int g = g0 + r, s = s0 + g;
+                if (ABL == 1) { m[r][0] = (float)s; m[r][1] = (float)c.xc; m[r][2] = 1.f; m[r][3] = 2.f; m[r][4] = (float)(s + c.xc); }
+                else fb_taps_eval(c, s, t[r], m[r]);
+#pragma unroll
+                for (int ch = 0; ch < 5; ch++) {
+                    S[ch] += (double)(m[r][ch] - ring[K0 + g][ch]); ring[K0 + g][ch] = m[r][ch];
+                    M[(g * 5 + ch) * FBI_HS + c.j] = S[ch];
+                }
+            }
+    }
+    if (ABL != 1) {
+#pragma unroll
+        for (int g = 0; g < GN; g++) fl[g] = fb_iter_flow_at(c, s0 + G + g);
+    }
+    __syncthreads();
+    fb_iter_chain_parts<G, PG>(c, s0, s0 - PG, has_prev, hand, lds);
+    __syncthreads();
+    const bool in_x = c.x_strip + c.j < c.W;
+    if (c.j < FBI_HL) {                                                // first wave: the left-part pixels of this group
+        if (in_x && !(c.abl & 4)) {
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int yo = s0 + r - FBI_M;
+                if (yo < c.H) fb_iter_solve(c, yo, M + (r * 5) * FBI_HS, FBI_HS, c.j);
+            }
+        }
+    } else {                                                           // second wave: the right-part pixels of the previous group ...
+        if (PG > 0 && has_prev && c.j < FBI_OW && in_x && !(c.abl & 4)) {
+#pragma unroll
+            for (int r = 0; r < (PG > 0 ? PG : 1); r++) {
+                const int yo = s0 - PG + r - FBI_M;
+                if (yo < c.H) fb_iter_solve(c, yo, Rb + (r * 5) * FBI_HR, FBI_HR, c.j - (FBI_HL - 1));
+            }
+        }
+        // ... then this group's column sums of slots 64 .. 127 into the side buffer, each thread the entry it has just read
+        const double *src = M + c.j;
+        double *dst = Rb + c.j - (FBI_HL - 1);
+#pragma unroll 1
+        for (int r = 0; r < G; r++) {                                  // (five entries at a time: the copy must not cost registers)
+            double v[5];
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) v[ch] = src[(r * 5 + ch) * FBI_HS];
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++) dst[(r * 5 + ch) * FBI_HR] = v[ch];
         }
     }
     __syncthreads();
@@ -1230,11 +1374,12 @@ __device__ __forceinline__ void fb_iter_group_seq(const FbIterCtx &c, int s0, fl
 
 // NDW = directions per workgroup: 2 = both directions of a strip share a workgroup (and the R rows they read), 1 = every
 // (strip, direction) is a two-wave workgroup of its own, four per CU (a.nq = 2 then: directions take tickets of their own)
-template <int NB, int ABL, int NDW>
+// HP = 1: the chain in two parts one row group apart (full strips; a ragged last strip chains whole, on the same LDS rows)
+template <int NB, int ABL, int NDW, int HP>
 __global__ void __launch_bounds__(NDW * FBI_T, 2)
 k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
 {
-    __shared__ double vrow_all[NDW][FBI_G * 5 * FBI_VS2];
+    __shared__ double vrow_all[NDW][HP ? FBI_HP_DOUBLES : FBI_G * 5 * FBI_VS2];
     // TICKETS, ONE LIST PER XCD.  Pair b belongs to the list of XCD b mod 8 -- with all its strips, both directions and all
     // column groups -- and a workgroup takes the next item of ITS XCD's list (s_getreg XCC_ID): the two directions of a
     // strip, which read each other's expansion rows, then run on the same XCD within microseconds and share them in its
@@ -1290,6 +1435,8 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
     c.j = threadIdx.x - qw * FBI_T;
     c.dj = c.j; c.tg = 0; c.tq = 0;
     c.sr = c.j / 5; c.sch = c.j - c.sr * 5;
+    c.rsr = c.j >= 32 ? (c.j - 32) / 5 : 0; c.rsch = c.j >= 32 ? (c.j - 32) - c.rsr * 5 : 0;
+    c.full = W - sx * FBI_OW >= FBI_OW;
     c.sx = sx; c.nx = a.nx; c.epoch = a.epoch; c.abl = a.abl; c.spins = (a.abl & 8) ? a.ticket - 16 * (a.epoch - 1) + FBI_HDR / 4 - 4 : nullptr;
     {
         // hand-over slots of (pair b, direction q, strip): [q][strip 0 .. nx - 2][row][FBI_HW words]
@@ -1357,10 +1504,30 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
         }
         __syncthreads();
     }
+    if (HP && c.full) {
+        for (int base = FBI_M; base <= s_last; base += FBI_WIN) {
+            fb_iter_group_half<0, 4, 4, NB, ABL, 5>(c, base, ring, S, fl, vrow, base > FBI_M);
+            fb_iter_group_half<4, 4, 5, NB, ABL, 4>(c, base + 4, ring, S, fl, vrow, true);
+            fb_iter_group_half<8, 5, 4, NB, ABL, 4>(c, base + 8, ring, S, fl, vrow, true);
+        }
+        // flush: the right part of the last group (its rows past H - 1 produce nothing)
+        const int s0p = FBI_M + ((s_last - FBI_M) / FBI_WIN) * FBI_WIN + 8;
+        const FbHand none = {0ull, 0ull, 0ull, 0ull};
+        fb_iter_chain_parts<0, 5>(c, s0p + 5, s0p, true, none, vrow);
+        __syncthreads();
+        if (c.j >= FBI_HL && c.j < FBI_OW && c.x_strip + c.j < c.W && !(c.abl & 4)) {
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+                const int yo = s0p + r - FBI_M;
+                if (yo < c.H) fb_iter_solve(c, yo, vrow + FBI_G * 5 * FBI_HS + (r * 5) * FBI_HR, FBI_HR, c.j - (FBI_HL - 1));
+            }
+        }
+        return;
+    }
     for (int base = FBI_M; base <= s_last; base += FBI_WIN) {
-        fb_iter_group_seq<0, 4, 4, NB, ABL>(c, base, ring, S, fl, vrow);
-        fb_iter_group_seq<4, 4, 5, NB, ABL>(c, base + 4, ring, S, fl, vrow);
-        fb_iter_group_seq<8, 5, 4, NB, ABL>(c, base + 8, ring, S, fl, vrow);
+        fb_iter_group_seq<0, 4, 4, NB, ABL, (HP ? FBI_HS : FBI_VS2)>(c, base, ring, S, fl, vrow);
+        fb_iter_group_seq<4, 4, 5, NB, ABL, (HP ? FBI_HS : FBI_VS2)>(c, base + 4, ring, S, fl, vrow);
+        fb_iter_group_seq<8, 5, 4, NB, ABL, (HP ? FBI_HS : FBI_VS2)>(c, base + 8, ring, S, fl, vrow);
     }
 }
 
@@ -1718,6 +1885,7 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             ia.R[0] = R[0]; ia.R[1] = R[1]; ia.bs_R = bs_R; ia.nd = nd; ia.nx = nx;
             // development switch: TF_FB_ROW_SUMS_TREE=1 -> the round-3 kernel (window sums as a tree: within 1e-4 px of OpenCV's order, not identical)
             static const bool tree = getenv("TF_FB_ROW_SUMS_TREE") != nullptr;
+            static const bool whole_chain = getenv("TF_FBI_WHOLE_CHAIN") != nullptr;   // development switch: one lane chains all 116 columns of its row (same flows)
             // sequential row sums: the strips' hand-over words and the launches' ticket counters live in the blur scratch,
             // idle from the polynomial expansion of this level to the blur of the next: [1 KB of counters][words] per pair
             const size_t hand_words = (size_t)nd * (size_t)(nx - 1) * (size_t)h * FBI_HW;
@@ -1767,11 +1935,15 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                         if (abl == 1) hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 1>), gi, bi, 0, s, ia, h, w, plane);
                         else if (abl == 2) hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 2>), gi, bi, 0, s, ia, h, w, plane);
                         else hipLaunchKernelGGL((k_fb_iter_tree<FBI_NB, 0>), gi, bi, 0, s, ia, h, w, plane);
-                    } else if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1, 2>), gi, bi, 0, s, ia, h, w, plane);
-                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2, 2>), gi, bi, 0, s, ia, h, w, plane);
-                    else if (ia.nq == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 1>), dim3(gi.x * 2), dim3(FBI_T), 0, s, ia, h, w, plane);
-                    else if (nd == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 1>), gi, bi, 0, s, ia, h, w, plane);
-                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 2>), gi, bi, 0, s, ia, h, w, plane);
+                    } else if (abl == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 1, 2, 0>), gi, bi, 0, s, ia, h, w, plane);
+                    else if (abl == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 2, 2, 0>), gi, bi, 0, s, ia, h, w, plane);
+                    else if (whole_chain) {
+                        if (ia.nq == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 1, 0>), dim3(gi.x * 2), dim3(FBI_T), 0, s, ia, h, w, plane);
+                        else if (nd == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 1, 0>), gi, bi, 0, s, ia, h, w, plane);
+                        else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 2, 0>), gi, bi, 0, s, ia, h, w, plane);
+                    } else if (ia.nq == 2) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 1, 1>), dim3(gi.x * 2), dim3(FBI_T), 0, s, ia, h, w, plane);
+                    else if (nd == 1) hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 1, 1>), gi, bi, 0, s, ia, h, w, plane);
+                    else hipLaunchKernelGGL((k_fb_iter<FBI_NB, 0, 2, 1>), gi, bi, 0, s, ia, h, w, plane);
                 }
                 for (int q = 0; q < nd; q++) cur[dirs[q]] = 1 - cur[dirs[q]];
             }
