@@ -336,9 +336,9 @@ def test_development_switches_do_not_change_results(tf, tmp_path):
         fw, bw = tf.calculate_flow(a, "Farneback", vr_steps=1)
         # (round 4) the iteration kernel's scheduling knobs: both directions of a strip in one workgroup, strips that let their
         # left neighbour get ahead before they start, one column group of tickets whatever the launch size, one ticket list
-        # instead of one per XCD, every chain walked whole by one lane instead of in two parts one row group apart
+        # instead of one per XCD, every chain in two parts one row group apart instead of walked whole by one lane
         for var in ("TF_FB_POLYEXP_GENERIC", "TF_VR_SOR_SWEEPS", "TF_VR_WEIGHTS_PASS", "TF_FB_BLUR_TWOPASS", "TF_FB_BLUR_NO_LDS",
-                    "TF_FBI_JOIN_DIRECTIONS", "TF_FBI_SLACK_ROWS", "TF_FBI_COLUMN_GROUPS", "TF_FBI_ONE_TICKET_LIST", "TF_FBI_WHOLE_CHAIN"):
+                    "TF_FBI_JOIN_DIRECTIONS", "TF_FBI_SLACK_ROWS", "TF_FBI_COLUMN_GROUPS", "TF_FBI_ONE_TICKET_LIST", "TF_FBI_TWO_PART_CHAIN"):
             out = tmp_path / f"{var}_{tag}.npy"
             env = dict(os.environ, **{var: "13" if var == "TF_FBI_SLACK_ROWS" else "1"})
             subprocess.check_call([sys.executable, "-c", code % (root, str(tmp_path / f"in_{tag}.npy"), str(out))], env=env)

@@ -1885,7 +1885,13 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             ia.R[0] = R[0]; ia.R[1] = R[1]; ia.bs_R = bs_R; ia.nd = nd; ia.nx = nx;
             // development switch: TF_FB_ROW_SUMS_TREE=1 -> the round-3 kernel (window sums as a tree: within 1e-4 px of OpenCV's order, not identical)
             static const bool tree = getenv("TF_FB_ROW_SUMS_TREE") != nullptr;
-            static const bool whole_chain = getenv("TF_FBI_WHOLE_CHAIN") != nullptr;   // development switch: one lane chains all 116 columns of its row (same flows)
+            // TF_FBI_TWO_PART_CHAIN=1: the chain in two parts one row group apart (HP form; same flows).  Alone on the GPU it is the
+            // faster form (level-0 launch of 21 pairs: 18.0 against 19.7 ms); it is NOT the default because its 39 KB of LDS per
+            // workgroup fill the CU (4 x 39 = 156 of 160 KB): in the pipelined benchmark the floods of the finished windows run
+            // beside the flow in what the one-lane form leaves free (4 x 27 KB), and with the two-part form they displace
+            // iteration workgroups instead -- the kernel then reads 1 985 against 1 860 ms per config-F step, the step is the same
+            // (4.75 s either way, back to back on one box)
+            static const bool whole_chain = getenv("TF_FBI_TWO_PART_CHAIN") == nullptr;
             // sequential row sums: the strips' hand-over words and the launches' ticket counters live in the blur scratch,
             // idle from the polynomial expansion of this level to the blur of the next: [1 KB of counters][words] per pair
             const size_t hand_words = (size_t)nd * (size_t)(nx - 1) * (size_t)h * FBI_HW;
