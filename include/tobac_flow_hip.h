@@ -110,6 +110,11 @@ size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const
  * <= max_pairs whose workspace fits max_bytes (0 = no limit) with the best ratio of work to rounds x rows summed over
  * the levels -- the largest one within 1 % of the best (42 pairs at 5424 x 5424 on 256 CUs: full rounds at levels 0, 1, 2). */
 int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneback_params *p, int64_t max_pairs, size_t max_bytes);
+/* Form of the row-sum chains of the iteration kernel from now on (process-wide; the flows are the same bits either way):
+ * 1 = two parts one row group apart -- faster when the flow has the GPU to itself (39 KB of LDS per workgroup: a CU is full);
+ * 0 = one lane per chain (default) -- leaves LDS for the kernels of other streams (e.g. floods of finished windows).
+ * TF_FBI_TWO_PART_CHAIN=0 / 1 in the environment overrides it. */
+void tf_farneback_prefer_two_part_chain(int on);
 /* Workgroups of the iteration kernel's full-resolution launch for B pairs, and (resident_out, may be NULL) how many the
  * device holds at once.  A launch costs whole rounds of resident workgroups: cut a batch into parts
  * (tf_farneback_batch_phase) only while a part still fills a round. */

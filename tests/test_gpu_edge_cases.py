@@ -340,7 +340,8 @@ def test_development_switches_do_not_change_results(tf, tmp_path):
         for var in ("TF_FB_POLYEXP_GENERIC", "TF_VR_SOR_SWEEPS", "TF_VR_WEIGHTS_PASS", "TF_FB_BLUR_TWOPASS", "TF_FB_BLUR_NO_LDS",
                     "TF_FBI_JOIN_DIRECTIONS", "TF_FBI_SLACK_ROWS", "TF_FBI_COLUMN_GROUPS", "TF_FBI_ONE_TICKET_LIST", "TF_FBI_TWO_PART_CHAIN"):
             out = tmp_path / f"{var}_{tag}.npy"
-            env = dict(os.environ, **{var: "13" if var == "TF_FBI_SLACK_ROWS" else "1"})
+            # (calculate_flow asks for the two-part chain when it hands out no windows: the switch's OTHER value is the test here)
+            env = dict(os.environ, **{var: "13" if var == "TF_FBI_SLACK_ROWS" else ("0" if var == "TF_FBI_TWO_PART_CHAIN" else "1")})
             subprocess.check_call([sys.executable, "-c", code % (root, str(tmp_path / f"in_{tag}.npy"), str(out))], env=env)
             alt = np.load(out)
             assert np.array_equal(alt[0], fw, equal_nan=True) and np.array_equal(alt[1], bw, equal_nan=True), (var, tag)

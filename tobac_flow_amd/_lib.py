@@ -51,6 +51,7 @@ _PROTOS = {
     "tf_farneback_batch_phase": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                             _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _c.c_int]),
     "tf_farneback_batch_hint": (_c.c_int64, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int64, _c.c_size_t]),
+    "tf_farneback_prefer_two_part_chain": (None, [_c.c_int]),
     "tf_farneback_iteration_workgroups": (_c.c_int64, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int64, _P]),
     "tf_farneback_batch": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                       _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),

@@ -28,6 +28,7 @@
 #include <math.h>
 #include <float.h>
 #include <stdlib.h>
+#include <atomic>
 
 #define FB_MAX_KSIZE 255
 #define FB_MAX_POLY_N 8
@@ -1718,6 +1719,12 @@ extern "C" int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneb
     return pick;
 }
 
+// Which form of the row-sum chain the iteration kernel uses from now on (process-wide; both give the same bits): 1 = two parts
+// one row group apart (faster when the flow has the GPU to itself), 0 = one lane per chain (default; leaves LDS for kernels
+// of other streams).  TF_FBI_TWO_PART_CHAIN=0 / 1 in the environment overrides it.
+static std::atomic<int> fb_two_part_chain{0};
+extern "C" void tf_farneback_prefer_two_part_chain(int on) { fb_two_part_chain.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 // Workgroups of the iteration kernel's full-resolution launch for B pairs (both directions), and how many of them the
 // device holds at once: a launch costs whole rounds of resident workgroups, so a caller that may cut a batch into parts
 // (tf_farneback_batch_phase) does so only while a part still fills a round.
@@ -1891,7 +1898,9 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             // beside the flow in what the one-lane form leaves free (4 x 27 KB), and with the two-part form they displace
             // iteration workgroups instead -- the kernel then reads 1 985 against 1 860 ms per config-F step, the step is the same
             // (4.75 s either way, back to back on one box)
-            static const bool whole_chain = getenv("TF_FBI_TWO_PART_CHAIN") == nullptr;
+            // (tf_farneback_prefer_two_part_chain: the host layer asks for it when nothing is going to run beside the flow)
+            static const char *chain_env = getenv("TF_FBI_TWO_PART_CHAIN");
+            const bool whole_chain = chain_env ? atoi(chain_env) == 0 : fb_two_part_chain.load(std::memory_order_relaxed) == 0;
             // sequential row sums: the strips' hand-over words and the launches' ticket counters live in the blur scratch,
             // idle from the polynomial expansion of this level to the blur of the next: [1 KB of counters][words] per pair
             const size_t hand_words = (size_t)nd * (size_t)(nx - 1) * (size_t)h * FBI_HW;

@@ -313,6 +313,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     t = _lib.torch()
     L = _lib.lib()
     H, W = shape
+    # the iteration kernel's chains in two parts when nothing is going to run beside the flow (no windows handed out while
+    # the later frames are computed): same bits, 8 % faster alone, but it fills the CUs' LDS (csrc/farneback.hip)
+    if hasattr(L, "tf_farneback_prefer_two_part_chain"):
+        L.tf_farneback_prefer_two_part_chain(0 if on_batch is not None else 1)
     forward = _lib.empty((T, H, W, 2), t.float32)
     backward = _lib.empty((T, H, W, 2), t.float32)
     # every frame is written below except the two mirrored ends, which tf_flow_finalize derives from their neighbours
