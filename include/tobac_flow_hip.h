@@ -33,6 +33,8 @@ extern "C" {
 #define TF_ENOCONV (-4)  /* an iterative kernel hit its sweep limit           */
 #define TF_EDEPTH (-5)   /* tf_watershed*: ties left at the deepest chain level the workspace allows; output written,
                             but not guaranteed to equal the reference at the reported pixels */
+#define TF_ESTARVED (-6) /* tf_farneback*: a row-sum chain of the iteration kernel gave up waiting for its left neighbour
+                            (a stalled device); the flow of the launches concerned holds NaN rows -- recompute */
 
 /* interpolation of the semi-Lagrangian gathers: cv2.INTER_NEAREST / _LINEAR / _CUBIC as selected
  * by tobac_flow/convolve.py:47-54 and tobac_flow/utils/flow_utils.py:22-34 */
@@ -85,7 +87,15 @@ typedef struct {
     int num_iters;      /* 10  */
     int poly_n;         /* 5   */
     double poly_sigma;  /* 1.1 */
+    int chain_form;     /* TF_FB_CHAIN_*: scheduling of the iteration kernel for THIS call; the flows are the same bits */
 } tf_farneback_params;
+/* chain_form: the row-sum chains of the iteration kernel as one lane per chain (leaves LDS for the kernels of other streams,
+ * e.g. floods of finished windows: what a caller that runs other work beside the flow wants) or in two parts one row group
+ * apart (39 KB of LDS per workgroup, a CU is full: 8 % faster when the flow has the GPU to itself).  DEFAULT = one lane.
+ * TF_FBI_TWO_PART_CHAIN=0 / 1 in the environment overrides it (development switch). */
+#define TF_FB_CHAIN_DEFAULT 0
+#define TF_FB_CHAIN_ONE_LANE 1
+#define TF_FB_CHAIN_TWO_PART 2
 void tf_farneback_default_params(tf_farneback_params *p);
 size_t tf_farneback_workspace_bytes(int64_t H, int64_t W, const tf_farneback_params *p);
 int tf_farneback_pair(const uint8_t *prev, const uint8_t *next, int64_t H, int64_t W,
@@ -110,11 +120,16 @@ size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const
  * <= max_pairs whose workspace fits max_bytes (0 = no limit) with the best ratio of work to rounds x rows summed over
  * the levels -- the largest one within 1 % of the best (42 pairs at 5424 x 5424 on 256 CUs: full rounds at levels 0, 1, 2). */
 int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneback_params *p, int64_t max_pairs, size_t max_bytes);
-/* Form of the row-sum chains of the iteration kernel from now on (process-wide; the flows are the same bits either way):
- * 1 = two parts one row group apart -- faster when the flow has the GPU to itself (39 KB of LDS per workgroup: a CU is full);
- * 0 = one lane per chain (default) -- leaves LDS for the kernels of other streams (e.g. floods of finished windows).
- * TF_FBI_TWO_PART_CHAIN=0 / 1 in the environment overrides it. */
-void tf_farneback_prefer_two_part_chain(int on);
+/* Launches are asynchronous, so what a launch found out arrives later: tf_farneback_check() -- call it once the stream the
+ * batches ran on has been synchronised (or an event after them has completed) -- returns TF_ESTARVED if a row-sum chain of
+ * any iteration launch of this device since the last report gave up waiting for its left neighbour's hand-over words
+ * (bounded polls: a device stalled for seconds by a profiler's serialisation or a preempted queue), TF_OK otherwise.  The
+ * flow of those launches then holds NaN rows.  Every tf_farneback_batch* call also reports (and clears) on entry what
+ * earlier launches left, so a caller that never checks still cannot go on unnoticed.  The reference has no counterpart
+ * (cv2's calc is synchronous); error convention of SURVEY section 8(b). */
+int tf_farneback_check(void);
+/* test hook: sets the device's status word from the host, as a starved chain would (tests of the host-side path) */
+int tf_farneback_debug_set_starved(void);
 /* Workgroups of the iteration kernel's full-resolution launch for B pairs, and (resident_out, may be NULL) how many the
  * device holds at once.  A launch costs whole rounds of resident workgroups: cut a batch into parts
  * (tf_farneback_batch_phase) only while a part still fills a round. */
@@ -470,6 +485,13 @@ int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *
  *   returns on the HOST the (left id, right id) pairs with count >= atol (count > 0 if atol == 0) and, if rtol > 0,
  *   max(count / pixels(left id), count / pixels(right id)) >= rtol; the reference uses atol = 5, rtol = 0.5.
  *   pairs_host: 2 * max_pairs int32.  Connected components of these pairs are the stitched objects (linking.py:153-161). */
+/* tf_pair_rank: tobac_flow/utils/label_utils.py:183-200 (`make_step_labels`, the first step of detection.relabel_anvils
+ *   :660-687) -- out[i] = 1 + the index of (a[i], b[i]) in the list of distinct pairs (pairs_a, pairs_b: device arrays as
+ *   tf_pair_counts returns them, sorted by (a, b)), 0 where a[i] <= 0, b[i] <= 0 or the pair is not listed.  With a = the
+ *   pieces of the non-zero mask connected within a time step (tf_label, t planes of the structure zeroed) and b = the
+ *   labels this is the reference's numbering: contiguous from 1, by piece, then by original label.  16-byte aligned volumes. */
+int tf_pair_rank(const int32_t *a, const int32_t *b, int64_t n, const int32_t *pairs_a, const int32_t *pairs_b,
+                 int64_t n_pairs, int32_t *out, void *stream);
 size_t tf_pair_counts_workspace_bytes(int64_t n, int64_t max_runs);
 int tf_pair_counts(const int32_t *a, const int32_t *b, int64_t n, int include_b_zero,
                    int32_t *out_a, int32_t *out_b, int64_t *out_count, int64_t max_pairs,

@@ -169,6 +169,42 @@ def test_get_anvil_markers_and_relabel(scene):
     lk = np_label.flow_link_overlap(fwd, bwd, make_step_labels(got), overlap=0.5, absolute_overlap=5)
     want = remap_labels(lk, find_object_lengths(lk) > 1)
     assert np.array_equal(re, want)
+    # round 5: the recipes run in HBM whatever the container; the variants with the reference's own numpy / SciPy glue between
+    # the device operators give the same labels, and device input gives device output
+    import torch
+    from tobac_flow_amd.detection import _get_anvil_markers_host, _relabel_anvils_host
+    assert np.array_equal(_get_anvil_markers_host(flow, wvd, threshold=-5, overlap=0.5, absolute_overlap=5, min_length=1), got)
+    for markers in (None, (wvd >= -2)):
+        want_re = _relabel_anvils_host(flow, got, markers=markers, overlap=0.5, absolute_overlap=5, min_length=1)
+        assert np.array_equal(relabel_anvils(flow, got, markers=markers, overlap=0.5, absolute_overlap=5, min_length=1), want_re)
+        dev = relabel_anvils(flow, torch.from_numpy(got).cuda(), markers=None if markers is None else torch.from_numpy(markers).cuda(),
+                             overlap=0.5, absolute_overlap=5, min_length=1)
+        assert isinstance(dev, torch.Tensor) and np.array_equal(dev.cpu().numpy(), want_re)
+
+
+def test_make_step_labels_on_the_device_equals_the_host_function():
+    """utils.label_utils.make_step_labels (reference: label_utils.py:183-200) as tf_label + tf_pair_counts + tf_pair_rank:
+    pieces connected within a step, split into the labels they contain, numbered by (piece, label) -- on volumes where one
+    piece holds several labels, one label several pieces, labels touch diagonally only, and on an empty volume."""
+    import torch
+    from tobac_flow_amd.label import make_step_labels_dev
+    from tobac_flow_amd.utils.label_utils import make_step_labels
+    rng = np.random.default_rng(8)
+    vols = []
+    for shape in ((4, 37, 53), (2, 64, 64), (3, 5, 9), (1, 1, 7)):
+        blobs = ndi.gaussian_filter(rng.normal(size=shape), (0, 2, 2)) > 0.02
+        ids = rng.integers(1, 6, size=shape).astype(np.int32)
+        ids = ndi.maximum_filter(ids, size=(1, 5, 5))                 # patches of equal label inside the blobs
+        vols.append((blobs * ids).astype(np.int32))
+    vols.append(np.zeros((2, 8, 8), np.int32))
+    checker = np.indices((2, 9, 9)).sum(0) % 2
+    vols.append((checker * 3).astype(np.int32))                       # 4-connected: every pixel its own piece
+    for v in vols:
+        want = make_step_labels(v)
+        got = make_step_labels_dev(torch.from_numpy(v).cuda())
+        assert got.dtype == torch.int32 and np.array_equal(got.cpu().numpy(), want), v.shape
+    with pytest.raises(ValueError, match="negative"):
+        make_step_labels_dev(torch.from_numpy(np.array([[[1, -1, 0]]], np.int32)).cuda())
 
 
 def test_get_combined_filters_runs_and_matches_any_reduction(scene):
@@ -237,7 +273,9 @@ def test_detect_anvils_device_path_equals_numpy_path(scene):
     from tobac_flow_amd.detection import detect_anvils
     bt = scene["bt"]
     wvd = ((250.0 - bt) / 2.0 - 10.0).astype(np.float32)
-    want = detect_anvils(scene["flow"], wvd, upper_threshold=-5, lower_threshold=-15, min_length=1)
+    from tobac_flow_amd.detection import _detect_anvils_host
+    want = _detect_anvils_host(scene["flow"], wvd, upper_threshold=-5, lower_threshold=-15, min_length=1)   # the reference's own glue
+    assert np.array_equal(detect_anvils(scene["flow"], wvd, upper_threshold=-5, lower_threshold=-15, min_length=1), want)
     got = detect_anvils(scene["flow"], torch.from_numpy(wvd).cuda(), upper_threshold=-5, lower_threshold=-15, min_length=1)
     assert isinstance(got, torch.Tensor) and np.array_equal(got.cpu().numpy(), want)
 
@@ -270,11 +308,12 @@ def test_label_matches_scipy(conn):
 def test_anvil_pipeline_device_resident_equals_numpy(scene):
     """get_anvil_markers -> detect_anvils(markers=...) entirely on the device == the numpy recipes"""
     import torch
-    from tobac_flow_amd.detection import detect_anvils, get_anvil_markers
+    from tobac_flow_amd.detection import _detect_anvils_host, _get_anvil_markers_host, detect_anvils, get_anvil_markers
     bt, flow = scene["bt"], scene["flow"]
     wvd = ((250.0 - bt) / 2.0 - 10.0).astype(np.float32)
-    m_np = get_anvil_markers(flow, wvd, threshold=-5, overlap=0.5, absolute_overlap=5, min_length=1)
-    a_np = detect_anvils(flow, wvd, markers=m_np, upper_threshold=-5, lower_threshold=-15, min_length=1)
+    m_np = _get_anvil_markers_host(flow, wvd, threshold=-5, overlap=0.5, absolute_overlap=5, min_length=1)
+    a_np = _detect_anvils_host(flow, wvd, markers=m_np, upper_threshold=-5, lower_threshold=-15, min_length=1)
+    assert np.array_equal(detect_anvils(flow, wvd, markers=m_np, upper_threshold=-5, lower_threshold=-15, min_length=1), a_np)
     wd = torch.from_numpy(wvd).cuda()
     m_dev = get_anvil_markers(flow, wd, threshold=-5, overlap=0.5, absolute_overlap=5, min_length=1)
     a_dev = detect_anvils(flow, wd, markers=m_dev, upper_threshold=-5, lower_threshold=-15, min_length=1)
@@ -534,6 +573,52 @@ def test_detect_cores_device_resident_equals_host_glue_and_meets_its_own_criteri
         drop = (mean_bt[:-3] - mean_bt[3:]) / (3.0 * minutes)
         assert np.nanmax(drop) >= 0.5 - 1e-4, (k, drop)
     assert "Initial core count" in host_log
+    # device-resident form (round 5): DeviceField in (tensor + time coordinate) -> tensor out, the same labels
+    import torch
+    from tobac_flow_amd.detection import DeviceField
+    tt = np.asarray(bt.t.data)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dev = detect_cores(flow, *(DeviceField(torch.from_numpy(np.asarray(x)).cuda(), tt) for x in (bt, wvd, swd)), use_wvd=use_wvd)
+    capsys.readouterr()
+    assert isinstance(dev, torch.Tensor) and _same(dev.cpu().numpy(), want)
+
+
+def test_core_cooling_statistics_on_the_device_equal_the_host_statistics():
+    """The last stage of detect_cores (detection.py:434-482) with its volume passes on the device: per (core, step) label the
+    core it belongs to, its mean BT and its time; then the reference's own host reduction over a core's steps.  The labels
+    equal the host form's; the per-step means agree with numpy's float32 nanmean to a few float32 ulps (the host value
+    depends on the order an unstable argsort leaves the values in; the device value is the correctly rounded mean)."""
+    import torch
+    from tobac_flow_amd import label as _label
+    from tobac_flow_amd.analysis import _label_stats
+    from tobac_flow_amd.detection import _core_cooling_filter, _core_cooling_filter_dev
+    from tobac_flow_amd.utils import labeled_comprehension, slice_labels
+    rng = np.random.default_rng(12)
+    T, H, W = 9, 60, 80
+    core = np.zeros((T, H, W), np.int32)
+    core[0:7, 5:20, 5:25] = 1                      # cools fast
+    core[2:9, 30:50, 10:30] = 2                    # cools slowly
+    core[1:4, 10:15, 50:60] = 3                    # too short for a min_length-step difference
+    core[3:9, 40:55, 50:75] = 4                    # holds NaN values
+    core[0:9:2, 25:28, 40:44] = 5                  # present at every other step only
+    bt = 250 + rng.normal(size=(T, H, W)).astype(np.float32)
+    for k, rate in ((1, 9.0), (2, 1.0), (3, 9.0), (4, 8.0), (5, 7.0)):
+        bt -= (core == k) * (rate * np.arange(T, dtype=np.float32)[:, None, None])
+    bt[5, 41:44, 51:60] = np.nan
+    bt[6][core[6] == 4] = np.nan                   # a whole step of core 4 without a value
+    fa = FakeDataArray(bt.astype(np.float32), minutes=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = _core_cooling_filter(core.copy(), fa, 3)
+        got = _core_cooling_filter_dev(torch.from_numpy(core).cuda(), torch.from_numpy(np.asarray(fa)).cuda(), np.asarray(fa.t.data), 3)
+        assert np.array_equal(got.cpu().numpy(), want) and 1 <= want.max() < 5
+        step = slice_labels(core)
+        host_mean = labeled_comprehension(np.asarray(fa), step, np.nanmean, default=np.nan)
+    dev_mean = _label_stats(torch.from_numpy(step.astype(np.int32)).cuda(), torch.from_numpy(np.asarray(fa)).cuda(), None, np.float64)[0].astype(np.float32)
+    assert np.array_equal(np.isnan(dev_mean), np.isnan(host_mean)) and np.isnan(host_mean).sum() == 1
+    ok = ~np.isnan(host_mean)
+    assert np.max(np.abs(dev_mean[ok] - host_mean[ok]) / np.abs(host_mean[ok])) < 4 * np.finfo(np.float32).eps
 
 
 def test_detect_cores_without_candidates_behaves_like_the_reference():

@@ -351,3 +351,86 @@ def test_create_flow_with_split_batches_is_bit_identical_and_hands_out_parts(mon
     monkeypatch.delenv("TF_FLOW_SPLIT_FORCE")
     raw0 = tf.calculate_flow(bt, "Farneback")
     assert torch.equal(torch.nan_to_num(raw[0], nan=-7.0), torch.nan_to_num(raw0[0], nan=-7.0))
+
+
+def test_out_of_memory_in_the_callback_is_the_callers_and_handed_out_frames_are_never_recomputed(monkeypatch):
+    """(i) an OutOfMemoryError raised by the caller's on_frames_ready callback propagates -- it used to be
+    taken for "this batch's scratch did not fit": workspace released, the batch recomputed at half size, the callback
+    re-entered with a SMALLER n.  (ii) When the library's own work of a split batch runs out of memory in part k, only the
+    pairs from that part on are queued again: the parts already handed out are not rewritten, the n the callback sees never
+    decreases, and the flow is the plain call's bit for bit."""
+    import pytest
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow
+    from tools.synth import blob_stack
+    bt = blob_stack(11, 203, 331, seed=9, t0=1)
+    kw = dict(vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    want = tf.create_flow(bt, **kw)
+    # (i)
+    calls = []
+
+    def greedy(flow, n):
+        calls.append(n)
+        raise torch.OutOfMemoryError("simulated: the caller's own allocation failed")
+    monkeypatch.setenv("TF_FLOW_BATCH", "4")
+    with pytest.raises(torch.OutOfMemoryError, match="caller's own"):
+        tf.create_flow(bt, on_frames_ready=greedy, **kw)
+    assert calls == [5]                                               # entered once, not again with a smaller batch
+    monkeypatch.delenv("TF_FLOW_BATCH")
+    # (ii)
+    monkeypatch.setenv("TF_FLOW_SPLIT", "2")
+    monkeypatch.setenv("TF_FLOW_SPLIT_FORCE", "1")
+    real = FarnebackFlow.calc_phase_dev
+    state = {"phase2_calls": 0, "refused": 0}
+
+    def picky(self, prev, nxt, fwd_out, bwd_out, phase, ws_pairs, tag="farneback"):
+        if phase == 2:
+            state["phase2_calls"] += 1
+            if state["phase2_calls"] == 2:                            # the SECOND part of the first (only) batch of ten pairs
+                state["refused"] += 1
+                raise torch.OutOfMemoryError("simulated: scratch of the second part does not fit")
+        return real(self, prev, nxt, fwd_out, bwd_out, phase, ws_pairs, tag)
+    monkeypatch.setattr(FarnebackFlow, "calc_phase_dev", picky)
+    seen, first_part = [], {}
+
+    def ready(flow, n):
+        seen.append(n)
+        if n == 6 and not first_part:
+            with flow.window_view(0, 6) as w:
+                first_part["f"], first_part["b"] = w.forward_flow.clone(), w.backward_flow.clone()
+    got = tf.create_flow(bt, on_frames_ready=ready, **kw)
+    assert state["refused"] == 1
+    assert seen == sorted(seen) and seen[0] == 6 and seen[-1] == 11 and seen.count(6) == 1, seen
+    for g, w in ((got.forward_flow, want.forward_flow), (got.backward_flow, want.backward_flow)):
+        assert torch.equal(torch.nan_to_num(g, nan=-7.0), torch.nan_to_num(w, nan=-7.0))
+    w6 = tf.create_flow(bt[:6], **kw)
+    assert torch.equal(first_part["f"], w6.forward_flow) and torch.equal(first_part["b"], w6.backward_flow)
+
+
+def test_create_flow_from_host_input_keeps_the_vectors_in_hbm_until_somebody_reads_them():
+    """Round 5: the drop-in scripts hand create_flow a host array and only pass the Flow object on (scripts/dcc_detect_goes.py:
+    164-303).  The vectors therefore stay on the device, where every Flow method works, and the numpy arrays
+    `forward_flow` / `backward_flow` of the reference's object are downloaded when first read -- same values as
+    calculate_flow's numpy result, and the object behaves like the eager one (slicing, assignment, window)."""
+    import tobac_flow_amd.flow as tf
+    from tools.synth import blob_stack
+    bt = blob_stack(5, 96, 128, seed=6).cpu().numpy()
+    kw = dict(vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    flow = tf.create_flow(bt, **kw)
+    assert flow._fw is None and flow.shape == (5, 96, 128)
+    edges = flow.sobel(bt, direction="uphill", method="cubic")
+    lab = flow.label(bt < 270)
+    assert isinstance(edges, np.ndarray) and isinstance(lab, np.ndarray) and flow._fw is None      # nothing was downloaded
+    fw, bw = tf.calculate_flow(bt, **kw)
+    fw, bw = np.clip(fw, -20, 20), np.clip(bw, -20, 20)
+    assert isinstance(flow.forward_flow, np.ndarray) and flow._fw is not None
+    assert np.array_equal(flow.forward_flow, fw, equal_nan=True) and np.array_equal(flow.backward_flow, bw, equal_nan=True)
+    eager = tf.Flow(fw, bw)
+    assert np.array_equal(eager.sobel(bt, direction="uphill", method="cubic"), edges, equal_nan=True)
+    part = flow[1:4]
+    assert part.shape == (3, 96, 128) and np.array_equal(part.forward_flow, fw[1:4], equal_nan=True)
+    w = flow.window(1, 4)
+    assert np.array_equal(w.forward_flow[-1], -bw[3], equal_nan=True)
+    flow.forward_flow = bw                                            # assignment drops the device copy
+    assert flow._dev is None and np.array_equal(flow.forward_flow, bw, equal_nan=True)

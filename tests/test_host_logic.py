@@ -26,6 +26,31 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().tf_version() >= 100
 
 
+def test_a_starved_chain_report_becomes_an_exception(monkeypatch):
+    """Host side of TF_ESTARVED (no device needed): with no status word allocated tf_farneback_check reports nothing; a
+    non-zero report (-6) from the library makes FarnebackFlow.check_launches -- what create_flow / calculate_flow /
+    calculate_flow_frame / FarnebackFlow.calc call after their launches -- raise TobacFlowHipError (a RuntimeError)."""
+    import pytest
+    import torch
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.utils.flow_utils import FarnebackFlow
+    L = _lib.lib()
+    assert L.tf_farneback_check() == 0
+    model = FarnebackFlow()
+    assert model.params.chain_form == _lib.FB_CHAIN_DEFAULT
+
+    class _Stream:
+        def synchronize(self):
+            pass
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
+    model.check_launches()                                                  # nothing reported: no exception
+    monkeypatch.setattr(L, "tf_farneback_check", lambda: _lib.TF_ESTARVED, raising=False)
+    with pytest.raises(_lib.TobacFlowHipError, match="code -6"):
+        model.check_launches("create_flow")
+    with pytest.raises(RuntimeError):
+        model.check_launches()
+
+
 def test_farneback_launch_arithmetic_of_the_host_side():
     """Host-only arithmetic of the C ABI (no device work): workspace sizes grow with the batch, hold the strips' hand-over
     words of the iteration kernel at every size (1 x 1 included), and the workgroup count the batching decisions rest on

@@ -24,7 +24,12 @@ class VarRefParams(ctypes.Structure):
 
 class FarnebackParams(ctypes.Structure):
     _fields_ = [("num_levels", ctypes.c_int), ("pyr_scale", ctypes.c_double), ("win_size", ctypes.c_int),
-                ("num_iters", ctypes.c_int), ("poly_n", ctypes.c_int), ("poly_sigma", ctypes.c_double)]
+                ("num_iters", ctypes.c_int), ("poly_n", ctypes.c_int), ("poly_sigma", ctypes.c_double),
+                ("chain_form", ctypes.c_int)]
+
+
+FB_CHAIN_DEFAULT, FB_CHAIN_ONE_LANE, FB_CHAIN_TWO_PART = 0, 1, 2
+TF_ESTARVED = -6
 
 
 _lib = None
@@ -51,7 +56,8 @@ _PROTOS = {
     "tf_farneback_batch_phase": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                             _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _c.c_int]),
     "tf_farneback_batch_hint": (_c.c_int64, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int64, _c.c_size_t]),
-    "tf_farneback_prefer_two_part_chain": (None, [_c.c_int]),
+    "tf_farneback_check": (_c.c_int, []),
+    "tf_farneback_debug_set_starved": (_c.c_int, []),
     "tf_farneback_iteration_workgroups": (_c.c_int64, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int64, _P]),
     "tf_farneback_batch": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                       _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),
@@ -106,6 +112,7 @@ _PROTOS = {
     "tf_slice_labels": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_size_t, _P]),
     "tf_pair_counts": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _P, _P, _P, _c.c_int64, _P, _P, _c.c_size_t, _P]),
     "tf_label_sizes": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P]),
+    "tf_pair_rank": (_c.c_int, [_P, _P, _c.c_int64, _P, _P, _c.c_int64, _P, _P]),
     "tf_flow_link_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64]),
     "tf_flow_link_overlap": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_double, _c.c_int64, _P, _P,
                                         _P, _c.c_size_t, _P]),

@@ -707,10 +707,12 @@ struct FbIterArgs {
     const float *R[2]; const float *fin[2]; float *fout[2]; int dir[2]; int nd, nx; int64_t bs_R, bs_fin[2], bs_fout[2];
     // sequential row sums (k_fb_iter): hand-over words of batch item 0 (item b adds b * bs_hand words), this launch's tag, its ticket counter
     unsigned long long *hand; int64_t bs_hand; unsigned epoch; int *ticket;
-    int abl;                        // timing aid (TF_FBI_SEQ_ABLATE): 1 no wait for the left neighbour, 2 no chain, 4 no solve, 16 hand-over without the chain (all wrong flows); 8 count waiting chains, 128 no priority for the chain wave, 256 priority 1 instead of 3 (right flows)
+    int abl;                        // timing aid (TF_FBI_SEQ_ABLATE): 1 no wait for the left neighbour, 2 no chain, 4 no solve, 16 hand-over without the chain (all wrong flows); 64 no hand-over stores (the chains right of strip 0 starve: tests of TF_ESTARVED); 8 count waiting chains, 128 no priority for the chain wave, 256 priority 1 instead of 3 (right flows)
     int xcd_lists;                  // 1: one ticket list per XCD (pairs dealt round robin), 0: one list
     int nq;                         // 1: a workgroup holds all directions of its strip; 2: one direction per workgroup, directions take tickets
     int nb, nxg, slack_rows;        // pairs in the launch; strips per column group (ticket order); rows a strip lets its left neighbour get ahead before it starts
+    int *starved;                   // host-visible word (fb_starved_word): set by a chain whose left neighbour's words never arrived -- its row is NaN, the call is an error
+    int poll_limit;                 // polls before such a chain gives up (1 << 22: several seconds; TF_FBI_POLL_LIMIT: tests)
 };
 #define FBI_G 5                     // rows per group (13 = 4 + 4 + 5)
 #ifndef FBI_NB
@@ -731,7 +733,7 @@ struct FbIterCtx {
     int H, W; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale; bool xborder;
     // sequential row sums: strip index / count, the (row of the group, channel) this lane scans, hand-over slots of the left
     // neighbour (read) and of this strip (written), the launch's tag
-    int sx, nx, sr, sch; const unsigned long long *hin; unsigned long long *hout; unsigned epoch; int abl; int *spins;
+    int sx, nx, sr, sch; const unsigned long long *hin; unsigned long long *hout; unsigned epoch; int abl; int *spins; int *starved; int poll_limit;
     int rsr, rsch; bool full;       // (row, channel) of a right-half chain lane (j - 32); a full strip of FBI_OW output columns
 };
 
@@ -1079,9 +1081,11 @@ __device__ __forceinline__ void fb_chain_enter(const FbIterCtx &c, int yo, int c
     } else {
         bool ok = fb_hand_valid(c, h);
         // (the left neighbour holds a lower ticket: it is running or done.  The poll count is bounded all the same -- several
-        // seconds -- so that the grid drains whatever happens; a chain that gives up continues with NaN, which no test misses)
+        // seconds -- so that the grid drains whatever happens.  A chain that gives up continues with NaN AND says so: it sets
+        // the launch's host-visible `starved` word, which turns the call that owns the launch into TF_ESTARVED -- a device
+        // slowed down enough for this, by a profiler's serialisation or a preempted queue, must not hand out NaN rows with rc 0)
         if (!ok && c.spins) atomicAdd(c.spins, 1);                     // (development aid: chains that found their words missing at scan time)
-        for (int spin = 0; !ok && spin < (1 << 22); spin++) {
+        for (int spin = 0; !ok && spin < c.poll_limit; spin++) {
             if (c.spins) atomicAdd(c.spins + 1, 1);
             __builtin_amdgcn_s_sleep(1);
             fb_hand_load(c, yo, ch, h);
@@ -1089,13 +1093,16 @@ __device__ __forceinline__ void fb_chain_enter(const FbIterCtx &c, int yo, int c
         }
         g = __longlong_as_double((long long)((h.w1 << 32) | (h.w0 & 0xffffffffull)));
         sub = __longlong_as_double((long long)((h.w3 << 32) | (h.w2 & 0xffffffffull)));
-        if (!ok) g = __longlong_as_double(0x7ff8000000000000ll);
+        if (!ok) {
+            g = __longlong_as_double(0x7ff8000000000000ll);
+            if (c.starved) __hip_atomic_store(c.starved, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 // (g, V[next strip's x - 7]) for the strip to the right
 __device__ __forceinline__ void fb_hand_store(const FbIterCtx &c, int yo, int ch, double g, double sub)
 {
-    if (c.sx >= c.nx - 1) return;
+    if (c.sx >= c.nx - 1 || (c.abl & 64)) return;                    // (64: test aid -- the words never leave: every chain to the right starves)
     unsigned long long *pg = c.hout + (int64_t)yo * 5 + ch;
     const int64_t pl = (int64_t)c.H * 5;
     const unsigned long long tag = (unsigned long long)c.epoch << 32;
@@ -1288,8 +1295,18 @@ __device__ __forceinline__ void fb_chain_run_lr(double *base, double &g, double 
 }
 
 // the right part of row group (s0p, PG rows) by lanes 32 .. 56, the left part of (s0, G rows) by lanes 0 .. 24; G = 0: flush
+// (gR, subR: what the previous group's left part left for the right lanes -- fb_right_entry, read BEFORE the barrier in front of
+// this phase: the left lanes overwrite both entries at the end of the phase, and the order of the two roles inside one wave
+// is not something to leave to the code layout)
+__device__ __forceinline__ void fb_right_entry(const FbIterCtx &c, const double *lds, double &gR, double &subR)
+{
+    const double *Rb = lds + FBI_G * 5 * FBI_HS, *gmid = Rb + FBI_G * 5 * FBI_HR;
+    const int jr = c.j - 32;
+    gR = 0.; subR = 0.;
+    if (jr >= 0 && jr < FBI_G * 5) { gR = gmid[jr]; subR = Rb[jr * FBI_HR]; }
+}
 template <int G, int PG>
-__device__ __forceinline__ void fb_iter_chain_parts(const FbIterCtx &c, int s0, int s0p, bool has_prev, FbHand hand, double *lds)
+__device__ __forceinline__ void fb_iter_chain_parts(const FbIterCtx &c, int s0, int s0p, bool has_prev, FbHand hand, double *lds, double gR, double subR)
 {
     double *M = lds, *Rb = lds + FBI_G * 5 * FBI_HS, *gmid = Rb + FBI_G * 5 * FBI_HR;
     const int jr = c.j - 32;
@@ -1298,11 +1315,11 @@ __device__ __forceinline__ void fb_iter_chain_parts(const FbIterCtx &c, int s0, 
     if ((chainL || chainR) && !(c.abl & 2)) {
         if (!(c.abl & 128)) __builtin_amdgcn_s_setprio(3);             // (the serial stretch of the workgroup: see fb_iter_group_seq)
         double g, sub, *base;
-        if (chainR) { base = Rb + jr * FBI_HR + 1; g = gmid[jr]; sub = base[-1]; }
+        if (chainR) { base = Rb + jr * FBI_HR + 1; g = gR; sub = subR; }
         else { base = M + c.j * FBI_HS; fb_chain_enter(c, s0 + c.sr - FBI_M, c.sch, base, hand, g, sub); }
         fb_chain_run_lr(base, g, sub, !chainR);
         if (chainR) fb_hand_store(c, s0p + c.rsr - FBI_M, c.rsch, g, sub);
-        else { gmid[c.j] = g; Rb[c.j * FBI_HR] = sub; }                // (the right lanes have read both entries: same wave, program order)
+        else { gmid[c.j] = g; Rb[c.j * FBI_HR] = sub; }                // (the right lanes hold both entries in registers since before the barrier)
         if (!(c.abl & 128)) __builtin_amdgcn_s_setprio(0);
     }
 }
@@ -1338,8 +1355,10 @@ __device__ __forceinline__ void fb_iter_group_half(const FbIterCtx &c, int s0, f
 #pragma unroll
         for (int g = 0; g < GN; g++) fl[g] = fb_iter_flow_at(c, s0 + G + g);
     }
+    double gR, subR;
+    fb_right_entry(c, lds, gR, subR);
     __syncthreads();
-    fb_iter_chain_parts<G, PG>(c, s0, s0 - PG, has_prev, hand, lds);
+    fb_iter_chain_parts<G, PG>(c, s0, s0 - PG, has_prev, hand, lds, gR, subR);
     __syncthreads();
     const bool in_x = c.x_strip + c.j < c.W;
     if (c.j < FBI_HL) {                                                // first wave: the left-part pixels of this group
@@ -1439,6 +1458,7 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
     c.rsr = c.j >= 32 ? (c.j - 32) / 5 : 0; c.rsch = c.j >= 32 ? (c.j - 32) - c.rsr * 5 : 0;
     c.full = W - sx * FBI_OW >= FBI_OW;
     c.sx = sx; c.nx = a.nx; c.epoch = a.epoch; c.abl = a.abl; c.spins = (a.abl & 8) ? a.ticket - 16 * (a.epoch - 1) + FBI_HDR / 4 - 4 : nullptr;
+    c.starved = a.starved; c.poll_limit = a.poll_limit;
     {
         // hand-over slots of (pair b, direction q, strip): [q][strip 0 .. nx - 2][row][FBI_HW words]
         unsigned long long *hb = a.hand + b * a.bs_hand + (int64_t)q * (a.nx - 1) * H * FBI_HW;
@@ -1501,7 +1521,9 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
         // words are then there when the row group asks for them, and a neighbour's hiccup is absorbed by the lead.
         if (threadIdx.x == 0) {
             const unsigned long long *p = c.hin + (int64_t)min(a.slack_rows, H - 1) * 5;
-            for (int spin = 0; spin < (1 << 22) && (unsigned)(fb_hand_ld(p) >> 32) != a.epoch; spin++) __builtin_amdgcn_s_sleep(8);
+            // (a wait that gives up here is not an error: the slack is a scheduling hint, every chain below still enters through
+            // fb_chain_enter, which is where a missing word is polled for and -- if it never comes -- reported)
+            for (int spin = 0; spin < a.poll_limit && (unsigned)(fb_hand_ld(p) >> 32) != a.epoch; spin++) __builtin_amdgcn_s_sleep(8);
         }
         __syncthreads();
     }
@@ -1514,7 +1536,9 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
         // flush: the right part of the last group (its rows past H - 1 produce nothing)
         const int s0p = FBI_M + ((s_last - FBI_M) / FBI_WIN) * FBI_WIN + 8;
         const FbHand none = {0ull, 0ull, 0ull, 0ull};
-        fb_iter_chain_parts<0, 5>(c, s0p + 5, s0p, true, none, vrow);
+        double gR, subR;
+        fb_right_entry(c, vrow, gR, subR);                              // (no left part in the flush: nobody writes these entries)
+        fb_iter_chain_parts<0, 5>(c, s0p + 5, s0p, true, none, vrow, gR, subR);
         __syncthreads();
         if (c.j >= FBI_HL && c.j < FBI_OW && c.x_strip + c.j < c.W && !(c.abl & 4)) {
 #pragma unroll
@@ -1597,6 +1621,7 @@ __global__ void __launch_bounds__(256) k_fb_zero(float *__restrict__ p, int64_t 
 // ---- host side -----------------------------------------------------------------------------------
 extern "C" void tf_farneback_default_params(tf_farneback_params *p) {
     p->num_levels = 5; p->pyr_scale = 0.5; p->win_size = 13; p->num_iters = 10; p->poly_n = 5; p->poly_sigma = 1.1;
+    p->chain_form = TF_FB_CHAIN_DEFAULT;
 }
 
 static void fb_gaussian_kernel(int n, double sigma, FbKernel *out) {
@@ -1719,21 +1744,69 @@ extern "C" int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneb
     return pick;
 }
 
-// Which form of the row-sum chain the iteration kernel uses from now on (process-wide; both give the same bits): 1 = two parts
-// one row group apart (faster when the flow has the GPU to itself), 0 = one lane per chain (default; leaves LDS for kernels
-// of other streams).  TF_FBI_TWO_PART_CHAIN=0 / 1 in the environment overrides it.
-static std::atomic<int> fb_two_part_chain{0};
-extern "C" void tf_farneback_prefer_two_part_chain(int on) { fb_two_part_chain.store(on ? 1 : 0, std::memory_order_relaxed); }
+// ---- starved chains -> TF_ESTARVED ---------------------------------------------------------------------------------------
+// One pinned, device-visible word per device.  A chain of k_fb_iter that gives up on its left neighbour's hand-over words
+// (fb_chain_enter) stores 1 into it; the host reads it once the launches are known to have finished -- tf_farneback_check()
+// after the caller's own synchronisation, and every tf_farneback_batch* call on entry (which catches an earlier call's
+// launches for a caller that never checks) -- and turns it into an error: rows of NaN never leave with TF_OK.
+static std::mutex fb_starved_mu;
+static int *fb_starved_words[TF_MAX_DEVICES] = {};
+static int *fb_starved_word(bool create)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TF_MAX_DEVICES) dev = 0;
+    std::lock_guard<std::mutex> lk(fb_starved_mu);
+    if (!fb_starved_words[dev] && create) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *(volatile int *)p = 0;
+        fb_starved_words[dev] = (int *)p;
+    }
+    return fb_starved_words[dev];
+}
+static int fb_report_starved(const char *who)
+{
+    int *w = fb_starved_word(false);
+    if (!w || __atomic_load_n(w, __ATOMIC_ACQUIRE) == 0) return TF_OK;
+    __atomic_store_n(w, 0, __ATOMIC_RELEASE);
+    tf_set_error("%s: a row-sum chain of the Farneback iteration kernel gave up waiting for its left neighbour's hand-over words "
+                 "(device stalled: profiler serialisation, preempted queue?) -- the flow of that launch holds NaN rows and must be recomputed", who);
+    return TF_ESTARVED;
+}
+extern "C" int tf_farneback_check(void) { return fb_report_starved("tf_farneback_check"); }
+// (test hook: what the kernel does when it gives up, done from the host -- the host-side path can be tested without a device
+// that stalls)
+extern "C" int tf_farneback_debug_set_starved(void)
+{
+    int *w = fb_starved_word(true);
+    if (!w) { tf_set_error("tf_farneback_debug_set_starved: no pinned word (no HIP device?)"); return TF_EHIP; }
+    __atomic_store_n(w, 1, __ATOMIC_RELEASE);
+    return TF_OK;
+}
 
 // Workgroups of the iteration kernel's full-resolution launch for B pairs (both directions), and how many of them the
 // device holds at once: a launch costs whole rounds of resident workgroups, so a caller that may cut a batch into parts
 // (tf_farneback_batch_phase) does so only while a part still fills a round.
+// resident two-wave workgroups of the current device (cached per device index: ADVICE r4 -- one `static int` kept the first
+// device's count for every device)
+static int fb_resident_slots()
+{
+    static std::atomic<int> cache[TF_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TF_MAX_DEVICES) dev = 0;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int n_cu = 256;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) { (void)hipGetLastError(); n_cu = 256; }
+        v = n_cu * 8 / (FBI_T / 64);
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 extern "C" int64_t tf_farneback_iteration_workgroups(int64_t H, int64_t W, const tf_farneback_params *p, int64_t B, int64_t *resident_out)
 {
     if (H <= 0 || W <= 0 || !p || B < 1) return 0;
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    if (resident_out) *resident_out = (int64_t)n_cu * 8 / (FBI_T / 64);
+    if (resident_out) *resident_out = fb_resident_slots();
     return 2 * B * ((W + FBI_OW - 1) / FBI_OW);
 }
 
@@ -1898,9 +1971,11 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             // beside the flow in what the one-lane form leaves free (4 x 27 KB), and with the two-part form they displace
             // iteration workgroups instead -- the kernel then reads 1 985 against 1 860 ms per config-F step, the step is the same
             // (4.75 s either way, back to back on one box)
-            // (tf_farneback_prefer_two_part_chain: the host layer asks for it when nothing is going to run beside the flow)
+            // (tf_farneback_params.chain_form: PER CALL -- the host layer asks for the two-part form when nothing is going to run
+            // beside this call's flow; a process-wide switch, as in round 4, let one thread's plain create_flow turn it on under
+            // another thread's pipelined one)
             static const char *chain_env = getenv("TF_FBI_TWO_PART_CHAIN");
-            const bool whole_chain = chain_env ? atoi(chain_env) == 0 : fb_two_part_chain.load(std::memory_order_relaxed) == 0;
+            const bool whole_chain = chain_env ? atoi(chain_env) == 0 : p->chain_form != TF_FB_CHAIN_TWO_PART;
             // sequential row sums: the strips' hand-over words and the launches' ticket counters live in the blur scratch,
             // idle from the polynomial expansion of this level to the blur of the next: [1 KB of counters][words] per pair
             const size_t hand_words = (size_t)nd * (size_t)(nx - 1) * (size_t)h * FBI_HW;
@@ -1908,12 +1983,7 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             ia.abl = seq_abl;
             {
                 // column groups: one per round of resident workgroups (two 4-wave workgroups per CU)
-                static int slots = 0;
-                if (slots == 0) {
-                    int dev = 0, n_cu = 256;
-                    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-                    slots = n_cu * 8 / (FBI_T / 64);                         // resident two-wave workgroups (one direction each)
-                }
+                const int slots = fb_resident_slots();                       // resident two-wave workgroups (one direction each) of THIS device
                 // one direction per workgroup (four two-wave workgroups per CU) unless TF_FBI_JOIN_DIRECTIONS=1: the chains make a
                 // workgroup latency-bound for a third of its time, and four independent workgroups per CU overlap those
                 // stretches better than two (config F: 2.05 s of k_fb_iter per step against 2.25 s), at the price of reading the
@@ -1929,6 +1999,10 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                 ia.nb = B; ia.nxg = (nx + n_groups - 1) / n_groups; ia.slack_rows = slack_env >= 0 ? slack_env : 0;
             }
             ia.hand = (unsigned long long *)((char *)tmp + FBI_HDR); ia.bs_hand = bs_tmp / 2; ia.ticket = (int *)tmp; ia.epoch = 0;
+            static const int poll_env = getenv("TF_FBI_POLL_LIMIT") ? atoi(getenv("TF_FBI_POLL_LIMIT")) : -1;
+            ia.poll_limit = poll_env >= 0 ? poll_env : (1 << 22);
+            ia.starved = tree ? nullptr : fb_starved_word(true);
+            if (!tree && !ia.starved) { tf_set_error("tf_farneback: no pinned status word for the iteration kernel (hipHostMalloc failed)"); return TF_EHIP; }
             if (!tree) {
                 TF_REQUIRE(FBI_HDR + hand_words * 8 <= (size_t)bs_tmp * sizeof(float), "tf_farneback: blur scratch too small for the strips' hand-over words");
                 TF_REQUIRE(p->num_iters <= 250, "tf_farneback: more than 250 iterations per level");
@@ -2033,6 +2107,7 @@ extern "C" int tf_farneback_batch_split(const uint8_t *prev, const uint8_t *next
     TF_REQUIRE(p->win_size >= 1 && p->win_size / 2 <= FB_MAX_M, "tf_farneback: win_size out of range");
     TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback: bad params");
     if (ws_bytes < tf_farneback_workspace_bytes_split(B64, parts64, H64, W64, p)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+    if (const int rc0 = fb_report_starved("tf_farneback (an earlier call's launches)")) return rc0;
     const int H = (int)H64, W = (int)W64, B = (int)B64;
     hipStream_t s = (hipStream_t)stream;
     const bool fused = p->win_size == FBI_WIN;
@@ -2125,6 +2200,7 @@ extern "C" int tf_farneback_batch_phase(const uint8_t *prev, const uint8_t *next
     TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback: bad params");
     TF_REQUIRE(tf_farneback_can_split(H64, W64, p), "tf_farneback_batch_phase: this geometry does not split (tf_farneback_can_split)");
     if (ws_bytes < tf_farneback_workspace_bytes_phase(B64, H64, W64, p, phase)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
+    if (const int rc0 = fb_report_starved("tf_farneback (an earlier call's launches)")) return rc0;
     const int H = (int)H64, W = (int)W64, B = (int)B64;
     hipStream_t s = (hipStream_t)stream;
     const bool fused = p->win_size == FBI_WIN;

@@ -199,6 +199,64 @@ extern "C" int tf_pair_counts(const int32_t *a, const int32_t *b, int64_t n, int
     return TF_OK;
 }
 
+// ---- rank of (a[i], b[i]) among the sorted distinct pairs ----------------------------------------------------------
+// tobac_flow/utils/label_utils.py:183-200 make_step_labels: the non-zero mask of a label volume is split into the pieces
+// connected within a time step (flat_label = tf_label with the structure's t planes zeroed), every piece into the
+// original labels it contains, ids contiguous from 1 in the order (piece, label) -- i.e. the RANK of the voxel's
+// (piece, label) pair among the distinct pairs, which tf_pair_counts returns sorted.  A voxel's rank is a binary search
+// in that list (a few thousand entries: L2-resident); consecutive voxels mostly repeat the pair, so a thread keeps the
+// last answer.  4 + 4 B read, 4 B written per voxel.
+__global__ void __launch_bounds__(256)
+k_pair_rank(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int64_t n, const int32_t *__restrict__ pa,
+            const int32_t *__restrict__ pb, int n_pairs, int32_t *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += stride) {
+        int32_t va[4], vb[4], r[4];
+        if (i0 + 4 <= n) {
+            const int4 qa = *(const int4 *)(a + i0), qb = *(const int4 *)(b + i0);
+            va[0] = qa.x; va[1] = qa.y; va[2] = qa.z; va[3] = qa.w; vb[0] = qb.x; vb[1] = qb.y; vb[2] = qb.z; vb[3] = qb.w;
+        } else {
+            for (int j = 0; j < 4; j++) { va[j] = i0 + j < n ? a[i0 + j] : 0; vb[j] = i0 + j < n ? b[i0 + j] : 0; }
+        }
+        u64 last_key = PC_INVALID; int32_t last_rank = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int32_t rank = 0;
+            if (va[j] > 0 && vb[j] > 0) {
+                const u64 key = ((u64)(uint32_t)va[j] << 32) | (uint32_t)vb[j];
+                if (key == last_key) rank = last_rank;
+                else {
+                    int lo = 0, hi = n_pairs;                         // first pair >= key
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const u64 km = ((u64)(uint32_t)pa[mid] << 32) | (uint32_t)pb[mid];
+                        if (km < key) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < n_pairs && pa[lo] == va[j] && pb[lo] == vb[j]) rank = lo + 1;
+                    last_key = key; last_rank = rank;
+                }
+            }
+            r[j] = rank;
+        }
+        if (i0 + 4 <= n) *(int4 *)(out + i0) = make_int4(r[0], r[1], r[2], r[3]);
+        else for (int j = 0; j < 4 && i0 + j < n; j++) out[i0 + j] = r[j];
+    }
+}
+
+extern "C" int tf_pair_rank(const int32_t *a, const int32_t *b, int64_t n, const int32_t *pairs_a, const int32_t *pairs_b,
+                            int64_t n_pairs, int32_t *out, void *stream)
+{
+    TF_REQUIRE(a && b && out && n > 0 && n_pairs >= 0 && n_pairs < (1ll << 31) && (n_pairs == 0 || (pairs_a && pairs_b)), "tf_pair_rank: bad arguments");
+    TF_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "tf_pair_rank: volumes must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t quads = (n + 3) / 4;
+    const unsigned grid = (unsigned)std::min<int64_t>((quads + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_pair_rank, dim3(grid), dim3(256), 0, s, a, b, n, pairs_a, pairs_b, (int)n_pairs, out);
+    TF_CHECK_LAUNCH();
+    return TF_OK;
+}
+
 // ---- np.bincount ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_label_sizes(const int32_t *__restrict__ labels, int64_t n, int64_t n_labels, unsigned long long *__restrict__ sizes)

@@ -33,9 +33,71 @@ def _nanmean0(x):
     return np.nanmean(x, 0)
 
 
+class _TimeCoord:
+    """the part of an xarray time coordinate the recipes touch: `.values` / `.data` = the datetime64 array"""
+
+    def __init__(self, values):
+        self.values = self.data = np.asarray(values)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.values if dtype is None else self.values.astype(dtype)
+
+    def __len__(self):
+        return len(self.values)
+
+
+class DeviceField:
+    """A (t, y, x) field that lives in HBM together with the time coordinate the recipes read as `field.t` -- what a
+    device-resident pipeline hands detect_cores / detect_growth_markers / get_anvil_markers / detect_anvils /
+    relabel_anvils in place of the reference's xr.DataArray (a bare torch tensor has no coordinates, and `Tensor.t` is
+    the transpose).  `data`: torch tensor on the GPU; `t`: datetime64 array of length data.shape[0].  Results of the
+    recipes are then device tensors.  `a - b` / `a + b` / `-a` of two fields give a field (the scripts pass `wvd - swd`)."""
+
+    def __init__(self, data, t):
+        if not isinstance(data, _lib.torch().Tensor):
+            raise TypeError("DeviceField wraps a torch tensor (use a numpy array / DataArray as it is)")
+        t = t.values if hasattr(t, "values") else t
+        if len(t) != data.shape[0]:
+            raise ValueError("time coordinate and leading dimension differ in length")
+        self.data, self.t = data, _TimeCoord(t)
+
+    shape = property(lambda self: tuple(self.data.shape))
+    dtype = property(lambda self: self.data.dtype)
+
+    def _other(self, o):
+        return o.data if isinstance(o, DeviceField) else o
+
+    def __sub__(self, o):
+        return DeviceField(self.data - self._other(o), self.t.values)
+
+    def __add__(self, o):
+        return DeviceField(self.data + self._other(o), self.t.values)
+
+    def __neg__(self):
+        return DeviceField(-self.data, self.t.values)
+
+
 def _values(a):
     """ndarray view of an ndarray / xr.DataArray"""
     return a.to_numpy() if hasattr(a, "to_numpy") and not isinstance(a, np.ndarray) else np.asarray(a)
+
+
+def _is_device(a):
+    return isinstance(a, (DeviceField, _lib.torch().Tensor))
+
+
+def _to_device(a):
+    """the field as a contiguous device tensor: a DeviceField's / tensor's own memory, a host array uploaded once"""
+    if isinstance(a, DeviceField):
+        return a.data.contiguous()
+    if isinstance(a, _lib.torch().Tensor):
+        return _lib.to_dev(a)
+    return _lib.to_dev(np.ascontiguousarray(_values(a)))
+
+
+def _deliver(result_dev, like):
+    """device result in the container kind of the input `like`: tensor for device input, numpy for host input"""
+    return result_dev if _is_device(like) else result_dev.cpu().numpy()
 
 
 def _is_dataarray(a):
@@ -117,8 +179,7 @@ def detect_growth_markers(flow, wvd):
     _detect_growth_markers_host gives identical results (tests/test_gpu_detection.py)."""
     from tobac_flow_amd import ndimage_dev as nd
     t = _lib.torch()
-    vals = np.ascontiguousarray(_values(wvd))
-    wvd_d = _lib.to_dev(vals)
+    wvd_d = _to_device(wvd)
     dt = t.from_numpy(np.asarray(get_time_diff_from_coord(wvd.t))).to(wvd_d.device)[:, None, None]
     wvd_diff_raw = flow.diff(wvd_d, method="linear") / dt              # float32 / float64 -> float64, as in numpy
     wvd_diff_smoothed = filtered_tdiff(flow, wvd_diff_raw)
@@ -136,6 +197,8 @@ def detect_growth_markers(flow, wvd):
             continue
         _, hit = nd.label_extent(marker_labels, mask)
         marker_labels = nd.remap_labels(marker_labels, hit)
+    if _is_device(wvd):                                                # device-resident pipeline: nothing visits the host
+        return wvd_diff_smoothed, marker_labels
     wvd_diff_smoothed, marker_labels = wvd_diff_smoothed.cpu().numpy(), marker_labels.cpu().numpy()
     if _is_dataarray(wvd):
         import xarray as xr
@@ -287,7 +350,7 @@ def detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overl
     exactly as in the reference (their float32 means feed a threshold).  Same result as _detect_cores_host."""
     from tobac_flow_amd import ndimage_dev as nd
     t = _lib.torch()
-    bt_d, wvd_d, swd_d = (_lib.to_dev(np.ascontiguousarray(_values(x))) for x in (bt, wvd, swd))
+    bt_d, wvd_d, swd_d = (_to_device(x) for x in (bt, wvd, swd))
     combined_filter = get_combined_filters(flow, bt_d, wvd_d, swd_d, use_wvd=use_wvd)
     s = ndi.generate_binary_structure(3, 1)
     s *= np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
@@ -312,8 +375,63 @@ def detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overl
     lengths, wvd_ok = nd.label_extent(core_labels, wvd_d > -5)
     print("Core labels meeting length threshold:", np.sum(lengths > min_length))
     print("Core labels meeting WVD threshold:", np.sum(wvd_ok))
-    core_labels = nd.remap_labels(core_labels, np.logical_and(lengths > min_length, wvd_ok)).cpu().numpy()
-    return _core_cooling_filter(core_labels, bt, min_length)
+    core_labels = nd.remap_labels(core_labels, np.logical_and(lengths > min_length, wvd_ok))
+    return _deliver(_core_cooling_filter_dev(core_labels, bt_d, np.asarray(bt.t.data), min_length), bt)
+
+
+def _core_cooling_filter_dev(core_d, bt_d, times, min_length):
+    """_core_cooling_filter with the volume passes on the device (round 5; VERDICT r4 item 1: at 16 x 5424^2 the host form
+    -- slice_labels, three labeled_comprehension passes with an argsort each -- cost more than the flow).  Per (core, step)
+    label: the core it belongs to (the reference takes the mode of a constant: one tf_pair_counts pass), its mean BT
+    (tf_label_stats) and its time (ids ascend with the step: from the per-step maxima).  The reduction over a core's steps
+    -- max_cooling, a few values per core -- stays the reference's host code, fed with these per-step aggregates.
+
+    The one number that is not the host form's bit for bit is the per-step mean: numpy adds the float32 values of a step
+    pairwise, in the order an UNSTABLE argsort leaves them (scipy.ndimage.labeled_comprehension: `labels.argsort()`), so
+    the reference's own value depends on the numpy build; here the sum is accumulated in double and rounded to float32
+    once -- the correctly rounded mean, within the spread of the reference's possible orders (a few float32 ulps).  It
+    feeds `cooling >= 0.5`: cores whose cooling rate lies within 1e-4 K / min of the threshold are reported by a
+    RuntimeWarning (none in any test scene)."""
+    from tobac_flow_amd import label as _label, ndimage_dev as nd
+    from tobac_flow_amd.analysis import _label_stats
+    t = _lib.torch()
+    T = core_d.shape[0]
+    step_d, n_steps = _label.slice_labels_dev(core_d)
+    if n_steps <= 0:
+        # nothing to filter: the reference hands scipy an empty label range here; run that very call on a one-pixel-per-step
+        # stand-in so that the behaviour (an exception, with this SciPy) is the reference's, whatever it is
+        class _Stub(np.ndarray):
+            pass
+        stub = np.zeros((T, 1, 1), np.float32).view(_Stub)
+        stub.t = _TimeCoord(times)
+        return _lib.to_dev(_core_cooling_filter(np.zeros((T, 1, 1), np.int32), stub, min_length))
+    ia, ib, _ = _label.pair_counts(step_d, core_d)
+    step_core = np.zeros(n_steps, np.int32)                           # (stats.mode of a constant = that constant)
+    ok = (ia >= 1) & (ia <= n_steps)
+    step_core[ia[ok] - 1] = ib[ok]
+    step_bt = _label_stats(step_d, bt_d, None, np.float64)[0][:n_steps].astype(np.float32)     # nanmean; NaN for an all-NaN step
+    per_step_top = step_d.reshape(T, -1).amax(dim=1).cpu().numpy().astype(np.int64)
+    frame_of = np.searchsorted(np.maximum.accumulate(per_step_top), np.arange(1, n_steps + 1), side="left")
+    step_t = np.asarray(times)[np.minimum(frame_of, T - 1)]
+
+    def max_cooling(bt_vals, pos):
+        when = step_t[pos]
+        order = np.argsort(when)
+        bt_vals, when = bt_vals[order], when[order]
+        rate = (bt_vals[:-min_length] - bt_vals[min_length:]) / (
+            (when[min_length:] - when[:-min_length]).astype("timedelta64[s]").astype("int") / 60)
+        return np.nanmax(rate) if rate.size > 0 else 0
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)               # (np.nanmax of an all-NaN slice, as on the host)
+        cooling = labeled_comprehension(step_bt, step_core, max_cooling, default=0, pass_positions=True)
+    valid = cooling >= 0.5
+    marginal = int(np.sum(np.abs(cooling - 0.5) < 1e-4))
+    if marginal:
+        warnings.warn(f"detect_cores: {marginal} core(s) cool within 1e-4 K/min of the 0.5 K/min threshold: their fate hangs on "
+                      "the summation order of a float32 mean (in the reference: on numpy's unstable argsort)", RuntimeWarning)
+    print("Core labels meeting cooling rate threshold:", np.sum(valid))
+    return nd.remap_labels(core_d, valid)
 
 
 def _core_cooling_filter(core_labels, bt, min_length):
@@ -369,14 +487,21 @@ def _detect_cores_host(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5,
                      cell_measures="area: area")
 def get_anvil_markers(flow, field, threshold=-5, overlap=0.5, absolute_overlap=5, subsegment_shrink=0, min_length=3):
     """Flow-linked labels of the regions above `threshold` (reference: detection.py:500-520)."""
+    from tobac_flow_amd import ndimage_dev as nd
     s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
-    if isinstance(field, _lib.torch().Tensor):       # device-resident recipe
-        from tobac_flow_amd import ndimage_dev as nd
-        mask = nd.binary_opening(field >= threshold, s)
-        marker_labels = flow.label(mask, overlap=overlap, absolute_overlap=absolute_overlap,
-                                   subsegment_shrink=subsegment_shrink)
-        lengths, _ = nd.label_extent(marker_labels)
-        return nd.remap_labels(marker_labels, lengths > min_length)
+    # one recipe, in HBM: host input is uploaded once and the labels come back once (every operator is SciPy's bit for bit,
+    # tests/test_gpu_detection.py; _get_anvil_markers_host is the same recipe with the reference's own SciPy glue)
+    field_d = _to_device(field)
+    mask = nd.binary_opening(field_d >= threshold, s)
+    marker_labels = flow.label(mask, overlap=overlap, absolute_overlap=absolute_overlap,
+                               subsegment_shrink=subsegment_shrink)
+    lengths, _ = nd.label_extent(marker_labels)
+    return _deliver(nd.remap_labels(marker_labels, lengths > min_length), field)
+
+
+def _get_anvil_markers_host(flow, field, threshold=-5, overlap=0.5, absolute_overlap=5, subsegment_shrink=0, min_length=3):
+    """get_anvil_markers with the reference's own SciPy / numpy glue between the device operators."""
+    s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
     mask = ndi.binary_opening(_values(field) >= threshold, structure=s)
     marker_labels = flow.label(mask, overlap=overlap, absolute_overlap=absolute_overlap,
                                subsegment_shrink=subsegment_shrink)
@@ -389,8 +514,18 @@ def detect_anvils(flow, field, markers=None, upper_threshold=-5, lower_threshold
     """Anvil extent by watershedding the combined edge field from eroded markers against an
     eroded background seed (reference: detection.py:538-587).  A torch GPU tensor as `field` keeps the
     whole recipe on the device (tobac_flow_amd/ndimage_dev.py) and returns a tensor."""
-    if isinstance(field, _lib.torch().Tensor):
-        return _detect_anvils_dev(flow, field, markers, upper_threshold, lower_threshold, erode_distance, min_length)
+    # one recipe, in HBM: host input is uploaded once, the labels come back once (_detect_anvils_host below is the same
+    # recipe with the reference's own SciPy glue; the two agree bit for bit, tests/test_gpu_detection.py)
+    if markers is not None and hasattr(markers, "values") and not _is_device(markers):
+        markers = markers.values
+    labels = _detect_anvils_dev(flow, _to_device(field), None if markers is None else _to_device(markers),
+                                upper_threshold, lower_threshold, erode_distance, min_length)
+    return _deliver(labels, field)
+
+
+def _detect_anvils_host(flow, field, markers=None, upper_threshold=-5, lower_threshold=-15, erode_distance=1, min_length=3):
+    """detect_anvils with the reference's own SciPy / numpy glue between the device operators (reference:
+    detection.py:538-587, statement for statement)."""
     field = linearise_field(_values(field), lower_threshold, upper_threshold)
     s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
     if markers is None:
@@ -480,7 +615,26 @@ def get_combined_edge_field(flow, field, **kwargs):
                      cell_measures="area: area")
 def relabel_anvils(flow, anvil_labels, markers=None, overlap: float = 0.5, absolute_overlap: int = 5,
                    min_length: int = 3):
-    """Split anvils per time step and re-link them by flow overlap (reference: detection.py:660-687)."""
+    """Split anvils per time step and re-link them by flow overlap (reference: detection.py:660-687).  One recipe, in
+    HBM: host input is uploaded once, the labels come back once (_relabel_anvils_host: the reference's own glue)."""
+    from tobac_flow_amd import label as _label, ndimage_dev as nd
+    like = anvil_labels
+    if hasattr(anvil_labels, "values") and not _is_device(anvil_labels):
+        anvil_labels = anvil_labels.values
+    labels_d = _to_device(anvil_labels)
+    linked = flow.link_overlap(_label.make_step_labels_dev(labels_d), overlap=overlap, absolute_overlap=absolute_overlap)
+    if markers is not None:
+        if hasattr(markers, "values") and not _is_device(markers):
+            markers = markers.values
+        lengths, touches = nd.label_extent(linked, _to_device(markers) != 0)
+        keep = np.logical_and(lengths > min_length, touches)
+    else:
+        keep = nd.label_extent(linked)[0] > min_length
+    return _deliver(nd.remap_labels(linked, keep), like)
+
+
+def _relabel_anvils_host(flow, anvil_labels, markers=None, overlap: float = 0.5, absolute_overlap: int = 5, min_length: int = 3):
+    """relabel_anvils with the reference's own numpy glue between the device operators."""
     anvil_labels = flow.link_overlap(make_step_labels(anvil_labels), overlap=overlap,
                                      absolute_overlap=absolute_overlap)
     keep = find_object_lengths(anvil_labels) > min_length

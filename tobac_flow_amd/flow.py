@@ -55,12 +55,20 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
                 holder["flow"] = Flow(forward, backward)
             on_frames_ready(holder["flow"], pairs_done + 1 if pairs_done < n_pairs else n_pairs + 1)
         extra["_on_batch"] = on_batch
+    # host (numpy / DataArray) input: the flow stays in HBM, where every Flow method works, and the object's numpy arrays
+    # `forward_flow` / `backward_flow` are downloaded when somebody reads them -- the drop-in scripts never do
+    # (scripts/dcc_detect_goes.py:164-303 only pass the object on), and 2 x 7.5 GB per 16 x 5424^2 window would cross PCIe
+    # twice otherwise (down here, up again at the first Flow method)
+    extra["_device_out"] = True
     forward_flow, backward_flow = calculate_flow(data, model=model, vr_steps=vr_steps,
                                                  smoothing_passes=smoothing_passes, interp_method=interp_method,
                                                  _max_value=float(max_value), **extra)
     if on_frames_ready is not None and "flow" in holder:
         return holder["flow"]
-    return Flow(forward_flow, backward_flow)
+    t = _lib.torch()
+    if isinstance(data, t.Tensor):
+        return Flow(forward_flow, backward_flow)
+    return Flow._lazy_host(forward_flow, backward_flow)
 
 
 @tag_func(_lib.FUNC_DIFF)
@@ -83,9 +91,41 @@ class Flow(AbstractFlow):
         if forward_flow.shape[-1] != 2:
             raise ValueError("Flow vectors must have a size of 2 in the trailing dimension")
         self.shape = tuple(forward_flow.shape[:-1])
-        self.forward_flow = forward_flow
-        self.backward_flow = backward_flow
+        self._fw = forward_flow
+        self._bw = backward_flow
         self._dev = None
+
+    @classmethod
+    def _lazy_host(cls, forward_dev, backward_dev) -> "Flow":
+        """The Flow create_flow returns for host input: the vectors live on the device (what every method works on);
+        the numpy arrays `forward_flow` / `backward_flow` of the reference's object are materialised when first read."""
+        obj = cls(forward_dev, backward_dev)
+        obj._dev = (forward_dev, backward_dev)
+        obj._fw = obj._bw = None
+        return obj
+
+    def _host_arrays(self):
+        if self._fw is None:
+            self._fw, self._bw = self._dev[0].cpu().numpy(), self._dev[1].cpu().numpy()
+        return self._fw, self._bw
+
+    @property
+    def forward_flow(self):
+        return self._host_arrays()[0]
+
+    @forward_flow.setter
+    def forward_flow(self, value):
+        self._host_arrays()
+        self._fw, self._dev = value, None
+
+    @property
+    def backward_flow(self):
+        return self._host_arrays()[1]
+
+    @backward_flow.setter
+    def backward_flow(self, value):
+        self._host_arrays()
+        self._bw, self._dev = value, None
 
     @property
     def flow(self):
@@ -97,13 +137,13 @@ class Flow(AbstractFlow):
     def _dev_flows(self):
         if self._dev is None:
             t = _lib.torch()
-            self._dev = (_lib.to_dev(self.forward_flow, t.float32), _lib.to_dev(self.backward_flow, t.float32))
+            self._dev = (_lib.to_dev(self._fw, t.float32), _lib.to_dev(self._bw, t.float32))
         return self._dev
 
     def convolve(self, data, structure=ndi.generate_binary_structure(3, 1), method: str = "linear",
                  fill_value: float = np.nan, dtype: type = np.float32, func: Callable | None = None):
         assert tuple(data.shape) == self.shape, "Data input must have the same shape as the Flow object"
-        return convolve(data, self.forward_flow, self.backward_flow, structure=structure, method=method,
+        return convolve(data, self._fw, self._bw, structure=structure, method=method,
                         dtype=dtype, fill_value=fill_value, func=func, _dev_flows=self._dev_flows())
 
     def diff(self, data, method: str = "linear", dtype: type = np.float32):
@@ -113,7 +153,7 @@ class Flow(AbstractFlow):
 
     def sobel(self, data, method: str = "linear", dtype: type = None, fill_value: float = np.nan,
               direction: str | None = None):
-        return sobel(data, self.forward_flow, self.backward_flow, method=method, dtype=dtype,
+        return sobel(data, self._fw, self._bw, method=method, dtype=dtype,
                      fill_value=fill_value, direction=direction, _dev_flows=self._dev_flows())
 
     def window(self, start: int, stop: int) -> "Flow":
@@ -183,7 +223,7 @@ class Flow(AbstractFlow):
     def watershed(self, field, markers, mask=None, connectivity=1, **kwargs):
         """reference: flow.py (Flow.watershed).  Extra keywords (`on_ambiguous`, `return_ambiguous`, `chain_depth`,
         `max_chain_depth`: the exactness contract of tobac_flow_amd.watershed.watershed) are passed through."""
-        return watershed(self.forward_flow, self.backward_flow, field, markers, mask=mask,
+        return watershed(self._fw, self._bw, field, markers, mask=mask,
                          connectivity=connectivity, _dev_flows=self._dev_flows(), **kwargs)
 
     def label(self, data, structure=ndi.generate_binary_structure(3, 1), dtype: type = np.int32,
@@ -314,9 +354,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     L = _lib.lib()
     H, W = shape
     # the iteration kernel's chains in two parts when nothing is going to run beside the flow (no windows handed out while
-    # the later frames are computed): same bits, 8 % faster alone, but it fills the CUs' LDS (csrc/farneback.hip)
-    if hasattr(L, "tf_farneback_prefer_two_part_chain"):
-        L.tf_farneback_prefer_two_part_chain(0 if on_batch is not None else 1)
+    # the later frames are computed): same bits, 8 % faster alone, but it fills the CUs' LDS (csrc/farneback.hip).  A field of
+    # THIS call's parameter block (select_of_model returns a fresh object per call), not a process-wide switch
+    if hasattr(of_model, "params") and hasattr(of_model.params, "chain_form"):
+        of_model.params.chain_form = _lib.FB_CHAIN_ONE_LANE if on_batch is not None else _lib.FB_CHAIN_TWO_PART
     forward = _lib.empty((T, H, W, 2), t.float32)
     backward = _lib.empty((T, H, W, 2), t.float32)
     # every frame is written below except the two mirrored ends, which tf_flow_finalize derives from their neighbours
@@ -422,7 +463,11 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         wgs = int(L.tf_farneback_iteration_workgroups(H, W, ctypes.byref(of_model.params), -(-B // parts), ctypes.byref(resident)))
         return parts if wgs >= 0.9 * max(1, resident.value) else 1
 
-    def run_batch(i0, B, after_part=None):
+    def run_batch(i0, B):
+        """GENERATOR over the library work of one batch: yields the number of leading frame pairs that are final after each
+        part of a split batch / after the batch.  Everything that allocates or launches for the batch happens inside
+        `next()`; what the caller does with the frames (on_frames_ready) happens between two `next()` calls, OUTSIDE the
+        out-of-memory handler of the loop below."""
         if B <= 0:
             return
         prev8, next8, f, bk = batch_buffers(B)
@@ -448,6 +493,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         else:
             of_model.calc_batch_dev(prev8, next8, f, bk, parts=parts)
         if vr_steps == 0 and smoothing_passes == 0 and not by_part:
+            yield i0 + B
             return
 
         def refine_and_smooth(i0=i0, B=B, prev8=prev8, next8=next8, f=f, bk=bk):
@@ -473,8 +519,8 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
                 of_model.calc_phase_dev(prev8[b0:b1], next8[b0:b1], f[b0:b1], bk[b0:b1], 2, (B, per))
                 if vr_steps > 0 or smoothing_passes > 0:
                     refine_and_smooth(i0 + b0, b1 - b0, prev8[b0:b1], next8[b0:b1], f[b0:b1], bk[b0:b1])
-                if after_part is not None and b1 < B:
-                    after_part(i0 + b1)
+                yield i0 + b1
+            return
         elif side is None:
             refine_and_smooth()
         else:
@@ -487,6 +533,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
             with t.cuda.stream(side):
                 side.wait_event(ready)
                 refine_and_smooth()
+        yield i0 + B
     # a batch that does not fit (the budget above is an estimate; a caching allocator's free memory can be fragmented) is
     # halved and tried again, and so are the batches after it
     def finalize_ends():
@@ -504,33 +551,44 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     pending = [(a_, b_ - a_) for a_, b_ in zip(starts[:-1], starts[1:])]
     while pending:
         i0, B = pending.pop(0)
-        def part_done(pairs_done):                            # (a part of a split batch: same hand-over as after a batch)
-            if on_batch is not None and pairs_done < n_pairs:
-                finalize_ends()
-                on_batch(forward, backward, pairs_done, n_pairs)
-        try:
-            run_batch(i0, B, part_done)
-            if on_batch is not None and i0 + B < n_pairs:
-                # the first i0 + B + 1 frames are final but for the stack's own first frame, whose backward vectors are the
+        work = run_batch(i0, B)
+        done = i0                                             # leading pairs that are final (and, with on_batch, handed out)
+        while True:
+            # ONLY the batch's own allocations and launches sit inside the handler: an out-of-memory error raised by the
+            # caller's callback (bench.py's allocates edge fields and flood scratch on a nearly full device) is the caller's,
+            # it must not be taken for "this batch's scratch did not fit" -- which used to release the workspace, recompute
+            # the batch at half size over frames already handed out and re-enter the callback with a smaller n
+            try:
+                done_now = next(work, None)
+            except t.OutOfMemoryError:
+                if os.environ.get("TF_FLOW_DEBUG"):
+                    print("flow: batch of %d pairs does not fit (free %.1f GB, cached %.1f GB): halving" % (
+                        B, t.cuda.mem_get_info()[0] / 1e9, (t.cuda.memory_reserved() - t.cuda.memory_allocated()) / 1e9), flush=True)
+                if B <= 1:
+                    raise
+                work.close()
+                _lib.release_workspaces("farneback")
+                t.cuda.empty_cache()
+                half = B // 2
+                pool["B_max"] = half
+                # never re-run pairs whose frames have been handed out: the parts of this batch that are done stay done, the
+                # rest of it (from `done` on) and the batches after it are cut to the new size
+                todo, pending = [(done, i0 + B - done)] + pending, []
+                for j0, Bj in todo:
+                    while Bj > half:
+                        pending.append((j0, half))
+                        j0, Bj = j0 + half, Bj - half
+                    if Bj > 0:
+                        pending.append((j0, Bj))
+                break
+            if done_now is None:
+                break
+            done = done_now
+            if on_batch is not None and done < n_pairs:
+                # the first done + 1 frames are final but for the stack's own first frame, whose backward vectors are the
                 # mirror of its forward ones: written now (and, with the still unknown other end, once more at the end)
                 finalize_ends()
-                on_batch(forward, backward, i0 + B, n_pairs)
-        except t.OutOfMemoryError:
-            if os.environ.get("TF_FLOW_DEBUG"):
-                print("flow: batch of %d pairs does not fit (free %.1f GB, cached %.1f GB): halving" % (
-                    B, t.cuda.mem_get_info()[0] / 1e9, (t.cuda.memory_reserved() - t.cuda.memory_allocated()) / 1e9), flush=True)
-            if B <= 1:
-                raise
-            _lib.release_workspaces("farneback")
-            t.cuda.empty_cache()
-            half = B // 2
-            pool["B_max"] = half
-            todo, pending = [(i0, B)] + pending, []
-            for j0, Bj in todo:
-                while Bj > half:
-                    pending.append((j0, half))
-                    j0, Bj = j0 + half, Bj - half
-                pending.append((j0, Bj))
+                on_batch(forward, backward, done, n_pairs)
     if side is not None:
         main.wait_stream(side)
     if n_batches > 0 and sizes and max(sizes) > 16:
@@ -542,6 +600,10 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         if free_now + (t.cuda.memory_reserved() - t.cuda.memory_allocated()) < 0.2 * total:
             _lib.release_workspaces("farneback")
     finalize_ends()
+    if hasattr(of_model, "check_launches"):
+        # before the last hand-over: a stack whose flow holds NaN rows (a starved chain of the iteration kernel) raises here
+        # instead of being returned -- one stream synchronisation per stack
+        of_model.check_launches("create_flow / calculate_flow")
     if on_batch is not None:
         on_batch(forward, backward, n_pairs, n_pairs)
     if on_device:
@@ -555,12 +617,13 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     forward[i] = flow i -> i+1, backward[i+1] = flow i+1 -> i; the end frames are mirrored."""
     max_value = normalisation_kwargs.pop("_max_value", float("inf"))
     on_batch = normalisation_kwargs.pop("_on_batch", None)
+    device_out = normalisation_kwargs.pop("_device_out", False)
     of_model = select_of_model(model)
     norm_method = select_normalisation_method(normalisation_method)
     t = _lib.torch()
     if _is_dataarray(data):
         data = data.compute().data if hasattr(data, "compute") else data.to_numpy()
-    on_device = isinstance(data, t.Tensor)
+    on_device = isinstance(data, t.Tensor) or device_out
     d = _lib.to_dev(data, t.float32)
     if d.dim() != 3:
         raise ValueError("data must have three dimensions (t, y, x)")
@@ -597,6 +660,8 @@ def calculate_flow_frame(prev_frame, next_frame, of_model, vr_steps: int = 0, sm
     if p.dtype != t.uint8 or n.dtype != t.uint8:
         raise ValueError("frames must be uint8 (see to_8bit)")
     f, b = _pair_flows_dev(p, n, of_model, vr_steps, smoothing_steps, interp_method)
+    if hasattr(of_model, "check_launches"):
+        of_model.check_launches("calculate_flow_frame")
     return (f, b) if on_device else (f.cpu().numpy(), b.cpu().numpy())
 
 

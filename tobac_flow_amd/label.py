@@ -131,7 +131,7 @@ def flow_link_overlap(flow, flat_labels, structure=ndi.generate_binary_structure
     return _finish(new_dev, flat_dev != 0, dtype, on_device)
 
 
-def pair_counts(a, b, include_b_zero=False):
+def pair_counts(a, b, include_b_zero=False, _keep_on_device=False):
     """Every distinct pair (a[i], b[i]) with a[i] > 0 and b[i] > 0 (b[i] >= 0 with include_b_zero) of two int32 label
     volumes and how often it occurs, sorted by (a, b): host int64 arrays (ids_a, ids_b, counts).  tf_pair_counts --
     the per-label np.bincount / np.unique of the reference (label_utils.py:352-376, linking.py:33-47, dataset.py:292-297)
@@ -158,7 +158,35 @@ def pair_counts(a, b, include_b_zero=False):
         break
     _lib.check(rc, "tf_pair_counts")
     k = int(n_out.value)
+    if _keep_on_device:
+        return oa[:k], ob[:k], oc[:k]
     return (oa[:k].cpu().numpy().astype(np.int64), ob[:k].cpu().numpy().astype(np.int64), oc[:k].cpu().numpy())
+
+
+def make_step_labels_dev(labels):
+    """utils.label_utils.make_step_labels (reference: label_utils.py:183-200) on a device int32 volume: the pieces of the
+    non-zero mask connected within a time step (flat_label = tf_label, t planes of the structure zeroed), every piece split
+    into the original labels it contains, ids contiguous from 1 ordered by piece, then by label = the rank of the voxel's
+    (piece, label) pair among the distinct pairs (tf_pair_counts returns them sorted; tf_pair_rank looks the rank up).
+    Labels must be >= 0 (label volumes of the detection recipes are)."""
+    from tobac_flow_amd import ndimage_dev as nd
+    t = _lib.torch()
+    lab = _lib.to_dev(labels, t.int32).contiguous()
+    out = t.zeros_like(lab)
+    if lab.numel() == 0:
+        return out
+    if int(lab.min().item()) < 0:
+        raise ValueError("make_step_labels_dev: negative labels (the device form ranks (piece, label) pairs of positive labels)")
+    plane = ndi.generate_binary_structure(3, 1)
+    plane[0] = 0
+    plane[2] = 0
+    pieces, n_pieces = nd.label(lab != 0, plane)
+    if n_pieces == 0:
+        return out
+    pa, pb, _ = pair_counts(pieces, lab, _keep_on_device=True)
+    _lib.check(_lib.lib().tf_pair_rank(_lib.ptr(pieces), _lib.ptr(lab), lab.numel(), _lib.ptr(pa), _lib.ptr(pb), pa.numel(),
+                                       _lib.ptr(out), _lib.stream_ptr()), "tf_pair_rank")
+    return out
 
 
 def label_sizes(labels, n_labels=None):
@@ -200,4 +228,4 @@ def slice_labels_dev(labels):
 
 
 __all__ = ("flow_label", "find_neighbour_labels", "flow_link_overlap", "flow_label_dev", "link_overlap_dev",
-           "pair_counts", "label_sizes", "slice_labels_dev")
+           "pair_counts", "label_sizes", "slice_labels_dev", "make_step_labels_dev")

@@ -28,7 +28,15 @@ class FarnebackFlow:
     (flow_utils.py:52-53): `.calc(prev, next, None)` -> (H, W, 2) float32 flow, OpenCV defaults."""
 
     def __init__(self, num_levels=5, pyr_scale=0.5, win_size=13, num_iters=10, poly_n=5, poly_sigma=1.1):
-        self.params = _lib.FarnebackParams(num_levels, pyr_scale, win_size, num_iters, poly_n, poly_sigma)
+        self.params = _lib.FarnebackParams(num_levels, pyr_scale, win_size, num_iters, poly_n, poly_sigma, _lib.FB_CHAIN_DEFAULT)
+
+    def check_launches(self, what="Farneback flow"):
+        """The launches are asynchronous; what a launch found out arrives later.  Waits for the current stream and raises
+        (TobacFlowHipError, a RuntimeError) if a row-sum chain of any iteration launch gave up waiting for its neighbour --
+        its rows are NaN (tf_farneback_check; csrc/farneback.hip fb_chain_enter).  cv2's calc is synchronous and has no such
+        state; this is where the asynchronous library reports like a synchronous one."""
+        _lib.torch().cuda.current_stream().synchronize()
+        _lib.check(_lib.lib().tf_farneback_check(), what)
 
     def calc_pair_dev(self, prev, nxt, want_fwd=True, want_bwd=True, tag="farneback"):
         """Both directions at once on device uint8 tensors (they share pyramid + expansion)."""
@@ -93,6 +101,7 @@ class FarnebackFlow:
         if p.shape != n.shape or p.dim() != 2:
             raise ValueError("prev and next must be 2-D arrays of the same shape")
         fwd, _ = self.calc_pair_dev(p, n, True, False)
+        self.check_launches("FarnebackFlow.calc")
         return fwd if on_device else fwd.cpu().numpy()
 
 

@@ -160,9 +160,18 @@ class WatershedJob:
             raise RuntimeError("WatershedJob: the job has already been finished or abandoned")
         t = _lib.torch()
         if stream is not None:
+            caller = t.cuda.current_stream()
             _lib.check(_lib.lib().tf_watershed_set_stream(self._h, ctypes.c_void_p(stream.cuda_stream)), "tf_watershed_set_stream")
             with t.cuda.stream(stream):
-                return self._step(_deepen)
+                res = self._step(_deepen)
+            # the outputs were allocated under `stream` (allocating them on the caller's stream and writing them from this one
+            # would race with whatever the caller's stream still has queued on a reused block), so the caching allocator ties
+            # them to it; they are handed to the caller for use on ITS stream: tell the allocator, or a later allocation on
+            # `stream` could reuse the block while the caller's kernels still read it
+            for x in res[1:]:
+                if isinstance(x, t.Tensor) and x.is_cuda:
+                    x.record_stream(caller)
+            return res
         return self._step(_deepen)
 
     def _step(self, _deepen):

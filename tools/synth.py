@@ -127,3 +127,38 @@ def anvil_seeds(bt, lower=270.0, upper=250.0, erode_distance=1):
     # get_watershed_mask (detection.py:590-617): (field <= 0 | NaN) eroded by the full cube, border_value 1, NaNs kept
     bg = nd.binary_erosion(le0, np.ones([3, 3, 3]), iterations=erode_distance, border_value=1)
     return lin, nd.merge_seeds(comp, bg, isn)
+
+
+class _TimeCoord:
+    """the part of an xarray time coordinate the detection recipes touch: `.values` / `.data` = the datetime64 array"""
+
+    def __init__(self, values):
+        self.values = self.data = values
+
+    def __array__(self, dtype=None, copy=None):
+        return self.values if dtype is None else self.values.astype(dtype)
+
+    def __len__(self):
+        return len(self.values)
+
+
+class _TimedArray(np.ndarray):
+    """ndarray with the two xarray attributes the recipes read: `.t` (time coordinate) and `.to_numpy()`"""
+
+    def __array_finalize__(self, obj):
+        self.t = getattr(obj, "t", None)
+
+    def to_numpy(self):
+        return np.asarray(self)
+
+
+def field_with_time(data, minutes=10, start="2020-06-01T00:00"):
+    """What the drop-in scripts hand the detection entry points, without xarray: a (t, y, x) numpy array with a `.t` time
+    coordinate `minutes` apart -- or, for a device tensor, the package's DeviceField (the device-resident form)."""
+    times = np.datetime64(start) + np.arange(data.shape[0]) * np.timedelta64(minutes, "m")
+    if not isinstance(data, np.ndarray):
+        from tobac_flow_amd.detection import DeviceField
+        return DeviceField(data, times)
+    out = np.asarray(data).view(_TimedArray)
+    out.t = _TimeCoord(times)
+    return out
