@@ -33,6 +33,12 @@ def _is_dataarray(x):
     return hasattr(x, "dims") and hasattr(x, "to_numpy")
 
 
+def _unwrap_device_field(x):
+    """detection.DeviceField (a device tensor + its time coordinate) -> the tensor"""
+    inner = getattr(x, "data", None)
+    return inner if isinstance(inner, _lib.torch().Tensor) and not isinstance(x, _lib.torch().Tensor) else x
+
+
 def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
                 interp_method: str = "linear", max_value=20, on_frames_ready=None) -> "Flow":
     """Forward and backward optical flow along the leading dimension of `data`, clipped to
@@ -60,6 +66,7 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
     # (scripts/dcc_detect_goes.py:164-303 only pass the object on), and 2 x 7.5 GB per 16 x 5424^2 window would cross PCIe
     # twice otherwise (down here, up again at the first Flow method)
     extra["_device_out"] = True
+    data = _unwrap_device_field(data)
     forward_flow, backward_flow = calculate_flow(data, model=model, vr_steps=vr_steps,
                                                  smoothing_passes=smoothing_passes, interp_method=interp_method,
                                                  _max_value=float(max_value), **extra)
@@ -621,6 +628,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     of_model = select_of_model(model)
     norm_method = select_normalisation_method(normalisation_method)
     t = _lib.torch()
+    data = _unwrap_device_field(data)
     if _is_dataarray(data):
         data = data.compute().data if hasattr(data, "compute") else data.to_numpy()
     on_device = isinstance(data, t.Tensor) or device_out
@@ -639,6 +647,7 @@ def calculate_flow_2(a, b, model: str = "Farneback", vr_steps: int = 0, smoothin
     of_model = select_of_model(model)
     norm_method = select_normalisation_method(normalisation_method)
     t = _lib.torch()
+    a, b = _unwrap_device_field(a), _unwrap_device_field(b)
     if _is_dataarray(a):
         a = a.compute().data if hasattr(a, "compute") else a.to_numpy()
     if _is_dataarray(b):
