@@ -293,15 +293,6 @@ def main():
                     help="diagnostic: do not record HIP events around the library's launches in the timed region "
                          "(roofline = null); the difference to a default run is what the instrumentation costs")
     a = ap.parse_args()
-    if a.stream_windows and CONFIGS[a.config][4] == 1:
-        # floods in flight beside the flow need ~12 GB each: leave room.  84 GB hold the full-size Farneback scratch of 21 pairs
-        # at 5424^2 and the 8-bit frames / raw vectors of 42.  TF_FLOW_SPLIT=2: a batch has 42 pairs at the pyramid levels >= 2
-        # (with 21 their launches are one half-empty round of workgroups: +4 % iteration time,
-        # profiles/round4_fb_levels_21_vs_42_pairs.txt) and is finished -- finest levels, refinement, smoothing, hand-over
-        # of its frames -- in two parts of 21 (tf_farneback_batch_phase): same step time as plain 21-pair batches within
-        # the run-to-run spread (4.45 - 4.50 s either way), the iteration kernel 3 % faster (frac 0.481 vs 0.467)
-        os.environ.setdefault("TF_FLOW_WORKSPACE_GB", os.environ.get("TF_BENCH_FLOW_GB", "84"))
-        os.environ.setdefault("TF_FLOW_SPLIT", "2")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
 
@@ -326,12 +317,7 @@ def main():
 
     import tobac_flow_amd.flow as tf
     from tobac_flow_amd import _lib
-    from tobac_flow_amd.detection import get_combined_edge_field
-    from tobac_flow_amd.parallel import stitch_rank_windows, window_bounds
-    from collections import deque
-    from concurrent.futures import FIRST_COMPLETED, ThreadPoolExecutor
-    from concurrent.futures import wait as futures_wait
-    from tobac_flow_amd.watershed import neighbour_offsets, watershed_begin
+    from tobac_flow_amd.parallel import detect_stack_windows, window_bounds
     from tools.synth import anvil_seeds, blob_stack
 
     cT, cH, cW, cN, C = CONFIGS[a.config]
@@ -350,199 +336,51 @@ def main():
     for f0 in range(0, T_all, 12):
         f1 = min(f0 + 12, T_all)
         bt_all[f0:f1] = blob_stack(f1 - f0, H, W, seed=20240601, t0=rank * (T - a.overlap) + f0)
-    nbr = neighbour_offsets(1)
     ws_stats = []                                            # tf_watershed stats of every window of every step (warmup included)
     ref_order = []                                           # reference order: (detour microseconds, replay form, replay us, export us) per flood that needed it
     tie_mode = {"order": a.tie_order}
     inflight = {}
-    replay_pool = ThreadPoolExecutor(max_workers=max(1, min(a.inflight, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)))
-
-    side_stream = [None]            # streaming windows: the floods are FINISHED on a second stream (the main one is busy with the flow)
     timeline = os.environ.get("TF_BENCH_TIMELINE") is not None      # development aid: when each part of a step starts and ends
-    t_step = [0.0]
+    info = {"floods": ws_stats, "reference_order": ref_order}
 
-    def mark(what):
-        if timeline:
-            print("  t+%7.1f ms  %s" % ((time.perf_counter() - t_step[0]) * 1e3, what), file=sys.stderr, flush=True)
+    def mark(what, ms):
+        print("  t+%7.1f ms  %s" % (ms, what), file=sys.stderr, flush=True)
 
-    def flood_begin(flow, w, c, scratch=None):
-        """seeds -> edge field -> device part of the watershed of channel c over the window `w` of the stack (Flow `flow`);
-        the host replay of the reference's heap order (if this window needs one) starts on a worker thread"""
+    def seeds_of(w, c):
+        """the detect_anvils recipe for a window (linearised field; label(binary_erosion(field >= 1)), -1 where
+        get_watershed_mask) of channel c (config F3: offsets 0 / -2 / -4 K)"""
         lin, seeds = anvil_seeds(w + CHANNEL_OFFSETS[c] if c else w)
         if a.single_label_seeds:
             seeds = torch.clamp(seeds, max=1)
-        # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
-        e = get_combined_edge_field(flow, lin, dtype=np.float32)
-        fw, bw = flow._dev_flows()
-        st = {}
-        mark("begin: seeds + edge field enqueued")
-        job = watershed_begin(fw, bw, e, seeds, None, nbr, a.chain_depth, stats=st,
-                              on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore", workspace=scratch)
-        mark("begin: done (replay %s)" % ("submitted" if job.needs_replay else "none"))
-        fut = replay_pool.submit(job.replay) if job.needs_replay else None
-        return job, fut, st, scratch
-
-    def flood_finish(job, fut, st, scratch=None):
-        """root phase (with the pop ranks), labels written: one label volume -- or None if the library had to export for a host
-        replay after the root phase (no guessed tie value, or one that was too low): the caller queues the job again"""
-        if fut is not None:
-            fut.result()
-        mark("finish: enter")
-        done, lab = job.step(stream=side_stream[0])
-        mark("finish: %s" % ("done" if done else "exported again, replay pending"))
-        if not done:
-            return None
-        if side_stream[0] is not None:
-            lab.record_stream(torch.cuda.current_stream())   # allocated on the second stream, used (stitch) on the main one
-        if st.get("reference_order", {}).get("microseconds", 0) > 0:
-            d = st["reference_order_detail"]
-            ref_order.append((st["reference_order"]["microseconds"], d["replay_form"], d["replay_us"], d["export_us"], d["guessed"], d["guess_covered_the_tie"],
-                              st["root_phases"]))
-        ws_stats.append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
-        return lab
-
-    class Windows:
-        """the floods of one channel of one step: begun window by window (each with its seeds and edge field), their host
-        replays on the worker threads, finished -- out of order -- as soon as their replay has ended"""
-
-        def __init__(self, bt, c, pieces, n_fly):
-            self.bt, self.c, self.pieces, self.n_fly = bt, c, pieces, n_fly
-            self.pending = deque()                           # floods in flight: (job, future, stats, scratch, window index)
-            self.wins = [None] * len(bounds)
-            self.next = 0                                    # next window to begin
-
-        def finish_one(self, block=True):
-            """finish a flood whose host replay has ended (the oldest such one); if none has, wait for the first that does:
-            a window whose replay takes long -- the dense form, ~1 s -- does not hold up the others.  block=False: only if
-            one is ready now (called after every begin: a flood whose guessed tie value turns out too low gets its
-            second export -- and with it the start of its long replay -- as early as possible)"""
-            pending = self.pending
-            ready = [p for p in pending if p[1] is None or p[1].done()]
-            if not ready and not block:
-                return False
-            if not ready:
-                futures_wait([p[1] for p in pending], return_when=FIRST_COMPLETED)
-                ready = [p for p in pending if p[1] is None or p[1].done()]
-            done = ready[0]
-            pending.remove(done)
-            lab = flood_finish(*done[:4])
-            if lab is None:                                  # exported after its root phase: the replay goes to a worker, the job comes back
-                pending.append((done[0], replay_pool.submit(done[0].replay)) + done[2:])
-                return True
-            self.wins[done[4]] = lab
-            self.pieces.append(done[3])
-            return True
-
-        def begin_up_to(self, flow, n_frames, wait_for=None):
-            """begin every window that ends within the first n_frames frames of the stack (their flow is final).
-            wait_for: an event on the main stream behind the flow these windows need: until it has passed, floods whose replay
-            has ended are finished (on the second stream) instead of blocking in the first synchronisation of a begin"""
-            while wait_for is not None and self.next < len(bounds) and bounds[self.next][1] <= n_frames and not wait_for.query():
-                if not self.finish_one(block=False):
-                    time.sleep(0.0005)
-            while self.next < len(bounds) and bounds[self.next][1] <= n_frames:
-                lo, hi = bounds[self.next]
-                while len(self.pending) >= self.n_fly:
-                    self.finish_one()
-                # the Flow create_flow(bt[lo:hi]) would return, bit for bit (tests/test_gpu_pipeline.py): the flow of a frame
-                # pair does not depend on the window it is in, only the two end frames of a window are mirrored (flow.py:425-426);
-                # window_view patches those two frames in the stack's arrays for the duration of the block instead of
-                # copying the window's 7.5 GB of flow vectors (Flow.window).  Only the device part of the flood reads the
-                # flows (its neighbour table has the displacements applied): the job is finished outside the block.
-                with flow.window_view(lo, hi) as flow_w:
-                    self.pending.append(flood_begin(flow_w, self.bt[lo:hi], self.c, self.pieces.pop()) + (self.next,))
-                self.next += 1
-                while self.finish_one(block=False):
-                    pass
-
-        def finish_all(self):
-            while self.pending:
-                self.finish_one()
-            return self.wins
+        return lin, seeds
 
     def step(bt, vr_steps=None):
-        """one pass over the stack `bt`; returns (stitched windows of the LAST channel, objects per channel)"""
-        vr = a.vr_steps if vr_steps is None else vr_steps
-        t_step[0] = time.perf_counter()
-        mark("step starts")
-        per_job = 18 * max(hi - lo for lo, hi in bounds) * H * W
-        stream = a.stream_windows and C == 1 and n_windows > 1
-        # flow of all T - 1 frame pairs of the stack, ONCE (the frames two windows share are not computed twice), in batches
-        # sized by the library (tf_farneback_batch_hint).  --stream-windows (default): a window is begun as soon as the batch
-        # that holds its last frame pair is enqueued (create_flow(on_frames_ready=...)): its host replay then runs beside the
-        # NEXT batches' flow, not after the whole stack's.  The floods in flight then need scratch of their own (the Farneback
-        # scratch is busy): TF_FLOW_WORKSPACE_GB is lowered to make room (set below, before the first create_flow).
-        first = None
-        if not stream and T * H * W * (1 + 4 + C) * 4 > 0.6 * torch.cuda.mem_get_info()[1]:
-            # a stack that takes most of the device: the flood slots of the previous step go back to the allocator's cache before
-            # the flow is sized (held, they cost the Farneback batches a third of their pairs); the floods take them again afterwards
-            for k in range(64):
-                _lib.release_workspaces("watershed_job%d" % k)
-        if stream:
-            n_fly = int(max(1, min(a.inflight, len(bounds), 5)))
-            first = Windows(bt, 0, [None] * n_fly, n_fly)
-            inflight["n"] = n_fly
-            if side_stream[0] is None:
-                side_stream[0] = torch.cuda.Stream()
+        """one pass over the stack `bt`: tobac_flow_amd.parallel.detect_stack_windows -- the flow of the stack once, the windows
+        begun while the later frames' flow is computed, their host replays on worker threads, floods finished out of order on
+        a second stream, the stitch (the scheduler lives in the package since round 5; this function only counts).
+        Returns (stitched windows of the LAST channel, objects per channel)"""
+        objects, keep = [], []
 
-            def frames_ready(fl, n):
-                mark("flow enqueued for %d frames" % n)
-                ev = torch.cuda.Event()
-                ev.record()
-                first.begin_up_to(fl, n, wait_for=ev)
-            flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic", on_frames_ready=frames_ready)
-        else:
-            flow_all = tf.create_flow(bt, model="Farneback", vr_steps=vr, smoothing_passes=1, interp_method="cubic")
-        mark("create_flow returned (device still working)")
-        flow_released = False
-        if T * H * W * (1 + 4 + C) * 4 > 0.6 * torch.cuda.mem_get_info()[1]:
-            # a stack whose frames + flow vectors + one channel's labels take most of the device (F3: 34 + 136 + 44 GB):
-            # the Farneback scratch goes back to the allocator (create_flow would otherwise keep it for the next call)
-            _lib.release_workspaces("farneback")
-            flow_released = True
-        objects, out = [], None
-        wq = None
-        for c in range(C):                                   # channels one after the other: one channel's labels resident
-            out = wq = None                                  # (the previous channel's windows go before this one's floods are sized)
-            if first is not None:
-                wq = first
-            else:
-                # Every flood in flight owns ~17 B of scratch per window voxel until it is finished.  The Farneback scratch of
-                # create_flow (up to 115 GB) is idle from here to the next step's create_flow: the floods take their scratch from
-                # it, piece by piece, instead of allocating another 50 - 100 GB beside it (which the device does not have).
-                fb = None if flow_released else _lib.borrow_workspace("farneback")
-                if fb is not None and fb.numel() >= per_job:
-                    n_fly = int(max(1, min(a.inflight, len(bounds), fb.numel() // per_job)))
-                    piece = fb.numel() // n_fly // 256 * 256
-                    pieces = [fb[k * piece:(k + 1) * piece] for k in range(n_fly)]
-                else:
-                    # no scratch to borrow (released above): every flood in flight allocates ~8 GB + its field and seeds; the
-                    # labels of the channel (4 B per window voxel, rewritten in place by the stitch) still have to fit beside them
-                    free = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
-                    held = sum(int(v.numel()) for k, v in list(_lib._WS.items()) if v is not None and k[0].startswith("watershed_job"))
-                    # (a flood in flight: scratch + field + seeds ~ 1.5 x the scratch; one window's transients: ~1.5 x more)
-                    room = 0.75 * (free + held - 4 * sum(hi - lo for lo, hi in bounds) * H * W - 3 * per_job // 2)
-                    n_fly = int(max(1, min(a.inflight, len(bounds), room // (3 * per_job // 2))))
-                    mark("floods in flight: %d (free %.1f GB, flood slots held %.1f GB)" % (n_fly, free / 1e9, held / 1e9))
-                    pieces = [None] * n_fly
-                inflight["n"] = n_fly
-                wq = Windows(bt, c, pieces, n_fly)
-            wq.begin_up_to(flow_all, T)
-            wins = wq.finish_all()
-            first = None
-            # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
-            mark("all windows finished")
-            out = stitch_rank_windows(wins, overlap=a.overlap, inplace=True) if (len(wins) > 1 or world > 1) else wins
-            mark("stitched")
-            del wins
-            n_obj = int(max(int(w.max()) for w in out))
+        def consume(c, wins):
+            n_obj = int(max(int(w.max()) for w in wins))
             if dist is not None:                             # ids are global after the stitch: the count is the largest id on ANY rank
                 tn = torch.tensor([n_obj], dtype=torch.int64, device="cpu" if a.backend == "gloo" else bt_all.device)
                 dist.all_reduce(tn, op=dist.ReduceOp.MAX)
                 n_obj = int(tn.item())
             objects.append(n_obj)
-        del flow_all
-        return out, objects
+            if c == C - 1:
+                keep[:] = [wins]                             # (one channel's labels resident at a time: only the last one's are kept)
+            return None
+        detect_stack_windows(bt, bounds, seeds_of, channels=C, consume=consume, overlap=a.overlap,
+                             vr_steps=a.vr_steps if vr_steps is None else vr_steps, smoothing_passes=1, interp_method="cubic",
+                             connectivity=1, chain_depth=a.chain_depth,
+                             on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore",
+                             max_in_flight=a.inflight, stream_windows=a.stream_windows,
+                             flow_workspace_gb=float(os.environ["TF_BENCH_FLOW_GB"]) if "TF_BENCH_FLOW_GB" in os.environ else None,
+                             info=info, mark=mark if timeline else None)
+        inflight["n"] = info.get("floods_in_flight", 1)
+        inflight["flow_workspace_gb"] = info.get("flow_workspace_gb")
+        return keep[0], objects
 
     def barrier():
         if dist is not None:
@@ -695,7 +533,7 @@ def main():
                             "floods_probing": int((timed[:, 5] >= 0).sum()), "floods_skipping_root_phase": int((timed[:, 5] < 0).sum()),
                             "tie_order": a.tie_order,
                             "labels_bit_exact_with_the_reference": a.tie_order == "reference" and int(timed[:, 11].sum()) == 0,
-                            "floods_in_flight": inflight.get("n", 1),
+                            "floods_in_flight": inflight.get("n", 1), "flow_workspace_GB_chosen_by_the_scheduler": inflight.get("flow_workspace_gb"),
                             "windows_begun_during_the_flow": bool(a.stream_windows and C == 1 and n_windows > 1)}
         if a.tie_order == "reference":
             ro = ref_order                                                          # warm-up floods included
@@ -707,7 +545,7 @@ def main():
                 "export_ms_mean": round(float(np.mean([r[3] for r in ro])) / 1e3, 1) if ro else 0.0,
                 "exports_on_a_guessed_tie_value": sum(1 for r in ro if r[4]), "guesses_that_covered_the_tie": sum(1 for r in ro if r[5]),
                 "root_phases_per_flood_mean": round(float(np.mean([r[6] for r in ro])), 2) if ro else 0.0,
-                "replay_threads": replay_pool._max_workers,
+                "replay_threads": __import__("tobac_flow_amd.parallel", fromlist=["x"])._REPLAY_POOL._max_workers,
                 "note": "host replays run on worker threads beside the next windows' device work (tf_watershed_begin / _replay / _finish)"}
             if raster_ms is not None:
                 out["watershed"]["raster_order_subreport"] = {

@@ -1,0 +1,125 @@
+"""tobac_flow_amd.parallel.detect_stack_windows -- a stack processed as overlapping time windows on one device: the flow of
+the stack once, windows begun from create_flow's callback while the later frames' flow is computed, floods in parts with
+their host replays on worker threads, finished out of order on a second stream, label ids stitched in place (round 5: the
+scheduler bench.py used to carry; reference: scripts/dcc_detect_goes.py:153, scripts/linking_parallel.py:26-27,
+linking.py:49-161).  Compared VOXEL FOR VOXEL with the same windows processed by the plain calls one after the other
+(create_flow(window) -> seeds -> get_combined_edge_field -> Flow.watershed -> stitch_window_list): streamed and not, in one
+process and as two gloo ranks on one device (the count comparison accepted a label volume with the right
+count and wrong voxels)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T, H, W, N_WIN, OVERLAP = 44, 1500, 2500, 4, 4
+
+
+def _seeds(w, c):
+    from tools.synth import anvil_seeds
+    return anvil_seeds(w)
+
+
+def _serial_windows(bt, bounds, overlap, per_window_flow=False):
+    """the plain calls, one window after the other; per_window_flow: create_flow on the window itself (what the reference's
+    scripts do per file group) instead of Flow.window of the stack's flow -- the same vectors bit for bit"""
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.parallel import stitch_window_list
+    kw = dict(model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    flow = None if per_window_flow else tf.create_flow(bt, **kw)
+    labs = []
+    for a, b in bounds:
+        fl = tf.create_flow(bt[a:b], **kw) if per_window_flow else flow.window(a, b)
+        lin, seeds = _seeds(bt[a:b], 0)
+        e = get_combined_edge_field(fl, lin, dtype=np.float32)
+        labs.append(fl.watershed(e, seeds, connectivity=1))
+    return stitch_window_list(labs, overlap=overlap)
+
+
+def test_detect_stack_windows_equals_the_serial_plain_calls_voxel_for_voxel():
+    import torch
+    from tobac_flow_amd.parallel import detect_stack_windows, window_bounds
+    from tools.synth import blob_stack
+    bt = blob_stack(T, H, W, seed=20240601, t0=0)
+    bounds = window_bounds(T, N_WIN, OVERLAP)
+    want = _serial_windows(bt, bounds, OVERLAP)
+    assert int(max(int(w.max()) for w in want)) > 10
+    # the first window through create_flow on the window itself: the reference's own per-window call
+    first = _serial_windows(bt, bounds[:1], OVERLAP, per_window_flow=True)[0]
+    assert torch.equal(first > 0, want[0] > 0)
+    for stream in (True, False):
+        info = {}
+        (got,), info = detect_stack_windows(bt, bounds, _seeds, overlap=OVERLAP, stream_windows=stream, info=info)
+        assert len(got) == N_WIN and len(info["floods"]) == N_WIN
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert g.dtype == torch.int32 and g.shape == w.shape
+            assert torch.equal(g, w), (stream, k, int((g != w).sum()))
+        assert (info.get("flow_workspace_gb") is not None) == stream
+        del got
+    # unstitched: every window's labels are those of the plain call on that window (window-local ids)
+    (raw,), _ = detect_stack_windows(bt, bounds, _seeds, overlap=OVERLAP, stitch=False)
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.detection import get_combined_edge_field
+    fl = tf.create_flow(bt[bounds[2][0]:bounds[2][1]], model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    lin, seeds = _seeds(bt[bounds[2][0]:bounds[2][1]], 0)
+    assert torch.equal(raw[2], fl.watershed(get_combined_edge_field(fl, lin, dtype=np.float32), seeds, connectivity=1))
+
+
+def test_detect_stack_windows_validates_its_input():
+    import torch
+    from tobac_flow_amd.parallel import detect_stack_windows
+    bt = torch.zeros((6, 32, 32), device="cuda")
+    with pytest.raises(ValueError, match="bounds"):
+        detect_stack_windows(bt, [(0, 4), (2, 9)], _seeds)
+    with pytest.raises(ValueError, match="bounds"):
+        detect_stack_windows(bt, [], _seeds)
+    with pytest.raises(ValueError, match="GPU"):
+        detect_stack_windows(bt.cpu(), [(0, 6)], _seeds)
+
+
+def _rank_worker(rank, world, port, out_dir, stream):
+    import torch
+    import torch.distributed as dist
+    from tobac_flow_amd.parallel import detect_stack_windows, window_bounds
+    from tools.synth import blob_stack
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t_rank = 24                                                     # rank r holds frames 20 r .. 20 r + 23: two windows of 14
+    bt = blob_stack(t_rank, H, W, seed=20240601, t0=rank * (t_rank - OVERLAP))
+    (got,), _ = detect_stack_windows(bt, window_bounds(t_rank, 2, OVERLAP), _seeds, overlap=OVERLAP, stream_windows=stream)
+    for j, g in enumerate(got):
+        np.save(os.path.join(out_dir, f"r{rank}_w{j}.npy"), g.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stream", [True, False])
+def test_two_gloo_ranks_on_one_device_equal_the_one_process_run_voxel_for_voxel(tmp_path, stream):
+    """rank r holds frames 20 r .. 20 r + 23 of one sequence as two 14-frame windows (consecutive ranks share four frames);
+    one process holding frames 0 .. 43 as the same four windows: every window's labels -- ids consistent over both ranks after
+    stitch_rank_windows -- equal, voxel for voxel."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from tobac_flow_amd.parallel import window_bounds
+    from tools.synth import blob_stack
+    bt = blob_stack(T, H, W, seed=20240601, t0=0)
+    bounds = window_bounds(T, N_WIN, OVERLAP)
+    assert bounds == [(0, 14), (10, 24), (20, 34), (30, 44)]
+    want = [w.cpu().numpy() for w in _serial_windows(bt, bounds, OVERLAP)]
+    del bt
+    torch.cuda.empty_cache()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_rank_worker, args=(2, port, str(tmp_path), stream), nprocs=2, join=True)
+    for r in range(2):
+        for j in range(2):
+            got = np.load(tmp_path / f"r{r}_w{j}.npy")
+            assert np.array_equal(got, want[2 * r + j]), (r, j, int((got != want[2 * r + j]).sum()))

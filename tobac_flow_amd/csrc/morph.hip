@@ -436,20 +436,55 @@ k_ccl_init4(const uint8_t *__restrict__ in, int64_t n, int *__restrict__ parent)
     }
 }
 
+// RUNS (round 5).  With one union per pixel and forward tap a big component -- the background that binary_fill_holes labels:
+// 95 % of a frame -- costs ~2 atomics and two root searches per pixel on ever longer chains (168 ms per 16 x 5424^2 volume, the
+// largest kernel of detect_cores).  When the structure holds the horizontal tap (every connectivity does), the pixels of a
+// horizontal run are connected whatever else happens, so: (i) the initial parent of a pixel is the HEAD of its run inside
+// the wave's 64-pixel row segment (one ballot: no union, no atomic; the head is the smallest index, as the numbering needs);
+// (ii) a run that continues across a segment boundary is joined there once; (iii) a tap without a horizontal component (dy
+// or dt only) joins p and q only where the overlap of the two runs STARTS -- if the left neighbours of both are set they are
+// joined by the thread to the left, and p, q hang on them through their runs.  Unions per volume fall from ~2 per pixel to
+// ~2 per run overlap.  (iv) A tap WITH a horizontal component (connectivity 2, 3) is skipped where its sibling without it does
+// the job: (x, y) -> (x + dx, y') is implied by (x, y) -> (x, y') plus the run of row y' when pixel (x, y') is set and the
+// structure holds that sibling tap (`sibling` bit i).
 __global__ void __launch_bounds__(256)
-k_ccl_union(const uint8_t *__restrict__ in, int64_t T, int H, int W, MorphTaps tp, int *__restrict__ parent)
+k_ccl_init_runs(const uint8_t *__restrict__ in, int64_t T, int H, int W, int *__restrict__ parent)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int64_t t = blockIdx.z;
+    const bool inside = x < W && y < H;
+    const int64_t plane = (int64_t)H * W, p = t * plane + (int64_t)y * W + x;
+    const bool on = inside && in[p] != 0;
+    const unsigned long long m = __ballot(on);                      // (a wave = one row segment: blockDim.x == 64)
+    if (!inside) return;
+    if (!on) { parent[p] = -1; return; }
+    const int lane = threadIdx.x;
+    const unsigned long long zeros_below = ~m & ((1ull << lane) - 1ull);
+    const int head = zeros_below ? 64 - __clzll((long long)zeros_below) : 0;
+    parent[p] = (int)(p - (lane - head));
+}
+
+template <bool RUNS>
+__global__ void __launch_bounds__(256)
+k_ccl_union(const uint8_t *__restrict__ in, int64_t T, int H, int W, MorphTaps tp, unsigned sibling, int *__restrict__ parent)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     const int64_t t = blockIdx.z;
     if (x >= W || y >= H) return;
     const int64_t plane = (int64_t)H * W, p = t * plane + (int64_t)y * W + x;
     if (!in[p]) return;
+    const bool left = RUNS && x > 0 && in[p - 1] != 0;
+    if (RUNS && left && threadIdx.x == 0) ccl_union(parent, (int)p, (int)(p - 1));        // the run crosses a segment boundary
     for (int i = 0; i < tp.n; i++) {
+        if (RUNS && tp.dt[i] == 0 && tp.dy[i] == 0) continue;       // the horizontal tap: runs
         const int64_t tt = t + tp.dt[i];
         const int yy = y + tp.dy[i], xx = x + tp.dx[i];
         if (tt < 0 || tt >= T || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
         const int64_t q = tt * plane + (int64_t)yy * W + xx;
-        if (in[q]) ccl_union(parent, (int)p, (int)q);
+        if (!in[q]) continue;
+        if (RUNS && tp.dx[i] == 0 && left && in[q - 1]) continue;   // not the start of the two runs' overlap
+        if (RUNS && tp.dx[i] != 0 && ((sibling >> i) & 1u) && in[q - tp.dx[i]]) continue;    // (x, y') is set: the sibling tap + row y' run
+        ccl_union(parent, (int)p, (int)q);
     }
 }
 
@@ -554,9 +589,19 @@ extern "C" int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, cons
     if (!ar.ok()) { tf_set_error("tf_label: workspace too small"); return TF_ENOMEM; }
     const unsigned nb = (unsigned)((n + 255) / 256);
     dim3 block(64, 4), grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
-    if (tf_vec4_ok({parent}, {in})) hipLaunchKernelGGL(k_ccl_init4, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, s, in, n, parent);
+    bool runs = false;                                              // the structure holds the horizontal tap (0, 0, +1)
+    for (int i = 0; i < tp.n; i++) runs = runs || (tp.dt[i] == 0 && tp.dy[i] == 0 && tp.dx[i] == 1);
+    static const bool no_runs_env = getenv("TF_CCL_NO_RUNS") != nullptr;                 // development switch: the plain form (same labels)
+    if (no_runs_env) runs = false;
+    if (runs) hipLaunchKernelGGL(k_ccl_init_runs, grid, block, 0, s, in, T, (int)H, (int)W, parent);
+    else if (tf_vec4_ok({parent}, {in})) hipLaunchKernelGGL(k_ccl_init4, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, s, in, n, parent);
     else hipLaunchKernelGGL(k_ccl_init, dim3(nb), dim3(256), 0, s, in, n, parent);
-    if (tp.n) hipLaunchKernelGGL(k_ccl_union, grid, block, 0, s, in, T, (int)H, (int)W, tp, parent);
+    unsigned sibling = 0;                                           // bit i: tap i has a horizontal component and (dt, dy, 0) is a tap too
+    for (int i = 0; i < tp.n; i++)
+        for (int j = 0; j < tp.n && tp.dx[i] != 0; j++)
+            if (tp.dx[j] == 0 && tp.dt[j] == tp.dt[i] && tp.dy[j] == tp.dy[i]) sibling |= 1u << i;
+    if (tp.n && runs) hipLaunchKernelGGL(k_ccl_union<true>, grid, block, 0, s, in, T, (int)H, (int)W, tp, sibling, parent);
+    else if (tp.n) hipLaunchKernelGGL(k_ccl_union<false>, grid, block, 0, s, in, T, (int)H, (int)W, tp, sibling, parent);
     hipLaunchKernelGGL(k_ccl_flatten, dim3(nb), dim3(256), 0, s, n, parent, isroot);
     TF_CHECK_LAUNCH();
     const unsigned nb4 = (unsigned)((nblk + 3) / 4);             // four 256-voxel blocks (waves) per workgroup

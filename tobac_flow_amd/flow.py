@@ -40,7 +40,8 @@ def _unwrap_device_field(x):
 
 
 def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
-                interp_method: str = "linear", max_value=20, on_frames_ready=None) -> "Flow":
+                interp_method: str = "linear", max_value=20, on_frames_ready=None, workspace_gb=None,
+                split_parts=None) -> "Flow":
     """Forward and backward optical flow along the leading dimension of `data`, clipped to
     +-`max_value` pixels, wrapped in a Flow object (reference: flow.py:23-65).
 
@@ -49,7 +50,13 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
     `flow.window_view(a, b)` / `flow.window(a, b)` with b <= n equal those of the finished object, bit for bit (the flow of
     a frame pair does not depend on the rest of the stack).  A long stack processed as overlapping time windows can so
     start on its first windows -- Sobel, seeds, flood, host work -- while the device computes the flow of the later frames
-    (bench.py).  The calls are made on the calling thread, in order; n == len(data) in the last one."""
+    (parallel.detect_stack_windows).  The calls are made on the calling thread, in order; n == len(data) in the last one.
+
+    workspace_gb / split_parts (not in the reference; scheduling only, the flow is the same bits): the scratch budget of the
+    Farneback batches in GB (default 115, and never more than 60 % of the free device memory) and the number of parts a batch's
+    two finest pyramid levels, refinement and smoothing are run in (default 1; a caller that runs other work beside the
+    flow -- detect_stack_windows -- asks for less scratch and for 2 parts).  The environment variables TF_FLOW_WORKSPACE_GB /
+    TF_FLOW_SPLIT (development switches) override them."""
     # the clip of flow.py:60-61 is applied by the same kernel that mirrors the end frames (tf_flow_finalize);
     # clipping commutes with the sign-flipped mirror
     extra = {}
@@ -66,6 +73,10 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
     # (scripts/dcc_detect_goes.py:164-303 only pass the object on), and 2 x 7.5 GB per 16 x 5424^2 window would cross PCIe
     # twice otherwise (down here, up again at the first Flow method)
     extra["_device_out"] = True
+    if workspace_gb is not None:
+        extra["_workspace_gb"] = float(workspace_gb)
+    if split_parts is not None:
+        extra["_split_parts"] = int(split_parts)
     data = _unwrap_device_field(data)
     forward_flow, backward_flow = calculate_flow(data, model=model, vr_steps=vr_steps,
                                                  smoothing_passes=smoothing_passes, interp_method=interp_method,
@@ -356,7 +367,8 @@ def _side_stream(main):
 
 
 def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_passes, interp_method,
-                         norm_name, norm_method, normalisation_kwargs, on_device, max_value=float("inf"), on_batch=None):
+                         norm_name, norm_method, normalisation_kwargs, on_device, max_value=float("inf"), on_batch=None,
+                         workspace_gb=None, split_parts=None):
     t = _lib.torch()
     L = _lib.lib()
     H, W = shape
@@ -391,7 +403,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     else:
         # budget: TF_FLOW_WORKSPACE_GB (default 115), and never more than 60 % of what the device has free now (the stages
         # after the flow need room too)
-        budget = float(os.environ.get("TF_FLOW_WORKSPACE_GB", "115")) * 1e9
+        budget = float(os.environ.get("TF_FLOW_WORKSPACE_GB", workspace_gb if workspace_gb is not None else "115")) * 1e9
         held = _lib.workspace_bytes("farneback")           # scratch kept from the previous call: reusable as it is
         free = t.cuda.mem_get_info()[0] + (t.cuda.memory_reserved() - t.cuda.memory_allocated())
         budget = int(max(min(budget, held + 0.6 * free), 1))   # (_lib.workspace empties the allocator's cache if fragments are in the way)
@@ -400,7 +412,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         # TF_FLOW_SPLIT=<parts> (default 1): a batch of B pairs runs its pyramid levels >= 2 for all pairs at once and the two
         # finest levels in `parts` parts (tf_farneback_batch_split): full-size library scratch for B / parts pairs only, so a
         # budget that holds the full-size scratch of 21 pairs still fills the coarse levels' launches with 42
-        split_parts = max(1, int(os.environ.get("TF_FLOW_SPLIT", "1")))
+        split_parts = max(1, int(os.environ.get("TF_FLOW_SPLIT", split_parts if split_parts is not None else "1")))
         per_pair = lib_per_pair // split_parts + H * W * (2 + 16)
         cap = max(1, budget // per_pair)
         # the library's hint counts ITS scratch only: hand it the share of the budget that is the library's, so that both
@@ -458,7 +470,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         return prev8, next8, f, bk
 
     def split_parts_used(B):
-        parts = max(1, int(os.environ.get("TF_FLOW_SPLIT", "1")))
+        parts = max(1, int(os.environ.get("TF_FLOW_SPLIT", split_parts if split_parts is not None else "1")))
         if parts == 1 or not hasattr(of_model, "params") or "TF_FLOW_BATCH" in os.environ or B < 2 * parts:
             return 1
         # a launch of the iteration kernel costs whole rounds of resident workgroups: parts that no longer fill a round at
@@ -625,6 +637,8 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     max_value = normalisation_kwargs.pop("_max_value", float("inf"))
     on_batch = normalisation_kwargs.pop("_on_batch", None)
     device_out = normalisation_kwargs.pop("_device_out", False)
+    workspace_gb = normalisation_kwargs.pop("_workspace_gb", None)
+    split_parts = normalisation_kwargs.pop("_split_parts", None)
     of_model = select_of_model(model)
     norm_method = select_normalisation_method(normalisation_method)
     t = _lib.torch()
@@ -638,7 +652,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     T = d.shape[0]
     return _calculate_flow_impl(lambda i: (d[i], d[i + 1]), T, tuple(d.shape[1:]), of_model, vr_steps,
                                 smoothing_passes, interp_method, normalisation_method, norm_method,
-                                normalisation_kwargs, on_device, max_value, on_batch)
+                                normalisation_kwargs, on_device, max_value, on_batch, workspace_gb, split_parts)
 
 
 def calculate_flow_2(a, b, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,

@@ -301,3 +301,282 @@ def apply_global_lut(labels, lut, inplace=False):
     _lib.check(_lib.lib().tf_apply_lut_keep_nonpositive(_lib.ptr(lab), lab.numel(), _lib.ptr(lut_t), lut_t.numel(), _lib.ptr(out),
                                                         _lib.stream_ptr()), "tf_apply_lut_keep_nonpositive")
     return out
+
+
+# ---- a stack processed as overlapping time windows on ONE device (round 5: the scheduler bench.py used to carry) --------
+# The reference processes a long sequence as independent windows of files with `n_pad_files` shared frames
+# (scripts/dcc_detect_goes.py:153), one process per window (scripts/linking_parallel.py:26-27 fans the linking out the same
+# way), and links the label ids afterwards (linking.py:49-161).  On one MI355X the whole stack is resident, so:
+#   * the flow of the stack's T - 1 frame pairs is computed ONCE (Flow.window_view gives every window the Flow
+#     create_flow(window) would return, bit for bit);
+#   * a window is BEGUN -- seeds, edge field, the device part of its flood (watershed_begin) -- as soon as the Farneback batch
+#     with its last frame pair is enqueued (create_flow(on_frames_ready=...)), and its host replay of the reference heap's
+#     order (WatershedJob.replay: sequential host work, 0.2 - 1 s per 16 x 5424^2 window) runs on a worker thread beside the
+#     device's next batches;
+#   * floods are FINISHED out of order, whichever replay ends first, on a second stream (the main one is busy with the flow);
+#   * the label ids of all windows (of all ranks, with a process group) are made consistent by stitch_rank_windows.
+# Every window's labels equal Flow.watershed on create_flow(window) -- tests/test_gpu_windows.py compares voxel for voxel.
+_REPLAY_POOL = None
+_SIDE_STREAMS = {}
+_BUDGET_MEMO = {}
+
+
+def _replay_pool(n):
+    global _REPLAY_POOL
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    if _REPLAY_POOL is None:
+        cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+        _REPLAY_POOL = ThreadPoolExecutor(max_workers=max(1, min(12, cpus)), thread_name_prefix="tf-ws-replay")
+    return _REPLAY_POOL
+
+
+def _side_stream():
+    import torch
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream()
+    return _SIDE_STREAMS[key]
+
+
+class _WindowFloods:
+    """The floods of one channel of one stack: begun window by window (each with its seeds and edge field), their host
+    replays on worker threads, finished -- out of order -- as soon as their replay has ended."""
+
+    def __init__(self, owner, bt, channel, pieces, n_fly):
+        from collections import deque
+        self.o, self.bt, self.c, self.pieces, self.n_fly = owner, bt, channel, pieces, n_fly
+        self.pending = deque()                               # floods in flight: (job, future, stats, scratch, window index)
+        self.wins = [None] * len(owner.bounds)
+        self.next = 0                                        # next window to begin
+
+    def _begin(self, flow, w, scratch):
+        """seeds -> edge field -> device part of the watershed of this channel over the window `w` of the stack; the host
+        replay of the reference's heap order (if this window needs one) starts on a worker thread"""
+        from tobac_flow_amd.detection import get_combined_edge_field
+        from tobac_flow_amd.watershed import watershed_begin
+        o = self.o
+        field, seeds = o.seeds_fn(w, self.c)
+        # Flow.sobel(uphill, cubic) in float64 + detection.py:638-642, rounded to float32 as watershed.py:64-65 does
+        e = get_combined_edge_field(flow, field, dtype=np.float32)
+        fw, bw = flow._dev_flows()
+        st = {}
+        o.mark("begin: seeds + edge field enqueued")
+        job = watershed_begin(fw, bw, e, seeds, None, o.nbr, o.chain_depth, stats=st, on_ambiguous=o.on_ambiguous, workspace=scratch)
+        o.mark("begin: done (replay %s)" % ("submitted" if job.needs_replay else "none"))
+        fut = o.pool.submit(job.replay) if job.needs_replay else None
+        return job, fut, st, scratch
+
+    def _finish(self, job, fut, st, scratch):
+        """root phase (with the pop ranks), labels written: one label volume -- or None if the library had to export for a host
+        replay after the root phase (no guessed tie value, or one that was too low): the caller queues the job again"""
+        o = self.o
+        if fut is not None:
+            fut.result()
+        o.mark("finish: enter")
+        done, lab = job.step(stream=o.side)                  # (WatershedJob.step records the caller's stream on the labels)
+        o.mark("finish: %s" % ("done" if done else "exported again, replay pending"))
+        if not done:
+            return None
+        if st.get("reference_order", {}).get("microseconds", 0) > 0:
+            d = st["reference_order_detail"]
+            o.info["reference_order"].append((st["reference_order"]["microseconds"], d["replay_form"], d["replay_us"], d["export_us"], d["guessed"],
+                                              d["guess_covered_the_tie"], st["root_phases"]))
+        o.info["floods"].append(st["sweeps"] + [st["chain_depth"], st["ambiguous_pixels"], st["marker_tie_origins"], st["depth_origins"]])
+        return lab
+
+    def finish_one(self, block=True):
+        """finish a flood whose host replay has ended (the oldest such one); if none has, wait for the first that does: a
+        window whose replay takes long -- the dense form, ~1 s -- does not hold up the others.  block=False: only if one is
+        ready now (called after every begin: a flood whose guessed tie value turns out too low gets its second export -- and
+        with it the start of its long replay -- as early as possible)"""
+        from concurrent.futures import FIRST_COMPLETED, wait
+        pending = self.pending
+        ready = [p for p in pending if p[1] is None or p[1].done()]
+        if not ready and not block:
+            return False
+        if not ready:
+            wait([p[1] for p in pending], return_when=FIRST_COMPLETED)
+            ready = [p for p in pending if p[1] is None or p[1].done()]
+        done = ready[0]
+        pending.remove(done)
+        lab = self._finish(*done[:4])
+        if lab is None:                                      # exported after its root phase: the replay goes to a worker, the job comes back
+            pending.append((done[0], self.o.pool.submit(done[0].replay)) + done[2:])
+            return True
+        self.wins[done[4]] = lab
+        self.pieces.append(done[3])
+        return True
+
+    def begin_up_to(self, flow, n_frames, wait_for=None):
+        """begin every window that ends within the first n_frames frames of the stack (their flow is final).
+        wait_for: an event on the main stream behind the flow these windows need: until it has passed, floods whose replay
+        has ended are finished (on the second stream) instead of blocking in the first synchronisation of a begin"""
+        import time
+        bounds = self.o.bounds
+        while wait_for is not None and self.next < len(bounds) and bounds[self.next][1] <= n_frames and not wait_for.query():
+            if not self.finish_one(block=False):
+                time.sleep(0.0005)
+        while self.next < len(bounds) and bounds[self.next][1] <= n_frames:
+            lo, hi = bounds[self.next]
+            while len(self.pending) >= self.n_fly:
+                self.finish_one()
+            # the Flow create_flow(bt[lo:hi]) would return, bit for bit: the flow of a frame pair does not depend on the window
+            # it is in, only the two end frames of a window are mirrored (flow.py:425-426); window_view patches those two frames
+            # in the stack's arrays for the duration of the block instead of copying the window's 7.5 GB of flow vectors.  Only
+            # the device part of the flood reads the flows (its neighbour table has the displacements applied): the job is
+            # finished outside the block.
+            with flow.window_view(lo, hi) as flow_w:
+                self.pending.append(self._begin(flow_w, self.bt[lo:hi], self.pieces.pop()) + (self.next,))
+            self.next += 1
+            while self.finish_one(block=False):
+                pass
+
+    def finish_all(self):
+        while self.pending:
+            self.finish_one()
+        return self.wins
+
+
+class _StackRun:
+    pass
+
+
+def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap=DEFAULT_OVERLAP, stitch=True, group=None,
+                         model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic", connectivity=1,
+                         chain_depth=3, on_ambiguous="reference", max_in_flight=12, stream_windows=True,
+                         flow_workspace_gb=None, info=None, mark=None):
+    """Flow -> edge field -> marker-controlled watershed over a stack processed as overlapping time windows, on this device.
+
+    bt: (T, H, W) float32 device tensor (the stack, resident).  bounds: [(start, stop), ...] consecutive windows sharing
+    `overlap` frames (window_bounds).  seeds_fn(window_bt, channel) -> (field, seeds): the caller's recipe for a window --
+    `field` the (linearised) field whose uphill Sobel edges are flooded (detection.get_combined_edge_field), `seeds` int32
+    markers (-1 = background seed), both device tensors of the window's shape; e.g. the detect_anvils recipe
+    (detection.py:547-561).  channels > 1: several detections share the one Flow (BASELINE config F3), processed one after
+    the other so that one channel's labels are resident at a time: `consume(channel, windows)` is called with each
+    channel's stitched windows and its return value collected (default: the windows themselves).
+
+    Returns (results, info): results[c] = the list of int32 label windows of channel c (ids consistent over all windows, and
+    over all ranks of `group` -- stitch_rank_windows -- unless stitch=False), or what `consume` made of them;
+    info["floods"] = per flood the library's sweep counts and tie statistics, info["reference_order"] = per flood that
+    needed it the host replay's figures, info["floods_in_flight"], info["flow_batches"].
+
+    Scheduling (no effect on results): stream_windows -- begin a window as soon as its flow is enqueued (one channel only;
+    otherwise all windows after the stack's flow, their scratch borrowed from the then idle Farneback workspace);
+    max_in_flight -- floods in flight at most; flow_workspace_gb -- scratch budget of the Farneback batches while floods run
+    beside them (default: what the device has left after the flow vectors, the labels and the floods in flight, memoised per
+    stack shape so that every call of a sweep batches alike).  Each window's labels are those of
+    Flow.watershed(get_combined_edge_field(create_flow(window), field), seeds) bit for bit."""
+    import time
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd import _lib
+    from tobac_flow_amd.watershed import neighbour_offsets
+    if not (isinstance(bt, torch.Tensor) and bt.is_cuda and bt.dim() == 3):
+        raise ValueError("detect_stack_windows: bt must be a (T, H, W) tensor on the GPU")
+    T, H, W = bt.shape
+    bounds = [(int(lo), int(hi)) for lo, hi in bounds]
+    if not bounds or any(not (0 <= lo < hi <= T) for lo, hi in bounds) or any(b[1] < a[1] or b[0] < a[0] for a, b in zip(bounds[:-1], bounds[1:])):
+        raise ValueError("detect_stack_windows: bounds must be ascending (start, stop) windows inside the stack")
+    C = int(channels)
+    o = _StackRun()
+    o.bounds, o.seeds_fn, o.nbr, o.chain_depth, o.on_ambiguous = bounds, seeds_fn, neighbour_offsets(connectivity), chain_depth, on_ambiguous
+    o.info = info if info is not None else {}
+    o.info.setdefault("floods", [])
+    o.info.setdefault("reference_order", [])
+    t_start = time.perf_counter()
+    o.mark = (lambda what: mark(what, (time.perf_counter() - t_start) * 1e3)) if mark is not None else (lambda what: None)
+    o.pool = _replay_pool(max_in_flight)
+    o.side = None
+    n_windows = len(bounds)
+    longest = max(hi - lo for lo, hi in bounds)
+    per_job = 18 * longest * H * W                           # scratch of a flood in flight (~17 B per window voxel)
+    stream = bool(stream_windows) and C == 1 and n_windows > 1
+    flow_kw = dict(model=model, vr_steps=vr_steps, smoothing_passes=smoothing_passes, interp_method=interp_method)
+    total = torch.cuda.mem_get_info()[1]
+    first = None
+    if not stream and T * H * W * (1 + 4 + C) * 4 > 0.6 * total:
+        # a stack that takes most of the device: the flood slots of the previous call go back to the allocator's cache before
+        # the flow is sized (held, they cost the Farneback batches a third of their pairs); the floods take them again afterwards
+        for k in range(64):
+            _lib.release_workspaces("watershed_job%d" % k)
+    if stream:
+        n_fly = int(max(1, min(max_in_flight, n_windows, 5)))
+        if flow_workspace_gb is None:
+            # floods in flight beside the flow need scratch of their own (the Farneback workspace is busy): the Farneback batches
+            # get what is left after the flow vectors, the labels of all windows, the floods (scratch + field + seeds ~ 1.5 x
+            # the scratch each, and one window's transients) -- with 30 % of it kept back: free memory that sits in the caching
+            # allocator as fragments cannot serve the one block the Farneback scratch is, and a budget the device can only just
+            # hold costs allocator retries (measured: 98.8 GB -> batches of 64 pairs, 268 GB at the peak, steps of 4.7 / 8.4 /
+            # 6.4 s instead of 4.6).  Memoised per stack shape: the batches of every call of a sweep are then the same, whatever
+            # an earlier call left cached.  Config F (144 x 5424^2, 12 windows) on 288 GB: 86 GB -- any budget from 65 to 98 GB
+            # gives the library's batch hint 21 full-resolution pairs, i.e. 42-pair batches finished in two parts of 21.
+            key = (torch.cuda.current_device(), T, H, W, tuple(bounds), n_fly)
+            if key not in _BUDGET_MEMO:
+                free = torch.cuda.mem_get_info()[0] + (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
+                held = sum(int(v.numel()) for k, v in list(_lib._WS.items()) if v is not None and k[1] == torch.cuda.current_device())
+                need = 2 * T * H * W * 8 + 4 * sum(hi - lo for lo, hi in bounds) * H * W + (n_fly + 1) * (3 * per_job // 2)
+                _BUDGET_MEMO[key] = max(4.0, 0.7 * (free + held - need) / 1e9)
+            flow_workspace_gb = _BUDGET_MEMO[key]
+        first = _WindowFloods(o, bt, 0, [None] * n_fly, n_fly)
+        o.info["floods_in_flight"] = n_fly
+        o.side = _side_stream()
+
+        def frames_ready(fl, n):
+            o.mark("flow enqueued for %d frames" % n)
+            ev = torch.cuda.Event()
+            ev.record()
+            first.begin_up_to(fl, n, wait_for=ev)
+        # a batch has twice the pairs at the pyramid levels >= 2 (with half, their launches are one half-empty round of
+        # workgroups) and is finished -- finest levels, refinement, smoothing, hand-over of its frames -- in two parts
+        flow_all = tf.create_flow(bt, on_frames_ready=frames_ready, workspace_gb=flow_workspace_gb, split_parts=2, **flow_kw)
+    else:
+        flow_all = tf.create_flow(bt, **flow_kw)
+    o.info["flow_workspace_gb"] = None if flow_workspace_gb is None else round(float(flow_workspace_gb), 1)
+    o.mark("create_flow returned (device still working)")
+    flow_released = False
+    if T * H * W * (1 + 4 + C) * 4 > 0.6 * total:
+        # a stack whose frames + flow vectors + one channel's labels take most of the device (F3: 34 + 136 + 44 GB):
+        # the Farneback scratch goes back to the allocator (create_flow would otherwise keep it for the next call)
+        _lib.release_workspaces("farneback")
+        flow_released = True
+    results = []
+    for c in range(C):                                       # channels one after the other: one channel's labels resident
+        wq = None
+        if first is not None:
+            wq = first
+        else:
+            # Every flood in flight owns ~17 B of scratch per window voxel until it is finished.  The Farneback scratch of
+            # create_flow (up to 115 GB) is idle from here to the next create_flow: the floods take their scratch from it,
+            # piece by piece, instead of allocating another 50 - 100 GB beside it (which the device does not have).
+            fb = None if flow_released else _lib.borrow_workspace("farneback")
+            if fb is not None and fb.numel() >= per_job:
+                n_fly = int(max(1, min(max_in_flight, n_windows, fb.numel() // per_job)))
+                piece = fb.numel() // n_fly // 256 * 256
+                pieces = [fb[k * piece:(k + 1) * piece] for k in range(n_fly)]
+            else:
+                # no scratch to borrow (released above): every flood in flight allocates ~8 GB + its field and seeds; the
+                # labels of the channel (4 B per window voxel, rewritten in place by the stitch) still have to fit beside them
+                free = torch.cuda.mem_get_info()[0] + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+                held = sum(int(v.numel()) for k, v in list(_lib._WS.items()) if v is not None and k[0].startswith("watershed_job"))
+                # (a flood in flight: scratch + field + seeds ~ 1.5 x the scratch; one window's transients: ~1.5 x more)
+                room = 0.75 * (free + held - 4 * sum(hi - lo for lo, hi in bounds) * H * W - 3 * per_job // 2)
+                n_fly = int(max(1, min(max_in_flight, n_windows, room // (3 * per_job // 2))))
+                o.mark("floods in flight: %d (free %.1f GB, flood slots held %.1f GB)" % (n_fly, free / 1e9, held / 1e9))
+                pieces = [None] * n_fly
+            o.info["floods_in_flight"] = n_fly
+            wq = _WindowFloods(o, bt, c, pieces, n_fly)
+        wq.begin_up_to(flow_all, T)
+        wins = wq.finish_all()
+        first = None
+        o.mark("all windows finished")
+        # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if stitch and (len(wins) > 1 or multi):
+            wins = stitch_rank_windows(wins, group=group, overlap=overlap, inplace=True)
+            o.mark("stitched")
+        results.append(wins if consume is None else consume(c, wins))
+        del wins, wq
+    del flow_all
+    return results, o.info
