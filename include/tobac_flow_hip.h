@@ -539,6 +539,16 @@ int tf_profile_kernel_count(void);
 const char *tf_profile_kernel_name(int id);
 int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
 
+/* A stream whose kernels may only occupy the CUs set in the mask (bit i of mask_words = CU i in the runtime's numbering;
+ * hipExtStreamCreateWithCUMask): parallel.detect_stack_windows finishes the floods of ready windows on such a stream, so
+ * that they displace the flow's iteration workgroups on a part of the chip only.  tf_debug_cu_histogram launches
+ * n_workgroups idle workgroups on a stream and returns how many ran where: hist[xcc * 256 + HW_ID bits 15:8].
+ * tf_copy16: dst = src, 16 bytes per lane per access -- the measured practical HBM ceiling of bench.py's roofline. */
+int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words, void **stream_out);
+int tf_stream_destroy(void *stream);
+int tf_debug_cu_histogram(void *stream, int n_workgroups, int *hist_host_2048);
+int tf_copy16(const void *src, void *dst, size_t bytes, void *stream);
+
 /* SURVEY.md 8(b) "ownership": the library never retains a caller's pointer past return and owns no device memory (all
  * scratch is the caller's workspace); its only pooled resource is the HIP events of the timing facility above.
  * tf_shutdown() switches timing off and destroys them.  Idempotent; the library remains usable afterwards. */

@@ -125,6 +125,10 @@ _PROTOS = {
     "tf_profile_kernel_count": (_c.c_int, []),
     "tf_profile_kernel_name": (_c.c_char_p, [_c.c_int]),
     "tf_profile_collect": (_c.c_int, [_P, _P, _P]),
+    "tf_stream_create_cu_mask": (_c.c_int, [_P, _c.c_int, _c.POINTER(_P)]),
+    "tf_stream_destroy": (_c.c_int, [_P]),
+    "tf_debug_cu_histogram": (_c.c_int, [_P, _c.c_int, _P]),
+    "tf_copy16": (_c.c_int, [_P, _P, _c.c_size_t, _P]),
     "tf_shutdown": (_c.c_int, []),
     "tf_selftest_shared_divide": (_c.c_int, [_c.c_int64, _c.c_uint64, _P, _P]),
 }

@@ -1,6 +1,7 @@
 // Library-level entry points of include/tobac_flow_hip.h: version, error string, device count.
 #include "tf_common.h"
 #include <stdarg.h>
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -72,5 +73,75 @@ extern "C" int tf_shutdown(void) {
     for (auto &r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : g_free) (void)hipEventDestroy(e);
     g_recs.clear(); g_free.clear();
+    return TF_OK;
+}
+
+// ---- streams confined to a part of the chip --------------------------------------------------------------------------
+// A caller that runs the floods of finished windows BESIDE the flow (parallel.detect_stack_windows) gives them a stream
+// whose kernels may only occupy some of the CUs: the flow's iteration kernel then keeps the LDS of all the others to itself
+// (its faster two-part chain needs 39 KB per workgroup, four per CU -- csrc/farneback.hip), while an unrestricted flood
+// stream displaces iteration workgroups on every CU.  mask_words: bit i of the mask = CU i in the runtime's numbering
+// (hipExtStreamCreateWithCUMask; tf_debug_cu_histogram shows which XCD / CU a bit maps to on this part).
+extern "C" int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words, void **stream_out)
+{
+    TF_REQUIRE(mask_words && n_words > 0 && n_words <= 32 && stream_out, "tf_stream_create_cu_mask: bad arguments");
+    hipStream_t s = nullptr;
+    TF_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask_words));
+    *stream_out = (void *)s;
+    return TF_OK;
+}
+extern "C" int tf_stream_destroy(void *stream)
+{
+    if (stream) TF_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return TF_OK;
+}
+
+// where do the workgroups of a stream run?  hist[xcc * 256 + (se, sh, cu) byte of HW_ID] += 1 per workgroup
+__global__ void __launch_bounds__(64)
+k_debug_cu_histogram(int *hist)
+{
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;           // HW_REG_XCC_ID, bits 3:0
+        const unsigned hw = (__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4)) & 0xffffu;   // HW_REG_HW_ID (id 4), 16 bits
+        atomicAdd(&hist[xcc * 256 + ((hw >> 8) & 0xffu)], 1);
+    }
+    // (long enough for every CU of the mask to be handed workgroups)
+    for (int i = 0; i < 2000; i++) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int tf_debug_cu_histogram(void *stream, int n_workgroups, int *hist_host_2048)
+{
+    TF_REQUIRE(hist_host_2048 && n_workgroups > 0, "tf_debug_cu_histogram: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int *d = nullptr;
+    TF_CHECK_HIP(hipMallocAsync((void **)&d, 2048 * sizeof(int), s));
+    TF_CHECK_HIP(hipMemsetAsync(d, 0, 2048 * sizeof(int), s));
+    hipLaunchKernelGGL(k_debug_cu_histogram, dim3((unsigned)n_workgroups), dim3(64), 0, s, d);
+    TF_CHECK_LAUNCH();
+    TF_CHECK_HIP(hipMemcpyAsync(hist_host_2048, d, 2048 * sizeof(int), hipMemcpyDeviceToHost, s));
+    TF_CHECK_HIP(hipStreamSynchronize(s));
+    TF_CHECK_HIP(hipFreeAsync(d, s));
+    return TF_OK;
+}
+
+// ---- the practical HBM ceiling: a plain copy, 16 bytes per lane per access (bench.py's `practical_peak`) ---------------
+__global__ void __launch_bounds__(256)
+k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four independent 16-byte loads in flight per lane before the first store
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+extern "C" int tf_copy16(const void *src, void *dst, size_t bytes, void *stream)
+{
+    TF_REQUIRE(src && dst && bytes >= 16 && bytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "tf_copy16: 16-byte aligned buffers of a multiple of 16 bytes");
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16);
+    TF_CHECK_LAUNCH();
     return TF_OK;
 }

@@ -331,11 +331,27 @@ def _replay_pool(n):
     return _REPLAY_POOL
 
 
-def _side_stream():
+def _side_stream(cus_per_xcd=0):
+    """the second stream of (device, calling stream) -- the floods of ready windows are finished on it while the calling
+    stream is busy with the flow.  cus_per_xcd > 0: a stream whose kernels may only occupy that many CUs of every XCD
+    (tf_stream_create_cu_mask; on this part bit i of the mask selects a CU of XCD i % 8, successive bits of an XCD going
+    round its shader engines -- tools/cu_mask_probe.py; an XCD cannot be left without CUs): the floods then displace the
+    flow's iteration workgroups on those CUs only."""
+    import ctypes
     import torch
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    from tobac_flow_amd import _lib
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, int(cus_per_xcd))
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream()
+        if cus_per_xcd > 0:
+            n_bits = 8 * int(cus_per_xcd)
+            words = np.zeros(8, np.uint32)
+            for b in range(n_bits):
+                words[b // 32] |= np.uint32(1 << (b % 32))
+            handle = ctypes.c_void_p()
+            _lib.check(_lib.lib().tf_stream_create_cu_mask(words.ctypes.data_as(_lib._P), 8, ctypes.byref(handle)), "tf_stream_create_cu_mask")
+            _SIDE_STREAMS[key] = torch.cuda.ExternalStream(handle.value)
+        else:
+            _SIDE_STREAMS[key] = torch.cuda.Stream()
     return _SIDE_STREAMS[key]
 
 
@@ -445,7 +461,7 @@ class _StackRun:
 def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap=DEFAULT_OVERLAP, stitch=True, group=None,
                          model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic", connectivity=1,
                          chain_depth=3, on_ambiguous="reference", max_in_flight=12, stream_windows=True,
-                         flow_workspace_gb=None, info=None, mark=None):
+                         flow_workspace_gb=None, flood_cus_per_xcd=None, info=None, mark=None):
     """Flow -> edge field -> marker-controlled watershed over a stack processed as overlapping time windows, on this device.
 
     bt: (T, H, W) float32 device tensor (the stack, resident).  bounds: [(start, stop), ...] consecutive windows sharing
@@ -467,6 +483,7 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
     beside them (default: what the device has left after the flow vectors, the labels and the floods in flight, memoised per
     stack shape so that every call of a sweep batches alike).  Each window's labels are those of
     Flow.watershed(get_combined_edge_field(create_flow(window), field), seeds) bit for bit."""
+    import os
     import time
     import torch
     import tobac_flow_amd.flow as tf
@@ -520,7 +537,10 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             flow_workspace_gb = _BUDGET_MEMO[key]
         first = _WindowFloods(o, bt, 0, [None] * n_fly, n_fly)
         o.info["floods_in_flight"] = n_fly
-        o.side = _side_stream()
+        if flood_cus_per_xcd is None:
+            flood_cus_per_xcd = int(os.environ.get("TF_WINDOWS_FLOOD_CUS", "0"))      # (development switch)
+        o.side = _side_stream(flood_cus_per_xcd)
+        o.info["flood_cus_per_xcd"] = int(flood_cus_per_xcd)
 
         def frames_ready(fl, n):
             o.mark("flow enqueued for %d frames" % n)
