@@ -31,16 +31,47 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); the device-to-device copy timed in this run (roofline.practical_peak, ~5.0 TB/s read + written) is the practical ceiling
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); the library's own 16-byte-per-lane copy timed in this run (roofline.practical_peak) is the practical ceiling
 
 
 # library profile name -> kernel symbol prefix in the rocprofv3 counter files
 _KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<", "vr_sor": "void k_vr_sor_tile<false>", "vr_system": "void k_vr_system<true, false>",
                   "sobel": "void k_sobel27<2, double, 2, true>", "fb_polyexp": "k_fb_polyexp", "vr_prepare": "k_vr_prepare",
-                  "smooth_flow": "void k_smooth<"}
-_TRAFFIC_FILE = "profiles/round4_pmc_traffic_bench.json"
-_VALU_FILE = "profiles/round4_pmc_valu_bench.json"
+                  "smooth_flow": "void k_smooth<", "ws_relax_sweep": "k_ws_sweep", "fb_gaussian_blur": "k_fb_blur", "fb_resize": "k_fb_resize",
+                  "binary_morph": "k_binary_morph", "ws_labels": "k_ws_labels", "to8bit_pair": ("k_minmax", "k_to8bit")}
+def _latest(*names):
+    """the newest committed recording that exists (a round whose counter passes could not be re-recorded keeps the last one)"""
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, n)):
+            return n
+    return names[-1]
+
+
+_TRAFFIC_FILE = _latest("profiles/round5_pmc_traffic_bench.json", "profiles/round4_pmc_traffic_bench.json")
+_VALU_FILE = _latest("profiles/round5_pmc_valu_bench.json", "profiles/round4_pmc_valu_bench.json")
 _CLOCK_GHZ_DEFAULT = 2.1       # GRBM_GUI_ACTIVE / 8 / duration under k_fb_iter (DESIGN.md section 7); used when a pass has no timestamps
+
+
+def _matching(doc, profile_name):
+    """the recorded kernels of one profile name: every kernel whose symbol starts with (one of) its prefix(es) -- a profile
+    name can stand for several kernels (the flood's sweeps: k_ws_sweep_a + k_ws_sweep_chain; the blur's variants)"""
+    pre = _KERNEL_SYMBOL[profile_name]
+    pre = pre if isinstance(pre, tuple) else (pre,)
+    pre = pre + tuple("void " + q for q in pre if not q.startswith("void "))
+    return [v for name, v in doc["kernels"].items() if name.startswith(pre)]
+
+
+def _traffic_ratio(profile_name, doc):
+    """measured HBM bytes (FETCH_SIZE corrected + WRITE_SIZE) over ALGORITHMIC bytes of one profile name in the recorded
+    counter passes -- a property of the kernel(s), independent of the size of the run (None if not recorded)"""
+    try:
+        ks = _matching(doc, profile_name)
+        rec = doc["recorded_on"]
+        alg = rec["algorithmic_bytes_per_launch"][profile_name] * rec["launches"][profile_name]
+        moved = sum(((k["fetch_bytes_corrected_per_launch"] or 0.0) + (k["write_bytes_per_launch"] or 0.0)) * k["launches"] for k in ks)
+        return moved / alg if (ks and alg > 0) else None
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None
 
 
 def _valu_floor(profile_name, alg_bytes_total, doc):
@@ -50,12 +81,14 @@ def _valu_floor(profile_name, alg_bytes_total, doc):
     over 1024 SIMDs at the clock the pass measured under that kernel.  float64 instructions occupy a SIMD for eight cycles,
     so the real floor of the float64-heavy kernels (Sobel, polynomial expansion) is higher.  None if the pass lacks the kernel."""
     try:
-        k = next(v for name, v in doc["kernels"].items() if name.startswith(_KERNEL_SYMBOL[profile_name]))
+        ks = _matching(doc, profile_name)
         rec_bytes = doc["recorded_on"]["algorithmic_bytes_per_launch"][profile_name] * doc["recorded_on"]["launches"][profile_name]
-        instr = k["valu_wave_instructions_per_launch"] * k["launches"]
-        clock = (k.get("clock_ghz_under_this_kernel") or _CLOCK_GHZ_DEFAULT) * 1e9
-        return instr / rec_bytes * alg_bytes_total * doc.get("cycles_per_wave64_instruction", 4) / (doc.get("simds", 1024) * clock) * 1e3
-    except (KeyError, TypeError, StopIteration, ZeroDivisionError):
+        # (several kernels under one name: each one's instructions at the clock it ran at)
+        cycles_over_clock = sum(k["valu_wave_instructions_per_launch"] * k["launches"] / ((k.get("clock_ghz_under_this_kernel") or _CLOCK_GHZ_DEFAULT) * 1e9) for k in ks)
+        if not ks or rec_bytes <= 0:
+            return None
+        return cycles_over_clock / rec_bytes * alg_bytes_total * doc.get("cycles_per_wave64_instruction", 4) / doc.get("simds", 1024) * 1e3
+    except (KeyError, TypeError, ZeroDivisionError):
         return None
 _TRAFFIC_WORKLOAD = ("F", 144, 5424, 5424, 1)      # (config, frames, height, width, vr_steps) the counter passes were recorded on
 
@@ -72,7 +105,7 @@ def _traffic(profile_name, alg_bytes_per_launch):
     try:
         with open(os.path.join(ROOT, _TRAFFIC_FILE)) as fh:
             doc = json.load(fh)
-        k = next(v for name, v in doc["kernels"].items() if name.startswith(_KERNEL_SYMBOL[profile_name]))   # symbol prefix
+        k = _matching(doc, profile_name)[0]                    # (the dominant kernel has one symbol)
         rec = doc.get("recorded_on") or {}
         scale = 1.0
         per_kernel = rec.get("algorithmic_bytes_per_launch")
@@ -83,15 +116,17 @@ def _traffic(profile_name, alg_bytes_per_launch):
                 "fetch_bytes_raw": k["fetch_bytes_raw_per_launch"] * scale, "fetch_bytes_corrected": k["fetch_bytes_corrected_per_launch"] * scale,
                 "write_bytes": k["write_bytes_per_launch"] * scale, "launches_profiled": k["launches"], "source": _TRAFFIC_FILE,
                 "scaled_by_pairs_per_launch": round(scale, 4), "recorded_on": rec.get("workload")}
-    except (OSError, ValueError, KeyError, TypeError, AttributeError, StopIteration):
+    except (OSError, ValueError, KeyError, TypeError, AttributeError, StopIteration, IndexError):
         return None
 
 
 def cpu_baseline(seed, vr_steps=1):
     """The oracle (CPU restatement of the reference's cv2/numpy/Cython path, kind = "port") timed on the host cores of
-    this box on a bounded sample of the same workload: a 5 x 1536 x 1536 stack.  The order-independent stages run on a
-    thread pool (Farneback: one task per frame pair and direction; Sobel: one task per frame -- the C restatements and
-    numpy release the GIL); the heap flood is sequential by construction (one thread, like the reference's)."""
+    this box on a bounded sample of the same workload: a 17 x 1536 x 1536 stack (round 5: 32 Farneback tasks, so that the
+    pool can use up to 32 of the box's cores; rounds 1 - 4 timed a 5-frame stack, whose eight tasks left all but eight cores
+    idle).  The order-independent stages run on a thread pool (Farneback and refinement: one task per frame pair and
+    direction; Sobel: one task per frame -- the C restatements and numpy release the GIL); the heap flood is sequential by
+    construction (one thread, like the reference's).  TF_BENCH_CPU_FRAMES overrides the number of frames."""
     import numpy as np
     import scipy.ndimage as ndi
     import ctypes
@@ -100,7 +135,7 @@ def cpu_baseline(seed, vr_steps=1):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import blob_sequence
     from oracle import _lib as ol, np_ops, ws_oracle
-    T, H, W = 5, 1536, 1536
+    T, H, W = int(os.environ.get("TF_BENCH_CPU_FRAMES", "17")), 1536, 1536
     rng = np.random.default_rng(seed)
     bt = blob_sequence(rng, T, H, W, n_blobs=36)
     L = ol.lib()
@@ -157,6 +192,7 @@ def cpu_baseline(seed, vr_steps=1):
     except Exception as e:                                   # the baseline figure stands on its own
         check = {"error": f"{type(e).__name__}: {e}"}
     return {"value": round(T * H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": threads, "kind": "port", "library_vs_oracle_on_the_sample": check,
+            "cores_available": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), "host_cores": os.cpu_count(),
             "sample": f"{T}x{H}x{W} synthetic stack, same stage sequence, oracle (C/numpy restatement of the "
                       f"cv2+scipy+Cython path{', with the refinement' if vr_steps > 0 else ''}): flow {t_flow:.1f} s and Sobel {t_sobel:.1f} s on {threads} threads, flood "
                       f"{dt - t_flow - t_sobel:.1f} s on one (sequential heap), {dt:.1f} s in all; host has {os.cpu_count()} cores"}
@@ -466,16 +502,31 @@ def main():
                     valu_doc = json.load(fh)
             except (OSError, ValueError):
                 valu_doc = None
+            try:
+                with open(os.path.join(ROOT, _TRAFFIC_FILE)) as fh:
+                    traffic_doc = json.load(fh)
+            except (OSError, ValueError):
+                traffic_doc = None
             for k, v in prof.items():
                 e = roof["all_kernels"][k]
                 if v[2] > 0:
                     e["hbm_floor_ms"] = round(v[2] / a.steps / (HBM_PEAK_GBS * 1e9) * 1e3, 3)
                     e["frac_hbm"] = round(v[2] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                # measured HBM bytes over algorithmic bytes, from the committed FETCH_SIZE / WRITE_SIZE passes (a ratio: it carries
+                # over to a run of another size); well above 1 = re-reads
+                tr_ratio = _traffic_ratio(k, traffic_doc) if (traffic_doc and k in _KERNEL_SYMBOL and v[2] > 0) else None
+                if tr_ratio is not None:
+                    e["traffic_over_algorithmic"] = round(tr_ratio, 3)
+                    e["traffic_GBps"] = round(tr_ratio * v[2] / (v[1] * 1e-3) / 1e9, 1)
+                    e["traffic_frac_of_peak"] = round(e["traffic_GBps"] / HBM_PEAK_GBS, 4)
                 vf = _valu_floor(k, v[2], valu_doc) if (valu_doc and k in _KERNEL_SYMBOL and v[2] > 0) else None
                 if vf is not None:
                     e["valu_floor_ms"] = round(vf / a.steps, 3)
                     e["frac_valu"] = round(vf / v[1], 4)
                     e["bound"] = "valu" if vf / a.steps > e.get("hbm_floor_ms", 0.0) else "hbm"
+            if "ws_relax_sweep" in roof["all_kernels"]:
+                roof["all_kernels"]["ws_relax_sweep"]["note"] = ("algorithmic bytes = SURVEY 8(d)'s 29 B per voxel for ONE ideal sweep over the window, booked once "
+                                                                 "per flood; a `launch` here is a batch of 32 sweep launches; the sweeps of all phases are timed")
             if valu_doc:
                 roof["valu_floor_source"] = _VALU_FILE + " (instructions per algorithmic byte of a 62-frame run, scaled by this run's algorithmic bytes; 4 cycles per wave64 instruction, 1024 SIMDs)"
             if "bound" in roof["all_kernels"].get(name, {}):
@@ -566,19 +617,27 @@ def main():
         out["stages"]["host_and_glue"] = {"ms_per_step": round(dt / a.steps * 1e3 - sum(stage_ms.values()), 2),
                                           "note": "step time minus the library's kernel time: seeds' torch glue, stitch, launches, syncs"}
         if roof is not None:
+            # the practical HBM ceiling: the library's own plain copy, 16 bytes per lane per access, four loads in flight per lane
+            # (tf_copy16; round 5 -- rounds 2 - 4 timed torch's copy_, which reaches 4.9 TB/s where MI355X_MICROARCH.md's
+            # float4 copy reaches 6.29: a flattering denominator)
             n_copy = 1 << 28                                                  # float32 elements: 1 GiB read + 1 GiB written
             src = torch.empty(n_copy, dtype=torch.float32, device=bt_all.device).normal_()
             dst = torch.empty_like(src)
-            dst.copy_(src)
+
+            def copy_once():
+                _lib.check(_lib.lib().tf_copy16(_lib.ptr(src), _lib.ptr(dst), 4 * n_copy, _lib.stream_ptr()), "tf_copy16")
+            copy_once()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                dst.copy_(src)
+                copy_once()
             e1.record()
             torch.cuda.synchronize()
             copy_gbps = 10 * 2 * 4 * n_copy / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            assert torch.equal(src, dst)
             roof["practical_peak"] = round(copy_gbps, 1)
-            roof["practical_peak_note"] = "device-to-device copy of 2 x %.2f GB measured in this run (read + written bytes)" % (4 * n_copy / 1e9)
+            roof["practical_peak_note"] = ("the library's 16-byte-per-lane copy kernel (tf_copy16) over 2 x %.2f GB, measured in this run (read + written "
+                                           "bytes); MI355X_MICROARCH.md's float4 copy: 6290 GB/s" % (4 * n_copy / 1e9))
             roof["frac_practical"] = round(roof["achieved"] / copy_gbps, 4)
             del src, dst
         if not a.no_cpu_baseline and world == 1:             # reported baseline: rank 0 at N = 1 only

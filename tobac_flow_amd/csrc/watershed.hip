@@ -1201,8 +1201,12 @@ extern "C" size_t tf_watershed_workspace_bytes(int64_t T, int64_t H, int64_t W, 
 struct WsQueues { int *q[2]; int *cnt; int *inq; int qcap; int *h_cnt; int64_t *processed; };
 
 // Run one relaxation phase to its fixpoint.  phase_k = 0: K2/M1; otherwise chain level k (k == depth: root).
+// alg_bytes: the algorithmic bytes the timing facility books on this phase's first batch of sweeps.  The flood's figure is
+// SURVEY section 8(d)'s: 29 B per voxel for ONE ideal sweep over the volume (field 4 + markers 4 + labels 4 + mask 1 + flows
+// 16) -- booked once per flood, on phase A; the other phases add time, not algorithmic bytes (the roofline entry of
+// `ws_relax_sweep` then says what the sweeps cost against the single pass an ideal flood would need).
 static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q, hipStream_t s, int64_t max_sweeps,
-                        int64_t *sweeps_out)
+                        int64_t *sweeps_out, double alg_bytes = 0.0)
 {
     const unsigned nbR = (unsigned)((c.R + 255) / 256);
     const unsigned nb = nbR < 2048u ? nbR : 2048u;
@@ -1222,7 +1226,8 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
         // one timing scope per batch of launches, not per launch: ~1000 event pairs per call cost more than the
         // small sweeps themselves (measured: 8.5 ms per 12x5424^2 step); the scope therefore includes dispatch gaps
         {
-            TfProfScope ps(TFK_WS_RELAX, 0.0, s);                      // stop event recorded right after the last launch
+            TfProfScope ps(TFK_WS_RELAX, alg_bytes, s);                // stop event recorded right after the last launch
+            alg_bytes = 0.0;                                           // (booked once, on the first batch)
             for (int b = 0; b < WS_BATCH; b++) {
                 const int *qin = first ? nullptr : Q.q[parity];
                 const unsigned blocks = first ? nbR : grid_hint;
@@ -1845,7 +1850,7 @@ static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers
             const int rc_x = ws_job_export(j);
             if (rc_x) return rc_x;
         }
-        int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0]);
+        int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0], 29.0 * (double)N);
         if (rc) return rc;
         {
             TfProfScope ps(TFK_WS_SETUP, 0.0, s);
