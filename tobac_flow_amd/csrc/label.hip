@@ -12,12 +12,12 @@
 //                         judged on the frames both windows hold
 //
 // Pair counting.  Labels are spatially coherent, so in raster order the key stream (a << 32 | b) consists of long
-// runs.  One run-length pass (hipcub) turns N voxels into n_runs (key, length) records -- typically N / 50 -- which
+// runs.  One run-length pass (rocPRIM) turns N voxels into n_runs (key, length) records -- typically N / 50 -- which
 // are radix-sorted by key and reduced by key.  HBM traffic: 8 B read per voxel once; everything after that works on
 // the run records.  The label GRAPH (a few thousand nodes) is walked on the host in the reference's own visiting
 // order, because that order decides the numbering (label.py:145-170: first come, first served).
 #include "tf_common.h"
-#include <hipcub/hipcub.hpp>
+#include "tf_prim.h"
 #include <vector>
 #include <algorithm>
 
@@ -32,8 +32,8 @@ struct PairKey {
         return (x > 0 && y >= min_b) ? (((u64)(uint32_t)x << 32) | (uint32_t)y) : PC_INVALID;
     }
 };
-typedef hipcub::CountingInputIterator<int64_t> PcCount;
-typedef hipcub::TransformInputIterator<u64, PairKey, PcCount> PcKeyIter;
+typedef rocprim::counting_iterator<int64_t> PcCount;
+typedef rocprim::transform_iterator<PcCount, PairKey, u64> PcKeyIter;
 
 // number of runs of the key stream (runs of the invalid key included)
 // (grid-stride over the stream, one atomic per workgroup: with one atomic per wave the 0.9 M returning atomics of a
@@ -79,11 +79,9 @@ static PcSizes pc_temp_sizes(int64_t n, int64_t max_runs)
     PcSizes z; z.rle = z.sort = z.reduce = 0;
     PairKey pk{nullptr, nullptr, 1};
     PcKeyIter it(PcCount(0), pk);
-    (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, z.rle, it, (u64 *)nullptr, (int *)nullptr, (int *)nullptr, (int)n);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, z.sort, (const u64 *)nullptr, (u64 *)nullptr, (const int64_t *)nullptr,
-                                             (int64_t *)nullptr, (int)max_runs);
-    (void)hipcub::DeviceReduce::ReduceByKey(nullptr, z.reduce, (const u64 *)nullptr, (u64 *)nullptr, (const int64_t *)nullptr,
-                                            (int64_t *)nullptr, (int *)nullptr, hipcub::Sum(), (int)max_runs);
+    (void)tf_run_length_encode(nullptr, z.rle, it, (u64 *)nullptr, (int *)nullptr, (int *)nullptr, (size_t)n);
+    (void)tf_sort_pairs(nullptr, z.sort, (const u64 *)nullptr, (u64 *)nullptr, (const int64_t *)nullptr, (int64_t *)nullptr, (size_t)max_runs);
+    (void)tf_sum_by_key(nullptr, z.reduce, (const u64 *)nullptr, (u64 *)nullptr, (const int64_t *)nullptr, (int64_t *)nullptr, (int *)nullptr, (size_t)max_runs);
     return z;
 }
 
@@ -158,14 +156,13 @@ static int pc_run(const int32_t *a, const int32_t *b, int64_t n, int min_b, void
     int *d_nruns = (int *)(d_cnt + 2), *d_npairs = (int *)(d_cnt + 4);
     PcKeyIter it(PcCount(0), pk);
     size_t tb = temp;
-    TF_CHECK_HIP(hipcub::DeviceRunLengthEncode::Encode(tmp, tb, it, rk, rl, d_nruns, (int)n, s));
+    TF_CHECK_HIP(tf_run_length_encode(tmp, tb, it, rk, rl, d_nruns, (size_t)n, s));
     hipLaunchKernelGGL(k_pc_widen, dim3((unsigned)((runs + 255) / 256)), dim3(256), 0, s, rl, runs, rl64);
     TF_CHECK_LAUNCH();
     tb = temp;
-    TF_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, (const u64 *)rk, sk, (const int64_t *)rl64, sl, (int)runs, 0, 64, s));
+    TF_CHECK_HIP(tf_sort_pairs(tmp, tb, (const u64 *)rk, sk, (const int64_t *)rl64, sl, (size_t)runs, s));
     tb = temp;
-    TF_CHECK_HIP(hipcub::DeviceReduce::ReduceByKey(tmp, tb, (const u64 *)sk, uk, (const int64_t *)sl, us, d_npairs,
-                                                   hipcub::Sum(), (int)runs, s));
+    TF_CHECK_HIP(tf_sum_by_key(tmp, tb, (const u64 *)sk, uk, (const int64_t *)sl, us, d_npairs, (size_t)runs, s));
     int h_npairs = 0; u64 last_key = 0;
     TF_CHECK_HIP(hipMemcpyAsync(&h_npairs, d_npairs, sizeof(int), hipMemcpyDeviceToHost, s));
     TF_CHECK_HIP(hipStreamSynchronize(s));
@@ -573,7 +570,7 @@ k_sl_apply(const int32_t *__restrict__ labels, int64_t hw, const int *__restrict
 static size_t sl_scan_bytes(int64_t n_ids)
 {
     size_t b = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const int *)nullptr, (int *)nullptr, (int)std::min<int64_t>(n_ids, INT32_MAX));
+    (void)tf_exclusive_sum(nullptr, b, (const int *)nullptr, (int *)nullptr, (size_t)std::min<int64_t>(n_ids, INT32_MAX));
     return b;
 }
 
@@ -614,7 +611,7 @@ extern "C" int tf_slice_labels(const int32_t *labels, int64_t T, int64_t hw, int
     TF_CHECK_HIP(hipMemsetAsync(d_present, 0, (size_t)ids * 4, s));
     hipLaunchKernelGGL(k_sl_mark, grid, dim3(256), 0, s, labels, hw, (const int *)d_off, d_present);
     TF_CHECK_LAUNCH();
-    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, (const int *)d_present, d_rank, (int)ids, s));
+    TF_CHECK_HIP(tf_exclusive_sum(d_scan, scan_bytes, (const int *)d_present, d_rank, (size_t)ids, s));
     hipLaunchKernelGGL(k_sl_apply, grid, dim3(256), 0, s, labels, hw, (const int *)d_off, (const int *)d_rank, out);
     TF_CHECK_LAUNCH();
     int last_rank = 0, last_present = 0;

@@ -399,7 +399,7 @@ extern "C" int tf_merge_seeds(const int32_t *comp, const uint8_t *bg, const uint
 // ascending root (an exclusive scan over the root flags) reproduces SciPy's numbering, which labels
 // components in the order their first pixel is met in a raster scan.  `structure` must be centro-symmetric
 // (SciPy requires that too); only the "forward" half of its offsets is needed for the unions.
-#include <hipcub/hipcub.hpp>
+#include "tf_prim.h"
 
 __device__ __forceinline__ int ccl_find(int *__restrict__ parent, int p) {
     int q = parent[p];
@@ -558,7 +558,7 @@ extern "C" size_t tf_label_workspace_bytes(int64_t T, int64_t H, int64_t W)
     const int64_t n = T * H * W;
     size_t scan = 0;
     const int64_t nblk = (n + 255) / 256;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const int *)nullptr, (int *)nullptr, (int)(nblk > 0x7fffffff ? 0x7fffffff : nblk));
+    (void)tf_exclusive_sum(nullptr, scan, (const int *)nullptr, (int *)nullptr, (size_t)(nblk > 0x7fffffff ? 0x7fffffff : nblk));
     return tf_align_up((size_t)n * 4, 256) * 2 + tf_align_up((size_t)n, 256) + 2 * tf_align_up((size_t)nblk * 4, 256) + tf_align_up(scan, 256) + 4096;
 }
 
@@ -584,7 +584,7 @@ extern "C" int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, cons
     const int64_t nblk = (n + 255) / 256;
     int *block_count = ar.take<int>(nblk), *block_base = ar.take<int>(nblk);
     size_t scan_bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const int *)nullptr, (int *)nullptr, (int)nblk);
+    (void)tf_exclusive_sum(nullptr, scan_bytes, (const int *)nullptr, (int *)nullptr, (size_t)nblk);
     char *scan_tmp = ar.take<char>(scan_bytes ? scan_bytes : 1);
     if (!ar.ok()) { tf_set_error("tf_label: workspace too small"); return TF_ENOMEM; }
     const unsigned nb = (unsigned)((n + 255) / 256);
@@ -606,7 +606,7 @@ extern "C" int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, cons
     TF_CHECK_LAUNCH();
     const unsigned nb4 = (unsigned)((nblk + 3) / 4);             // four 256-voxel blocks (waves) per workgroup
     hipLaunchKernelGGL(k_ccl_count_roots, dim3(nb4), dim3(256), 0, s, n, (const uint8_t *)isroot, block_count);
-    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, (const int *)block_count, block_base, (int)nblk, s));
+    TF_CHECK_HIP(tf_exclusive_sum(scan_tmp, scan_bytes, (const int *)block_count, block_base, (size_t)nblk, s));
     hipLaunchKernelGGL(k_ccl_rank_roots, dim3(nb4), dim3(256), 0, s, n, (const uint8_t *)isroot, (const int *)block_base, rank);
     if (tf_vec4_ok({parent, labels}, {})) hipLaunchKernelGGL(k_ccl_number4, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, s, n, parent, rank, labels);
     else hipLaunchKernelGGL(k_ccl_number, dim3(nb), dim3(256), 0, s, n, parent, rank, labels);

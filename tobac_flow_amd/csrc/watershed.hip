@@ -36,7 +36,7 @@
 #include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
-#include <hipcub/hipcub.hpp>
+#include "tf_prim.h"
 #include <new>
 
 typedef unsigned long long u64;
@@ -1134,23 +1134,23 @@ k_ws_tie_value_max(WsC c, const int *__restrict__ org, const float *__restrict__
 }
 
 struct WsU8ToInt { __host__ __device__ __forceinline__ int operator()(uint8_t v) const { return (int)v; } };
-typedef hipcub::TransformInputIterator<int, WsU8ToInt, const uint8_t *> WsFlagIter;
+typedef rocprim::transform_iterator<const uint8_t *, WsU8ToInt, int> WsFlagIter;
 
 // The flag scan runs in chunks of at most 2^30 voxels (the scan primitive counts its items in an int), each continuing
 // from the total of the chunks before it: volumes beyond 2^31 voxels -- config F's 144 full-disk frames as ONE exact
 // flood -- only need the RELEVANT pixel count to fit the int32 compact ids.
 #define WS_SCAN_CHUNK (1ll << 30)
 struct WsIntToLL { __host__ __device__ __forceinline__ long long operator()(int v) const { return (long long)v; } };
-typedef hipcub::TransformInputIterator<long long, WsIntToLL, const int *> WsCountIter;
+typedef rocprim::transform_iterator<const int *, WsIntToLL, long long> WsCountIter;
 static size_t ws_scan_temp_bytes(int64_t n) {
     size_t bytes = 0, b2 = 0, b3 = 0;
     WsFlagIter it((const uint8_t *)nullptr, WsU8ToInt());
     // size queries only (null temp storage): the flag scan over n positions, and the 64-bit scans of per-block counts
     // (tile ids; seed numbers of the reference-order export) -- on a small volume the latter need MORE than the former
-    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, bytes, it, (int *)nullptr, hipcub::Sum(), 0, (int)(n > WS_SCAN_CHUNK ? WS_SCAN_CHUNK : n));
+    (void)tf_exclusive_sum_from(nullptr, bytes, it, (int *)nullptr, 0, (size_t)(n > WS_SCAN_CHUNK ? WS_SCAN_CHUNK : n));
     const int64_t nb = (n + 255) / 256 < 0x7fffffffll ? (n + 255) / 256 : 0x7ffffffell;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b2, (const long long *)nullptr, (long long *)nullptr, (int)nb);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b3, WsCountIter((const int *)nullptr, WsIntToLL()), (long long *)nullptr, (int)nb);
+    (void)tf_exclusive_sum(nullptr, b2, (const long long *)nullptr, (long long *)nullptr, (size_t)nb);
+    (void)tf_exclusive_sum(nullptr, b3, WsCountIter((const int *)nullptr, WsIntToLL()), (long long *)nullptr, (size_t)nb);
     if (b2 > bytes) bytes = b2;
     if (b3 > bytes) bytes = b3;
     return bytes;
@@ -1164,7 +1164,7 @@ static int ws_scan_flags(const uint8_t *flag, int *scan, int64_t N, void *tmp, s
         const int64_t n = N - off < WS_SCAN_CHUNK ? N - off : WS_SCAN_CHUNK;
         size_t tb = tmp_bytes;
         WsFlagIter it(flag + off, WsU8ToInt());
-        TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveScan(tmp, tb, it, scan + off, hipcub::Sum(), (int)carry, (int)n, s));
+        TF_CHECK_HIP(tf_exclusive_sum_from(tmp, tb, it, scan + off, (int)carry, (size_t)n, s));
         int last_scan = 0; uint8_t last_flag = 0;
         TF_CHECK_HIP(hipMemcpyAsync(&last_scan, scan + off + n - 1, sizeof(int), hipMemcpyDeviceToHost, s));
         TF_CHECK_HIP(hipMemcpyAsync(&last_flag, flag + off + n - 1, 1, hipMemcpyDeviceToHost, s));
@@ -1423,16 +1423,16 @@ static int ws_job_export(tf_ws_job *j)
     int *n_seed = (int *)j->seed_blocks, *n_small = n_seed + nb256;
     long long *base_seed = (long long *)(((uintptr_t)(n_small + nb256) + 15) & ~(uintptr_t)15), *base_small = base_seed + nb256;
     size_t need = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need, WsCountIter((const int *)nullptr, WsIntToLL()), (long long *)nullptr, (int)nb256);
+    (void)tf_exclusive_sum(nullptr, need, WsCountIter((const int *)nullptr, WsIntToLL()), (long long *)nullptr, (size_t)nb256);
     TF_REQUIRE(need <= j->scan_bytes, "tf_watershed: scan scratch too small for the seed numbering");
     int *d_any = j->d_flags + WS_BATCH + 6;                             // [0] a seed below the tie value, [1] a floodable pixel below it
     TF_CHECK_HIP(hipMemsetAsync(d_any, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(k_ws_seed_counts, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, j->field, N, h_vmax, n_seed, n_small, d_any);
     TF_CHECK_LAUNCH();
     size_t tb = j->scan_bytes;
-    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(j->scan_tmp, tb, WsCountIter(n_seed, WsIntToLL()), base_seed, (int)nb256, s));
+    TF_CHECK_HIP(tf_exclusive_sum(j->scan_tmp, tb, WsCountIter(n_seed, WsIntToLL()), base_seed, (size_t)nb256, s));
     tb = j->scan_bytes;
-    TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(j->scan_tmp, tb, WsCountIter(n_small, WsIntToLL()), base_small, (int)nb256, s));
+    TF_CHECK_HIP(tf_exclusive_sum(j->scan_tmp, tb, WsCountIter(n_small, WsIntToLL()), base_small, (size_t)nb256, s));
     long long h_last[4] = {0, 0, 0, 0}; int h_lastc[2] = {0, 0};
     TF_CHECK_HIP(hipMemcpyAsync(&h_last[0], base_seed + nb256 - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
     TF_CHECK_HIP(hipMemcpyAsync(&h_last[1], base_small + nb256 - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -1579,7 +1579,7 @@ static int ws_job_export(tf_ws_job *j)
             hipLaunchKernelGGL(k_ws_code_counts, dim3((unsigned)nb256), dim3(256), 0, s, (const uint8_t *)j->cls, (const int *)j->cid, j->field, N, h_vmax, D, n_exc);
             TF_CHECK_LAUNCH();
             tb = j->scan_bytes;
-            TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(j->scan_tmp, tb, WsCountIter(n_exc, WsIntToLL()), base_exc, (int)nb256, s));
+            TF_CHECK_HIP(tf_exclusive_sum(j->scan_tmp, tb, WsCountIter(n_exc, WsIntToLL()), base_exc, (size_t)nb256, s));
             long long h_e = 0; int h_ec = 0;
             TF_CHECK_HIP(hipMemcpyAsync(&h_e, base_exc + nb256 - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
             TF_CHECK_HIP(hipMemcpyAsync(&h_ec, n_exc + nb256 - 1, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1761,13 +1761,13 @@ static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers
         // (NV ints) holds the 64-bit counts and bases (2 x NV / 256 x 8 bytes)
         const int64_t n_tiles = NV / 256;
         size_t tile_scan_bytes = 0;
-        if (!rv) (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tile_scan_bytes, (const long long *)nullptr, (long long *)nullptr, (int)n_tiles);
+        if (!rv) (void)tf_exclusive_sum(nullptr, tile_scan_bytes, (const long long *)nullptr, (long long *)nullptr, (size_t)n_tiles);
         tiles = !rv && NV % 256 == 0 && n_tiles > 0 && n_tiles < 0x7fffffffll && tile_scan_bytes <= scan_bytes;
         if (tiles) {
             long long *t_count = (long long *)scan, *t_base = t_count + n_tiles;
             hipLaunchKernelGGL(k_ws_count_tiles, dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, s, (const uint8_t *)flag, n_tiles, t_count);
             size_t tb = scan_bytes;
-            TF_CHECK_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, tb, (const long long *)t_count, t_base, (int)n_tiles, s));
+            TF_CHECK_HIP(tf_exclusive_sum(scan_tmp, tb, (const long long *)t_count, t_base, (size_t)n_tiles, s));
             long long h_last[2] = {0, 0};
             TF_CHECK_HIP(hipMemcpyAsync(&h_last[0], t_base + n_tiles - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
             TF_CHECK_HIP(hipMemcpyAsync(&h_last[1], t_count + n_tiles - 1, sizeof(long long), hipMemcpyDeviceToHost, s));
