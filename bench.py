@@ -123,9 +123,10 @@ def _traffic(profile_name, alg_bytes_per_launch):
 
 def cpu_baseline(seed, vr_steps=1):
     """The oracle (CPU restatement of the reference's cv2/numpy/Cython path, kind = "port") timed on the host cores of
-    this box on a bounded sample of the same workload: a 17 x 1536 x 1536 stack (round 5: 32 Farneback tasks, so that the
-    pool can use up to 32 of the box's cores; rounds 1 - 4 timed a 5-frame stack, whose eight tasks left all but eight cores
-    idle).  The order-independent stages run on a thread pool (Farneback and refinement: one task per frame pair and
+    this box on a bounded sample of the same workload: a 9 x 1536 x 1536 stack (round 5: 16 Farneback tasks -- the CPU share
+    of a one-GPU box of this pool; rounds 1 - 4 timed a 5-frame stack with eight tasks.  17 frames / 32 threads were measured too:
+    flow 5.6 s and Sobel 13.2 s on 32 threads, then 30.2 s of sequential heap flood on one: 0.82 Mpix/s in 49 s -- the flood, one
+    thread in the reference too, dominates any wider sample and a 49-second baseline is outside the benchmark's time budget).  The order-independent stages run on a thread pool (Farneback and refinement: one task per frame pair and
     direction; Sobel: one task per frame -- the C restatements and numpy release the GIL); the heap flood is sequential by
     construction (one thread, like the reference's).  TF_BENCH_CPU_FRAMES overrides the number of frames."""
     import numpy as np
@@ -136,7 +137,7 @@ def cpu_baseline(seed, vr_steps=1):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import blob_sequence
     from oracle import _lib as ol, np_ops, ws_oracle
-    T, H, W = int(os.environ.get("TF_BENCH_CPU_FRAMES", "17")), 1536, 1536
+    T, H, W = int(os.environ.get("TF_BENCH_CPU_FRAMES", "9")), 1536, 1536
     rng = np.random.default_rng(seed)
     bt = blob_sequence(rng, T, H, W, n_blobs=36)
     L = ol.lib()

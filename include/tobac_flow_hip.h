@@ -548,6 +548,7 @@ int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words, void **str
 int tf_stream_destroy(void *stream);
 int tf_debug_cu_histogram(void *stream, int n_workgroups, int *hist_host_2048);
 int tf_copy16(const void *src, void *dst, size_t bytes, void *stream);
+int tf_copy16_variant(const void *src, void *dst, size_t bytes, void *stream, int variant);   /* development forms of the same copy */
 
 /* SURVEY.md 8(b) "ownership": the library never retains a caller's pointer past return and owns no device memory (all
  * scratch is the caller's workspace); its only pooled resource is the HIP events of the timing facility above.

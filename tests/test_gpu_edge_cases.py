@@ -504,3 +504,32 @@ def test_farneback_split_batch_equals_the_unsplit_one(B, parts):
     m.calc_batch_dev(prev, nxt, f1, b1, parts=parts)
     assert torch.equal(f0, f1) and torch.equal(b0, b1)
     assert float(f0.abs().max()) > 0
+
+
+def test_cu_masked_stream_and_the_copy_kernel():
+    """Round 5 plumbing of the C ABI: tf_stream_create_cu_mask gives a stream whose kernels occupy only the CUs of the mask (on
+    this part bit i selects a CU of XCD i mod 8: 32 bits = four CUs of every XCD), tf_debug_cu_histogram shows where workgroups
+    ran, tf_copy16 -- the plain copy bench.py measures its practical HBM ceiling with -- copies, and refuses misaligned input."""
+    import ctypes
+    import torch
+    from tobac_flow_amd import _lib
+    L = _lib.lib()
+    torch.zeros(1, device="cuda")
+    words = np.zeros(8, np.uint32)
+    words[0] = 0xFFFFFFFF
+    s = ctypes.c_void_p()
+    _lib.check(L.tf_stream_create_cu_mask(words.ctypes.data_as(_lib._P), 8, ctypes.byref(s)), "tf_stream_create_cu_mask")
+    hist = np.zeros(2048, np.int32)
+    _lib.check(L.tf_debug_cu_histogram(s, 2048, hist.ctypes.data_as(_lib._P)), "tf_debug_cu_histogram")
+    assert hist.sum() == 2048 and np.count_nonzero(hist) <= 32 and (hist.reshape(8, 256).sum(1) > 0).all()
+    ext = torch.cuda.ExternalStream(s.value)
+    with torch.cuda.stream(ext):                                       # torch work on the masked stream
+        a = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
+        b = torch.empty_like(a)
+        _lib.check(L.tf_copy16(_lib.ptr(a), _lib.ptr(b), a.numel() * 4, ctypes.c_void_p(ext.cuda_stream)), "tf_copy16")
+    ext.synchronize()
+    assert torch.equal(a, b)
+    assert L.tf_copy16(ctypes.c_void_p(a.data_ptr() + 4), _lib.ptr(b), 1024, None) == -1      # misaligned: TF_EINVAL
+    del ext
+    assert L.tf_stream_destroy(s) == 0
+    assert L.tf_stream_create_cu_mask(None, 8, ctypes.byref(s)) == -1

@@ -51,6 +51,32 @@ def test_a_starved_chain_report_becomes_an_exception(monkeypatch):
         model.check_launches()
 
 
+def test_device_field_is_a_tensor_with_a_time_coordinate():
+    """detection.DeviceField: what a device-resident pipeline hands the recipes in place of an xr.DataArray (a torch tensor
+    has no coordinates and Tensor.t is the transpose): `.data`, `.t` with `.data` / `.values`, the arithmetic the drop-in
+    scripts use on their fields (wvd - swd, wvd + swd, -bt), and the checks of its constructor.  (CPU tensors do for the
+    container; the recipes themselves need the GPU.)"""
+    import numpy as np
+    import pytest
+    import torch
+    from tobac_flow_amd.detection import DeviceField, _is_device
+    from tobac_flow_amd.flow import _unwrap_device_field
+    times = np.datetime64("2020-06-01T00:00") + np.arange(3) * np.timedelta64(10, "m")
+    a = DeviceField(torch.arange(24, dtype=torch.float32).reshape(3, 2, 4), times)
+    b = DeviceField(torch.ones(3, 2, 4), times)
+    assert a.shape == (3, 2, 4) and a.dtype == torch.float32 and len(a.t) == 3 and np.array_equal(a.t.data, times) and np.array_equal(np.asarray(a.t), times)
+    for got, want in (((a - b), a.data - 1), ((a + b), a.data + 1), ((-a), -a.data), ((a - 2.0), a.data - 2)):
+        assert isinstance(got, DeviceField) and torch.equal(got.data, want) and np.array_equal(got.t.values, times)
+    assert _is_device(a) and _is_device(a.data) and not _is_device(np.zeros(3))
+    assert _unwrap_device_field(a) is a.data and _unwrap_device_field(a.data) is a.data
+    arr = np.zeros((3, 2, 4), np.float32)
+    assert _unwrap_device_field(arr) is arr
+    with pytest.raises(TypeError):
+        DeviceField(arr, times)
+    with pytest.raises(ValueError, match="time coordinate"):
+        DeviceField(torch.zeros(4, 2, 2), times)
+
+
 def test_farneback_launch_arithmetic_of_the_host_side():
     """Host-only arithmetic of the C ABI (no device work): workspace sizes grow with the batch, hold the strips' hand-over
     words of the iteration kernel at every size (1 x 1 included), and the workgroup count the batching decisions rest on

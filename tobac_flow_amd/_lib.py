@@ -129,6 +129,7 @@ _PROTOS = {
     "tf_stream_destroy": (_c.c_int, [_P]),
     "tf_debug_cu_histogram": (_c.c_int, [_P, _c.c_int, _P]),
     "tf_copy16": (_c.c_int, [_P, _P, _c.c_size_t, _P]),
+    "tf_copy16_variant": (_c.c_int, [_P, _P, _c.c_size_t, _P, _c.c_int]),
     "tf_shutdown": (_c.c_int, []),
     "tf_selftest_shared_divide": (_c.c_int, [_c.c_int64, _c.c_uint64, _P, _P]),
 }

@@ -124,24 +124,48 @@ extern "C" int tf_debug_cu_histogram(void *stream, int n_workgroups, int *hist_h
 }
 
 // ---- the practical HBM ceiling: a plain copy, 16 bytes per lane per access (bench.py's `practical_peak`) ---------------
+// A workgroup copies tiles of UNROLL x 256 consecutive 16-byte words (all loads of a tile in flight before its first store);
+// the grid is 8 workgroups per CU, grid-stride over the tiles (cdna_hip_programming.md, guideline 11).
+template <int UNROLL, bool NT>
 __global__ void __launch_bounds__(256)
 k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // four independent 16-byte loads in flight per lane before the first store
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    const size_t tile = (size_t)UNROLL * 256, n_tiles = n16 / tile;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const size_t base = t * tile + threadIdx.x;
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+            if (NT) { typedef unsigned int u4 __attribute__((ext_vector_type(4))); const u4 r = __builtin_nontemporal_load((const u4 *)(src + base + k * 256)); v[k] = make_uint4(r.x, r.y, r.z, r.w); }
+            else v[k] = src[base + k * 256];
+        }
+#pragma unroll
+        for (int k = 0; k < UNROLL; k++) {
+            if (NT) { typedef unsigned int u4 __attribute__((ext_vector_type(4))); u4 r; r.x = v[k].x; r.y = v[k].y; r.z = v[k].z; r.w = v[k].w; __builtin_nontemporal_store(r, (u4 *)(dst + base + k * 256)); }
+            else dst[base + k * 256] = v[k];
+        }
     }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    for (size_t i = n_tiles * tile + (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
-extern "C" int tf_copy16(const void *src, void *dst, size_t bytes, void *stream)
+// variant: 0 = the default form; 1 .. : development forms (tools/copy_bw.py picks the default)
+extern "C" int tf_copy16_variant(const void *src, void *dst, size_t bytes, void *stream, int variant)
 {
     TF_REQUIRE(src && dst && bytes >= 16 && bytes % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "tf_copy16: 16-byte aligned buffers of a multiple of 16 bytes");
     const size_t n16 = bytes / 16;
-    const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst, n16);
+    hipStream_t s = (hipStream_t)stream;
+    const uint4 *a = (const uint4 *)src; uint4 *b = (uint4 *)dst;
+    const unsigned g8 = (unsigned)std::min<size_t>((n16 + 255) / 256, 256 * 8), g16 = (unsigned)std::min<size_t>((n16 + 255) / 256, 256 * 16);
+    switch (variant) {
+    case 1: hipLaunchKernelGGL((k_copy16<4, false>), dim3(g16), dim3(256), 0, s, a, b, n16); break;
+    case 2: hipLaunchKernelGGL((k_copy16<8, false>), dim3(g8), dim3(256), 0, s, a, b, n16); break;
+    case 3: hipLaunchKernelGGL((k_copy16<4, true>), dim3(g8), dim3(256), 0, s, a, b, n16); break;
+    case 4: hipLaunchKernelGGL((k_copy16<8, true>), dim3(g8), dim3(256), 0, s, a, b, n16); break;
+    case 5: hipLaunchKernelGGL((k_copy16<2, false>), dim3(g8), dim3(256), 0, s, a, b, n16); break;
+    case 6: hipLaunchKernelGGL((k_copy16<1, false>), dim3(g16), dim3(256), 0, s, a, b, n16); break;
+    case 7: hipLaunchKernelGGL((k_copy16<4, false>), dim3(g8), dim3(256), 0, s, a, b, n16); break;
+    default: hipLaunchKernelGGL((k_copy16<4, true>), dim3(g8), dim3(256), 0, s, a, b, n16); break;      // nontemporal loads and stores: 5.9 TB/s over 2 x 1 GiB (plain: 5.6; torch copy_: 5.1; tools/copy_bw.py)
+    }
     TF_CHECK_LAUNCH();
     return TF_OK;
 }
+extern "C" int tf_copy16(const void *src, void *dst, size_t bytes, void *stream) { return tf_copy16_variant(src, dst, bytes, stream, 0); }
