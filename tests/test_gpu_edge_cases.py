@@ -395,6 +395,24 @@ def test_a_starved_chain_is_an_error_not_a_flow_of_nans(tf, tmp_path):
     assert np.array_equal(again[0], want[0]) and np.array_equal(again[1], want[1])
     assert L.tf_farneback_debug_set_starved() == 0
     assert L.tf_farneback_check() == _lib.TF_ESTARVED and L.tf_farneback_check() == 0
+    # (iii) device-resident input: create_flow returns before the device is done, its check is deferred to an event -- the report
+    # of a launch that finishes later arrives at the next use of the Flow object (non-blocking poll) or at Flow.check()
+    import torch
+    ad = torch.from_numpy(a).cuda()
+    fl = tf.create_flow(ad, "Farneback")
+    assert fl._pending_check is not None
+    torch.cuda.synchronize()
+    assert L.tf_farneback_debug_set_starved() == 0                        # "a chain of those launches gave up"
+    with pytest.raises(_lib.TobacFlowHipError, match="gave up"):
+        fl.sobel(ad, direction="uphill", method="cubic")                 # first use after the launches have finished
+    assert L.tf_farneback_check() == 0
+    fl.sobel(ad, direction="uphill", method="cubic")                     # reported once
+    fl2 = tf.create_flow(ad, "Farneback")
+    assert L.tf_farneback_debug_set_starved() == 0
+    with pytest.raises(_lib.TobacFlowHipError, match="gave up"):
+        fl2.check()
+    fl2.check()
+    assert torch.equal(torch.nan_to_num(fl2.forward_flow, nan=-7.0), torch.nan_to_num(torch.from_numpy(np.clip(want[0], -20, 20)).cuda(), nan=-7.0))
 
 
 def test_shutdown_releases_the_timing_pool_and_leaves_the_library_usable(tf):

@@ -491,7 +491,9 @@ k_ws_init_labelset(const u64 *__restrict__ pix, const int32_t *__restrict__ mark
 // (~2 x 10^10 / s, MI355X_MICROARCH.md "Global float atomics": 64 lanes in 64 rows).  Fewer launches is what is kept.
 // Chaotic relaxation of a monotone system reaches the same fixpoint in any order, and the in-queue flags work as
 // before (a staged pixel has its flag set; whoever processes it clears the flag before reading the key).
+#ifndef WS_LDS_CAP
 #define WS_LDS_CAP 4096
+#endif
 struct WsStage { int cnt[2]; int base; int buf[2][WS_LDS_CAP]; };
 
 // stage an append in LDS buffer w (one LDS atomic per appended id); a full buffer spills straight to the global queue

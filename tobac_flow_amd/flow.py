@@ -73,6 +73,8 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
     # (scripts/dcc_detect_goes.py:164-303 only pass the object on), and 2 x 7.5 GB per 16 x 5424^2 window would cross PCIe
     # twice otherwise (down here, up again at the first Flow method)
     extra["_device_out"] = True
+    checks = []
+    extra["_check_out"] = checks                # device output: the starved-chain check arrives as a poll bound to an event
     if workspace_gb is not None:
         extra["_workspace_gb"] = float(workspace_gb)
     if split_parts is not None:
@@ -81,12 +83,19 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
     forward_flow, backward_flow = calculate_flow(data, model=model, vr_steps=vr_steps,
                                                  smoothing_passes=smoothing_passes, interp_method=interp_method,
                                                  _max_value=float(max_value), **extra)
-    if on_frames_ready is not None and "flow" in holder:
-        return holder["flow"]
     t = _lib.torch()
-    if isinstance(data, t.Tensor):
-        return Flow(forward_flow, backward_flow)
-    return Flow._lazy_host(forward_flow, backward_flow)
+    if on_frames_ready is not None and "flow" in holder:
+        flow = holder["flow"]
+    elif isinstance(data, t.Tensor):
+        flow = Flow(forward_flow, backward_flow)
+    else:
+        flow = Flow._lazy_host(forward_flow, backward_flow)
+    if checks:
+        if isinstance(data, t.Tensor):
+            flow._pending_check = checks[0]       # polled at every use of the object (Flow._dev_flows); Flow.check() waits for it
+        else:
+            checks[0](block=True)                # host input: the reference's call is synchronous, so is this one
+    return flow
 
 
 @tag_func(_lib.FUNC_DIFF)
@@ -112,6 +121,14 @@ class Flow(AbstractFlow):
         self._fw = forward_flow
         self._bw = backward_flow
         self._dev = None
+        self._pending_check = None
+
+    def check(self):
+        """Wait for the launches that produced this object and raise if one of them reported a starved chain (create_flow on
+        device-resident input returns before the device is done: its check is deferred to the object's uses and to this call)."""
+        if self._pending_check is not None:
+            poll, self._pending_check = self._pending_check, None
+            poll(block=True)
 
     @classmethod
     def _lazy_host(cls, forward_dev, backward_dev) -> "Flow":
@@ -153,6 +170,8 @@ class Flow(AbstractFlow):
         return Flow(self.forward_flow[items], self.backward_flow[items])
 
     def _dev_flows(self):
+        if self._pending_check is not None:
+            self._pending_check()                # (non-blocking: reports once the producing launches have finished)
         if self._dev is None:
             t = _lib.torch()
             self._dev = (_lib.to_dev(self._fw, t.float32), _lib.to_dev(self._bw, t.float32))
@@ -368,7 +387,7 @@ def _side_stream(main):
 
 def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_passes, interp_method,
                          norm_name, norm_method, normalisation_kwargs, on_device, max_value=float("inf"), on_batch=None,
-                         workspace_gb=None, split_parts=None):
+                         workspace_gb=None, split_parts=None, check_out=None):
     t = _lib.torch()
     L = _lib.lib()
     H, W = shape
@@ -619,15 +638,23 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         if free_now + (t.cuda.memory_reserved() - t.cuda.memory_allocated()) < 0.2 * total:
             _lib.release_workspaces("farneback")
     finalize_ends()
-    if hasattr(of_model, "check_launches"):
-        # before the last hand-over: a stack whose flow holds NaN rows (a starved chain of the iteration kernel) raises here
-        # instead of being returned -- one stream synchronisation per stack
-        of_model.check_launches("create_flow / calculate_flow")
+    # A stack whose flow holds NaN rows (a starved chain of the iteration kernel) must not be returned as if nothing had
+    # happened.  Host output: the download below synchronises anyway -- check behind it.  Device output: the caller's pipeline is
+    # asynchronous; the check is DEFERRED to an event recorded here (`pending`): the Flow object polls it at every use and
+    # create_flow's callers with a synchronisation of their own (detect_stack_windows) wait for it there
+    pending = of_model.deferred_check("create_flow / calculate_flow") if hasattr(of_model, "deferred_check") else None
     if on_batch is not None:
         on_batch(forward, backward, n_pairs, n_pairs)
     if on_device:
+        if check_out is not None and pending is not None:
+            check_out.append(pending)
+        elif pending is not None:
+            pending(block=True)                  # (a caller that cannot take the deferred check gets the synchronous one)
         return forward, backward
-    return forward.cpu().numpy(), backward.cpu().numpy()
+    out = forward.cpu().numpy(), backward.cpu().numpy()
+    if pending is not None:
+        pending(block=True)
+    return out
 
 
 def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
@@ -639,6 +666,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     device_out = normalisation_kwargs.pop("_device_out", False)
     workspace_gb = normalisation_kwargs.pop("_workspace_gb", None)
     split_parts = normalisation_kwargs.pop("_split_parts", None)
+    check_out = normalisation_kwargs.pop("_check_out", None)
     of_model = select_of_model(model)
     norm_method = select_normalisation_method(normalisation_method)
     t = _lib.torch()
@@ -652,7 +680,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     T = d.shape[0]
     return _calculate_flow_impl(lambda i: (d[i], d[i + 1]), T, tuple(d.shape[1:]), of_model, vr_steps,
                                 smoothing_passes, interp_method, normalisation_method, norm_method,
-                                normalisation_kwargs, on_device, max_value, on_batch, workspace_gb, split_parts)
+                                normalisation_kwargs, on_device, max_value, on_batch, workspace_gb, split_parts, check_out)
 
 
 def calculate_flow_2(a, b, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,

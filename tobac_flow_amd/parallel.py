@@ -598,5 +598,8 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             o.mark("stitched")
         results.append(wins if consume is None else consume(c, wins))
         del wins, wq
+    # the stack's flow was computed asynchronously: by now every window has been finished (host synchronisations behind the
+    # flow's last launch) -- a starved chain of the iteration kernel (NaN rows, TF_ESTARVED) is reported here at the latest
+    flow_all.check()
     del flow_all
     return results, o.info

@@ -38,6 +38,29 @@ class FarnebackFlow:
         _lib.torch().cuda.current_stream().synchronize()
         _lib.check(_lib.lib().tf_farneback_check(), what)
 
+    def deferred_check(self, what="Farneback flow"):
+        """check_launches without stalling a device-resident pipeline: returns a callable `poll(block=False)` bound to an event
+        recorded NOW on the current stream.  poll() reports (raises like check_launches) once the event has passed and is a
+        no-op afterwards; poll(block=True) waits for it first.  A host that runs seconds ahead of the device -- enqueuing the
+        next stages, allocating their scratch -- keeps doing so (a full synchronisation at the end of create_flow cost config
+        F3 0.9 s per step of exposed allocator work), and the report still arrives: at the next use of the Flow, at the
+        next tf_farneback_batch* call (which reports on entry), or at the caller's own synchronisation."""
+        t = _lib.torch()
+        ev = t.cuda.Event()
+        ev.record()
+        state = {"done": False}
+
+        def poll(block=False):
+            if state["done"]:
+                return
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            state["done"] = True
+            _lib.check(_lib.lib().tf_farneback_check(), what)
+        return poll
+
     def calc_pair_dev(self, prev, nxt, want_fwd=True, want_bwd=True, tag="farneback"):
         """Both directions at once on device uint8 tensors (they share pyramid + expansion)."""
         import ctypes
