@@ -543,6 +543,8 @@ int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
  * hipExtStreamCreateWithCUMask): parallel.detect_stack_windows finishes the floods of ready windows on such a stream, so
  * that they displace the flow's iteration workgroups on a part of the chip only.  tf_debug_cu_histogram launches
  * n_workgroups idle workgroups on a stream and returns how many ran where: hist[xcc * 256 + HW_ID bits 15:8].
+ * tf_stream_destroy synchronises the stream and RETIRES it (kept until the process ends: on ROCm 7.2 a later large hipMalloc crashes
+ * in a process that has destroyed a CU-masked stream).
  * tf_copy16: dst = src, 16 bytes per lane per access -- the measured practical HBM ceiling of bench.py's roofline. */
 int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words, void **stream_out);
 int tf_stream_destroy(void *stream);

@@ -540,14 +540,15 @@ def test_cu_masked_stream_and_the_copy_kernel():
     hist = np.zeros(2048, np.int32)
     _lib.check(L.tf_debug_cu_histogram(s, 2048, hist.ctypes.data_as(_lib._P)), "tf_debug_cu_histogram")
     assert hist.sum() == 2048 and np.count_nonzero(hist) <= 32 and (hist.reshape(8, 256).sum(1) > 0).all()
-    ext = torch.cuda.ExternalStream(s.value)
-    with torch.cuda.stream(ext):                                       # torch work on the masked stream
-        a = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
-        b = torch.empty_like(a)
-        _lib.check(L.tf_copy16(_lib.ptr(a), _lib.ptr(b), a.numel() * 4, ctypes.c_void_p(ext.cuda_stream)), "tf_copy16")
-    ext.synchronize()
+    # (the tensors are allocated on the default stream: torch's caching allocator keeps the blocks of a stream it has allocated on
+    # for ever and synchronises that stream when it empties its cache -- a stream that is going to be destroyed must never be
+    # the current stream of an allocation; the first version of this test did that and a LATER test's empty_cache() crashed)
+    a = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
+    b = torch.empty_like(a)
+    torch.cuda.synchronize()
+    _lib.check(L.tf_copy16(_lib.ptr(a), _lib.ptr(b), a.numel() * 4, s), "tf_copy16")
+    torch.cuda.ExternalStream(s.value).synchronize()
     assert torch.equal(a, b)
     assert L.tf_copy16(ctypes.c_void_p(a.data_ptr() + 4), _lib.ptr(b), 1024, None) == -1      # misaligned: TF_EINVAL
-    del ext
     assert L.tf_stream_destroy(s) == 0
     assert L.tf_stream_create_cu_mask(None, 8, ctypes.byref(s)) == -1

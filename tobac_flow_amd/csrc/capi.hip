@@ -90,9 +90,18 @@ extern "C" int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words,
     *stream_out = (void *)s;
     return TF_OK;
 }
+// tf_stream_destroy RETIRES the stream: it is synchronised and kept until the process ends.  On this ROCm (7.2) a process that has
+// destroyed a CU-masked stream crashes inside a LATER large hipMalloc (found by the test suite: hipStreamDestroy of the masked
+// stream in one test, a segmentation fault in the 132-GiB allocation of another; with the stream left alive the same sequence
+// passes).  A stream costs a few KB; a caller creates one per (device, mask).
+static std::mutex g_retired_mu;
+static std::vector<hipStream_t> g_retired;
 extern "C" int tf_stream_destroy(void *stream)
 {
-    if (stream) TF_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    if (!stream) return TF_OK;
+    TF_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    std::lock_guard<std::mutex> lk(g_retired_mu);
+    g_retired.push_back((hipStream_t)stream);
     return TF_OK;
 }
 
@@ -112,14 +121,20 @@ extern "C" int tf_debug_cu_histogram(void *stream, int n_workgroups, int *hist_h
 {
     TF_REQUIRE(hist_host_2048 && n_workgroups > 0, "tf_debug_cu_histogram: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    // (plain hipMalloc / hipFree: a stream-ordered allocation would leave a block of the runtime's memory pool tied to `stream`,
+    // and the caller may destroy that stream -- a later out-of-memory trim of the pool then walks a dead stream: the crash
+    // the first version of this function caused in a LATER test's 132-GiB allocation)
     int *d = nullptr;
-    TF_CHECK_HIP(hipMallocAsync((void **)&d, 2048 * sizeof(int), s));
-    TF_CHECK_HIP(hipMemsetAsync(d, 0, 2048 * sizeof(int), s));
-    hipLaunchKernelGGL(k_debug_cu_histogram, dim3((unsigned)n_workgroups), dim3(64), 0, s, d);
-    TF_CHECK_LAUNCH();
-    TF_CHECK_HIP(hipMemcpyAsync(hist_host_2048, d, 2048 * sizeof(int), hipMemcpyDeviceToHost, s));
-    TF_CHECK_HIP(hipStreamSynchronize(s));
-    TF_CHECK_HIP(hipFreeAsync(d, s));
+    TF_CHECK_HIP(hipMalloc((void **)&d, 2048 * sizeof(int)));
+    hipError_t e = hipMemsetAsync(d, 0, 2048 * sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_cu_histogram, dim3((unsigned)n_workgroups), dim3(64), 0, s, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hist_host_2048, d, 2048 * sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) { tf_set_error("tf_debug_cu_histogram: %s", hipGetErrorString(e)); return TF_EHIP; }
     return TF_OK;
 }
 
