@@ -548,6 +548,7 @@ int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
  * tf_copy16: dst = src, 16 bytes per lane per access -- the measured practical HBM ceiling of bench.py's roofline. */
 int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words, void **stream_out);
 int tf_stream_destroy(void *stream);
+int tf_stream_create_priority(int low, void **stream_out);   /* lowest (low != 0) / highest priority of the device's range */
 int tf_debug_cu_histogram(void *stream, int n_workgroups, int *hist_host_2048);
 int tf_copy16(const void *src, void *dst, size_t bytes, void *stream);
 int tf_copy16_variant(const void *src, void *dst, size_t bytes, void *stream, int variant);   /* development forms of the same copy */

@@ -49,15 +49,22 @@ def test_detect_stack_windows_equals_the_serial_plain_calls_voxel_for_voxel():
     # the first window through create_flow on the window itself: the reference's own per-window call
     first = _serial_windows(bt, bounds[:1], OVERLAP, per_window_flow=True)[0]
     assert torch.equal(first > 0, want[0] > 0)
-    for stream in (True, False):
+    # streamed with the windows driven by a thread of their own on the second stream (opt-in), streamed from create_flow's
+    # callback on the calling thread (the default), and all windows after the stack's flow
+    for stream, thread in ((True, True), (True, False), (False, None)):
         info = {}
-        (got,), info = detect_stack_windows(bt, bounds, _seeds, overlap=OVERLAP, stream_windows=stream, info=info)
+        (got,), info = detect_stack_windows(bt, bounds, _seeds, overlap=OVERLAP, stream_windows=stream, flood_thread=thread, info=info)
         assert len(got) == N_WIN and len(info["floods"]) == N_WIN
         for k, (g, w) in enumerate(zip(got, want)):
             assert g.dtype == torch.int32 and g.shape == w.shape
-            assert torch.equal(g, w), (stream, k, int((g != w).sum()))
-        assert (info.get("flow_workspace_gb") is not None) == stream
+            assert torch.equal(g, w), (stream, thread, k, int((g != w).sum()))
+        assert (info.get("flow_workspace_gb") is not None) == stream and info.get("flood_thread", None) == (thread if stream else None)
         del got
+    # an exception on the flood thread (here: the caller's seeds_fn) reaches the caller
+    def bad_seeds(w, c):
+        raise RuntimeError("seeds_fn failed")
+    with pytest.raises(RuntimeError, match="seeds_fn failed"):
+        detect_stack_windows(bt, bounds, bad_seeds, overlap=OVERLAP)
     # unstitched: every window's labels are those of the plain call on that window (window-local ids)
     (raw,), _ = detect_stack_windows(bt, bounds, _seeds, overlap=OVERLAP, stitch=False)
     import tobac_flow_amd.flow as tf

@@ -127,6 +127,7 @@ _PROTOS = {
     "tf_profile_collect": (_c.c_int, [_P, _P, _P]),
     "tf_stream_create_cu_mask": (_c.c_int, [_P, _c.c_int, _c.POINTER(_P)]),
     "tf_stream_destroy": (_c.c_int, [_P]),
+    "tf_stream_create_priority": (_c.c_int, [_c.c_int, _c.POINTER(_P)]),
     "tf_debug_cu_histogram": (_c.c_int, [_P, _c.c_int, _P]),
     "tf_copy16": (_c.c_int, [_P, _P, _c.c_size_t, _P]),
     "tf_copy16_variant": (_c.c_int, [_P, _P, _c.c_size_t, _P, _c.c_int]),

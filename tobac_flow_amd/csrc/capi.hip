@@ -90,6 +90,18 @@ extern "C" int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words,
     *stream_out = (void *)s;
     return TF_OK;
 }
+// a stream of the LOWEST (low != 0) or the highest priority the device offers: the flood thread of parallel.detect_stack_windows
+// runs on a low-priority stream, so that the flow's workgroups are dispatched first and the floods take what is left
+extern "C" int tf_stream_create_priority(int low, void **stream_out)
+{
+    TF_REQUIRE(stream_out, "tf_stream_create_priority: null pointer");
+    int least = 0, greatest = 0;
+    TF_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s = nullptr;
+    TF_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, low ? least : greatest));
+    *stream_out = (void *)s;
+    return TF_OK;
+}
 // tf_stream_destroy RETIRES the stream: it is synchronised and kept until the process ends.  On this ROCm (7.2) a process that has
 // destroyed a CU-masked stream crashes inside a LATER large hipMalloc (found by the test suite: hipStreamDestroy of the masked
 // stream in one test, a segmentation fault in the 132-GiB allocation of another; with the stream left alive the same sequence

@@ -331,7 +331,7 @@ def _replay_pool(n):
     return _REPLAY_POOL
 
 
-def _side_stream(cus_per_xcd=0):
+def _side_stream(cus_per_xcd=0, low_priority=False):
     """the second stream of (device, calling stream) -- the floods of ready windows are finished on it while the calling
     stream is busy with the flow.  cus_per_xcd > 0: a stream whose kernels may only occupy that many CUs of every XCD
     (tf_stream_create_cu_mask; on this part bit i of the mask selects a CU of XCD i % 8, successive bits of an XCD going
@@ -340,9 +340,13 @@ def _side_stream(cus_per_xcd=0):
     import ctypes
     import torch
     from tobac_flow_amd import _lib
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, int(cus_per_xcd))
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, int(cus_per_xcd), bool(low_priority))
     if key not in _SIDE_STREAMS:
-        if cus_per_xcd > 0:
+        if low_priority and cus_per_xcd <= 0:
+            handle = ctypes.c_void_p()
+            _lib.check(_lib.lib().tf_stream_create_priority(1, ctypes.byref(handle)), "tf_stream_create_priority")
+            _SIDE_STREAMS[key] = torch.cuda.ExternalStream(handle.value)
+        elif cus_per_xcd > 0:
             n_bits = 8 * int(cus_per_xcd)
             words = np.zeros(8, np.uint32)
             for b in range(n_bits):
@@ -461,7 +465,7 @@ class _StackRun:
 def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap=DEFAULT_OVERLAP, stitch=True, group=None,
                          model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic", connectivity=1,
                          chain_depth=3, on_ambiguous="reference", max_in_flight=12, stream_windows=True,
-                         flow_workspace_gb=None, flood_cus_per_xcd=None, info=None, mark=None):
+                         flow_workspace_gb=None, flood_cus_per_xcd=None, flood_thread=None, info=None, mark=None):
     """Flow -> edge field -> marker-controlled watershed over a stack processed as overlapping time windows, on this device.
 
     bt: (T, H, W) float32 device tensor (the stack, resident).  bounds: [(start, stop), ...] consecutive windows sharing
@@ -479,7 +483,8 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
 
     Scheduling (no effect on results): stream_windows -- begin a window as soon as its flow is enqueued (one channel only;
     otherwise all windows after the stack's flow, their scratch borrowed from the then idle Farneback workspace);
-    max_in_flight -- floods in flight at most; flow_workspace_gb -- scratch budget of the Farneback batches while floods run
+    max_in_flight -- floods in flight at most; flood_thread -- drive the windows from a thread of their own on the second stream
+    instead of from create_flow's callback on the calling thread (default: the calling thread; measured equal on average, steadier); flow_workspace_gb -- scratch budget of the Farneback batches while floods run
     beside them (default: what the device has left after the flow vectors, the labels and the floods in flight, memoised per
     stack shape so that every call of a sweep batches alike).  Each window's labels are those of
     Flow.watershed(get_combined_edge_field(create_flow(window), field), seeds) bit for bit."""
@@ -539,17 +544,78 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
         o.info["floods_in_flight"] = n_fly
         if flood_cus_per_xcd is None:
             flood_cus_per_xcd = int(os.environ.get("TF_WINDOWS_FLOOD_CUS", "0"))      # (development switch)
-        o.side = _side_stream(flood_cus_per_xcd)
+        o.side = _side_stream(flood_cus_per_xcd, low_priority=os.environ.get("TF_WINDOWS_LOW_PRIORITY", "0") == "1")
         o.info["flood_cus_per_xcd"] = int(flood_cus_per_xcd)
 
-        def frames_ready(fl, n):
-            o.mark("flow enqueued for %d frames" % n)
-            ev = torch.cuda.Event()
-            ev.record()
-            first.begin_up_to(fl, n, wait_for=ev)
+        # (measured, config F, six steps each: flood thread 4.48 - 5.11 s per step, mean 4.72; calling thread 4.66 - 4.75, mean 4.71;
+        # flood thread on a low-priority stream 4.72 - 4.87 -- beside the flow the floods' kernels take as much from the flow's
+        # as they gain, and the step time scatters more: the calling thread stays the default)
+        threaded = flood_thread if flood_thread is not None else os.environ.get("TF_WINDOWS_THREAD", "0") == "1"
+        o.info["flood_thread"] = bool(threaded)
+        if not threaded:
+            # the calling thread begins the windows itself, inside create_flow's callback -- on the calling stream, i.e. BETWEEN the
+            # flow's batches (a window's set-up, phase A and chain phases: small, latency-bound launches with a host
+            # synchronisation every 32 sweeps); finished floods' root phases run on the second stream
+            def frames_ready(fl, n):
+                o.mark("flow enqueued for %d frames" % n)
+                ev = torch.cuda.Event()
+                ev.record()
+                first.begin_up_to(fl, n, wait_for=ev)
+            worker = None
+        else:
+            # (opt-in) A FLOOD THREAD with the second stream as its current stream drives every window -- seeds, edge field, begin,
+            # finish -- while the calling thread does nothing but enqueue the flow's batches: the floods' latency-bound sweeps
+            # run BESIDE the next batches' kernels instead of between them (the library is re-entrant per stream; scratch and
+            # memos of the Python layer are keyed by (device, stream)).  The callback hands over (flow, n, event behind the
+            # batch); the thread polls the event on the host, finishing ready floods meanwhile, then begins the windows that
+            # end within the first n frames.  What it reads of the stack's flow arrays is final by then (the flow of a frame
+            # pair is written once, before its event); window_view's two patched end frames lie inside windows of this same
+            # thread only, which it handles one after the other.
+            import queue
+            import threading
+            handover = queue.Queue()
+            failure = []
+            flood_stream, dev_index = o.side, torch.cuda.current_device()
+            o.side = None                                      # (the thread's CURRENT stream is the second stream: floods are finished on it)
+
+            def flood_loop():
+                try:
+                    torch.cuda.set_device(dev_index)
+                    with torch.cuda.stream(flood_stream):
+                        while True:
+                            item = handover.get()
+                            if item is None:
+                                break
+                            first.begin_up_to(item[0], item[1], wait_for=item[2])
+                        first.finish_all()
+                        flood_stream.synchronize()
+                except BaseException as exc:                    # noqa: BLE001 -- re-raised on the calling thread
+                    failure.append(exc)
+                    while True:                                # drain: the calling thread must never block on a full hand-over
+                        try:
+                            if handover.get_nowait() is None:
+                                break
+                        except queue.Empty:
+                            break
+
+            worker = threading.Thread(target=flood_loop, name="tf-window-floods", daemon=True)
+            worker.start()
+
+            def frames_ready(fl, n):
+                o.mark("flow enqueued for %d frames" % n)
+                ev = torch.cuda.Event()
+                ev.record()
+                handover.put((fl, n, ev))
         # a batch has twice the pairs at the pyramid levels >= 2 (with half, their launches are one half-empty round of
         # workgroups) and is finished -- finest levels, refinement, smoothing, hand-over of its frames -- in two parts
-        flow_all = tf.create_flow(bt, on_frames_ready=frames_ready, workspace_gb=flow_workspace_gb, split_parts=2, **flow_kw)
+        try:
+            flow_all = tf.create_flow(bt, on_frames_ready=frames_ready, workspace_gb=flow_workspace_gb, split_parts=2, **flow_kw)
+        finally:
+            if worker is not None:
+                handover.put(None)
+                worker.join()
+        if worker is not None and failure:
+            raise failure[0]
     else:
         flow_all = tf.create_flow(bt, **flow_kw)
     o.info["flow_workspace_gb"] = None if flow_workspace_gb is None else round(float(flow_workspace_gb), 1)
