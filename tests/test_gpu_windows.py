@@ -130,3 +130,40 @@ def test_two_gloo_ranks_on_one_device_equal_the_one_process_run_voxel_for_voxel(
         for j in range(2):
             got = np.load(tmp_path / f"r{r}_w{j}.npy")
             assert np.array_equal(got, want[2 * r + j]), (r, j, int((got != want[2 * r + j]).sum()))
+
+
+def test_several_channels_share_the_flow_and_equal_the_plain_calls():
+    """BASELINE config F3's shape of the problem at a small size: several detections (channels: the same stack at offsets 0 / -2
+    K) share ONE Flow and are processed one after the other, all windows of a channel after the stack's flow (no streaming with
+    more than one channel), `consume` called per channel.  Every channel's stitched windows equal the serial plain calls on
+    that channel, voxel for voxel."""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.parallel import detect_stack_windows, stitch_window_list, window_bounds
+    from tools.synth import anvil_seeds, blob_stack
+    t_, h_, w_ = 26, 400, 600
+    bt = blob_stack(t_, h_, w_, seed=20240601, t0=5)
+    bounds = window_bounds(t_, 2, 4)
+    offsets = (0.0, -2.0)
+
+    def seeds_fn(w, c):
+        return anvil_seeds(w + offsets[c] if c else w)
+    seen = []
+
+    def consume(c, wins):
+        seen.append(c)
+        return [w.clone() for w in wins]
+    got, info = detect_stack_windows(bt, bounds, seeds_fn, channels=2, consume=consume, overlap=4)
+    assert seen == [0, 1] and len(got) == 2 and info["floods_in_flight"] >= 1 and "flood_thread" not in info
+    flow = tf.create_flow(bt, model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    for c in range(2):
+        labs = []
+        for a, b in bounds:
+            fl = flow.window(a, b)
+            lin, seeds = seeds_fn(bt[a:b], c)
+            labs.append(fl.watershed(get_combined_edge_field(fl, lin, dtype=np.float32), seeds, connectivity=1))
+        want = stitch_window_list(labs, overlap=4)
+        for k, (g, w) in enumerate(zip(got[c], want)):
+            assert torch.equal(g, w), (c, k, int((g != w).sum()))
+    assert not torch.equal(got[0][0], got[1][0])                        # the channels do differ
