@@ -640,20 +640,20 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
     finalize_ends()
     # A stack whose flow holds NaN rows (a starved chain of the iteration kernel) must not be returned as if nothing had
     # happened.  Host output: the download below synchronises anyway -- check behind it.  Device output: the caller's pipeline is
-    # asynchronous; the check is DEFERRED to an event recorded here (`pending`): the Flow object polls it at every use and
+    # asynchronous; the check is DEFERRED to an event recorded here (`deferred`): the Flow object polls it at every use and
     # create_flow's callers with a synchronisation of their own (detect_stack_windows) wait for it there
-    pending = of_model.deferred_check("create_flow / calculate_flow") if hasattr(of_model, "deferred_check") else None
+    deferred = of_model.deferred_check("create_flow / calculate_flow") if hasattr(of_model, "deferred_check") else None
     if on_batch is not None:
         on_batch(forward, backward, n_pairs, n_pairs)
     if on_device:
-        if check_out is not None and pending is not None:
-            check_out.append(pending)
-        elif pending is not None:
-            pending(block=True)                  # (a caller that cannot take the deferred check gets the synchronous one)
+        if check_out is not None and deferred is not None:
+            check_out.append(deferred)
+        elif deferred is not None:
+            deferred(block=True)                  # (a caller that cannot take the deferred check gets the synchronous one)
         return forward, backward
     out = forward.cpu().numpy(), backward.cpu().numpy()
-    if pending is not None:
-        pending(block=True)
+    if deferred is not None:
+        deferred(block=True)
     return out
 
 
