@@ -376,6 +376,13 @@ def detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overl
     print("Core labels meeting length threshold:", np.sum(lengths > min_length))
     print("Core labels meeting WVD threshold:", np.sum(wvd_ok))
     core_labels = nd.remap_labels(core_labels, np.logical_and(lengths > min_length, wvd_ok))
+    if bt_d.dtype != t.float32:
+        # (a float64 BT: the reference's per-step means are float64 then, tf_label_stats reads float32 -- the host form keeps them)
+        class _HostBT(np.ndarray):
+            pass
+        host_bt = (bt_d.cpu().numpy() if _is_device(bt) else np.asarray(_values(bt))).view(_HostBT)
+        host_bt.t = _TimeCoord(np.asarray(bt.t.data))
+        return _deliver(_lib.to_dev(_core_cooling_filter(core_labels.cpu().numpy(), host_bt, min_length)), bt)
     return _deliver(_core_cooling_filter_dev(core_labels, bt_d, np.asarray(bt.t.data), min_length), bt)
 
 
