@@ -731,6 +731,7 @@ struct FbIterCtx {
     // +1 row, both) is folded into four wave-uniform base pointers
     const char *R1c[4], *R1ec[4];
     int H, W; int j, dj, tg, tq, x_strip, xc, y0, y1; float xscale; bool xborder;
+    bool strip_xborder;             // wave-uniform: some column of this strip lies in OpenCV's border band (xborder of any thread)
     // sequential row sums: strip index / count, the (row of the group, channel) this lane scans, hand-over slots of the left
     // neighbour (read) and of this strip (written), the launch's tag
     int sx, nx, sr, sch; const unsigned long long *hin; unsigned long long *hout; unsigned epoch; int abl; int *spins; int *starved; int poll_limit;
@@ -798,12 +799,16 @@ __device__ __forceinline__ void fb_taps_eval(const FbIterCtx &c, int s, const Fb
     // border attenuation: (x factors, fixed per thread) * (y factors, uniform).  It is applied under OpenCV's own
     // test, (unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10), whose unsigned
     // wrap-around leaves some border columns / rows of images narrower than 10 pixels UNscaled: reproduced as is
-    const int yb = c.H - 1 - y;
-    const float b0 = y == 0 ? 0.14f : (y == 1 ? 0.14f : 0.4472f);
-    const float b1 = yb == 0 ? 0.14f : (yb == 1 ? 0.14f : 0.4472f);
-    const bool in_border = c.xborder || (unsigned)(y - 5) >= (unsigned)(c.H - 10);
-    const float scale = in_border ? c.xscale * (y < 5 ? b0 : 1.f) * (yb < 5 ? b1 : 1.f) : 1.f;
-    r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    // (round 5: the test is wave-uniform -- interior rows of interior strips, i.e. nearly every evaluation, skip the scale's
+    // selects and five multiplications by exactly 1, which change no bit)
+    if (c.strip_xborder || (unsigned)(y - 5) >= (unsigned)(c.H - 10)) {
+        const int yb = c.H - 1 - y;
+        const float b0 = y == 0 ? 0.14f : (y == 1 ? 0.14f : 0.4472f);
+        const float b1 = yb == 0 ? 0.14f : (yb == 1 ? 0.14f : 0.4472f);
+        const bool in_border = c.xborder || (unsigned)(y - 5) >= (unsigned)(c.H - 10);
+        const float scale = in_border ? c.xscale * (y < 5 ? b0 : 1.f) * (yb < 5 ? b1 : 1.f) : 1.f;
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
     m[0] = r4 * r4 + r6 * r6;
     m[1] = (r4 + r5) * r6;
     m[2] = r5 * r5 + r6 * r6;
@@ -976,6 +981,7 @@ k_fb_iter_tree(FbIterArgs a, int H, int W, int64_t plane)
         for (int k = 0; k < 5; k++) { lo = c.xc == k ? border[k] : lo; hi = xb == k ? border[k] : hi; }
         c.xscale = lo * hi;
         c.xborder = (unsigned)(c.xc - 5) >= (unsigned)(W - 10);
+        c.strip_xborder = W < 10 || c.x_strip - FBI_M < 5 || c.x_strip + FBI_T - FBI_M - 1 > W - 6;     // (columns x_strip - 6 .. x_strip + 121, clamped)
     }
     float ring[FBI_WIN][5];
     double S[5];
@@ -1118,38 +1124,45 @@ __device__ __forceinline__ void fb_hand_store(const FbIterCtx &c, int yo, int ch
 // chain is bound by its instruction count, not by the adds).  The reads of chunk c + 1 are issued before the chain of chunk
 // c, whose writes go to slots below them.  Returns in `sub` the column sum base[NSTEP - 1] held on entry: the first
 // subtrahend of whoever continues the chain.
+// one chunk of WIN steps from slot i0: `mn` holds the minuends base[i0 + 12 + k], `prev` the subtrahends base[i0 - 1 + k].  Once the
+// differences are formed `prev` is dead: the NEXT chunk's minuends are read into it (during the dependent additions), so two
+// chunks with the two arrays swapped are one loop trip without a single register move (round 5: the rotating form
+// prev <- mn <- nxt cost 25 v_mov_b64 per 13 steps, a third of the instructions of a loop that is bound by their number)
+__device__ __forceinline__ void fb_chain_chunk(double *base, int i0, int last, double (&prev)[FBI_WIN], const double (&mn)[FBI_WIN], double &g)
+{
+    double d[FBI_WIN];
+#pragma unroll
+    for (int k = 0; k < FBI_WIN; k++) d[k] = mn[k] - prev[k];
+#pragma unroll
+    for (int k = 0; k < FBI_WIN; k++) prev[k] = base[min(i0 + FBI_WIN + 2 * FBI_M + k, last)];   // (a last chunk may be shorter: clamped, unused)
+#pragma unroll
+    for (int k = 0; k < FBI_WIN; k++) { g += d[k]; base[i0 + k] = g; }
+}
+
 template <int NSTEP>
 __device__ __forceinline__ void fb_chain_run(double *base, double &g, double &sub)
 {
     constexpr int CH = FBI_WIN, NFULL = NSTEP / CH, TAIL = NSTEP - NFULL * CH, LAST = NSTEP + 2 * FBI_M - 1;
-    static_assert(NFULL >= 1, "chain chunks");
-    double prev[CH], mn[CH];
-    prev[0] = sub;
+    static_assert(NFULL >= 2 && NFULL % 2 == 0, "chain chunks come in pairs");
+    double pa[CH], pb[CH];
+    pa[0] = sub;
 #pragma unroll
-    for (int k = 1; k < CH; k++) prev[k] = base[k - 1];
+    for (int k = 1; k < CH; k++) pa[k] = base[k - 1];
 #pragma unroll
-    for (int k = 0; k < CH; k++) mn[k] = base[2 * FBI_M + k];
+    for (int k = 0; k < CH; k++) pb[k] = base[2 * FBI_M + k];
 #pragma unroll 1
-    for (int i0 = 0; i0 < NFULL * CH; i0 += CH) {
-        double nxt[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) nxt[k] = base[min(i0 + CH + 2 * FBI_M + k, LAST)];       // (the last chunk may be shorter: clamped, unused)
-        double d[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) d[k] = mn[k] - prev[k];
-#pragma unroll
-        for (int k = 0; k < CH; k++) { g += d[k]; base[i0 + k] = g; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) { prev[k] = mn[k]; mn[k] = nxt[k]; }
+    for (int i0 = 0; i0 < NFULL * CH; i0 += 2 * CH) {
+        fb_chain_chunk(base, i0, LAST, pa, pb, g);
+        fb_chain_chunk(base, i0 + CH, LAST, pb, pa, g);
     }
     if (TAIL > 0) {
         double d[TAIL > 0 ? TAIL : 1];
 #pragma unroll
-        for (int k = 0; k < TAIL; k++) d[k] = mn[k] - prev[k];
+        for (int k = 0; k < TAIL; k++) d[k] = pb[k] - pa[k];
 #pragma unroll
         for (int k = 0; k < TAIL; k++) { g += d[k]; base[NFULL * CH + k] = g; }
     }
-    sub = prev[TAIL];
+    sub = pa[TAIL];
 }
 
 // one whole chain by one lane: row `row` of output row yo, channel ch
@@ -1263,34 +1276,27 @@ static_assert(FBI_T == 128 && FBI_HRN == 4 * FBI_WIN && FBI_HL == FBI_HRN + FBI_
 __device__ __forceinline__ void fb_chain_run_lr(double *base, double &g, double &sub, bool left)
 {
     constexpr int CH = FBI_WIN, NFULL = FBI_HRN / CH, TAIL = FBI_HL - FBI_HRN;
+    static_assert(NFULL % 2 == 0, "chain chunks come in pairs");
     const int last = (left ? FBI_HL : FBI_HRN) + 2 * FBI_M - 1;
-    double prev[CH], mn[CH];
-    prev[0] = sub;
+    double pa[CH], pb[CH];
+    pa[0] = sub;
 #pragma unroll
-    for (int k = 1; k < CH; k++) prev[k] = base[k - 1];
+    for (int k = 1; k < CH; k++) pa[k] = base[k - 1];
 #pragma unroll
-    for (int k = 0; k < CH; k++) mn[k] = base[2 * FBI_M + k];
+    for (int k = 0; k < CH; k++) pb[k] = base[2 * FBI_M + k];
 #pragma unroll 1
-    for (int i0 = 0; i0 < NFULL * CH; i0 += CH) {
-        double nxt[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) nxt[k] = base[min(i0 + CH + 2 * FBI_M + k, last)];
-        double d[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k++) d[k] = mn[k] - prev[k];
-#pragma unroll
-        for (int k = 0; k < CH; k++) { g += d[k]; base[i0 + k] = g; }
-#pragma unroll
-        for (int k = 0; k < CH; k++) { prev[k] = mn[k]; mn[k] = nxt[k]; }
+    for (int i0 = 0; i0 < NFULL * CH; i0 += 2 * CH) {
+        fb_chain_chunk(base, i0, last, pa, pb, g);
+        fb_chain_chunk(base, i0 + CH, last, pb, pa, g);
     }
-    sub = prev[0];                                                     // right part: slot 115, the next strip's first subtrahend
+    sub = pa[0];                                                       // right part: slot 115, the next strip's first subtrahend
     if (left) {
         double d[TAIL];
 #pragma unroll
-        for (int k = 0; k < TAIL; k++) d[k] = mn[k] - prev[k];
+        for (int k = 0; k < TAIL; k++) d[k] = pb[k] - pa[k];
 #pragma unroll
         for (int k = 0; k < TAIL; k++) { g += d[k]; base[NFULL * CH + k] = g; }
-        sub = prev[TAIL];                                              // left part: slot 63, the right part's first subtrahend
+        sub = pa[TAIL];                                                // left part: slot 63, the right part's first subtrahend
     }
 }
 
@@ -1477,6 +1483,7 @@ k_fb_iter(FbIterArgs a, int H, int W, int64_t plane)
         for (int k = 0; k < 5; k++) { lo = c.xc == k ? border[k] : lo; hi = xb == k ? border[k] : hi; }
         c.xscale = lo * hi;
         c.xborder = (unsigned)(c.xc - 5) >= (unsigned)(W - 10);
+        c.strip_xborder = W < 10 || c.x_strip - FBI_M < 5 || c.x_strip + FBI_T - FBI_M - 1 > W - 6;     // (columns x_strip - 6 .. x_strip + 121, clamped)
     }
     float ring[FBI_WIN][5];
     double S[5];
