@@ -49,8 +49,8 @@ def test_detect_stack_windows_equals_the_serial_plain_calls_voxel_for_voxel():
     # the first window through create_flow on the window itself: the reference's own per-window call
     first = _serial_windows(bt, bounds[:1], OVERLAP, per_window_flow=True)[0]
     assert torch.equal(first > 0, want[0] > 0)
-    # streamed with the windows driven by a thread of their own on the second stream (opt-in), streamed from create_flow's
-    # callback on the calling thread (the default), and all windows after the stack's flow
+    # streamed with the windows driven by a thread of their own on the second stream (the default), streamed from create_flow's
+    # callback on the calling thread, and all windows after the stack's flow
     for stream, thread in ((True, True), (True, False), (False, None)):
         info = {}
         (got,), info = detect_stack_windows(bt, bounds, _seeds, overlap=OVERLAP, stream_windows=stream, flood_thread=thread, info=info)

@@ -484,7 +484,8 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
     Scheduling (no effect on results): stream_windows -- begin a window as soon as its flow is enqueued (one channel only;
     otherwise all windows after the stack's flow, their scratch borrowed from the then idle Farneback workspace);
     max_in_flight -- floods in flight at most; flood_thread -- drive the windows from a thread of their own on the second stream
-    instead of from create_flow's callback on the calling thread (default: the calling thread; measured equal on average, steadier); flow_workspace_gb -- scratch budget of the Farneback batches while floods run
+    (default since the end of round 5: the calling thread then only enqueues the flow, whose batches no longer wait for the begins
+    between them) or from create_flow's callback on the calling thread (False); flow_workspace_gb -- scratch budget of the Farneback batches while floods run
     beside them (default: what the device has left after the flow vectors, the labels and the floods in flight, memoised per
     stack shape so that every call of a sweep batches alike).  Each window's labels are those of
     Flow.watershed(get_combined_edge_field(create_flow(window), field), seeds) bit for bit."""
@@ -547,10 +548,13 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
         o.side = _side_stream(flood_cus_per_xcd, low_priority=os.environ.get("TF_WINDOWS_LOW_PRIORITY", "0") == "1")
         o.info["flood_cus_per_xcd"] = int(flood_cus_per_xcd)
 
-        # (measured, config F, six steps each: flood thread 4.48 - 5.11 s per step, mean 4.72; calling thread 4.66 - 4.75, mean 4.71;
-        # flood thread on a low-priority stream 4.72 - 4.87 -- beside the flow the floods' kernels take as much from the flow's
-        # as they gain, and the step time scatters more: the calling thread stays the default)
-        threaded = flood_thread if flood_thread is not None else os.environ.get("TF_WINDOWS_THREAD", "0") == "1"
+        # (measured, config F.  Middle of round 5, six steps each: flood thread 4.48 - 5.11 s per step, mean 4.72; calling thread
+        # 4.66 - 4.75, mean 4.71; flood thread on a low-priority stream 4.72 - 4.87.  End of round 5, with the build that no longer
+        # pairs float operations (csrc/Makefile), two runs of eight steps each, alternating: flood thread 4.53 / 4.59 s per step
+        # (4.44 - 4.70), calling thread 4.62 / 4.65 (4.49 - 4.86) -- the flow's seven parts are enqueued back to back (4.04 s
+        # instead of 4.36 s until the last part has passed), the begins run beside them at 70 - 290 ms each instead of 50 ms
+        # between them: the flood thread is the default, TF_WINDOWS_THREAD=0 / flood_thread=False the calling thread)
+        threaded = flood_thread if flood_thread is not None else os.environ.get("TF_WINDOWS_THREAD", "1") == "1"
         o.info["flood_thread"] = bool(threaded)
         if not threaded:
             # the calling thread begins the windows itself, inside create_flow's callback -- on the calling stream, i.e. BETWEEN the
@@ -563,7 +567,7 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
                 first.begin_up_to(fl, n, wait_for=ev)
             worker = None
         else:
-            # (opt-in) A FLOOD THREAD with the second stream as its current stream drives every window -- seeds, edge field, begin,
+            # A FLOOD THREAD with the second stream as its current stream drives every window -- seeds, edge field, begin,
             # finish -- while the calling thread does nothing but enqueue the flow's batches: the floods' latency-bound sweeps
             # run BESIDE the next batches' kernels instead of between them (the library is re-entrant per stream; scratch and
             # memos of the Python layer are keyed by (device, stream)).  The callback hands over (flow, n, event behind the
