@@ -529,15 +529,21 @@ __device__ __forceinline__ void ws_flush(WsStage &st, int w, int *__restrict__ q
 #define WS_NB 8
 
 // one queue entry of phase A: pop p, relax its out-edges WS_NB at a time, stage the pixels whose key it lowered
+// NN = 6 (round 5): the six face neighbours as a compile-time count -- one trip of SIX slots instead of eight with two dead
+// ones (a dead slot still cost its registers and two loads of element 0 per entry): k_ws_sweep_a 80 -> 64 VGPRs; NN = 0:
+// any neighbour count, eight slots per trip
+template <int NN>
 __device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, int w, bool act, int p, int *__restrict__ inq,
                                            int *__restrict__ qout, int *__restrict__ cnt_out, int qcap)
 {
-    const int *np = c.nbr + (int64_t)p * c.n_nbr;
+    constexpr int NB = NN ? NN : WS_NB;
+    const int n_nbr = NN ? NN : c.n_nbr;
+    const int *np = c.nbr + (int64_t)p * n_nbr;
     u64 kp = WS_INF;
-    for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
-        int n[WS_NB];
+    for (int s0 = 0; s0 < n_nbr; s0 += NB) {
+        int n[NB];
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) n[j] = (act && s0 + j < c.n_nbr) ? np[s0 + j] : -1;
+        for (int j = 0; j < NB; j++) n[j] = (act && s0 + j < n_nbr) ? np[s0 + j] : -1;
         if (s0 == 0 && act) {
             // relaxed L2 atomics only: the key is loaded after the exchange has returned (the flag is cleared BEFORE
             // the key is read, so a later decrease re-queues the pixel); the id loads above are already in flight
@@ -545,17 +551,17 @@ __device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, int w, boo
             kp = ws_load(&WS_K2(c, p) + 2 * dep);
         }
         const u64 lp = kp >> 32;
-        u64 vn[WS_NB], m1[WS_NB], k2[WS_NB];
+        u64 vn[NB], m1[NB], k2[NB];
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) {
+        for (int j = 0; j < NB; j++) {
             const int q = n[j] >= 0 ? n[j] : 0;
             vn[j] = c.val[q];
             const ulonglong2 km = *(const ulonglong2 *)&WS_K2(c, q);
             k2[j] = km.x; m1[j] = km.y;
         }
-        u64 cand[WS_NB], old[WS_NB];
+        u64 cand[NB], old[NB];
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) {
+        for (int j = 0; j < NB; j++) {
             cand[j] = vn[j] > lp ? ((vn[j] << 32) | 1ull) : (vn[j] == lp ? kp + 1ull : kp);
             old[j] = 0ull;                                             // "no improvement"
             if (n[j] >= 0) {
@@ -564,17 +570,18 @@ __device__ __forceinline__ void ws_entry_a(const WsC &c, WsStage &st, int w, boo
                 if (cand[j] < k2[j]) old[j] = atomicMin(&WS_K2(c, n[j]), cand[j]);
             }
         }
-        int was_q[WS_NB];                                              // raw returns: consumed only after all are issued
+        int was_q[NB];                                              // raw returns: consumed only after all are issued
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) {
+        for (int j = 0; j < NB; j++) {
             was_q[j] = 1;
             if (n[j] >= 0 && cand[j] < old[j]) was_q[j] = inq ? atomicExch(&inq[n[j]], 1) : 0;
         }
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) ws_stage(st, w, was_q[j] == 0, n[j], qout, cnt_out, qcap);
+        for (int j = 0; j < NB; j++) ws_stage(st, w, was_q[j] == 0, n[j], qout, cnt_out, qcap);
     }
 }
 
+template <int NN>
 __global__ void __launch_bounds__(256)
 k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in, int *__restrict__ qout,
              int *__restrict__ cnt_out, int *__restrict__ inq, int qcap, int rounds)
@@ -590,7 +597,7 @@ k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in,
         const bool act = i < n_in;
         const int p = act ? (qin ? qin[i] : (int)i) : 0;
         int w = 0;
-        ws_entry_a(c, st, w, act, p, inq, qout, cnt_out, qcap);
+        ws_entry_a<NN>(c, st, w, act, p, inq, qout, cnt_out, qcap);
         for (int r = 0; r < rounds; r++) {                     // local rounds: relax what this workgroup has just lowered
             __syncthreads();
             const int n = min(st.cnt[w], WS_LDS_CAP);
@@ -598,7 +605,7 @@ k_ws_sweep_a(WsC c, const int *__restrict__ qin, const int *__restrict__ cnt_in,
             for (int j0 = 0; j0 < n; j0 += 256) {
                 const int j = j0 + threadIdx.x;
                 const bool a2 = j < n;
-                ws_entry_a(c, st, w ^ 1, a2, a2 ? st.buf[w][j] : 0, inq, qout, cnt_out, qcap);
+                ws_entry_a<NN>(c, st, w ^ 1, a2, a2 ? st.buf[w][j] : 0, inq, qout, cnt_out, qcap);
             }
             __syncthreads();
             if (threadIdx.x == 0) st.cnt[w] = 0;
@@ -653,16 +660,19 @@ __device__ __forceinline__ int ws_load_i(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <int NN>
 __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u64 *__restrict__ dst, WsStage &st, int w,
                                                bool act0, int p, int *__restrict__ inq,
                                                int *__restrict__ qout, int *__restrict__ cnt_out, int qcap)
 {
-    const int *np = c.nbr + (int64_t)p * c.n_nbr;
+    constexpr int NB = NN ? NN : WS_NB;
+    const int n_nbr = NN ? NN : c.n_nbr;
+    const int *np = c.nbr + (int64_t)p * n_nbr;
     const bool root = k == depth;
     u64 kp = WS_INF, own = WS_INF, em = 0ull;
     int own_lo = 0x7fffffff, own_hi = (int)0x80000000;   // label set of p (root phase only)
     u64 cp[WS_MAX_DEPTH];                        // C_j[p], j < k: final since their own phases, read once per entry
-    for (int s0 = 0; s0 < c.n_nbr; s0 += WS_NB) {
+    for (int s0 = 0; s0 < n_nbr; s0 += NB) {
         if (s0 == 0 && act0) {
             // the in-queue flag is cleared BEFORE p's own keys are read (the loads take the exchange's
             // return value as an address term), so a later decrease re-queues p: no lost update
@@ -674,20 +684,20 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
             for (int j = 1; j < k; j++) cp[j] = c.C[j][p];
         }
         // candidate edges only: one or two of the six at connectivity 1
-        int n[WS_NB];
+        int n[NB];
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) n[j] = (s0 + j < c.n_nbr && ((em >> (s0 + j)) & 1ull)) ? np[s0 + j] : -1;
-        u64 dn[WS_NB];
-        int lon[WS_NB], hin[WS_NB];
+        for (int j = 0; j < NB; j++) n[j] = (s0 + j < n_nbr && ((em >> (s0 + j)) & 1ull)) ? np[s0 + j] : -1;
+        u64 dn[NB];
+        int lon[NB], hin[NB];
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) {
+        for (int j = 0; j < NB; j++) {
             dn[j] = WS_INF; lon[j] = 0; hin[j] = 0;
             if (n[j] >= 0) { dn[j] = dst[n[j]]; if (root) { lon[j] = c.Llo[n[j]]; hin[j] = c.Lhi[n[j]]; } }
         }
-        u64 offered[WS_NB], old[WS_NB];
-        int olo[WS_NB], ohi[WS_NB];              // raw atomic returns of the label-set relaxations
+        u64 offered[NB], old[NB];
+        int olo[NB], ohi[NB];              // raw atomic returns of the label-set relaxations
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) {
+        for (int j = 0; j < NB; j++) {
             offered[j] = WS_INF; old[j] = 0ull; olo[j] = (int)0x80000000; ohi[j] = 0x7fffffff;
             if (n[j] >= 0) {
                 const bool entry = ((em >> (32 + s0 + j)) & 1ull) != 0ull;
@@ -708,18 +718,19 @@ __device__ __forceinline__ void ws_entry_chain(const WsC &c, int k, int depth, u
                 }
             }
         }
-        int was_q[WS_NB];
+        int was_q[NB];
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) {
+        for (int j = 0; j < NB; j++) {
             was_q[j] = 1;
             const bool improved = offered[j] < old[j] || (root && (own_lo < olo[j] || own_hi > ohi[j]));
             if (improved) was_q[j] = inq ? atomicExch(&inq[n[j]], 1) : 0;
         }
 #pragma unroll
-        for (int j = 0; j < WS_NB; j++) ws_stage(st, w, was_q[j] == 0, n[j], qout, cnt_out, qcap);
+        for (int j = 0; j < NB; j++) ws_stage(st, w, was_q[j] == 0, n[j], qout, cnt_out, qcap);
     }
 }
 
+template <int NN>
 __global__ void __launch_bounds__(256)
 k_ws_sweep_chain(WsC c, int k, int depth, const int *__restrict__ qin, const int *__restrict__ cnt_in,
                  int *__restrict__ qout, int *__restrict__ cnt_out, int *__restrict__ inq, int qcap, int rounds)
@@ -735,7 +746,7 @@ k_ws_sweep_chain(WsC c, int k, int depth, const int *__restrict__ qin, const int
         const bool act0 = i < n_in;
         const int p = act0 ? (qin ? qin[i] : (int)i) : 0;
         int w = 0;
-        ws_entry_chain(c, k, depth, dst, st, w, act0, p, inq, qout, cnt_out, qcap);
+        ws_entry_chain<NN>(c, k, depth, dst, st, w, act0, p, inq, qout, cnt_out, qcap);
         for (int r = 0; r < rounds; r++) {
             __syncthreads();
             const int n = min(st.cnt[w], WS_LDS_CAP);
@@ -743,7 +754,7 @@ k_ws_sweep_chain(WsC c, int k, int depth, const int *__restrict__ qin, const int
             for (int j0 = 0; j0 < n; j0 += 256) {
                 const int j = j0 + threadIdx.x;
                 const bool a2 = j < n;
-                ws_entry_chain(c, k, depth, dst, st, w ^ 1, a2, a2 ? st.buf[w][j] : 0, inq, qout, cnt_out, qcap);
+                ws_entry_chain<NN>(c, k, depth, dst, st, w ^ 1, a2, a2 ? st.buf[w][j] : 0, inq, qout, cnt_out, qcap);
             }
             __syncthreads();
             if (threadIdx.x == 0) st.cnt[w] = 0;
@@ -1233,10 +1244,13 @@ static int ws_run_phase(const WsC &c, int phase_k, int depth, const WsQueues &Q,
             for (int b = 0; b < WS_BATCH; b++) {
                 const int *qin = first ? nullptr : Q.q[parity];
                 const unsigned blocks = first ? nbR : grid_hint;
-                if (phase_k == 0)
-                    hipLaunchKernelGGL(k_ws_sweep_a, dim3(blocks), dim3(256), 0, s, c, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, inq, Q.qcap, rounds);
-                else
-                    hipLaunchKernelGGL(k_ws_sweep_chain, dim3(blocks), dim3(256), 0, s, c, phase_k, depth, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, inq, Q.qcap, rounds);
+                if (phase_k == 0) {
+                    if (c.n_nbr == 6) hipLaunchKernelGGL(k_ws_sweep_a<6>, dim3(blocks), dim3(256), 0, s, c, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, inq, Q.qcap, rounds);
+                    else hipLaunchKernelGGL(k_ws_sweep_a<0>, dim3(blocks), dim3(256), 0, s, c, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, inq, Q.qcap, rounds);
+                } else {
+                    if (c.n_nbr == 6) hipLaunchKernelGGL(k_ws_sweep_chain<6>, dim3(blocks), dim3(256), 0, s, c, phase_k, depth, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, inq, Q.qcap, rounds);
+                    else hipLaunchKernelGGL(k_ws_sweep_chain<0>, dim3(blocks), dim3(256), 0, s, c, phase_k, depth, qin, Q.cnt + b, Q.q[parity ^ 1], Q.cnt + b + 1, inq, Q.qcap, rounds);
+                }
                 parity ^= 1;
                 first = false;
             }
