@@ -463,6 +463,23 @@ def main():
     _lib.profile_enable(False)
     del out_labels
     n_timed = len(ws_stats)
+    # Sub-report, outside the timed region: the dominant flow kernels with NOTHING beside them -- create_flow over the first 43
+    # frames (one batch of 42 pairs finished in two parts, as in the timed steps) on an otherwise idle device.  Since the end of
+    # round 5 the floods run on a thread and a stream of their own beside the whole flow, so the launch durations the library's
+    # HIP events record inside the timed region (`roofline.frac`) include what the floods' kernels take from the flow's.
+    prof_alone = None
+    if rank == 0 and full_size and not a.no_kernel_events and T >= 43:
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        _lib.profile_collect()
+        fl_alone = tf.create_flow(bt_all[:43], model="Farneback", vr_steps=a.vr_steps, smoothing_passes=1, interp_method="cubic",
+                                  workspace_gb=inflight.get("flow_workspace_gb"), split_parts=2,
+                                  on_frames_ready=(lambda fl, n: None) if (a.stream_windows and C == 1 and n_windows > 1) else None)   # (the same form of the kernel as in the timed steps)
+        fl_alone.check()
+        torch.cuda.synchronize()
+        prof_alone = _lib.profile_collect()
+        _lib.profile_enable(False)
+        del fl_alone
     raster_ms = None
     if a.tie_order == "reference" and not a.no_raster_subreport:
         # sub-report, outside the timed region: ONE step with equal-valued markers in raster order (on_ambiguous="ignore")
@@ -536,6 +553,14 @@ def main():
             if tr:                                       # what the kernel really moves, at the measured launch time
                 roof["traffic_GBps"] = round(tr["bytes_per_launch"] / (ms * 1e-3 / calls) / 1e9, 1)
                 roof["traffic_frac_of_peak"] = round(roof["traffic_GBps"] / HBM_PEAK_GBS, 4)
+            if prof_alone and name in prof_alone and prof_alone[name][1] > 0:
+                c1, ms1, by1 = prof_alone[name]
+                roof["uncontended"] = {"achieved": round(by1 / (ms1 * 1e-3) / 1e9, 1), "frac": round(by1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "launches": c1, "avg_launch_us": round(ms1 * 1e3 / c1, 2),
+                                       "all_kernels_ms": {k: round(v[1], 2) for k, v in sorted(prof_alone.items(), key=lambda kv: -kv[1][1])},
+                                       "note": "the same kernel with nothing beside it: create_flow over the first 43 frames (one batch of 42 pairs in two "
+                                               "parts) after the timed region; `frac` above is measured inside the timed region, where the floods of the "
+                                               "windows run beside the flow on a second stream"}
             if name == "fb_iteration_fused":
                 # SURVEY.md 8(d) prices an iteration at 56 B per level pixel per DIRECTION; the fused launch serves both
                 # directions of a pair and reads the two expansions R0, R1 once: 40 + 2 x 16 = 72 B per level pixel per
