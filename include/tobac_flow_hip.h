@@ -332,6 +332,11 @@ int tf_watershed(const float *field, const int32_t *markers, const int8_t *mask,
  *   stats[13] = items the replay popped, [14] = seeds the replay was given, [15] = microseconds the detour took on the
  *   host clock (export + replay + repeated root phase; 0 if not needed). */
 #define TF_WS_REFERENCE_ORDER 2
+/* TF_WS_DEFER_SWEEPS (tf_watershed_begin only; round 5): begin returns after the set-up and the export on a guessed tie value
+ * -- the only parts that read `fwd` / `bwd`, `field` and `markers` arrays of the window -- and leaves phase A and the chain
+ * levels to tf_watershed_sweeps (or to tf_watershed_finish, which runs them if nobody has).  A caller that begins several
+ * windows at once starts all their host replays first and sweeps afterwards (parallel.detect_stack_windows).  Same labels. */
+#define TF_WS_DEFER_SWEEPS 4
 int tf_watershed_ex(const float *field, const int32_t *markers, const int8_t *mask,
                     const float *fwd, const float *bwd, int64_t T, int64_t H, int64_t W,
                     const int8_t *nbr_host, int n_nbr, int chain_depth, int flags, int32_t *labels,
@@ -364,6 +369,10 @@ int tf_watershed_ex2(const float *field, const int32_t *markers, const int8_t *m
  *                        falls back on export - replay - second root phase when the guess was too low (a guess that is too
  *                        high only makes the replay longer).
  *   tf_watershed_needs_replay   1 if tf_watershed_replay has work to do (a guess was given)
+ *   tf_watershed_sweeps  phase A and the chain levels of a job begun with TF_WS_DEFER_SWEEPS (a no-op otherwise); same stream,
+ *                        same thread rules as begin / finish; synchronises the stream; stats_host (NULL or TF_WS_NSTATS x int64)
+ *                        receives the job's statistics so far ([0] phase A's sweeps, [5] the scheduling probe).  Optional: finish
+ *                        runs them if nobody has.  On an error the job stays the caller's to abandon.
  *   tf_watershed_replay  the host replay; no HIP call, any thread, different jobs concurrently.  Optional: finish runs it
  *                        if the caller did not.  MUST have returned before the job is finished or abandoned.
  *   tf_watershed_finish  root phase (with the pop ranks if there are any) + exactness check, labels (and report) written;
@@ -380,6 +389,7 @@ int tf_watershed_begin(const float *field, const int32_t *markers, const int8_t 
                        const int8_t *nbr_host, int n_nbr, int chain_depth, int max_depth, int flags,
                        int64_t guessed_tie_key, void *ws, size_t ws_bytes, int64_t *stats_host, void *stream, void **job_out);
 int tf_watershed_needs_replay(const void *job);
+int tf_watershed_sweeps(void *job, int64_t *stats_host);
 int tf_watershed_replay(void *job);
 int tf_watershed_finish(void *job, int32_t *labels, uint8_t *ambiguous, int64_t *stats_host, int64_t *info_host);
 void tf_watershed_abandon(void *job);

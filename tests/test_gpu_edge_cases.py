@@ -185,8 +185,8 @@ def test_watershed_custom_structure_and_inf_field(tf):
 
 
 def test_watershed_ex_rejects_unknown_flags_and_chain_depth_one_ignores_the_hint(tf):
-    """C ABI: flags other than TF_WS_SKIP_FAST_PATH / TF_WS_REFERENCE_ORDER are TF_EINVAL; with chain_depth 1 there are no chain phases to
-    skip to, so the hint is ignored and the root phase runs."""
+    """C ABI: flags other than TF_WS_SKIP_FAST_PATH / TF_WS_REFERENCE_ORDER are TF_EINVAL (TF_WS_DEFER_SWEEPS = 4 belongs to
+    tf_watershed_begin alone); with chain_depth 1 there are no chain phases to skip to, so the hint is ignored and the root phase runs."""
     import torch
     from tobac_flow_amd import _lib
     from tobac_flow_amd.watershed import neighbour_offsets, watershed_dev
@@ -204,6 +204,7 @@ def test_watershed_ex_rejects_unknown_flags_and_chain_depth_one_ignores_the_hint
     args = lambda flags: (_lib.ptr(f), _lib.ptr(m), None, _lib.ptr(fl), _lib.ptr(fl), T, H, W, nbr.ctypes.data_as(_lib._P),
                           len(nbr), 3, flags, _lib.ptr(out), _lib.ptr(ws), ws.numel(), st.ctypes.data_as(_lib._P), None)
     assert L.tf_watershed_ex(*args(4)) == -1 and b"unknown flag" in L.tf_last_error()
+    assert L.tf_watershed_ex(*args(8)) == -1 and b"unknown flag" in L.tf_last_error()
     assert L.tf_watershed_ex(*args(0)) == 0
     probe = out.cpu().numpy().copy()
     assert L.tf_watershed_ex(*args(2)) == 0 and np.array_equal(out.cpu().numpy(), probe)      # TF_WS_REFERENCE_ORDER: nothing to reorder here

@@ -325,6 +325,32 @@ def test_watershed_job_in_parts_on_a_second_stream_equals_the_one_call(golden_ws
         assert np.array_equal(lab.cpu().numpy(), c["labels"]), guess
         assert st["reference_order_detail"]["guess_covered_the_tie"] == (guess == "memo")
         assert st["root_phases"] == (1 if guess == "memo" else 2)
+    # TF_WS_DEFER_SWEEPS (round 5): begin returns after the set-up and the export; phase A and the chain levels run in
+    # sweeps() -- beside the replay -- or, if nobody calls it, at the start of the first step(): the same labels and statistics
+    for explicit in (True, False):
+        with W._MEMO_LOCK:
+            W._tie_memo.pop(k, None)
+            W._conflict_memo.pop(k, None)
+        ref = {}
+        want = W.watershed_begin(*args, stats=ref, expect_conflict=None).finish()
+        with W._MEMO_LOCK:
+            W._tie_memo.pop(k, None)
+            W._conflict_memo.pop(k, None)
+        st = {}
+        job = W.watershed_begin(*args, stats=st, expect_conflict=None, defer_sweeps=True)
+        assert job._sweeps_pending and k not in W._conflict_memo          # (the scheduling probe belongs to the sweeps)
+        fut = pool.submit(job.replay) if job.needs_replay else None
+        if explicit:
+            job.sweeps()
+            assert not job._sweeps_pending and k in W._conflict_memo
+            job.sweeps()                                                     # (a second call does nothing)
+        if fut is not None:
+            fut.result()
+        lab = job.finish()
+        assert not job._sweeps_pending and k in W._conflict_memo
+        assert torch.equal(lab, want) and np.array_equal(lab.cpu().numpy(), c["labels"]), explicit
+        # (sweeps[7], the entries processed, depends on the order the chaotic relaxation happened to take)
+        assert st["sweeps"][:7] == ref["sweeps"][:7] and st["root_phases"] == ref["root_phases"] and st["chain_depth"] == ref["chain_depth"], (st, ref)
 
 
 def test_create_flow_with_split_batches_is_bit_identical_and_hands_out_parts(monkeypatch):

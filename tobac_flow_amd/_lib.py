@@ -84,6 +84,7 @@ _PROTOS = {
     "tf_watershed_begin": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int, _c.c_int,
                                       _c.c_int, _c.c_int, _c.c_int64, _P, _c.c_size_t, _P, _P, _c.POINTER(_P)]),
     "tf_watershed_needs_replay": (_c.c_int, [_P]),
+    "tf_watershed_sweeps": (_c.c_int, [_P, _P]),
     "tf_watershed_replay": (_c.c_int, [_P]),
     "tf_watershed_finish": (_c.c_int, [_P, _P, _P, _P, _P]),
     "tf_watershed_abandon": (None, [_P]),

@@ -1386,6 +1386,7 @@ struct tf_ws_job {
     bool need_replay, replay_done, applied, sparse, plain, identity, coded;
     bool speculative;            // the export ran before the root phase, for a tie value the caller guessed (spec_vmax)
     bool root_pending;           // finish starts with the root phase (begin has run phase A and the chain levels below `depth`)
+    bool sweeps_pending;         // TF_WS_DEFER_SWEEPS: begin returned after the set-up and the export; phase A and the chain levels are tf_watershed_sweeps' (or finish's)
     bool speculate_fast; int levels_done;
     unsigned true_vmax; bool has_tie, spec_hit; int *subid;
     bool ranked, late_export; double ms_detour;
@@ -1690,6 +1691,48 @@ static int ws_root_and_check(tf_ws_job *j, bool ranked)
     return TF_OK;
 }
 
+// begin, part 3: phase A, the edge masks, the speculative root phase or the chain levels below the job's depth.  Part of
+// tf_watershed_begin unless the caller asked for TF_WS_DEFER_SWEEPS: it then runs them through tf_watershed_sweeps (or leaves
+// them to finish) -- none of it reads the flow fields, the seeds' set-up of the NEXT window can run first, and the host replay
+// of an export on a guessed tie value is under way meanwhile.
+static int ws_job_sweeps(tf_ws_job *j)
+{
+    if (!j->sweeps_pending) return TF_OK;
+    j->sweeps_pending = false;
+    int64_t *st = j->st;
+    const WsC &c = j->c;
+    hipStream_t s = j->s;
+    const unsigned nbr_blocks = (unsigned)((j->R + 255) / 256);
+    int rc = ws_run_phase(c, 0, j->depth_max, j->Q, s, j->max_sweeps, &st[0], 29.0 * (double)j->N);
+    if (rc) return rc;
+    {
+        TfProfScope ps(TFK_WS_SETUP, 0.0, s);
+        hipLaunchKernelGGL(k_ws_edge_masks, dim3(nbr_blocks), dim3(256), 0, s, c, (u64 *)c.emask);
+    }
+    TF_CHECK_LAUNCH();
+    // Speculative start: a root phase on K2 alone (depth 1).  If its exactness check finds no origin at all the
+    // labelling cannot depend on any tie-break and is final (tie-free fields).  The caller's hint skips it for
+    // inputs known to contain exact plateaus: the labels are the same either way, only the work differs.
+    j->speculate_fast = !((j->flags & TF_WS_SKIP_FAST_PATH) && j->depth0 > 1);
+    st[5] = j->speculate_fast ? 0 : -1;
+    j->depth = j->depth0;
+    j->root_pending = true;
+    if (j->speculate_fast) {
+        j->depth = 1;
+        rc = ws_root_and_check(j, false);
+        if (rc) return rc;
+        st[5] = j->h_amb[2] != 0;
+        if (j->h_amb[2] == 0 || j->depth_max <= 1) j->root_pending = false;        // final (at depth 1 every origin counts as cut off)
+        else j->depth = j->depth0;
+    }
+    if (j->root_pending) {
+        rc = ws_chain_levels(j);                                                    // C_1 .. C_{depth - 1}; the root phase is finish's
+        if (rc) return rc;
+    }
+    st[8] = j->depth; st[9] = (int64_t)j->h_amb[0]; st[10] = (int64_t)j->h_amb[1]; st[11] = (int64_t)j->h_amb[2];
+    return TF_OK;
+}
+
 // `rv` != nullptr: the raveled form (tf_watershed_raveled): `field` = image, `markers` = `labels` = output (in place),
 // seeds = rv_locs; T, H, W, fwd, bwd, nbr_host unused.
 static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers, const int8_t *mask,
@@ -1700,7 +1743,7 @@ static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers
 {
     int64_t *st = j->st;
     for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = 0;
-    TF_REQUIRE((flags & ~(TF_WS_SKIP_FAST_PATH | TF_WS_REFERENCE_ORDER)) == 0, "tf_watershed: unknown flag");
+    TF_REQUIRE((flags & ~(TF_WS_SKIP_FAST_PATH | TF_WS_REFERENCE_ORDER | TF_WS_DEFER_SWEEPS)) == 0, "tf_watershed: unknown flag");
     TF_REQUIRE(field && markers && ws, "tf_watershed: null pointer");
     if (!rv) {
         TF_REQUIRE(fwd && bwd && nbr_host, "tf_watershed: null pointer");
@@ -1866,32 +1909,10 @@ static int ws_job_begin(tf_ws_job *j, const float *field, const int32_t *markers
             const int rc_x = ws_job_export(j);
             if (rc_x) return rc_x;
         }
-        int rc = ws_run_phase(c, 0, depth_max, Q, s, max_sweeps, &st[0], 29.0 * (double)N);
-        if (rc) return rc;
-        {
-            TfProfScope ps(TFK_WS_SETUP, 0.0, s);
-            hipLaunchKernelGGL(k_ws_edge_masks, dim3(nbr_blocks), dim3(256), 0, s, c, emask);
-        }
-        TF_CHECK_LAUNCH();
-        // Speculative start: a root phase on K2 alone (depth 1).  If its exactness check finds no origin at all the
-        // labelling cannot depend on any tie-break and is final (tie-free fields).  The caller's hint skips it for
-        // inputs known to contain exact plateaus: the labels are the same either way, only the work differs.
-        j->speculate_fast = !((flags & TF_WS_SKIP_FAST_PATH) && depth0 > 1);
-        st[5] = j->speculate_fast ? 0 : -1;
-        j->depth = depth0;
-        j->root_pending = true;
-        if (j->speculate_fast) {
-            j->depth = 1;
-            rc = ws_root_and_check(j, false);
-            if (rc) return rc;
-            st[5] = j->h_amb[2] != 0;
-            if (j->h_amb[2] == 0 || depth_max <= 1) j->root_pending = false;        // final (at depth 1 every origin counts as cut off)
-            else j->depth = depth0;
-        }
-        if (j->root_pending) {
-            rc = ws_chain_levels(j);                                                // C_1 .. C_{depth - 1}; the root phase is finish's
-            if (rc) return rc;
-        }
+        (void)nbr_blocks;
+        j->sweeps_pending = true;
+        if (flags & TF_WS_DEFER_SWEEPS) return TF_OK;                               // phase A and the chain levels: tf_watershed_sweeps / finish
+        return ws_job_sweeps(j);
     }
     st[8] = j->depth; st[9] = (int64_t)j->h_amb[0]; st[10] = (int64_t)j->h_amb[1]; st[11] = (int64_t)j->h_amb[2];
     return TF_OK;
@@ -1951,6 +1972,10 @@ static int ws_job_finish(tf_ws_job *j, int32_t *labels, uint8_t *amb_out)
     const unsigned nb1 = (unsigned)((N + 255) / 256);
     static const bool ref_debug = ws_env("TF_WS_REF_DEBUG");
     bool ranked = j->ranked;                                             // root keys are (pop rank << 32) | compact id
+    if (R > 0 && j->sweeps_pending) {                                    // TF_WS_DEFER_SWEEPS and nobody has called tf_watershed_sweeps
+        const int rc_s = ws_job_sweeps(j);
+        if (rc_s) return rc_s;
+    }
     if (R > 0 && j->late_export) {
         // second entry: the replay of the export that followed the root phase has run (or runs here): ranks up, root phase again
         j->late_export = false;
@@ -2072,6 +2097,7 @@ static int ws_run(const float *field, const int32_t *markers, const int8_t *mask
                   uint8_t *amb_out, void *ws, size_t ws_bytes, int64_t *st, void *stream,
                   const WsRavel *rv = nullptr, const int64_t *rv_locs = nullptr, int64_t rv_n_locs = 0)
 {
+    TF_REQUIRE(!(flags & TF_WS_DEFER_SWEEPS), "tf_watershed: unknown flag (TF_WS_DEFER_SWEEPS is tf_watershed_begin's)");
     for (int i = 0; i < TF_WS_NSTATS; i++) st[i] = 0;
     TF_REQUIRE(labels, "tf_watershed: null pointer");
     tf_ws_job *j = ws_job_new();
@@ -2104,6 +2130,14 @@ extern "C" int tf_watershed_begin(const float *field, const int32_t *markers, co
     return TF_OK;
 }
 extern "C" int tf_watershed_needs_replay(const void *job) { return job && ((const tf_ws_job *)job)->need_replay ? 1 : 0; }
+extern "C" int tf_watershed_sweeps(void *job, int64_t *stats_host)
+{
+    TF_REQUIRE(job, "tf_watershed_sweeps: null job");
+    tf_ws_job *j = (tf_ws_job *)job;
+    const int rc = j->R > 0 ? ws_job_sweeps(j) : TF_OK;
+    if (stats_host) for (int i = 0; i < TF_WS_NSTATS; i++) stats_host[i] = j->st[i];
+    return rc;
+}
 extern "C" int tf_watershed_replay(void *job)
 {
     TF_REQUIRE(job, "tf_watershed_replay: null job");

@@ -316,6 +316,7 @@ def apply_global_lut(labels, lut, inplace=False):
 #   * floods are FINISHED out of order, whichever replay ends first, on a second stream (the main one is busy with the flow);
 #   * the label ids of all windows (of all ranks, with a process group) are made consistent by stitch_rank_windows.
 # Every window's labels equal Flow.watershed on create_flow(window) -- tests/test_gpu_windows.py compares voxel for voxel.
+_os_environ_get = __import__("os").environ.get
 _REPLAY_POOL = None
 _SIDE_STREAMS = {}
 _BUDGET_MEMO = {}
@@ -382,8 +383,11 @@ class _WindowFloods:
         fw, bw = flow._dev_flows()
         st = {}
         o.mark("begin: seeds + edge field enqueued")
-        job = watershed_begin(fw, bw, e, seeds, None, o.nbr, o.chain_depth, stats=st, on_ambiguous=o.on_ambiguous, workspace=scratch)
-        o.mark("begin: done (replay %s)" % ("submitted" if job.needs_replay else "none"))
+        # (defer_sweeps: the call returns after the set-up and the export -- the parts that read the window's flow fields; phase
+        # A and the chain levels are begin_up_to's second pass, when the replays of ALL windows of this hand-over are under way)
+        job = watershed_begin(fw, bw, e, seeds, None, o.nbr, o.chain_depth, stats=st, on_ambiguous=o.on_ambiguous, workspace=scratch,
+                              defer_sweeps=_os_environ_get("TF_WINDOWS_DEFER_SWEEPS", "1") == "1")     # (development switch: 0 = one pass)
+        o.mark("begin: set up (replay %s)" % ("submitted" if job.needs_replay else "none"))
         fut = o.pool.submit(job.replay) if job.needs_replay else None
         return job, fut, st, scratch
 
@@ -437,20 +441,28 @@ class _WindowFloods:
         while wait_for is not None and self.next < len(bounds) and bounds[self.next][1] <= n_frames and not wait_for.query():
             if not self.finish_one(block=False):
                 time.sleep(0.0005)
+        begun = []
         while self.next < len(bounds) and bounds[self.next][1] <= n_frames:
             lo, hi = bounds[self.next]
             while len(self.pending) >= self.n_fly:
-                self.finish_one()
+                self.finish_one()                            # (a flood begun in this call is completed there: its sweeps first)
             # the Flow create_flow(bt[lo:hi]) would return, bit for bit: the flow of a frame pair does not depend on the window
             # it is in, only the two end frames of a window are mirrored (flow.py:425-426); window_view patches those two frames
             # in the stack's arrays for the duration of the block instead of copying the window's 7.5 GB of flow vectors.  Only
-            # the device part of the flood reads the flows (its neighbour table has the displacements applied): the job is
-            # finished outside the block.
+            # the set-up of the flood reads the flows (its neighbour table has the displacements applied): sweeps and root
+            # phase run outside the block.
             with flow.window_view(lo, hi) as flow_w:
-                self.pending.append(self._begin(flow_w, self.bt[lo:hi], self.pieces.pop()) + (self.next,))
+                item = self._begin(flow_w, self.bt[lo:hi], self.pieces.pop()) + (self.next,)
+            self.pending.append(item)
+            begun.append(item[0])
             self.next += 1
-            while self.finish_one(block=False):
-                pass
+        # second pass: phase A and the chain levels of the windows set up above -- all their host replays are running by now (at
+        # the end of a stack, where nothing else is left to do, the last window's replay so starts one window's sweeps earlier)
+        for job in begun:
+            job.sweeps()                                     # (a no-op for a job finish_one has completed meanwhile)
+            self.o.mark("begin: swept")
+        while self.finish_one(block=False):
+            pass
 
     def finish_all(self):
         while self.pending:

@@ -82,7 +82,7 @@ _relevant_memo = {}      # (T, H, W, neighbours, depth, stream) -> relevant pixe
 _conflict_memo = {}
 _MEMO_LOCK = __import__("threading").Lock()
 _REPROBE = 8
-TF_WS_SKIP_FAST_PATH, TF_WS_REFERENCE_ORDER = 1, 2
+TF_WS_SKIP_FAST_PATH, TF_WS_REFERENCE_ORDER, TF_WS_DEFER_SWEEPS = 1, 2, 4
 
 
 _SLOTS_LOCK = __import__("threading").Lock()
@@ -125,12 +125,38 @@ class WatershedJob:
         self.needs_replay = bool(_lib.lib().tf_watershed_needs_replay(handle))
         self.info = {}
         self._out = None
+        self._sweeps_pending = False
+        self._probe_noted = False
 
     @staticmethod
     def _info_dict(a):
         return {"replay_form": ("none", "sparse", "dense", "device")[int(a[0])], "seeds": int(a[1]), "seeds_at_or_below_tie_value": int(a[2]),
                 "subgraph_pixels": int(a[3]), "relevant_pixels": int(a[4]), "export_us": int(a[5]), "replay_us": int(a[6]),
                 "tie_key": int(a[7]), "guessed": bool(a[8]), "guess_covered_the_tie": bool(a[9]), "exported_for_key": int(a[10])}
+
+    def sweeps(self):
+        """Phase A and the chain levels of a job begun with defer_sweeps=True (tf_watershed_sweeps; a no-op otherwise), on the
+        stream the job was begun on.  Optional -- step() / finish() run them if nobody has -- but a caller that begins several
+        windows in a row gets all their set-ups (which read the flow fields) and host replays under way first."""
+        if self._h is not None and self._sweeps_pending:
+            self._sweeps_pending = False
+            _lib.check(_lib.lib().tf_watershed_sweeps(self._h, self._st.ctypes.data_as(_lib._P)), "tf_watershed_sweeps")
+            self._note_probe()
+        return self
+
+    def _note_probe(self):
+        """the scheduling memo of this shape: did this job probe (speculative root phase), and did the probe find a conflict?"""
+        if self._probe_noted:
+            return
+        self._probe_noted = True
+        probed = int(self._st[5])
+        with _MEMO_LOCK:
+            memo = list(_conflict_memo.get(self._memo_key, (False, 0)))
+            if probed >= 0:
+                memo[0], memo[1] = bool(probed), 0             # this call probed
+            else:
+                memo[1] += 1
+            _conflict_memo[self._memo_key] = memo
 
     def replay(self):
         if self._h is not None and self.needs_replay:
@@ -190,6 +216,9 @@ class WatershedJob:
                 self._h = None
                 self._ws = self._keep = self._out = None
                 _give_slot(self._slot)
+        if self._sweeps_pending:                             # finish has run the deferred sweeps itself
+            self._sweeps_pending = False
+            self._note_probe()
         if rc == TF_WS_REPLAY_PENDING:
             self.needs_replay = True
             self.info = self._info_dict(info)
@@ -249,7 +278,7 @@ _TIE_HISTORY = 32
 
 def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
                     expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="reference", return_ambiguous=False,
-                    workspace=None, guess_tie_value=True, _all_levels=False):
+                    workspace=None, guess_tie_value=True, _all_levels=False, defer_sweeps=False):
     """Device-resident core, first part: torch tensors in (field f32, markers i32, mask i8 or None) -> WatershedJob.
 
     expect_conflict: True / False force the scheduling hint, None (default) uses the per-shape memo.
@@ -267,7 +296,9 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
     workspace: a uint8 device tensor the flood may use as its scratch until the job is finished (e.g. a slice of another
     stage's idle scratch, _lib.borrow_workspace); too small a one is ignored and the job allocates its own.
     guess_tie_value: with on_ambiguous="reference", begin the export for the tie value of the previous flood of this shape
-    and stream (scheduling only: finish verifies the guess; see tf_watershed_begin)."""
+    and stream (scheduling only: finish verifies the guess; see tf_watershed_begin).
+    defer_sweeps: return after the set-up and the export (the parts that read the flow fields); WatershedJob.sweeps() -- or
+    step() / finish() -- runs phase A and the chain levels (TF_WS_DEFER_SWEEPS; scheduling only)."""
     if on_ambiguous not in ("warn", "raise", "ignore", "reference"):
         raise ValueError("on_ambiguous must be 'warn', 'raise', 'ignore' or 'reference'")
     t = _lib.torch()
@@ -298,6 +329,8 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
     if on_ambiguous == "reference":
         flags |= TF_WS_REFERENCE_ORDER
     spec = tie_key if (on_ambiguous == "reference" and guess_tie_value) else -1
+    if defer_sweeps:
+        flags |= TF_WS_DEFER_SWEEPS
     # levels beyond chain_depth are rarely needed: the first job gets room for two more, a second one for all
     start, cap = chain_depth, min(max_chain_depth, chain_depth + 2)
     if _all_levels:
@@ -323,16 +356,15 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
     except BaseException:
         _give_slot(slot)
         raise
-    probed = int(st[5])
-    if probed >= 0:
-        memo[0], memo[1] = bool(probed), 0                     # this call probed
-    else:
-        memo[1] += 1
     with _MEMO_LOCK:
         _relevant_memo[key] = int(st[6])
-        _conflict_memo[key] = memo
-    return WatershedJob(handle, slot, ws, (field, markers, mask), (T, H, W), on_ambiguous, return_ambiguous, stats, st, key,
-                        can_deepen=cap < max_chain_depth)
+    job = WatershedJob(handle, slot, ws, (field, markers, mask), (T, H, W), on_ambiguous, return_ambiguous, stats, st, key,
+                       can_deepen=cap < max_chain_depth)
+    if defer_sweeps:
+        job._sweeps_pending = True                           # (the scheduling probe is the sweeps': noted when they have run)
+    else:
+        job._note_probe()
+    return job
 
 
 def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
