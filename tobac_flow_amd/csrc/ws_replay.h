@@ -264,7 +264,20 @@ static int64_t ws_reference_ranks_sparse(int64_t M, int64_t S, const long long *
         store(child, e);
     };
     const double t_alloc = now_ms();
-    for (int64_t j = 0; j < S; j++) push_small((int64_t)sk[j], Item{(u64)sval[j] << 32, sid[j], 0});    // seed k enters at position k, age 0
+    // (round 5: the bitmap words of a seed's position, of its parent and of its grandparent -- the cold bottom of its chain; the
+    // levels above are shared with its neighbours and stay cached -- are requested a few seeds ahead: the build was paced by
+    // those misses, two 56 MB bitmaps per 16 x 5424^2 window)
+    constexpr int64_t AHEAD = 12;
+    for (int64_t j = 0; j < S; j++) {
+        if (j + AHEAD < S) {
+            int64_t q = (int64_t)sk[j + AHEAD];
+            for (int lvl = 0; lvl < 3 && q > 0; lvl++, q = (q + 1) / 2 - 1) {
+                __builtin_prefetch(&occ[q >> 6], 1, 1);
+                __builtin_prefetch(&expl[q >> 6], 1, 1);
+            }
+        }
+        push_small((int64_t)sk[j], Item{(u64)sval[j] << 32, sid[j], 0});     // seed k enters at position k, age 0
+    }
     hint_on = false;
     if (phase_ms) phase_ms[0] = now_ms() - t_start;
     if (getenv("WSR_DEBUG")) fprintf(stderr, "sparse: scratch %.1f ms, %lld pushes %.1f ms, table of items with an id / another value: %zu entries\n", t_alloc - t_start, (long long)S, now_ms() - t_alloc, deep.n);
