@@ -463,23 +463,6 @@ def main():
     _lib.profile_enable(False)
     del out_labels
     n_timed = len(ws_stats)
-    # Sub-report, outside the timed region: the dominant flow kernels with NOTHING beside them -- create_flow over the first 43
-    # frames (one batch of 42 pairs finished in two parts, as in the timed steps) on an otherwise idle device.  Since the end of
-    # round 5 the floods run on a thread and a stream of their own beside the whole flow, so the launch durations the library's
-    # HIP events record inside the timed region (`roofline.frac`) include what the floods' kernels take from the flow's.
-    prof_alone = None
-    if rank == 0 and full_size and not a.no_kernel_events and T >= 43:
-        torch.cuda.synchronize()
-        _lib.profile_enable(True)
-        _lib.profile_collect()
-        fl_alone = tf.create_flow(bt_all[:43], model="Farneback", vr_steps=a.vr_steps, smoothing_passes=1, interp_method="cubic",
-                                  workspace_gb=inflight.get("flow_workspace_gb"), split_parts=2,
-                                  on_frames_ready=(lambda fl, n: None) if (a.stream_windows and C == 1 and n_windows > 1) else None)   # (the same form of the kernel as in the timed steps)
-        fl_alone.check()
-        torch.cuda.synchronize()
-        prof_alone = _lib.profile_collect()
-        _lib.profile_enable(False)
-        del fl_alone
     raster_ms = None
     if a.tie_order == "reference" and not a.no_raster_subreport:
         # sub-report, outside the timed region: ONE step with equal-valued markers in raster order (on_ambiguous="ignore")
@@ -491,6 +474,26 @@ def main():
         raster_ms = (time.perf_counter() - ts) * 1e3
         del out_labels
         tie_mode["order"] = a.tie_order
+    # Sub-report, outside the timed region: the dominant flow kernels with NOTHING beside them -- create_flow over the first 43
+    # frames (one batch of 42 pairs finished in two parts, as in the timed steps) on an otherwise idle device.  Since the end of
+    # round 5 the floods run on a thread and a stream of their own beside the whole flow, so the launch durations the library's
+    # HIP events record inside the timed region (`roofline.frac`) include what the floods' kernels take from the flow's.
+    prof_alone = None
+    if world == 1 and full_size and not a.no_kernel_events and T >= 43:
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        _lib.profile_collect()
+        try:
+            fl_alone = tf.create_flow(bt_all[:43], model="Farneback", vr_steps=a.vr_steps, smoothing_passes=1, interp_method="cubic",
+                                      workspace_gb=inflight.get("flow_workspace_gb"), split_parts=2,
+                                      on_frames_ready=(lambda fl, n: None) if (a.stream_windows and C == 1 and n_windows > 1) else None)   # (the same form of the kernel as in the timed steps)
+            fl_alone.check()
+            torch.cuda.synchronize()
+            prof_alone = _lib.profile_collect()
+            del fl_alone
+        except torch.OutOfMemoryError:                           # (a configuration that fills the device: no sub-report)
+            prof_alone = None
+        _lib.profile_enable(False)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=bt_all.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
