@@ -670,6 +670,13 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             wq = _WindowFloods(o, bt, c, pieces, n_fly)
         wq.begin_up_to(flow_all, T)
         wins = wq.finish_all()
+        if o.info.get("flood_thread"):
+            # the flood thread allocated the labels under ITS stream; from here on they are the caller's, used on the caller's
+            # stream: tell the caching allocator, or a later allocation of the flood stream could take a block the caller has
+            # dropped while kernels of the caller's stream still read it (the same rule as WatershedJob.step(stream=...))
+            for w_ in wins:
+                if w_ is not None and w_.is_cuda:
+                    w_.record_stream(torch.cuda.current_stream())
         first = None
         o.mark("all windows finished")
         # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
