@@ -327,6 +327,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--no-pipeline-stacks", dest="pipeline_stacks", action="store_false",
+                    help="time the steps one after the other, each through detect_stack_windows (default, with windows begun during "
+                         "the flow and one channel: the timed steps are ONE detect_stack_sequence call over the rotated stacks -- the end "
+                         "of a stack, i.e. its last windows' host replays, root phases and the stitch, runs beside the next stack's flow, "
+                         "as in a sweep over many days; `step_ms` are then the intervals between the stacks' completions)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: do not record HIP events around the library's launches in the timed region "
                          "(roofline = null); the difference to a default run is what the instrumentation costs")
@@ -355,7 +360,7 @@ def main():
 
     import tobac_flow_amd.flow as tf
     from tobac_flow_amd import _lib
-    from tobac_flow_amd.parallel import detect_stack_windows, window_bounds
+    from tobac_flow_amd.parallel import detect_stack_sequence, detect_stack_windows, window_bounds
     from tools.synth import anvil_seeds, blob_stack
 
     cT, cH, cW, cN, C = CONFIGS[a.config]
@@ -445,7 +450,39 @@ def main():
     t0 = time.perf_counter()
     n_objects, step_ms = [], []
     objects_per_step = []
-    for i in range(a.steps):
+    pipelined = bool(a.pipeline_stacks and a.stream_windows and C == 1 and n_windows > 1 and a.steps > 1)
+    if pipelined:
+        # THE TIMED STEPS AS ONE SWEEP (round 5): detect_stack_sequence over the a.steps rotated stacks -- every stack is processed
+        # exactly as a detect_stack_windows step is (same windows, same labels: tests/test_gpu_windows.py), but the calling thread
+        # enqueues stack k + 1's flow as soon as stack k's last window has been SET UP, and stack k's last sweeps, host replays,
+        # root phases and stitch run beside it on the flood thread instead of with an idle device.  All of it inside the timed
+        # region; the previous stack's labels are released when a stack completes (one stack's labels resident, as before).
+        out_labels = None
+        done_at, kept = [], []
+
+        def consume_seq(k, wins):
+            n_obj = int(max(int(w.max()) for w in wins))
+            if dist is not None:                             # ids are global after the stitch: the count is the largest id on ANY rank
+                tn = torch.tensor([n_obj], dtype=torch.int64, device="cpu" if a.backend == "gloo" else bt_all.device)
+                dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                n_obj = int(tn.item())
+            objects_per_step.append(n_obj)
+            torch.cuda.current_stream().synchronize()
+            done_at.append(time.perf_counter())
+            if k == a.steps - 1:
+                kept[:] = [wins]
+            return None
+        detect_stack_sequence((stack_of(a.warmup + i) for i in range(a.steps)), bounds, seeds_of, consume=consume_seq, overlap=a.overlap,
+                              vr_steps=a.vr_steps, smoothing_passes=1, interp_method="cubic", connectivity=1, chain_depth=a.chain_depth,
+                              on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore", max_in_flight=a.inflight,
+                              flow_workspace_gb=float(os.environ["TF_BENCH_FLOW_GB"]) if "TF_BENCH_FLOW_GB" in os.environ else None,
+                              info=info, mark=mark if timeline else None)
+        inflight["n"] = info.get("floods_in_flight", 1)
+        inflight["flow_workspace_gb"] = info.get("flow_workspace_gb")
+        out_labels = kept[0]
+        n_objects = [objects_per_step[-1]]
+        step_ms = [round((b_ - a_) * 1e3, 1) for a_, b_ in zip([t0] + done_at[:-1], done_at)]
+    for i in range(0 if pipelined else a.steps):
         out_labels = None                                    # the previous step's labels are released before the next step's exist
         ts = time.perf_counter()
         out_labels, n_objects = step(stack_of(a.warmup + i))
@@ -463,6 +500,15 @@ def main():
     _lib.profile_enable(False)
     del out_labels
     n_timed = len(ws_stats)
+    alone_ms = None
+    if pipelined and not a.no_raster_subreport:
+        # sub-report, outside the timed region: ONE stack processed by itself (detect_stack_windows), its end with nothing beside it
+        barrier()
+        ts = time.perf_counter()
+        out_labels, _ = step(stack_of(a.warmup + a.steps))
+        barrier()
+        alone_ms = (time.perf_counter() - ts) * 1e3
+        del out_labels
     raster_ms = None
     if a.tie_order == "reference" and not a.no_raster_subreport:
         # sub-report, outside the timed region: ONE step with equal-valued markers in raster order (on_ambiguous="ignore")
@@ -584,7 +630,13 @@ def main():
                else f"Mpix/s end-to-end flow+sobel+watershed, {H}x{W} frames", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
                "unit": "Mpix/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist is not None else 1,
                "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(dt / a.steps * 1e3, 2), "step_ms": step_ms, "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / a.steps * 1e3, 2), "step_ms": step_ms,
+               "steps_pipelined": ({"on": True, "note": "the timed steps are ONE tobac_flow_amd.parallel.detect_stack_sequence call over the rotated stacks: the end of a "
+                                    "stack (its last windows' host replays, root phases, the stitch) runs beside the next stack's flow; step_ms = intervals "
+                                    "between the stacks' completions, the first one from the start of the timed region; --no-pipeline-stacks times them one by one"}
+                                   if pipelined else {"on": False}),
+               "one_stack_by_itself_ms": None if alone_ms is None else round(alone_ms, 1),
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": what,
                           "frames_delivered_per_step": T, "window_frames_computed_per_step": frames_computed, "channels": C,

@@ -39,6 +39,14 @@ def test_two_ranks_on_one_device_equal_the_one_process_run():
     assert two["config"]["objects_after_stitch"] == one["config"]["objects_after_stitch"] > 10
     # whole-job value: both ranks' frames over the slower rank's time
     assert two["value"] > 0 and abs(two["value"] - 2 * 24 * 1500 * 2500 / (two["ms_per_step"] * 1e-3) / 1e6) < 0.02 * two["value"]
+    # round 5: several timed steps are ONE detect_stack_sequence call (the end of a stack beside the next stack's flow); under
+    # --gpus N the stitch of every stack is a collective issued from the flood threads of the ranks, in the same order
+    two_p = _bench("--gpus", "2", "--single-device", "--backend", "gloo", "--steps", "2")
+    one_p = _bench("--frames", "44", "--n-windows", "4", "--steps", "2")
+    assert two_p["steps_pipelined"]["on"] and one_p["steps_pipelined"]["on"] and not two["steps_pipelined"]["on"]
+    n_obj = one["config"]["objects_after_stitch"]
+    assert two_p["config"]["objects_after_stitch_per_step"] == [n_obj, n_obj] == one_p["config"]["objects_after_stitch_per_step"]
+    assert len(two_p["step_ms"]) == 2 and two_p["n_gpus"] == 2
 
 
 def test_bench_pipeline_equals_the_plain_calls():

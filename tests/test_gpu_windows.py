@@ -167,3 +167,45 @@ def test_several_channels_share_the_flow_and_equal_the_plain_calls():
         for k, (g, w) in enumerate(zip(got[c], want)):
             assert torch.equal(g, w), (c, k, int((g != w).sum()))
     assert not torch.equal(got[0][0], got[1][0])                        # the channels do differ
+
+
+def test_a_sequence_of_stacks_equals_the_per_stack_calls_voxel_for_voxel():
+    """detect_stack_sequence (round 5): three stacks of one sequence processed back to back, the end of a stack -- its last
+    windows' sweeps, host replays, root phases, the stitch -- beside the next stack's flow.  Every stack's stitched windows equal
+    those of detect_stack_windows on that stack alone, voxel for voxel; `consume` is called once per stack, in order; an
+    exception of the caller's seeds_fn on the flood thread reaches the caller."""
+    import torch
+    from tobac_flow_amd.parallel import detect_stack_sequence, detect_stack_windows, window_bounds
+    from tools.synth import blob_stack
+    t_, h_, w_, n_win = 34, 700, 900, 3
+    all_bt = blob_stack(t_ + 2 * 5, h_, w_, seed=20240601, t0=3)
+    stacks = [all_bt[5 * k:5 * k + t_] for k in range(3)]
+    bounds = window_bounds(t_, n_win, OVERLAP)
+    want = []
+    for bt in stacks:
+        (w,), _ = detect_stack_windows(bt, bounds, _seeds, overlap=OVERLAP)
+        want.append([x.clone() for x in w])
+        del w
+    assert int(max(int(x.max()) for x in want[0])) > 3
+    seen = []
+
+    def consume(k, wins):
+        seen.append(k)
+        return [x.clone() for x in wins]
+    info = {}
+    got, info = detect_stack_sequence(iter(stacks), bounds, _seeds, consume=consume, overlap=OVERLAP, info=info)
+    assert seen == [0, 1, 2] and len(got) == 3 and info["stacks_pipelined"] and len(info["floods"]) == 3 * n_win
+    for k in range(3):
+        for j, (g, w) in enumerate(zip(got[k], want[k])):
+            assert g.dtype == torch.int32 and torch.equal(g, w), (k, j, int((g != w).sum()))
+    assert not torch.equal(got[0][0], got[1][0])                        # (the stacks do differ)
+    # default consume: the windows themselves
+    got2, _ = detect_stack_sequence(stacks[:2], bounds, _seeds, overlap=OVERLAP)
+    assert all(torch.equal(g, w) for k in range(2) for g, w in zip(got2[k], want[k]))
+
+    def bad_seeds(w, c):
+        raise RuntimeError("seeds_fn failed")
+    with pytest.raises(RuntimeError, match="seeds_fn failed"):
+        detect_stack_sequence(stacks, bounds, bad_seeds, overlap=OVERLAP)
+    with pytest.raises(ValueError, match="bounds"):
+        detect_stack_sequence(stacks, [(0, t_)], _seeds)

@@ -370,6 +370,11 @@ class _WindowFloods:
         self.pending = deque()                               # floods in flight: (job, future, stats, scratch, window index)
         self.wins = [None] * len(owner.bounds)
         self.next = 0                                        # next window to begin
+        self.family = None                                   # detect_stack_sequence: the stacks in flight share the flood slots
+
+    def _finish_any(self, block=True):
+        """finish one ready flood -- of this stack, or (detect_stack_sequence) of any stack still in flight"""
+        return self.family.finish_any(block) if self.family is not None else self.finish_one(block)
 
     def _begin(self, flow, w, scratch):
         """seeds -> edge field -> device part of the watershed of this channel over the window `w` of the stack; the host
@@ -439,13 +444,13 @@ class _WindowFloods:
         import time
         bounds = self.o.bounds
         while wait_for is not None and self.next < len(bounds) and bounds[self.next][1] <= n_frames and not wait_for.query():
-            if not self.finish_one(block=False):
+            if not self._finish_any(block=False):
                 time.sleep(0.0005)
         begun = []
         while self.next < len(bounds) and bounds[self.next][1] <= n_frames:
             lo, hi = bounds[self.next]
-            while len(self.pending) >= self.n_fly:
-                self.finish_one()                            # (a flood begun in this call is completed there: its sweeps first)
+            while not self.pieces:                           # every flood slot is taken (by this stack's floods, or an earlier stack's)
+                self._finish_any()                           # (a flood begun in this call is completed there: its sweeps first)
             # the Flow create_flow(bt[lo:hi]) would return, bit for bit: the flow of a frame pair does not depend on the window
             # it is in, only the two end frames of a window are mirrored (flow.py:425-426); window_view patches those two frames
             # in the stack's arrays for the duration of the block instead of copying the window's 7.5 GB of flow vectors.  Only
@@ -461,7 +466,7 @@ class _WindowFloods:
         for job in begun:
             job.sweeps()                                     # (a no-op for a job finish_one has completed meanwhile)
             self.o.mark("begin: swept")
-        while self.finish_one(block=False):
+        while self._finish_any(block=False):
             pass
 
     def finish_all(self):
@@ -692,3 +697,187 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
     flow_all.check()
     del flow_all
     return results, o.info
+
+
+class _SequenceFloods:
+    """The stacks of a detect_stack_sequence call that still have floods in flight, oldest first: they share the flood slots,
+    and whoever waits -- for a slot, for a hand-over's event -- finishes whichever flood of whichever stack is ready."""
+
+    def __init__(self, deliver):
+        self.active, self.deliver = [], deliver
+
+    def finish_any(self, block=True):
+        from concurrent.futures import FIRST_COMPLETED, wait
+        while True:
+            for wf in list(self.active):
+                if wf.pending and wf.finish_one(block=False):
+                    self.settle(wf)
+                    return True
+            if not block:
+                return False
+            futs = [p[1] for wf in self.active for p in wf.pending if p[1] is not None]
+            if not futs:
+                return False
+            wait(futs, return_when=FIRST_COMPLETED)
+
+    def settle(self, wf):
+        """a stack whose every window has its labels: stitch, hand over, forget"""
+        if wf in self.active and wf.next == len(wf.o.bounds) and not wf.pending and getattr(wf, "flow_enqueued", False):
+            self.active.remove(wf)
+            self.deliver(wf)
+
+
+def detect_stack_sequence(stacks, bounds, seeds_fn, consume=None, overlap=DEFAULT_OVERLAP, stitch=True, group=None,
+                          model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic", connectivity=1,
+                          chain_depth=3, on_ambiguous="reference", max_in_flight=12, flow_workspace_gb=None, info=None, mark=None):
+    """detect_stack_windows(stack, bounds, seeds_fn, ...) for every stack of `stacks` (an iterable of (T, H, W) float32 device
+    tensors of ONE shape: the days of a sweep), one channel, windows begun during the flow -- with the END of a stack run beside
+    the flow of the next one: a stack's last windows are set up (the only part of a flood that reads the flow fields) as soon
+    as its last frames' flow has passed, the calling thread then releases that stack's flow vectors and enqueues the next
+    stack's flow at once, and the flood thread finishes the old stack's sweeps, host replays, root phases and its stitch beside
+    it.  Alone, the end of a stack is 0.25 - 0.6 s in which the device waits for a sequential host replay.
+    Every window's labels are those of the per-stack call, bit for bit (tests/test_gpu_windows.py).
+
+    consume(k, windows): called ON THE FLOOD THREAD (its stream current) when stack k is complete -- stitched, unless
+    stitch=False -- and its return value collected (default: the windows themselves; a sweep that keeps every stack's label
+    windows resident runs out of memory: reduce or store them there).  Returns (results, info) like detect_stack_windows.
+    With a process group every rank must pass the same number of stacks (the stitch of stack k is a collective)."""
+    import os
+    import queue
+    import threading
+    import time
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.watershed import neighbour_offsets
+    bounds = [(int(lo), int(hi)) for lo, hi in bounds]
+    if len(bounds) < 2 or any(b[1] < a[1] or b[0] < a[0] for a, b in zip(bounds[:-1], bounds[1:])):
+        raise ValueError("detect_stack_sequence: bounds must be two or more ascending (start, stop) windows")
+    info = info if info is not None else {}
+    info.setdefault("floods", [])
+    info.setdefault("reference_order", [])
+    t_start = time.perf_counter()
+    marker = (lambda what: mark(what, (time.perf_counter() - t_start) * 1e3)) if mark is not None else (lambda what: None)
+    n_windows = len(bounds)
+    n_fly = int(max(1, min(max_in_flight, n_windows, 5)))
+    pieces = [None] * n_fly                                  # the flood slots, shared by the stacks in flight
+    pool = _replay_pool(max_in_flight)
+    nbr = neighbour_offsets(connectivity)
+    flow_kw = dict(model=model, vr_steps=vr_steps, smoothing_passes=smoothing_passes, interp_method=interp_method)
+    results, failure = {}, []
+    handover = queue.Queue()
+    dev_index = torch.cuda.current_device()
+    main_stream = torch.cuda.current_stream()
+    flood_stream = _side_stream(0, low_priority=os.environ.get("TF_WINDOWS_LOW_PRIORITY", "0") == "1")
+    info["floods_in_flight"], info["flood_thread"], info["stacks_pipelined"] = n_fly, True, True
+
+    def deliver(wf):
+        wins = wf.wins
+        wf.o.mark("stack %d: all windows finished" % wf.index)
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if stitch and (len(wins) > 1 or multi):
+            wins = stitch_rank_windows(wins, group=group, overlap=overlap, inplace=True)
+            wf.o.mark("stack %d: stitched" % wf.index)
+        for w_ in wins:                                      # (allocated under the flood stream; the caller's stream may use them afterwards)
+            if w_ is not None and w_.is_cuda:
+                w_.record_stream(main_stream)
+        results[wf.index] = wins if consume is None else consume(wf.index, wins)
+        wf.wins = None
+        wf.delivered.set()
+
+    fam = _SequenceFloods(deliver)
+
+    def flood_loop():
+        try:
+            torch.cuda.set_device(dev_index)
+            with torch.cuda.stream(flood_stream):
+                while True:
+                    try:
+                        item = handover.get(timeout=0.0005) if fam.active else handover.get()
+                    except queue.Empty:
+                        fam.finish_any(block=False)
+                        continue
+                    if item is None:
+                        break
+                    what, wf = item[0], item[1]
+                    if what == "new":
+                        fam.active.append(wf)
+                    elif what == "frames":
+                        wf.begin_up_to(item[2], item[3], wait_for=item[4])
+                        if wf.next == n_windows and not wf.setups_done.is_set():
+                            flood_stream.synchronize()           # (window_view's restored frames have landed: the flow arrays may go)
+                            wf.setups_done.set()
+                    elif what == "end":
+                        wf.flow_enqueued = True
+                        fam.settle(wf)
+                    item = wf = None                             # (a hand-over holds the stack's Flow: 68 GB at config F that must be free for the next stack)
+                while fam.active:                                # the last stack's end: nothing left to run beside it
+                    if not fam.finish_any(block=True):
+                        for wf in list(fam.active):
+                            fam.settle(wf)
+                        if fam.active:
+                            raise RuntimeError("detect_stack_sequence: a stack is left with windows that were never begun")
+                flood_stream.synchronize()
+        except BaseException as exc:                             # noqa: BLE001 -- re-raised on the calling thread
+            failure.append(exc)
+            while True:                                          # drain: the calling thread must never block on the hand-over
+                try:
+                    if handover.get(timeout=0.05) is None:
+                        break
+                except queue.Empty:
+                    if stop.is_set():
+                        break
+
+    stop = threading.Event()
+    worker = threading.Thread(target=flood_loop, name="tf-window-floods", daemon=True)
+    worker.start()
+    n_stacks = 0
+    try:
+        for k, bt in enumerate(stacks):
+            if not (isinstance(bt, torch.Tensor) and bt.is_cuda and bt.dim() == 3):
+                raise ValueError("detect_stack_sequence: every stack must be a (T, H, W) tensor on the GPU")
+            T, H, W = bt.shape
+            if any(not (0 <= lo < hi <= T) for lo, hi in bounds) or bounds[-1][1] != T:
+                raise ValueError("detect_stack_sequence: bounds must lie inside every stack and end with it")
+            o = _StackRun()
+            o.bounds, o.seeds_fn, o.nbr, o.chain_depth, o.on_ambiguous = bounds, seeds_fn, nbr, chain_depth, on_ambiguous
+            o.info, o.pool, o.side, o.mark = info, pool, None, (lambda what, k_=k: marker("[stack %d] %s" % (k_, what)))
+            if flow_workspace_gb is None:
+                longest = max(hi - lo for lo, hi in bounds)
+                per_job = 18 * longest * H * W
+                key = (torch.cuda.current_device(), T, H, W, tuple(bounds), n_fly)
+                if key not in _BUDGET_MEMO:
+                    free = torch.cuda.mem_get_info()[0] + (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
+                    from tobac_flow_amd import _lib
+                    held = sum(int(v.numel()) for kk, v in list(_lib._WS.items()) if v is not None and kk[1] == torch.cuda.current_device())
+                    need = 2 * T * H * W * 8 + 4 * sum(hi - lo for lo, hi in bounds) * H * W + (n_fly + 1) * (3 * per_job // 2)
+                    _BUDGET_MEMO[key] = max(4.0, 0.7 * (free + held - need) / 1e9)
+                flow_workspace_gb = _BUDGET_MEMO[key]
+                info["flow_workspace_gb"] = round(float(flow_workspace_gb), 1)
+            wf = _WindowFloods(o, bt, 0, pieces, n_fly)
+            wf.family, wf.index, wf.flow_enqueued = fam, k, False
+            wf.setups_done, wf.delivered = threading.Event(), threading.Event()
+            handover.put(("new", wf))
+
+            def frames_ready(fl, n, wf_=wf, o_=o):
+                o_.mark("flow enqueued for %d frames" % n)
+                ev = torch.cuda.Event()
+                ev.record()
+                handover.put(("frames", wf_, fl, n, ev))
+            flow = tf.create_flow(bt, on_frames_ready=frames_ready, workspace_gb=flow_workspace_gb, split_parts=2, **flow_kw)
+            handover.put(("end", wf))
+            n_stacks += 1
+            # this stack's flow vectors are read until its last window has been set up: then they go, and the next stack's flow
+            # is enqueued while the flood thread is still sweeping, replaying and stitching this one
+            while not wf.setups_done.wait(0.002):
+                if failure:
+                    raise failure[0]
+            flow.check()                                         # (a starved chain of the iteration kernel is reported per stack)
+            del flow
+    finally:
+        stop.set()
+        handover.put(None)
+        worker.join()
+    if failure:
+        raise failure[0]
+    return [results[k] for k in range(n_stacks)], info
