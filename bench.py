@@ -480,6 +480,7 @@ def main():
         inflight["n"] = info.get("floods_in_flight", 1)
         inflight["flow_workspace_gb"] = info.get("flow_workspace_gb")
         out_labels = kept[0]
+        kept.clear()                                         # (out_labels is the one reference: released with it)
         n_objects = [objects_per_step[-1]]
         step_ms = [round((b_ - a_) * 1e3, 1) for a_, b_ in zip([t0] + done_at[:-1], done_at)]
     for i in range(0 if pipelined else a.steps):
