@@ -209,3 +209,12 @@ def test_a_sequence_of_stacks_equals_the_per_stack_calls_voxel_for_voxel():
         detect_stack_sequence(stacks, bounds, bad_seeds, overlap=OVERLAP)
     with pytest.raises(ValueError, match="bounds"):
         detect_stack_sequence(stacks, [(0, t_)], _seeds)
+
+    def bad_consume(k, wins):
+        if k == 1:
+            raise KeyError("consume failed")
+        return None
+    with pytest.raises(KeyError, match="consume failed"):                # (raised on the flood thread while stack 2's flow is enqueued)
+        detect_stack_sequence(stacks, bounds, _seeds, consume=bad_consume, overlap=OVERLAP)
+    (again,), _ = detect_stack_windows(stacks[0], bounds, _seeds, overlap=OVERLAP)      # the library is usable afterwards
+    assert all(torch.equal(g, w) for g, w in zip(again, want[0]))

@@ -11,6 +11,8 @@ the stitched objects are the connected components of those pairs (linking.py:153
 which every rank runs the same union-find and rewrites its own labels (tf_apply_lut).  Pair counting on the GPU is
 the library's tf_window_overlap_pairs; CPU tensors (the gloo rehearsals) take the numpy statement of the same rule.
 """
+import os
+
 import numpy as np
 
 LINK_ATOL, LINK_RTOL = 5, 0.5          # linking.py:70-76
@@ -316,7 +318,6 @@ def apply_global_lut(labels, lut, inplace=False):
 #   * floods are FINISHED out of order, whichever replay ends first, on a second stream (the main one is busy with the flow);
 #   * the label ids of all windows (of all ranks, with a process group) are made consistent by stitch_rank_windows.
 # Every window's labels equal Flow.watershed on create_flow(window) -- tests/test_gpu_windows.py compares voxel for voxel.
-_os_environ_get = __import__("os").environ.get
 _REPLAY_POOL = None
 _SIDE_STREAMS = {}
 _BUDGET_MEMO = {}
@@ -391,7 +392,7 @@ class _WindowFloods:
         # (defer_sweeps: the call returns after the set-up and the export -- the parts that read the window's flow fields; phase
         # A and the chain levels are begin_up_to's second pass, when the replays of ALL windows of this hand-over are under way)
         job = watershed_begin(fw, bw, e, seeds, None, o.nbr, o.chain_depth, stats=st, on_ambiguous=o.on_ambiguous, workspace=scratch,
-                              defer_sweeps=_os_environ_get("TF_WINDOWS_DEFER_SWEEPS", "1") == "1")     # (development switch: 0 = one pass)
+                              defer_sweeps=os.environ.get("TF_WINDOWS_DEFER_SWEEPS", "1") == "1")     # (development switch: 0 = one pass)
         o.mark("begin: set up (replay %s)" % ("submitted" if job.needs_replay else "none"))
         fut = o.pool.submit(job.replay) if job.needs_replay else None
         return job, fut, st, scratch
