@@ -759,7 +759,7 @@ def detect_stack_sequence(stacks, bounds, seeds_fn, consume=None, overlap=DEFAUL
     t_start = time.perf_counter()
     marker = (lambda what: mark(what, (time.perf_counter() - t_start) * 1e3)) if mark is not None else (lambda what: None)
     n_windows = len(bounds)
-    n_fly = int(max(1, min(max_in_flight, n_windows, 5)))
+    n_fly = int(max(1, min(max_in_flight, n_windows, int(os.environ.get("TF_WINDOWS_SLOTS", "5")))))      # (development switch: flood slots)
     pieces = [None] * n_fly                                  # the flood slots, shared by the stacks in flight
     pool = _replay_pool(max_in_flight)
     nbr = neighbour_offsets(connectivity)
