@@ -438,8 +438,10 @@ class _WindowFloods:
         self.pieces.append(done[3])
         return True
 
-    def begin_up_to(self, flow, n_frames, wait_for=None):
-        """begin every window that ends within the first n_frames frames of the stack (their flow is final).
+    def setup_up_to(self, flow, n_frames, wait_for=None):
+        """first pass: set up every window that ends within the first n_frames frames of the stack (their flow is final) --
+        seeds, edge field, the flood's set-up and export: the only part that reads the flow fields; the host replays start.
+        Returns the jobs for sweep().
         wait_for: an event on the main stream behind the flow these windows need: until it has passed, floods whose replay
         has ended are finished (on the second stream) instead of blocking in the first synchronisation of a begin"""
         import time
@@ -462,13 +464,21 @@ class _WindowFloods:
             self.pending.append(item)
             begun.append(item[0])
             self.next += 1
-        # second pass: phase A and the chain levels of the windows set up above -- all their host replays are running by now (at
-        # the end of a stack, where nothing else is left to do, the last window's replay so starts one window's sweeps earlier)
+        return begun
+
+    def sweep(self, begun):
+        """second pass: phase A and the chain levels of the windows set up by setup_up_to -- all their host replays are running
+        by now (at the end of a stack, where nothing else is left to do, the last window's replay so starts one window's
+        sweeps earlier)"""
         for job in begun:
             job.sweeps()                                     # (a no-op for a job finish_one has completed meanwhile)
             self.o.mark("begin: swept")
         while self._finish_any(block=False):
             pass
+
+    def begin_up_to(self, flow, n_frames, wait_for=None):
+        """begin every window that ends within the first n_frames frames of the stack: setup_up_to, then sweep"""
+        self.sweep(self.setup_up_to(flow, n_frames, wait_for))
 
     def finish_all(self):
         while self.pending:
@@ -804,10 +814,15 @@ def detect_stack_sequence(stacks, bounds, seeds_fn, consume=None, overlap=DEFAUL
                     if what == "new":
                         fam.active.append(wf)
                     elif what == "frames":
-                        wf.begin_up_to(item[2], item[3], wait_for=item[4])
+                        begun = wf.setup_up_to(item[2], item[3], wait_for=item[4])
+                        item = None                              # (the hand-over holds the stack's Flow: 68 GB at config F)
                         if wf.next == n_windows and not wf.setups_done.is_set():
-                            flood_stream.synchronize()           # (window_view's restored frames have landed: the flow arrays may go)
+                            # the stack's last window is set up: nothing reads its flow vectors any more (the sweeps that follow
+                            # work on the compact graph) -- the calling thread releases them and enqueues the next stack's flow
+                            flood_stream.synchronize()           # (window_view's restored frames have landed)
                             wf.setups_done.set()
+                        wf.sweep(begun)
+                        begun = None
                     elif what == "end":
                         wf.flow_enqueued = True
                         fam.settle(wf)
