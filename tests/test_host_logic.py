@@ -729,3 +729,101 @@ def test_the_three_host_replays_of_the_reference_heap_agree(tmp_path):
     for seed in ("101", "202"):
         out = subprocess.run([str(exe), "random", "4000", seed], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "plain == sparse == dense" in out.stdout, out.stdout + out.stderr
+
+
+def test_window_scheduler_shares_its_slots_between_stacks_and_delivers_them_in_order():
+    """host logic of parallel._WindowFloods / _SequenceFloods (detect_stack_windows, detect_stack_sequence) with the device
+    parts replaced by stand-ins: never more floods in flight than slots, whichever stack they belong to; a flood whose first
+    finish ends in a late export is queued again and finished later; a stack is delivered once its flow has been enqueued,
+    every window begun and every flood finished -- the stacks in order; set-ups precede sweeps within a hand-over."""
+    import contextlib
+    from concurrent.futures import ThreadPoolExecutor
+    from tobac_flow_amd.parallel import _SequenceFloods, _StackRun, _WindowFloods
+    log, in_flight, peak = [], [0], [0]
+    pool = ThreadPoolExecutor(4)
+
+    class Job:
+        def __init__(self, tag, late):
+            self.tag, self.late, self.swept, self.needs_replay = tag, late, False, True
+
+        def sweeps(self):
+            log.append(("sweep", self.tag))
+            self.swept = True
+
+        def replay(self):
+            return self
+
+    class FakeFlow:
+        @contextlib.contextmanager
+        def window_view(self, lo, hi):
+            log.append(("view", lo, hi))
+            yield self
+
+    def make(stack, n_win, slots, late=()):
+        o = _StackRun()
+        o.bounds = [(4 * k, 4 * k + 6) for k in range(n_win)]
+        o.mark = lambda what: None
+        o.pool = pool
+        wf = _WindowFloods(o, list(range(4 * n_win + 2)), 0, slots, len(slots))
+
+        def begin(flow_w, w, scratch, wf=wf):
+            in_flight[0] += 1
+            peak[0] = max(peak[0], in_flight[0])
+            job = Job((stack, wf.next), (stack, wf.next) in late)
+            log.append(("setup", job.tag))
+            return job, pool.submit(job.replay), {}, scratch
+
+        def finish(job, fut, st, scratch):
+            fut.result()
+            assert job.swept, "finished before its sweeps"
+            if job.late:
+                job.late = False
+                log.append(("late", job.tag))
+                return None
+            in_flight[0] -= 1
+            log.append(("done", job.tag))
+            return "labels%s" % (job.tag,)
+        wf._begin, wf._finish = begin, finish
+        # (WatershedJob.step runs pending sweeps itself: the stand-in's finish is only reached through sweep() or a job swept there)
+        real_finish_one = wf.finish_one
+
+        def finish_one(block=True, wf=wf):
+            for p in wf.pending:
+                if not p[0].swept:
+                    p[0].sweeps()
+            return real_finish_one(block)
+        wf.finish_one = finish_one
+        return wf
+    # one stack, two slots, five windows, the third one with a late export
+    slots = [None, None]
+    wf = make(0, 5, slots, late={(0, 2)})
+    wf.begin_up_to(FakeFlow(), 14)                                       # windows 0 .. 2 end within 14 frames
+    assert wf.next == 3 and peak[0] <= 2
+    wf.begin_up_to(FakeFlow(), 22)
+    assert wf.finish_all() == ["labels(0, %d)" % k for k in range(5)] and peak[0] <= 2 and in_flight[0] == 0 and len(slots) == 2
+    assert ("late", (0, 2)) in log and log.index(("late", (0, 2))) < log.index(("done", (0, 2)))
+    first = [e for e in log if e[0] in ("setup", "sweep")][:4]
+    assert [e[0] for e in first[:2]] == ["setup", "setup"]               # a hand-over's windows are all set up before any is swept
+    # two stacks sharing three slots
+    del log[:]
+    peak[0] = 0
+    delivered = []
+    fam = _SequenceFloods(lambda w: delivered.append((w.index, list(w.wins))))
+    slots = [None, None, None]
+    a, b = make(0, 4, slots, late={(0, 3)}), make(1, 4, slots)
+    for k, w in enumerate((a, b)):
+        w.family, w.index, w.flow_enqueued = fam, k, False
+    fam.active.append(a)
+    a.sweep(a.setup_up_to(FakeFlow(), 18))                               # all four windows of stack 0: three slots -> one finished on the way
+    a.flow_enqueued = True
+    fam.settle(a)
+    fam.active.append(b)
+    b.sweep(b.setup_up_to(FakeFlow(), 18))                               # stack 1 begins while stack 0 still holds slots
+    assert peak[0] <= 3
+    b.flow_enqueued = True
+    while fam.active:
+        assert fam.finish_any(block=True) or not fam.active
+        for w in list(fam.active):
+            fam.settle(w)
+    assert [d[0] for d in delivered] == [0, 1] and in_flight[0] == 0 and len(slots) == 3
+    assert delivered[0][1] == ["labels(0, %d)" % k for k in range(4)] and delivered[1][1] == ["labels(1, %d)" % k for k in range(4)]
