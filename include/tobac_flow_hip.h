@@ -88,6 +88,7 @@ typedef struct {
     int poly_n;         /* 5   */
     double poly_sigma;  /* 1.1 */
     int chain_form;     /* TF_FB_CHAIN_*: scheduling of the iteration kernel for THIS call; the flows are the same bits */
+    int status_slot;    /* 0 = the device's shared status word; > 0 = a word of this caller's own (tf_farneback_status_acquire) */
 } tf_farneback_params;
 /* chain_form: the row-sum chains of the iteration kernel as one lane per chain (leaves LDS for the kernels of other streams,
  * e.g. floods of finished windows: what a caller that runs other work beside the flow wants) or in two parts one row group
@@ -122,14 +123,25 @@ size_t tf_farneback_workspace_bytes_batch(int64_t B, int64_t H, int64_t W, const
 int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneback_params *p, int64_t max_pairs, size_t max_bytes);
 /* Launches are asynchronous, so what a launch found out arrives later: tf_farneback_check() -- call it once the stream the
  * batches ran on has been synchronised (or an event after them has completed) -- returns TF_ESTARVED if a row-sum chain of
- * any iteration launch of this device since the last report gave up waiting for its left neighbour's hand-over words
- * (bounded polls: a device stalled for seconds by a profiler's serialisation or a preempted queue), TF_OK otherwise.  The
- * flow of those launches then holds NaN rows.  Every tf_farneback_batch* call also reports (and clears) on entry what
- * earlier launches left, so a caller that never checks still cannot go on unnoticed.  The reference has no counterpart
- * (cv2's calc is synchronous); error convention of SURVEY section 8(b). */
+ * any iteration launch of this device (made with status_slot 0) since the last report gave up waiting for its left
+ * neighbour's hand-over words (bounded polls: a device stalled for seconds by a profiler's serialisation or a preempted
+ * queue), TF_OK otherwise.  The flow of those launches then holds NaN rows.  Every tf_farneback_batch* call also reports (and
+ * clears) on entry what earlier launches left in ITS status word, so a caller that never checks still cannot go on
+ * unnoticed.  The reference has no counterpart (cv2's calc is synchronous); error convention of SURVEY section 8(b).
+ *
+ * Status slots (round 6): the shared word is read and cleared by whoever looks first, which is wrong as soon as two flows are
+ * in flight on one device (two host threads; a deferred check beside the next stack's first batch): one flow's entry check
+ * would consume the other's report.  tf_farneback_status_acquire() hands out a word of the caller's own (1 .. 255; 0 = none
+ * left or no device: share the device's word); put it into tf_farneback_params.status_slot for every call of ONE flow, read
+ * it with tf_farneback_status_check(slot) once that flow's launches have finished (TF_ESTARVED / TF_OK; clears), give it back
+ * with tf_farneback_status_release(slot).  Calls with a slot of their own neither read nor clear the shared word. */
 int tf_farneback_check(void);
-/* test hook: sets the device's status word from the host, as a starved chain would (tests of the host-side path) */
+int tf_farneback_status_acquire(void);
+int tf_farneback_status_check(int slot);
+void tf_farneback_status_release(int slot);
+/* test hooks: set a status word from the host, as a starved chain would (tests of the host-side path) */
 int tf_farneback_debug_set_starved(void);
+int tf_farneback_debug_set_starved_slot(int slot);
 /* Workgroups of the iteration kernel's full-resolution launch for B pairs, and (resident_out, may be NULL) how many the
  * device holds at once.  A launch costs whole rounds of resident workgroups: cut a batch into parts
  * (tf_farneback_batch_phase) only while a part still fills a round. */
@@ -499,7 +511,8 @@ int tf_label(const uint8_t *in, int64_t T, int64_t H, int64_t W, const uint8_t *
  *   :660-687) -- out[i] = 1 + the index of (a[i], b[i]) in the list of distinct pairs (pairs_a, pairs_b: device arrays as
  *   tf_pair_counts returns them, sorted by (a, b)), 0 where a[i] <= 0, b[i] <= 0 or the pair is not listed.  With a = the
  *   pieces of the non-zero mask connected within a time step (tf_label, t planes of the structure zeroed) and b = the
- *   labels this is the reference's numbering: contiguous from 1, by piece, then by original label.  16-byte aligned volumes. */
+ *   labels this is the reference's numbering: contiguous from 1, by piece, then by original label.  Volumes that are all
+ *   16-byte aligned take wide loads; any other (4-byte aligned) views -- labels[1:] with H * W % 4 != 0 -- scalar ones. */
 int tf_pair_rank(const int32_t *a, const int32_t *b, int64_t n, const int32_t *pairs_a, const int32_t *pairs_b,
                  int64_t n_pairs, int32_t *out, void *stream);
 size_t tf_pair_counts_workspace_bytes(int64_t n, int64_t max_runs);

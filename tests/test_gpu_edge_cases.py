@@ -385,35 +385,66 @@ def test_a_starved_chain_is_an_error_not_a_flow_of_nans(tf, tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TF_FBI_SEQ_ABLATE="64", TF_FBI_POLL_LIMIT="4"),
                          capture_output=True, text=True, timeout=600)
     assert "STARVED-RAISED" in out.stdout, (out.stdout, out.stderr[-2000:])
-    # (ii) host path in this process
+    # (ii) host path in this process: the status word of a flow's own (round 6: one per model object = per flow) set from the
+    # host makes that flow's next batch call return TF_ESTARVED on entry, the report clears it, the following call computes
+    # the same flow as before; the device's shared word (status_slot 0) behaves the same for callers of the bare C ABI
+    from tobac_flow_amd.utils.normalisation_utils import linear_norm
     L = _lib.lib()
-    assert L.tf_farneback_check() == 0
-    assert L.tf_farneback_debug_set_starved() == 0
+    p8 = tf.to_8bit(linear_norm(a[:2]), 0, 1)
+    model = tf.select_of_model("Farneback")
+    f0 = model.calc(p8[0], p8[1], None)
+    slot = model.params.status_slot
+    assert slot > 0 and L.tf_farneback_status_check(slot) == 0 and L.tf_farneback_check() == 0
+    assert L.tf_farneback_debug_set_starved_slot(slot) == 0
     with pytest.raises(_lib.TobacFlowHipError, match="gave up"):
-        tf.calculate_flow(a, "Farneback")
-    assert L.tf_farneback_check() == 0                                   # reported once, cleared
+        model.calc(p8[0], p8[1], None)
+    assert L.tf_farneback_status_check(slot) == 0                         # reported once, cleared
+    assert np.array_equal(model.calc(p8[0], p8[1], None), f0)
+    assert L.tf_farneback_debug_set_starved() == 0
+    assert np.array_equal(model.calc(p8[0], p8[1], None), f0)             # (the shared word is not this flow's)
+    assert L.tf_farneback_check() == _lib.TF_ESTARVED and L.tf_farneback_check() == 0
     again = tf.calculate_flow(a, "Farneback")
     assert np.array_equal(again[0], want[0]) and np.array_equal(again[1], want[1])
-    assert L.tf_farneback_debug_set_starved() == 0
-    assert L.tf_farneback_check() == _lib.TF_ESTARVED and L.tf_farneback_check() == 0
     # (iii) device-resident input: create_flow returns before the device is done, its check is deferred to an event -- the report
-    # of a launch that finishes later arrives at the next use of the Flow object (non-blocking poll) or at Flow.check()
+    # of a launch that finishes later arrives at the results the Flow hands out (round 6: Flow.sobel / watershed / ... wait for
+    # it) or at Flow.check().  Round 6: every flow reports to a status word of its own (tf_farneback_status_*)
     import torch
     ad = torch.from_numpy(a).cuda()
     fl = tf.create_flow(ad, "Farneback")
     assert fl._pending_check is not None
+    slot = fl._pending_check.status_slot
+    assert slot > 0
     torch.cuda.synchronize()
-    assert L.tf_farneback_debug_set_starved() == 0                        # "a chain of those launches gave up"
+    assert L.tf_farneback_debug_set_starved_slot(slot) == 0               # "a chain of those launches gave up"
     with pytest.raises(_lib.TobacFlowHipError, match="gave up"):
         fl.sobel(ad, direction="uphill", method="cubic")                 # first use after the launches have finished
-    assert L.tf_farneback_check() == 0
+    assert L.tf_farneback_status_check(slot) == 0
     fl.sobel(ad, direction="uphill", method="cubic")                     # reported once
     fl2 = tf.create_flow(ad, "Farneback")
-    assert L.tf_farneback_debug_set_starved() == 0
+    assert L.tf_farneback_debug_set_starved_slot(fl2._pending_check.status_slot) == 0
     with pytest.raises(_lib.TobacFlowHipError, match="gave up"):
         fl2.check()
     fl2.check()
     assert torch.equal(torch.nan_to_num(fl2.forward_flow, nan=-7.0), torch.nan_to_num(torch.from_numpy(np.clip(want[0], -20, 20)).cuda(), nan=-7.0))
+    # (iv) two flows in flight: B's calls neither consume nor report A's starved chain; A's own check still finds it
+    fa = tf.create_flow(ad, "Farneback")
+    slot_a = fa._pending_check.status_slot
+    assert L.tf_farneback_debug_set_starved_slot(slot_a) == 0
+    fb = tf.create_flow(ad, "Farneback")                                  # (entry checks of B's batches read B's word only)
+    assert fb._pending_check.status_slot not in (0, slot_a)
+    fb.check()
+    assert L.tf_farneback_check() == 0                                    # nor has the device's shared word been touched
+    with pytest.raises(_lib.TobacFlowHipError, match="gave up"):
+        fa.check()
+    # the shared word still works for callers that construct their parameter block themselves (status_slot 0)
+    assert L.tf_farneback_debug_set_starved() == 0 and L.tf_farneback_status_check(0) == _lib.TF_ESTARVED and L.tf_farneback_check() == 0
+    # slots go back when their flow object is dropped
+    del fa, fb, fl, fl2
+    import gc
+    gc.collect()
+    k = L.tf_farneback_status_acquire()
+    assert 0 < k <= max(slot, slot_a) + 2
+    L.tf_farneback_status_release(k)
 
 
 def test_shutdown_releases_the_timing_pool_and_leaves_the_library_usable(tf):

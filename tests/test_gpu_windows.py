@@ -218,3 +218,40 @@ def test_a_sequence_of_stacks_equals_the_per_stack_calls_voxel_for_voxel():
         detect_stack_sequence(stacks, bounds, _seeds, consume=bad_consume, overlap=OVERLAP)
     (again,), _ = detect_stack_windows(stacks[0], bounds, _seeds, overlap=OVERLAP)      # the library is usable afterwards
     assert all(torch.equal(g, w) for g, w in zip(again, want[0]))
+
+
+def test_a_window_that_ends_at_a_hand_over_waits_for_the_next_one_on_the_flood_thread(monkeypatch):
+    """ADVICE r5 (high).  create_flow hands over n = pairs_done + 1 frames; forward[n - 1] is written by the flow's next part.
+    A window that ends exactly at n has that frame saved / patched / restored by Flow.window_view: ordered on the calling
+    stream, a race on the flood thread's stream (the stale copy restored over the flow's real write -> the next overlapping
+    window reads garbage as an interior frame).  T = 30 in one forced-split batch hands over 16 then 30 frames; bounds
+    [(0, 16), (12, 30)] put a window end on the first hand-over; a slow seeds_fn lets the flow run ahead of the flood thread.
+    flood thread == calling thread == the serial plain calls, voxel for voxel."""
+    import time
+    import torch
+    from tobac_flow_amd.parallel import detect_stack_windows
+    from tools.synth import blob_stack
+    monkeypatch.setenv("TF_FLOW_SPLIT_FORCE", "1")
+    t_, h_, w_ = 30, 500, 700
+    bt = blob_stack(t_, h_, w_, seed=20240601, t0=2)
+    bounds = [(0, 16), (12, 30)]
+    want = _serial_windows(bt, bounds, OVERLAP)
+
+    def slow_seeds(w, c):
+        time.sleep(0.4)
+        return _seeds(w, c)
+    marks = []
+    (on_caller,), _ = detect_stack_windows(bt, bounds, slow_seeds, overlap=OVERLAP, flood_thread=False, mark=lambda what, ms: marks.append(what))
+    assert "flow enqueued for 16 frames" in marks, marks        # the window end does coincide with a hand-over
+    for k in range(2):
+        assert torch.equal(on_caller[k], want[k]), ("calling thread", k, int((on_caller[k] != want[k]).sum()))
+    for attempt in range(3):
+        marks = []
+        (on_thread,), info = detect_stack_windows(bt, bounds, slow_seeds, overlap=OVERLAP, flood_thread=True, mark=lambda what, ms: marks.append(what))
+        assert info["flood_thread"] is True
+        for k in range(2):
+            assert torch.equal(on_thread[k], want[k]), ("flood thread", attempt, k, int((on_thread[k] != want[k]).sum()))
+        # window 0 was begun only after the whole stack's flow had been handed over
+        first_setup = next(i for i, m in enumerate(marks) if m.startswith("begin:"))
+        assert marks.index("flow enqueued for 30 frames") < first_setup, marks
+        del on_thread

@@ -49,6 +49,13 @@ def test_a_starved_chain_report_becomes_an_exception(monkeypatch):
         model.check_launches("create_flow")
     with pytest.raises(RuntimeError):
         model.check_launches()
+    # status slots (round 6): without a device there is no pinned ring -- acquire hands out 0 (= share the device's word), the
+    # checks report nothing, a slot number outside the ring is an argument error
+    assert L.tf_farneback_status_acquire() == 0 and L.tf_farneback_status_check(0) == 0 and L.tf_farneback_status_check(7) == 0
+    assert L.tf_farneback_status_check(4096) == -1
+    L.tf_farneback_status_release(0)
+    L.tf_farneback_status_release(4096)
+    assert model.params.status_slot == 0
 
 
 def test_device_field_is_a_tensor_with_a_time_coordinate():
@@ -827,3 +834,57 @@ def test_window_scheduler_shares_its_slots_between_stacks_and_delivers_them_in_o
             fam.settle(w)
     assert [d[0] for d in delivered] == [0, 1] and in_flight[0] == 0 and len(slots) == 3
     assert delivered[0][1] == ["labels(0, %d)" % k for k in range(4)] and delivered[1][1] == ["labels(1, %d)" % k for k in range(4)]
+
+
+def test_flood_thread_never_begins_a_window_whose_last_frame_is_the_handovers_last():
+    """create_flow hands over n = pairs_done + 1 frames, of which forward[n - 1] is written by the flow's NEXT
+    part on the calling stream; Flow.window_view saves / patches / restores exactly that frame of a window that ends at n.
+    Driven from the flood thread (a stream of its own) that restore races with the flow's write, so such a window waits for
+    the next hand-over -- unless the stack ends there.  On the calling thread (ordered by the stream) nothing changes.
+    Also: abandon_all gives every slot back (failure path)."""
+    import contextlib
+    from concurrent.futures import ThreadPoolExecutor
+    from tobac_flow_amd.parallel import _StackRun, _WindowFloods
+    pool = ThreadPoolExecutor(2)
+    views, abandoned = [], []
+
+    class Job:
+        needs_replay = True
+
+        def sweeps(self):
+            pass
+
+        def replay(self):
+            return self
+
+        def abandon(self):
+            abandoned.append(self)
+
+    class FakeFlow:
+        @contextlib.contextmanager
+        def window_view(self, lo, hi):
+            views.append((lo, hi))
+            yield self
+
+    def make(own_stream, slots):
+        o = _StackRun()
+        o.bounds = [(0, 16), (12, 30)]
+        o.mark = lambda what: None
+        o.pool = pool
+        wf = _WindowFloods(o, list(range(30)), 0, slots, len(slots))
+        wf.own_stream = own_stream
+        wf._begin = lambda flow_w, w, scratch: (Job(), pool.submit(lambda: None), {}, scratch)
+        return wf
+    slots = [None, None, None]
+    wf = make(True, slots)
+    assert wf.setup_up_to(FakeFlow(), 15) == [] and views == []
+    assert wf.setup_up_to(FakeFlow(), 16) == [] and views == []          # window 0 ends AT the hand-over: frame 15 is not final
+    assert len(wf.setup_up_to(FakeFlow(), 17)) == 1 and views == [(0, 16)]
+    assert wf.setup_up_to(FakeFlow(), 29) == []
+    assert len(wf.setup_up_to(FakeFlow(), 30)) == 1 and views == [(0, 16), (12, 30)]   # the stack ends here: its last frame is final
+    assert len(slots) == 1
+    wf.abandon_all()
+    assert len(abandoned) == 2 and len(slots) == 3 and not wf.pending
+    del views[:]
+    wf = make(False, [None, None])                                       # calling thread: ordered by the stream, begun at once
+    assert len(wf.setup_up_to(FakeFlow(), 16)) == 1 and views == [(0, 16)]

@@ -25,7 +25,7 @@ class VarRefParams(ctypes.Structure):
 class FarnebackParams(ctypes.Structure):
     _fields_ = [("num_levels", ctypes.c_int), ("pyr_scale", ctypes.c_double), ("win_size", ctypes.c_int),
                 ("num_iters", ctypes.c_int), ("poly_n", ctypes.c_int), ("poly_sigma", ctypes.c_double),
-                ("chain_form", ctypes.c_int)]
+                ("chain_form", ctypes.c_int), ("status_slot", ctypes.c_int)]
 
 
 FB_CHAIN_DEFAULT, FB_CHAIN_ONE_LANE, FB_CHAIN_TWO_PART = 0, 1, 2
@@ -58,6 +58,10 @@ _PROTOS = {
     "tf_farneback_batch_hint": (_c.c_int64, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int64, _c.c_size_t]),
     "tf_farneback_check": (_c.c_int, []),
     "tf_farneback_debug_set_starved": (_c.c_int, []),
+    "tf_farneback_status_acquire": (_c.c_int, []),
+    "tf_farneback_status_check": (_c.c_int, [_c.c_int]),
+    "tf_farneback_status_release": (None, [_c.c_int]),
+    "tf_farneback_debug_set_starved_slot": (_c.c_int, [_c.c_int]),
     "tf_farneback_iteration_workgroups": (_c.c_int64, [_c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams), _c.c_int64, _P]),
     "tf_farneback_batch": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(FarnebackParams),
                                       _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),

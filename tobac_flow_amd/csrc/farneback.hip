@@ -1628,7 +1628,7 @@ __global__ void __launch_bounds__(256) k_fb_zero(float *__restrict__ p, int64_t 
 // ---- host side -----------------------------------------------------------------------------------
 extern "C" void tf_farneback_default_params(tf_farneback_params *p) {
     p->num_levels = 5; p->pyr_scale = 0.5; p->win_size = 13; p->num_iters = 10; p->poly_n = 5; p->poly_sigma = 1.1;
-    p->chain_form = TF_FB_CHAIN_DEFAULT;
+    p->chain_form = TF_FB_CHAIN_DEFAULT; p->status_slot = 0;
 }
 
 static void fb_gaussian_kernel(int n, double sigma, FbKernel *out) {
@@ -1752,28 +1752,46 @@ extern "C" int64_t tf_farneback_batch_hint(int64_t H, int64_t W, const tf_farneb
 }
 
 // ---- starved chains -> TF_ESTARVED ---------------------------------------------------------------------------------------
-// One pinned, device-visible word per device.  A chain of k_fb_iter that gives up on its left neighbour's hand-over words
-// (fb_chain_enter) stores 1 into it; the host reads it once the launches are known to have finished -- tf_farneback_check()
-// after the caller's own synchronisation, and every tf_farneback_batch* call on entry (which catches an earlier call's
-// launches for a caller that never checks) -- and turns it into an error: rows of NaN never leave with TF_OK.
+// A ring of pinned, device-visible status words per device.  A chain of k_fb_iter that gives up on its left neighbour's
+// hand-over words (fb_chain_enter) stores 1 into the word its launch was handed; the host reads it once the launches are
+// known to have finished and turns it into an error: rows of NaN never leave with TF_OK.
+// Round 6: WHICH word a launch is handed is the caller's -- tf_farneback_params.status_slot.  Slot 0 is the
+// device's shared word (round 5's only one): every call with status_slot 0 reports and clears it on entry, tf_farneback_check()
+// reads it.  A caller that runs several flows side by side on one device (detect_stack_windows' flood thread beside the next
+// stack's flow; two host threads) acquires a slot per flow (tf_farneback_status_acquire): its calls write, report on entry and
+// are checked on THAT word only, so one flow's check can neither consume nor be blamed for another flow's starved chain.
+#define FB_STATUS_SLOTS 256
 static std::mutex fb_starved_mu;
-static int *fb_starved_words[TF_MAX_DEVICES] = {};
-static int *fb_starved_word(bool create)
+static int *fb_status_ring[TF_MAX_DEVICES] = {};
+static unsigned char fb_status_busy[TF_MAX_DEVICES][FB_STATUS_SLOTS] = {};
+static int fb_current_device()
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TF_MAX_DEVICES) dev = 0;
-    std::lock_guard<std::mutex> lk(fb_starved_mu);
-    if (!fb_starved_words[dev] && create) {
-        void *p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        *(volatile int *)p = 0;
-        fb_starved_words[dev] = (int *)p;
-    }
-    return fb_starved_words[dev];
+    return dev;
 }
-static int fb_report_starved(const char *who)
+static int *fb_status_ring_locked(int dev, bool create)
 {
-    int *w = fb_starved_word(false);
+    if (!fb_status_ring[dev] && create) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, FB_STATUS_SLOTS * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        for (int k = 0; k < FB_STATUS_SLOTS; k++) ((volatile int *)p)[k] = 0;
+        fb_status_ring[dev] = (int *)p;
+        fb_status_busy[dev][0] = 1;              // the shared word is never handed out
+    }
+    return fb_status_ring[dev];
+}
+static int *fb_starved_word(bool create, int slot = 0)
+{
+    if (slot < 0 || slot >= FB_STATUS_SLOTS) slot = 0;
+    const int dev = fb_current_device();
+    std::lock_guard<std::mutex> lk(fb_starved_mu);
+    int *ring = fb_status_ring_locked(dev, create);
+    return ring ? ring + slot : nullptr;
+}
+static int fb_report_starved(const char *who, int slot = 0)
+{
+    int *w = fb_starved_word(false, slot);
     if (!w || __atomic_load_n(w, __ATOMIC_ACQUIRE) == 0) return TF_OK;
     __atomic_store_n(w, 0, __ATOMIC_RELEASE);
     tf_set_error("%s: a row-sum chain of the Farneback iteration kernel gave up waiting for its left neighbour's hand-over words "
@@ -1781,15 +1799,39 @@ static int fb_report_starved(const char *who)
     return TF_ESTARVED;
 }
 extern "C" int tf_farneback_check(void) { return fb_report_starved("tf_farneback_check"); }
-// (test hook: what the kernel does when it gives up, done from the host -- the host-side path can be tested without a device
-// that stalls)
-extern "C" int tf_farneback_debug_set_starved(void)
+extern "C" int tf_farneback_status_acquire(void)
 {
-    int *w = fb_starved_word(true);
+    const int dev = fb_current_device();
+    std::lock_guard<std::mutex> lk(fb_starved_mu);
+    int *ring = fb_status_ring_locked(dev, true);
+    if (!ring) return 0;
+    for (int k = 1; k < FB_STATUS_SLOTS; k++)
+        if (!fb_status_busy[dev][k]) { fb_status_busy[dev][k] = 1; __atomic_store_n(ring + k, 0, __ATOMIC_RELEASE); return k; }
+    return 0;                                    // all taken: the caller shares the device's word (round 5 behaviour)
+}
+extern "C" void tf_farneback_status_release(int slot)
+{
+    if (slot <= 0 || slot >= FB_STATUS_SLOTS) return;
+    const int dev = fb_current_device();
+    std::lock_guard<std::mutex> lk(fb_starved_mu);
+    fb_status_busy[dev][slot] = 0;
+}
+extern "C" int tf_farneback_status_check(int slot)
+{
+    if (slot < 0 || slot >= FB_STATUS_SLOTS) { tf_set_error("tf_farneback_status_check: no such slot"); return TF_EINVAL; }
+    return fb_report_starved(slot ? "tf_farneback_status_check" : "tf_farneback_check", slot);
+}
+// (test hooks: what the kernel does when it gives up, done from the host -- the host-side path can be tested without a device
+// that stalls)
+extern "C" int tf_farneback_debug_set_starved_slot(int slot)
+{
+    if (slot < 0 || slot >= FB_STATUS_SLOTS) { tf_set_error("tf_farneback_debug_set_starved_slot: no such slot"); return TF_EINVAL; }
+    int *w = fb_starved_word(true, slot);
     if (!w) { tf_set_error("tf_farneback_debug_set_starved: no pinned word (no HIP device?)"); return TF_EHIP; }
     __atomic_store_n(w, 1, __ATOMIC_RELEASE);
     return TF_OK;
 }
+extern "C" int tf_farneback_debug_set_starved(void) { return tf_farneback_debug_set_starved_slot(0); }
 
 // Workgroups of the iteration kernel's full-resolution launch for B pairs (both directions), and how many of them the
 // device holds at once: a launch costs whole rounds of resident workgroups, so a caller that may cut a batch into parts
@@ -2008,7 +2050,7 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             ia.hand = (unsigned long long *)((char *)tmp + FBI_HDR); ia.bs_hand = bs_tmp / 2; ia.ticket = (int *)tmp; ia.epoch = 0;
             static const int poll_env = getenv("TF_FBI_POLL_LIMIT") ? atoi(getenv("TF_FBI_POLL_LIMIT")) : -1;
             ia.poll_limit = poll_env >= 0 ? poll_env : (1 << 22);
-            ia.starved = tree ? nullptr : fb_starved_word(true);
+            ia.starved = tree ? nullptr : fb_starved_word(true, p->status_slot);
             if (!tree && !ia.starved) { tf_set_error("tf_farneback: no pinned status word for the iteration kernel (hipHostMalloc failed)"); return TF_EHIP; }
             if (!tree) {
                 TF_REQUIRE(FBI_HDR + hand_words * 8 <= (size_t)bs_tmp * sizeof(float), "tf_farneback: blur scratch too small for the strips' hand-over words");
@@ -2114,7 +2156,7 @@ extern "C" int tf_farneback_batch_split(const uint8_t *prev, const uint8_t *next
     TF_REQUIRE(p->win_size >= 1 && p->win_size / 2 <= FB_MAX_M, "tf_farneback: win_size out of range");
     TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback: bad params");
     if (ws_bytes < tf_farneback_workspace_bytes_split(B64, parts64, H64, W64, p)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
-    if (const int rc0 = fb_report_starved("tf_farneback (an earlier call's launches)")) return rc0;
+    if (const int rc0 = fb_report_starved("tf_farneback (an earlier call's launches)", p->status_slot)) return rc0;
     const int H = (int)H64, W = (int)W64, B = (int)B64;
     hipStream_t s = (hipStream_t)stream;
     const bool fused = p->win_size == FBI_WIN;
@@ -2207,7 +2249,7 @@ extern "C" int tf_farneback_batch_phase(const uint8_t *prev, const uint8_t *next
     TF_REQUIRE(p->num_iters >= 1 && p->num_levels >= 0 && p->pyr_scale > 0 && p->pyr_scale < 1, "tf_farneback: bad params");
     TF_REQUIRE(tf_farneback_can_split(H64, W64, p), "tf_farneback_batch_phase: this geometry does not split (tf_farneback_can_split)");
     if (ws_bytes < tf_farneback_workspace_bytes_phase(B64, H64, W64, p, phase)) { tf_set_error("tf_farneback: workspace too small"); return TF_ENOMEM; }
-    if (const int rc0 = fb_report_starved("tf_farneback (an earlier call's launches)")) return rc0;
+    if (const int rc0 = fb_report_starved("tf_farneback (an earlier call's launches)", p->status_slot)) return rc0;
     const int H = (int)H64, W = (int)W64, B = (int)B64;
     hipStream_t s = (hipStream_t)stream;
     const bool fused = p->win_size == FBI_WIN;

@@ -203,6 +203,9 @@ extern "C" int tf_pair_counts(const int32_t *a, const int32_t *b, int64_t n, int
 // (piece, label) pair among the distinct pairs, which tf_pair_counts returns sorted.  A voxel's rank is a binary search
 // in that list (a few thousand entries: L2-resident); consecutive voxels mostly repeat the pair, so a thread keeps the
 // last answer.  4 + 4 B read, 4 B written per voxel.
+// ALIGNED: all three volumes are 16-byte aligned (wide loads / stores); otherwise -- a view such as labels[1:] of a volume
+// whose H * W is not a multiple of 4 -- the same quads with scalar accesses.
+template <bool ALIGNED>
 __global__ void __launch_bounds__(256)
 k_pair_rank(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int64_t n, const int32_t *__restrict__ pa,
             const int32_t *__restrict__ pb, int n_pairs, int32_t *__restrict__ out)
@@ -210,7 +213,7 @@ k_pair_rank(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int64_
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += stride) {
         int32_t va[4], vb[4], r[4];
-        if (i0 + 4 <= n) {
+        if (ALIGNED && i0 + 4 <= n) {
             const int4 qa = *(const int4 *)(a + i0), qb = *(const int4 *)(b + i0);
             va[0] = qa.x; va[1] = qa.y; va[2] = qa.z; va[3] = qa.w; vb[0] = qb.x; vb[1] = qb.y; vb[2] = qb.z; vb[3] = qb.w;
         } else {
@@ -236,7 +239,7 @@ k_pair_rank(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int64_
             }
             r[j] = rank;
         }
-        if (i0 + 4 <= n) *(int4 *)(out + i0) = make_int4(r[0], r[1], r[2], r[3]);
+        if (ALIGNED && i0 + 4 <= n) *(int4 *)(out + i0) = make_int4(r[0], r[1], r[2], r[3]);
         else for (int j = 0; j < 4 && i0 + j < n; j++) out[i0 + j] = r[j];
     }
 }
@@ -245,11 +248,13 @@ extern "C" int tf_pair_rank(const int32_t *a, const int32_t *b, int64_t n, const
                             int64_t n_pairs, int32_t *out, void *stream)
 {
     TF_REQUIRE(a && b && out && n > 0 && n_pairs >= 0 && n_pairs < (1ll << 31) && (n_pairs == 0 || (pairs_a && pairs_b)), "tf_pair_rank: bad arguments");
-    TF_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "tf_pair_rank: volumes must be 16-byte aligned");
+    TF_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 3) == 0, "tf_pair_rank: volumes must be 4-byte aligned");
+    const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
     hipStream_t s = (hipStream_t)stream;
     const int64_t quads = (n + 3) / 4;
     const unsigned grid = (unsigned)std::min<int64_t>((quads + 255) / 256, 256 * 32);
-    hipLaunchKernelGGL(k_pair_rank, dim3(grid), dim3(256), 0, s, a, b, n, pairs_a, pairs_b, (int)n_pairs, out);
+    if (aligned) hipLaunchKernelGGL(k_pair_rank<true>, dim3(grid), dim3(256), 0, s, a, b, n, pairs_a, pairs_b, (int)n_pairs, out);
+    else hipLaunchKernelGGL(k_pair_rank<false>, dim3(grid), dim3(256), 0, s, a, b, n, pairs_a, pairs_b, (int)n_pairs, out);
     TF_CHECK_LAUNCH();
     return TF_OK;
 }

@@ -41,7 +41,7 @@ def _unwrap_device_field(x):
 
 def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,
                 interp_method: str = "linear", max_value=20, on_frames_ready=None, workspace_gb=None,
-                split_parts=None) -> "Flow":
+                split_parts=None, deferred_check=None) -> "Flow":
     """Forward and backward optical flow along the leading dimension of `data`, clipped to
     +-`max_value` pixels, wrapped in a Flow object (reference: flow.py:23-65).
 
@@ -56,7 +56,15 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
     Farneback batches in GB (default 115, and never more than 60 % of the free device memory) and the number of parts a batch's
     two finest pyramid levels, refinement and smoothing are run in (default 1; a caller that runs other work beside the
     flow -- detect_stack_windows -- asks for less scratch and for 2 parts).  The environment variables TF_FLOW_WORKSPACE_GB /
-    TF_FLOW_SPLIT (development switches) override them."""
+    TF_FLOW_SPLIT (development switches) override them.
+
+    deferred_check (not in the reference; device-resident input only): create_flow on a device tensor returns while the device
+    is still computing, so the library's report on those launches (a starved chain of the iteration kernel -> NaN rows,
+    TF_ESTARVED) arrives later.  False (the default without on_frames_ready): the first method of the returned Flow that is
+    called WAITS for the flow's launches and raises if they failed -- a plain caller can never compute from NaN rows unnoticed
+    (the reference's call is synchronous).  True (the default with on_frames_ready): the Flow's methods only poll,
+    and the caller -- a pipeline that keeps the host ahead of the device, parallel.detect_stack_windows -- calls `flow.check()`
+    before it hands results on."""
     # the clip of flow.py:60-61 is applied by the same kernel that mirrors the end frames (tf_flow_finalize);
     # clipping commutes with the sign-flipped mirror
     extra = {}
@@ -92,7 +100,8 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
         flow = Flow._lazy_host(forward_flow, backward_flow)
     if checks:
         if isinstance(data, t.Tensor):
-            flow._pending_check = checks[0]       # polled at every use of the object (Flow._dev_flows); Flow.check() waits for it
+            flow._pending_check = checks[0]       # looked at by every use of the object (Flow._dev_flows); Flow.check() waits for it
+            flow._check_blocking = not (deferred_check if deferred_check is not None else on_frames_ready is not None)
         else:
             checks[0](block=True)                # host input: the reference's call is synchronous, so is this one
     return flow
@@ -122,6 +131,7 @@ class Flow(AbstractFlow):
         self._bw = backward_flow
         self._dev = None
         self._pending_check = None
+        self._check_blocking = True               # a pending check is WAITED for by the first method called (create_flow: deferred_check)
 
     def check(self):
         """Wait for the launches that produced this object and raise if one of them reported a starved chain (create_flow on
@@ -140,6 +150,8 @@ class Flow(AbstractFlow):
         return obj
 
     def _host_arrays(self):
+        if self._pending_check is not None and self._check_blocking:
+            self.check()                          # (the vectors themselves are a result: never handed out unchecked)
         if self._fw is None:
             self._fw, self._bw = self._dev[0].cpu().numpy(), self._dev[1].cpu().numpy()
         return self._fw, self._bw
@@ -171,7 +183,10 @@ class Flow(AbstractFlow):
 
     def _dev_flows(self):
         if self._pending_check is not None:
-            self._pending_check()                # (non-blocking: reports once the producing launches have finished)
+            if self._check_blocking:             # plain callers: like the reference's synchronous call, never results from NaN rows
+                self.check()
+            else:                                # pipelined callers (deferred_check): reports once the producing launches have finished
+                self._pending_check()
         if self._dev is None:
             t = _lib.torch()
             self._dev = (_lib.to_dev(self._fw, t.float32), _lib.to_dev(self._bw, t.float32))

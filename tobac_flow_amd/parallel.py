@@ -372,6 +372,23 @@ class _WindowFloods:
         self.wins = [None] * len(owner.bounds)
         self.next = 0                                        # next window to begin
         self.family = None                                   # detect_stack_sequence: the stacks in flight share the flood slots
+        self.own_stream = False                              # True: driven from a flood thread on a stream of its own (_ready)
+
+    def _ready(self, n_frames):
+        """may the next window be begun now that the flow of the stack's first n_frames frames is enqueued?  Its last frame
+        must be among them -- and, when the windows are driven from a flood thread on a stream of its own, must not be the
+        hand-over's last frame unless the stack ends there: create_flow hands over n = pairs_done + 1 frames, of which
+        forward[n - 1] is written by the NEXT part of the flow on the calling stream, and window_view saves, patches and
+        restores exactly that frame of a window that ends at n -- on the calling stream (between two parts) that is ordered, on
+        the flood stream the restore of the stale copy would race with the flow's real write (the frame would then
+        hold garbage for the next overlapping window).  Such a window waits for the next hand-over."""
+        bounds = self.o.bounds
+        if self.next >= len(bounds):
+            return False
+        hi = bounds[self.next][1]
+        if hi > n_frames:
+            return False
+        return (not self.own_stream) or hi < n_frames or n_frames >= len(self.bt)
 
     def _finish_any(self, block=True):
         """finish one ready flood -- of this stack, or (detect_stack_sequence) of any stack still in flight"""
@@ -446,11 +463,11 @@ class _WindowFloods:
         has ended are finished (on the second stream) instead of blocking in the first synchronisation of a begin"""
         import time
         bounds = self.o.bounds
-        while wait_for is not None and self.next < len(bounds) and bounds[self.next][1] <= n_frames and not wait_for.query():
+        while wait_for is not None and self._ready(n_frames) and not wait_for.query():
             if not self._finish_any(block=False):
                 time.sleep(0.0005)
         begun = []
-        while self.next < len(bounds) and bounds[self.next][1] <= n_frames:
+        while self._ready(n_frames):
             lo, hi = bounds[self.next]
             while not self.pieces:                           # every flood slot is taken (by this stack's floods, or an earlier stack's)
                 self._finish_any()                           # (a flood begun in this call is completed there: its sweeps first)
@@ -484,6 +501,22 @@ class _WindowFloods:
         while self.pending:
             self.finish_one()
         return self.wins
+
+    def abandon_all(self):
+        """failure path: give up every flood still in flight -- wait for its host replay (a worker thread that still reads the
+        job), free the job, return its slot and scratch (they used to stay held until garbage collection)"""
+        while self.pending:
+            job, fut, _, scratch = self.pending.popleft()[:4]
+            if fut is not None:
+                try:
+                    fut.result()
+                except BaseException:                        # noqa: BLE001 -- the first failure is the one that is reported
+                    pass
+            try:
+                job.abandon()
+            except BaseException:                            # noqa: BLE001
+                pass
+            self.pieces.append(scratch)
 
 
 class _StackRun:
@@ -608,6 +641,7 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             handover = queue.Queue()
             failure = []
             flood_stream, dev_index = o.side, torch.cuda.current_device()
+            first.own_stream = True
             o.side = None                                      # (the thread's CURRENT stream is the second stream: floods are finished on it)
 
             def flood_loop():
@@ -623,6 +657,11 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
                         flood_stream.synchronize()
                 except BaseException as exc:                    # noqa: BLE001 -- re-raised on the calling thread
                     failure.append(exc)
+                    try:
+                        flood_stream.synchronize()
+                    except BaseException:                       # noqa: BLE001
+                        pass
+                    first.abandon_all()                        # (slots and scratch of the floods in flight go back now)
                     while True:                                # drain: the calling thread must never block on a full hand-over
                         try:
                             if handover.get_nowait() is None:
@@ -634,6 +673,8 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             worker.start()
 
             def frames_ready(fl, n):
+                if failure:                                    # the flood thread has failed: stop the flow here, not after the
+                    raise failure[0]                           # rest of the stack has been enqueued
                 o.mark("flow enqueued for %d frames" % n)
                 ev = torch.cuda.Event()
                 ev.record()
@@ -642,6 +683,10 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
         # workgroups) and is finished -- finest levels, refinement, smoothing, hand-over of its frames -- in two parts
         try:
             flow_all = tf.create_flow(bt, on_frames_ready=frames_ready, workspace_gb=flow_workspace_gb, split_parts=2, **flow_kw)
+        except BaseException:
+            if worker is None:                                 # (the calling thread drives the floods: theirs to give up)
+                first.abandon_all()
+            raise
         finally:
             if worker is not None:
                 handover.put(None)
@@ -649,7 +694,7 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
         if worker is not None and failure:
             raise failure[0]
     else:
-        flow_all = tf.create_flow(bt, **flow_kw)
+        flow_all = tf.create_flow(bt, deferred_check=True, **flow_kw)     # (flow_all.check() below, behind the last flood)
     o.info["flow_workspace_gb"] = None if flow_workspace_gb is None else round(float(flow_workspace_gb), 1)
     o.mark("create_flow returned (device still working)")
     flow_released = False
@@ -836,6 +881,12 @@ def detect_stack_sequence(stacks, bounds, seeds_fn, consume=None, overlap=DEFAUL
                 flood_stream.synchronize()
         except BaseException as exc:                             # noqa: BLE001 -- re-raised on the calling thread
             failure.append(exc)
+            try:
+                flood_stream.synchronize()
+            except BaseException:                                # noqa: BLE001
+                pass
+            for wf_ in list(fam.active):                         # (slots and scratch of the floods in flight go back now)
+                wf_.abandon_all()
             while True:                                          # drain: the calling thread must never block on the hand-over
                 try:
                     if handover.get(timeout=0.05) is None:
@@ -871,11 +922,13 @@ def detect_stack_sequence(stacks, bounds, seeds_fn, consume=None, overlap=DEFAUL
                 flow_workspace_gb = _BUDGET_MEMO[key]
                 info["flow_workspace_gb"] = round(float(flow_workspace_gb), 1)
             wf = _WindowFloods(o, bt, 0, pieces, n_fly)
-            wf.family, wf.index, wf.flow_enqueued = fam, k, False
+            wf.family, wf.index, wf.flow_enqueued, wf.own_stream = fam, k, False, True
             wf.setups_done, wf.delivered = threading.Event(), threading.Event()
             handover.put(("new", wf))
 
             def frames_ready(fl, n, wf_=wf, o_=o):
+                if failure:                                      # (stop this stack's flow where the flood thread failed)
+                    raise failure[0]
                 o_.mark("flow enqueued for %d frames" % n)
                 ev = torch.cuda.Event()
                 ev.record()

@@ -28,7 +28,33 @@ class FarnebackFlow:
     (flow_utils.py:52-53): `.calc(prev, next, None)` -> (H, W, 2) float32 flow, OpenCV defaults."""
 
     def __init__(self, num_levels=5, pyr_scale=0.5, win_size=13, num_iters=10, poly_n=5, poly_sigma=1.1):
-        self.params = _lib.FarnebackParams(num_levels, pyr_scale, win_size, num_iters, poly_n, poly_sigma, _lib.FB_CHAIN_DEFAULT)
+        self.params = _lib.FarnebackParams(num_levels, pyr_scale, win_size, num_iters, poly_n, poly_sigma, _lib.FB_CHAIN_DEFAULT, 0)
+        self._slot_device = None
+
+    def _own_status_word(self):
+        """A status word of this object's own for the starved-chain report (tf_farneback_status_acquire; select_of_model returns
+        a fresh object per create_flow / calculate_flow call, so: one word per flow).  Two flows in flight on one device -- the
+        flood thread finishing stack k beside stack k + 1's flow, two host threads -- then neither consume nor get blamed for
+        each other's report.  Taken on first use, on the device that is current then; 0 (the device's shared word)
+        if the library has none left."""
+        if self._slot_device is None:
+            t = _lib.torch()
+            self._slot_device = t.cuda.current_device()
+            self.params.status_slot = int(_lib.lib().tf_farneback_status_acquire())
+        return self.params.status_slot
+
+    def _status(self):
+        L = _lib.lib()
+        return L.tf_farneback_status_check(self.params.status_slot) if self.params.status_slot else L.tf_farneback_check()
+
+    def __del__(self):
+        try:
+            if self._slot_device is not None and self.params.status_slot:
+                t = _lib.torch()
+                with t.cuda.device(self._slot_device):
+                    _lib.lib().tf_farneback_status_release(self.params.status_slot)
+        except Exception:                                   # interpreter shutdown
+            pass
 
     def check_launches(self, what="Farneback flow"):
         """The launches are asynchronous; what a launch found out arrives later.  Waits for the current stream and raises
@@ -36,7 +62,7 @@ class FarnebackFlow:
         its rows are NaN (tf_farneback_check; csrc/farneback.hip fb_chain_enter).  cv2's calc is synchronous and has no such
         state; this is where the asynchronous library reports like a synchronous one."""
         _lib.torch().cuda.current_stream().synchronize()
-        _lib.check(_lib.lib().tf_farneback_check(), what)
+        _lib.check(self._status(), what)
 
     def deferred_check(self, what="Farneback flow"):
         """check_launches without stalling a device-resident pipeline: returns a callable `poll(block=False)` bound to an event
@@ -58,7 +84,8 @@ class FarnebackFlow:
             elif not ev.query():
                 return
             state["done"] = True
-            _lib.check(_lib.lib().tf_farneback_check(), what)
+            _lib.check(self._status(), what)
+        poll.status_slot = self.params.status_slot          # (tests: which word this flow's launches report to)
         return poll
 
     def calc_pair_dev(self, prev, nxt, want_fwd=True, want_bwd=True, tag="farneback"):
@@ -67,6 +94,7 @@ class FarnebackFlow:
         t = _lib.torch()
         L = _lib.lib()
         H, W = prev.shape
+        self._own_status_word()
         fwd = _lib.empty((H, W, 2), t.float32) if want_fwd else None
         bwd = _lib.empty((H, W, 2), t.float32) if want_bwd else None
         nbytes = L.tf_farneback_workspace_bytes(H, W, ctypes.byref(self.params))
@@ -84,6 +112,7 @@ class FarnebackFlow:
         import ctypes
         L = _lib.lib()
         B, H, W = prev.shape
+        self._own_status_word()
         assert prev.is_contiguous() and nxt.is_contiguous()
         for o in (fwd_out, bwd_out):
             assert o.shape == (B, H, W, 2) and o[0].is_contiguous() and (B == 1 or o.stride(0) >= H * W * 2)
@@ -106,6 +135,7 @@ class FarnebackFlow:
         import ctypes
         L = _lib.lib()
         B, H, W = prev.shape
+        self._own_status_word()
         nbytes = max(L.tf_farneback_workspace_bytes_phase(ws_pairs[0], H, W, ctypes.byref(self.params), 1),
                      L.tf_farneback_workspace_bytes_phase(ws_pairs[1], H, W, ctypes.byref(self.params), 2))
         ws = _lib.workspace(nbytes, tag)
