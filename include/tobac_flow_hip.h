@@ -562,17 +562,44 @@ int tf_profile_kernel_count(void);
 const char *tf_profile_kernel_name(int id);
 int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
 
-/* A stream whose kernels may only occupy the CUs set in the mask (bit i of mask_words = CU i in the runtime's numbering;
- * hipExtStreamCreateWithCUMask): parallel.detect_stack_windows finishes the floods of ready windows on such a stream, so
- * that they displace the flow's iteration workgroups on a part of the chip only.  tf_debug_cu_histogram launches
- * n_workgroups idle workgroups on a stream and returns how many ran where: hist[xcc * 256 + HW_ID bits 15:8].
- * tf_stream_destroy synchronises the stream and RETIRES it (kept until the process ends: on ROCm 7.2 a later large hipMalloc crashes
- * in a process that has destroyed a CU-masked stream).
- * tf_copy16: dst = src, 16 bytes per lane per access -- the measured practical HBM ceiling of bench.py's roofline. */
-int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words, void **stream_out);
-int tf_stream_destroy(void *stream);
-int tf_stream_create_priority(int low, void **stream_out);   /* lowest (low != 0) / highest priority of the device's range */
-int tf_debug_cu_histogram(void *stream, int n_workgroups, int *hist_host_2048);
+/* ---- host staging: the containers of the reference's API <-> HBM ------------------------------------------------------
+ * The reference's entry points take and return numpy / xarray containers (tobac_flow/decorators.py:21-61,
+ * scripts/dcc_detect_goes.py:164-303); a drop-in caller therefore pays PCIe for every field and every label volume, and
+ * pageable memory moves at a third of the link's rate.  These entry points are what the Python layer moves host containers
+ * with ("pinned-host staging to HBM"); pointers named *_host are HOST pointers.
+ *
+ * tf_host_alloc / tf_host_free: PINNED host blocks from a pool kept by size class (hipHostMalloc costs hundreds of ms per GB:
+ *   a freed block is handed out again, tf_host_pool_trim(keep_bytes) returns cached blocks to the system).  A result is
+ *   downloaded straight into such a block, which the caller wraps as the array it returns: no second host copy.
+ *   tf_host_is_pinned: 1 if [ptr, ptr + bytes) lies inside a block that is handed out.
+ * tf_upload(dst, src_host, bytes, hash_out_host, stream): host -> device on `stream`.  A pageable source is copied by host
+ *   threads (<= 16, TF_STAGING_THREADS) chunk by chunk (8 MiB, TF_STAGING_CHUNK_MB) into a ring of pinned slots, each chunk's
+ *   DMA enqueued as soon as it is staged; returns when the SOURCE has been read completely (the caller may free or change it),
+ *   the last DMAs and everything enqueued after the call stay asynchronous.  A source inside a pool block goes out as one DMA
+ *   (the block must stay untouched until `stream` has passed it).  hash_out_host != NULL: the 128-bit content checksum of the
+ *   source (two uint64), computed by the copying threads on the way.
+ * tf_download(dst_host, src, bytes, stream): device -> host, complete on return (DMA at the link's rate into a pool block).
+ * tf_hash_host / tf_hash_dev: the same 128-bit checksum of a host buffer (host threads) / of device memory (one kernel; the
+ *   two words are returned on the host, the call synchronises `stream`): sums over 16-byte blocks of
+ *   fold(mul128(w0 ^ a_i, w1 ^ b_i)), position-keyed, the byte length folded in -- any split over threads or lanes gives the
+ *   same words, so the checksum of a device result equals the checksum of its downloaded copy.  The Python layer keys its
+ *   cache of device twins with it (tobac_flow_amd/_staging.py): a host array presented again is recognised by CONTENT -- the
+ *   same object, or another temporary with the same values (`wvd - swd` of scripts/dcc_detect_goes.py:227,241) -- never
+ *   trusted by its address.  Not cryptographic. */
+int tf_host_alloc(size_t bytes, void **ptr_out_host);
+int tf_host_free(void *ptr_host);
+int tf_host_is_pinned(const void *ptr_host, size_t bytes);
+int tf_host_pool_stats(int64_t *live_bytes, int64_t *cached_bytes);
+int tf_host_pool_trim(size_t keep_bytes);
+int tf_upload(void *dst, const void *src_host, size_t bytes, uint64_t *hash_out_host, void *stream);
+int tf_download(void *dst_host, const void *src, size_t bytes, void *stream);
+int tf_hash_host(const void *src_host, size_t bytes, uint64_t *hash_out_host);
+int tf_hash_dev(const void *src, size_t bytes, uint64_t *hash_out_host, void *stream);
+
+/* tf_copy16: dst = src, 16 bytes per lane per access -- the measured practical HBM ceiling of bench.py's roofline.
+ * (Round 5's tf_stream_create_cu_mask / tf_stream_create_priority / tf_stream_destroy / tf_debug_cu_histogram served two
+ * scheduling experiments that were not adopted; they live in tools/experiments/stream_experiments.hip now, outside the
+ * library: DESIGN.md section 7.) */
 int tf_copy16(const void *src, void *dst, size_t bytes, void *stream);
 int tf_copy16_variant(const void *src, void *dst, size_t bytes, void *stream, int variant);   /* development forms of the same copy */
 

@@ -130,10 +130,15 @@ _PROTOS = {
     "tf_profile_kernel_count": (_c.c_int, []),
     "tf_profile_kernel_name": (_c.c_char_p, [_c.c_int]),
     "tf_profile_collect": (_c.c_int, [_P, _P, _P]),
-    "tf_stream_create_cu_mask": (_c.c_int, [_P, _c.c_int, _c.POINTER(_P)]),
-    "tf_stream_destroy": (_c.c_int, [_P]),
-    "tf_stream_create_priority": (_c.c_int, [_c.c_int, _c.POINTER(_P)]),
-    "tf_debug_cu_histogram": (_c.c_int, [_P, _c.c_int, _P]),
+    "tf_host_alloc": (_c.c_int, [_c.c_size_t, _c.POINTER(_P)]),
+    "tf_host_free": (_c.c_int, [_P]),
+    "tf_host_is_pinned": (_c.c_int, [_P, _c.c_size_t]),
+    "tf_host_pool_stats": (_c.c_int, [_P, _P]),
+    "tf_host_pool_trim": (_c.c_int, [_c.c_size_t]),
+    "tf_upload": (_c.c_int, [_P, _P, _c.c_size_t, _P, _P]),
+    "tf_download": (_c.c_int, [_P, _P, _c.c_size_t, _P]),
+    "tf_hash_host": (_c.c_int, [_P, _c.c_size_t, _P]),
+    "tf_hash_dev": (_c.c_int, [_P, _c.c_size_t, _P, _P]),
     "tf_copy16": (_c.c_int, [_P, _P, _c.c_size_t, _P]),
     "tf_copy16_variant": (_c.c_int, [_P, _P, _c.c_size_t, _P, _c.c_int]),
     "tf_shutdown": (_c.c_int, []),
@@ -208,22 +213,35 @@ def is_tensor(x):
     return _torch is not None and isinstance(x, _torch.Tensor) or (type(x).__module__.startswith("torch"))
 
 
-def to_dev(x, dtype=None):
-    """numpy array / torch tensor -> contiguous torch tensor on the current HIP device."""
+def to_dev(x, dtype=None, share=False):
+    """numpy array / torch tensor -> contiguous torch tensor on the current HIP device.  Host arrays go through the pinned
+    staging ring (_staging.upload: host threads + pipelined DMA instead of the runtime's pageable copy).  share=True -- for
+    inputs the caller only READS (the fields and label volumes handed to the entry points): an array whose content has been
+    uploaded or downloaded before is served from HBM instead of crossing PCIe again (recognised by a content checksum)."""
     t = torch()
     dev = device()
     if isinstance(x, t.Tensor):
         y = x.to(dev)
     else:
+        from tobac_flow_amd import _staging
         a = np.asarray(x)
-        if a.dtype == np.bool_:
-            a = a.astype(np.uint8)
-        if not a.flags.c_contiguous:
-            a = np.ascontiguousarray(a)
-        y = t.from_numpy(a).to(dev)
+        try:
+            y = _staging.upload(a, fresh=not share)
+        except TypeError:                       # a dtype the staging path does not take (object, big-endian, ...): torch's own
+            if a.dtype == np.bool_:
+                a = a.astype(np.uint8)
+            y = t.from_numpy(np.ascontiguousarray(a)).to(dev)
     if dtype is not None and y.dtype != dtype:
         y = y.to(dtype)
     return y.contiguous()
+
+
+def to_host(x, remember=False):
+    """device tensor -> numpy array in a pooled pinned block (_staging.download: DMA at the link's rate, no second host
+    copy).  remember=True -- for results handed back through the reference's interface: the device tensor stays cached as
+    the array's twin, so that the array coming back as an input (`markers=`) does not cross PCIe again."""
+    from tobac_flow_amd import _staging
+    return _staging.download(x, remember=remember)
 
 
 def ptr(tensor):

@@ -119,7 +119,7 @@ def convolve(
     T, H, W = d.shape
     if code is not None:
         out = convolve_dev(d, fwd, bwd, structure, method, nd, fill_value, code)
-        return out if on_device else out.cpu().numpy()
+        return out if on_device else _lib.to_host(out)
     # arbitrary Python callable: gather the stack on the GPU frame by frame, reduce on the host
     data_np = d.cpu().numpy() if on_device else np.asarray(data)
     res = np.full(data_np.shape, fill_value, dtype=nd)

@@ -76,80 +76,6 @@ extern "C" int tf_shutdown(void) {
     return TF_OK;
 }
 
-// ---- streams confined to a part of the chip --------------------------------------------------------------------------
-// A caller that runs the floods of finished windows BESIDE the flow (parallel.detect_stack_windows) gives them a stream
-// whose kernels may only occupy some of the CUs: the flow's iteration kernel then keeps the LDS of all the others to itself
-// (its faster two-part chain needs 39 KB per workgroup, four per CU -- csrc/farneback.hip), while an unrestricted flood
-// stream displaces iteration workgroups on every CU.  mask_words: bit i of the mask = CU i in the runtime's numbering
-// (hipExtStreamCreateWithCUMask; tf_debug_cu_histogram shows which XCD / CU a bit maps to on this part).
-extern "C" int tf_stream_create_cu_mask(const uint32_t *mask_words, int n_words, void **stream_out)
-{
-    TF_REQUIRE(mask_words && n_words > 0 && n_words <= 32 && stream_out, "tf_stream_create_cu_mask: bad arguments");
-    hipStream_t s = nullptr;
-    TF_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask_words));
-    *stream_out = (void *)s;
-    return TF_OK;
-}
-// a stream of the LOWEST (low != 0) or the highest priority the device offers: the flood thread of parallel.detect_stack_windows
-// runs on a low-priority stream, so that the flow's workgroups are dispatched first and the floods take what is left
-extern "C" int tf_stream_create_priority(int low, void **stream_out)
-{
-    TF_REQUIRE(stream_out, "tf_stream_create_priority: null pointer");
-    int least = 0, greatest = 0;
-    TF_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    hipStream_t s = nullptr;
-    TF_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, low ? least : greatest));
-    *stream_out = (void *)s;
-    return TF_OK;
-}
-// tf_stream_destroy RETIRES the stream: it is synchronised and kept until the process ends.  On this ROCm (7.2) a process that has
-// destroyed a CU-masked stream crashes inside a LATER large hipMalloc (found by the test suite: hipStreamDestroy of the masked
-// stream in one test, a segmentation fault in the 132-GiB allocation of another; with the stream left alive the same sequence
-// passes).  A stream costs a few KB; a caller creates one per (device, mask).
-static std::mutex g_retired_mu;
-static std::vector<hipStream_t> g_retired;
-extern "C" int tf_stream_destroy(void *stream)
-{
-    if (!stream) return TF_OK;
-    TF_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    std::lock_guard<std::mutex> lk(g_retired_mu);
-    g_retired.push_back((hipStream_t)stream);
-    return TF_OK;
-}
-
-// where do the workgroups of a stream run?  hist[xcc * 256 + (se, sh, cu) byte of HW_ID] += 1 per workgroup
-__global__ void __launch_bounds__(64)
-k_debug_cu_histogram(int *hist)
-{
-    if (threadIdx.x == 0) {
-        const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;           // HW_REG_XCC_ID, bits 3:0
-        const unsigned hw = (__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4)) & 0xffffu;   // HW_REG_HW_ID (id 4), 16 bits
-        atomicAdd(&hist[xcc * 256 + ((hw >> 8) & 0xffu)], 1);
-    }
-    // (long enough for every CU of the mask to be handed workgroups)
-    for (int i = 0; i < 2000; i++) __builtin_amdgcn_s_sleep(8);
-}
-extern "C" int tf_debug_cu_histogram(void *stream, int n_workgroups, int *hist_host_2048)
-{
-    TF_REQUIRE(hist_host_2048 && n_workgroups > 0, "tf_debug_cu_histogram: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    // (plain hipMalloc / hipFree: a stream-ordered allocation would leave a block of the runtime's memory pool tied to `stream`,
-    // and the caller may destroy that stream -- a later out-of-memory trim of the pool then walks a dead stream: the crash
-    // the first version of this function caused in a LATER test's 132-GiB allocation)
-    int *d = nullptr;
-    TF_CHECK_HIP(hipMalloc((void **)&d, 2048 * sizeof(int)));
-    hipError_t e = hipMemsetAsync(d, 0, 2048 * sizeof(int), s);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_cu_histogram, dim3((unsigned)n_workgroups), dim3(64), 0, s, d);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(hist_host_2048, d, 2048 * sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d);
-    if (e != hipSuccess) { tf_set_error("tf_debug_cu_histogram: %s", hipGetErrorString(e)); return TF_EHIP; }
-    return TF_OK;
-}
-
 // ---- the practical HBM ceiling: a plain copy, 16 bytes per lane per access (bench.py's `practical_peak`) ---------------
 // A workgroup copies tiles of UNROLL x 256 consecutive 16-byte words (all loads of a tile in flight before its first store);
 // the grid is 8 workgroups per CU, grid-stride over the tiles (cdna_hip_programming.md, guideline 11).

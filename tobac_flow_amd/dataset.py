@@ -39,12 +39,12 @@ class LabelDataset(dict):
 
 
 def _host(x):
-    return x.cpu().numpy() if _lib.is_tensor(x) else np.asarray(x)
+    return _lib.to_host(x) if _lib.is_tensor(x) else np.asarray(x)
 
 
 def _like(result_dev, template):
     """device result in the container kind of `template` (numpy in -> numpy out)"""
-    return result_dev if _lib.is_tensor(template) else result_dev.cpu().numpy()
+    return result_dev if _lib.is_tensor(template) else _lib.to_host(result_dev)
 
 
 def _apply_lut(labels_dev, lut):

@@ -92,12 +92,12 @@ def _to_device(a):
         return a.data.contiguous()
     if isinstance(a, _lib.torch().Tensor):
         return _lib.to_dev(a)
-    return _lib.to_dev(np.ascontiguousarray(_values(a)))
+    return _lib.to_dev(_values(a), share=True)
 
 
 def _deliver(result_dev, like):
     """device result in the container kind of the input `like`: tensor for device input, numpy for host input"""
-    return result_dev if _is_device(like) else result_dev.cpu().numpy()
+    return result_dev if _is_device(like) else _lib.to_host(result_dev, remember=True)
 
 
 def _is_dataarray(a):
@@ -199,7 +199,7 @@ def detect_growth_markers(flow, wvd):
         marker_labels = nd.remap_labels(marker_labels, hit)
     if _is_device(wvd):                                                # device-resident pipeline: nothing visits the host
         return wvd_diff_smoothed, marker_labels
-    wvd_diff_smoothed, marker_labels = wvd_diff_smoothed.cpu().numpy(), marker_labels.cpu().numpy()
+    wvd_diff_smoothed, marker_labels = _lib.to_host(wvd_diff_smoothed), _lib.to_host(marker_labels, remember=True)
     if _is_dataarray(wvd):
         import xarray as xr
         marker_labels = xr.DataArray(marker_labels, wvd.coords, wvd.dims)

@@ -153,7 +153,7 @@ class Flow(AbstractFlow):
         if self._pending_check is not None and self._check_blocking:
             self.check()                          # (the vectors themselves are a result: never handed out unchecked)
         if self._fw is None:
-            self._fw, self._bw = self._dev[0].cpu().numpy(), self._dev[1].cpu().numpy()
+            self._fw, self._bw = _lib.to_host(self._dev[0]), _lib.to_host(self._dev[1])
         return self._fw, self._bw
 
     @property
@@ -666,7 +666,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         elif deferred is not None:
             deferred(block=True)                  # (a caller that cannot take the deferred check gets the synchronous one)
         return forward, backward
-    out = forward.cpu().numpy(), backward.cpu().numpy()
+    out = _lib.to_host(forward), _lib.to_host(backward)
     if deferred is not None:
         deferred(block=True)
     return out
@@ -689,7 +689,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     if _is_dataarray(data):
         data = data.compute().data if hasattr(data, "compute") else data.to_numpy()
     on_device = isinstance(data, t.Tensor) or device_out
-    d = _lib.to_dev(data, t.float32)
+    d = _lib.to_dev(data, t.float32, share=True)          # (only read: the same array usually goes to detect_cores next)
     if d.dim() != 3:
         raise ValueError("data must have three dimensions (t, y, x)")
     T = d.shape[0]
@@ -728,7 +728,7 @@ def calculate_flow_frame(prev_frame, next_frame, of_model, vr_steps: int = 0, sm
     f, b = _pair_flows_dev(p, n, of_model, vr_steps, smoothing_steps, interp_method)
     if hasattr(of_model, "check_launches"):
         of_model.check_launches("calculate_flow_frame")
-    return (f, b) if on_device else (f.cpu().numpy(), b.cpu().numpy())
+    return (f, b) if on_device else (_lib.to_host(f), _lib.to_host(b))
 
 
 def smooth_flow_step(forward_flow, backward_flow, method: str = "linear"):
@@ -742,7 +742,7 @@ def smooth_flow_step(forward_flow, backward_flow, method: str = "linear"):
     f2, b2 = t.empty_like(f), t.empty_like(b)
     _lib.check(L.tf_smooth_flow_step(_lib.ptr(f), _lib.ptr(b), H, W, interp, _lib.ptr(f2), _lib.ptr(b2),
                                      _lib.stream_ptr()), "tf_smooth_flow_step")
-    return (f2, b2) if on_device else (f2.cpu().numpy(), b2.cpu().numpy())
+    return (f2, b2) if on_device else (_lib.to_host(f2), _lib.to_host(b2))
 
 
 # ---- diagnostics (host numpy; reference: flow.py:571-666) -------------------------------------------

@@ -87,7 +87,7 @@ def flow_label_dev(flow, mask_dev, structure, overlap, absolute_overlap):
 def _finish(new_dev, present_dev, dtype, on_device):
     if not bool(((new_dev != 0) == present_dev).all()):
         warnings.warn("Not all regions present in labeled array", RuntimeWarning)      # label.py:172-174
-    return new_dev if on_device else new_dev.cpu().numpy().astype(dtype)
+    return new_dev if on_device else _lib.to_host(new_dev).astype(dtype, copy=False)
 
 
 def flow_label(flow, mask, structure=ndi.generate_binary_structure(3, 1), dtype=np.int32, overlap: float = 0.0,
@@ -201,7 +201,7 @@ def label_sizes(labels, n_labels=None):
     if lab.numel() == 0:
         return np.zeros(int(n_labels) + 1, np.int64)
     _lib.check(L.tf_label_sizes(_lib.ptr(lab), lab.numel(), int(n_labels), _lib.ptr(out), _lib.stream_ptr()), "tf_label_sizes")
-    return out.cpu().numpy()
+    return _lib.to_host(out)
 
 
 def slice_labels_dev(labels):

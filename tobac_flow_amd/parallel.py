@@ -333,31 +333,15 @@ def _replay_pool(n):
     return _REPLAY_POOL
 
 
-def _side_stream(cus_per_xcd=0, low_priority=False):
+def _side_stream():
     """the second stream of (device, calling stream) -- the floods of ready windows are finished on it while the calling
-    stream is busy with the flow.  cus_per_xcd > 0: a stream whose kernels may only occupy that many CUs of every XCD
-    (tf_stream_create_cu_mask; on this part bit i of the mask selects a CU of XCD i % 8, successive bits of an XCD going
-    round its shader engines -- tools/cu_mask_probe.py; an XCD cannot be left without CUs): the floods then displace the
-    flow's iteration workgroups on those CUs only."""
-    import ctypes
+    stream is busy with the flow.  (Round 5 could confine it to k CUs of every XCD or give it the lowest priority: both
+    measured slower than a plain stream, profiles/round5_scheduling_experiments.txt, and gone with round 6 --
+    tools/experiments/stream_experiments.hip.)"""
     import torch
-    from tobac_flow_amd import _lib
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, int(cus_per_xcd), bool(low_priority))
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
     if key not in _SIDE_STREAMS:
-        if low_priority and cus_per_xcd <= 0:
-            handle = ctypes.c_void_p()
-            _lib.check(_lib.lib().tf_stream_create_priority(1, ctypes.byref(handle)), "tf_stream_create_priority")
-            _SIDE_STREAMS[key] = torch.cuda.ExternalStream(handle.value)
-        elif cus_per_xcd > 0:
-            n_bits = 8 * int(cus_per_xcd)
-            words = np.zeros(8, np.uint32)
-            for b in range(n_bits):
-                words[b // 32] |= np.uint32(1 << (b % 32))
-            handle = ctypes.c_void_p()
-            _lib.check(_lib.lib().tf_stream_create_cu_mask(words.ctypes.data_as(_lib._P), 8, ctypes.byref(handle)), "tf_stream_create_cu_mask")
-            _SIDE_STREAMS[key] = torch.cuda.ExternalStream(handle.value)
-        else:
-            _SIDE_STREAMS[key] = torch.cuda.Stream()
+        _SIDE_STREAMS[key] = torch.cuda.Stream()
     return _SIDE_STREAMS[key]
 
 
@@ -526,7 +510,7 @@ class _StackRun:
 def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap=DEFAULT_OVERLAP, stitch=True, group=None,
                          model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic", connectivity=1,
                          chain_depth=3, on_ambiguous="reference", max_in_flight=12, stream_windows=True,
-                         flow_workspace_gb=None, flood_cus_per_xcd=None, flood_thread=None, info=None, mark=None):
+                         flow_workspace_gb=None, flood_thread=None, info=None, mark=None):
     """Flow -> edge field -> marker-controlled watershed over a stack processed as overlapping time windows, on this device.
 
     bt: (T, H, W) float32 device tensor (the stack, resident).  bounds: [(start, stop), ...] consecutive windows sharing
@@ -604,10 +588,7 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             flow_workspace_gb = _BUDGET_MEMO[key]
         first = _WindowFloods(o, bt, 0, [None] * n_fly, n_fly)
         o.info["floods_in_flight"] = n_fly
-        if flood_cus_per_xcd is None:
-            flood_cus_per_xcd = int(os.environ.get("TF_WINDOWS_FLOOD_CUS", "0"))      # (development switch)
-        o.side = _side_stream(flood_cus_per_xcd, low_priority=os.environ.get("TF_WINDOWS_LOW_PRIORITY", "0") == "1")
-        o.info["flood_cus_per_xcd"] = int(flood_cus_per_xcd)
+        o.side = _side_stream()
 
         # (measured, config F.  Middle of round 5, six steps each: flood thread 4.48 - 5.11 s per step, mean 4.72; calling thread
         # 4.66 - 4.75, mean 4.71; flood thread on a low-priority stream 4.72 - 4.87.  End of round 5, with the build that no longer
@@ -823,7 +804,7 @@ def detect_stack_sequence(stacks, bounds, seeds_fn, consume=None, overlap=DEFAUL
     handover = queue.Queue()
     dev_index = torch.cuda.current_device()
     main_stream = torch.cuda.current_stream()
-    flood_stream = _side_stream(0, low_priority=os.environ.get("TF_WINDOWS_LOW_PRIORITY", "0") == "1")
+    flood_stream = _side_stream()
     info["floods_in_flight"], info["flood_thread"], info["stacks_pipelined"] = n_fly, True, True
 
     def deliver(wf):

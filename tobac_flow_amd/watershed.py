@@ -424,8 +424,8 @@ def watershed(
     out = watershed_dev(fwd, bwd, f, m, k, nbr, chain_depth, max_chain_depth=max_chain_depth,
                         on_ambiguous=on_ambiguous, return_ambiguous=return_ambiguous)
     if return_ambiguous:
-        return out if on_device else (out[0].cpu().numpy(), out[1].cpu().numpy())
-    return out if on_device else out.cpu().numpy()
+        return out if on_device else (_lib.to_host(out[0]), _lib.to_host(out[1]))
+    return out if on_device else _lib.to_host(out)
 
 
 __all__ = ("watershed", "watershed_dev", "watershed_begin", "WatershedJob", "neighbour_offsets", "WatershedAmbiguityWarning", "WatershedAmbiguityError",

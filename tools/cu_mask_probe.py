@@ -9,7 +9,9 @@ import numpy as np
 
 from tobac_flow_amd import _lib
 
-L = _lib.lib()
+# (round 6: these entry points are no longer in libtobac_flow_hip.so -- build tools/experiments/stream_experiments.hip, see its head)
+_lib.lib()
+L = ctypes.CDLL(os.environ.get("TF_STREAM_EXPERIMENTS_LIB", "gpurun_out/libstream_experiments.so"))
 t = _lib.torch()
 t.cuda.init()
 t.zeros(1, device="cuda")
@@ -20,9 +22,9 @@ def probe(name, bits):
     for b in bits:
         words[b // 32] |= np.uint32(1 << (b % 32))
     s = ctypes.c_void_p()
-    _lib.check(L.tf_stream_create_cu_mask(words.ctypes.data_as(_lib._P), 8, ctypes.byref(s)), "mask")
+    assert L.tf_stream_create_cu_mask(words.ctypes.data_as(_lib._P), 8, ctypes.byref(s)) == 0
     hist = np.zeros(2048, np.int32)
-    _lib.check(L.tf_debug_cu_histogram(s, 4096, hist.ctypes.data_as(_lib._P)), "hist")
+    assert L.tf_debug_cu_histogram(s, 4096, hist.ctypes.data_as(_lib._P)) == 0
     L.tf_stream_destroy(s)
     h = hist.reshape(8, 256)
     per_xcc = h.sum(1)
