@@ -202,6 +202,17 @@ int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const 
 #define TF_VR_FAST_SOR 2
 int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
                  float *flow, int flags, void *ws, size_t ws_bytes, void *stream);
+/* tf_varref_batch (round 6): the refinement of B images in ONE set of launches -- the loop of tobac_flow/flow.py:411-423 over
+ * the frame pairs, one direction: image b reads I0 + b * img_stride and I1 + b * img_stride (pixels) and refines flow +
+ * b * flow_stride (floats, even) in place.  The grid gains an image dimension, the code per tile is tf_varref's: the same
+ * bits.  What it buys is launches that fill the chip -- at 1500 x 2500 the fused SOR kernel of ONE image is 282 tiles on
+ * 256 CUs (a full round plus one that is 10 % full), of 23 images 6486 tiles in one launch -- and 11 launches per direction
+ * and batch instead of 11 per image.  ws: tf_varref_workspace_bytes_batch(B, H, W) (72 B per pixel and image); with less
+ * (>= one image's) the images are refined one after the other. */
+size_t tf_varref_workspace_bytes_batch(int64_t B, int64_t H, int64_t W);
+int tf_varref_batch(const uint8_t *I0, const uint8_t *I1, int64_t B, int64_t img_stride, int64_t H, int64_t W,
+                    const tf_varref_params *params, float *flow, int64_t flow_stride, int flags,
+                    void *ws, size_t ws_bytes, void *stream);
 
 /* ---- a6: forward/backward consistency smoothing ----------------------------------------------
  * replaces tobac_flow/flow.py:530-568 smooth_flow_step (4 x cv2.remap via

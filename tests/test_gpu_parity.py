@@ -617,6 +617,62 @@ def test_variational_refinement_bit_exact_vs_oracle(tf, shape):
     assert np.array_equal(vr.calc(i0, i1, flow.copy()), flow + np.float32(0))
 
 
+@pytest.mark.parametrize("shape", [(37, 53), (90, 120), (200, 333)])
+def test_variational_refinement_batch_equals_the_oracle_image_for_image(tf, shape):
+    """tf_varref_batch (round 6): B images per set of launches, the grid's z dimension = the image -- every image's refined flow
+    is the oracle's bit for bit (and so tf_varref's), with the flows as views into a larger (T, H, W, 2) array (a stride
+    between images that is not H * W * 2), in groups smaller than the batch, with more sweeps than the fused kernel covers
+    (per-image fallback inside the library) and with a workspace sized for one image only."""
+    import ctypes
+    import torch
+    from oracle import np_ops
+    from tobac_flow_amd import _lib
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    H, W = shape
+    B = 5
+    a = ndi.gaussian_filter(rng.normal(size=(B + 1, H + 8, W + 8)), (0, 2.0, 2.0))
+    a = ((a - a.min()) / max(np.ptp(a), 1e-9) * 255)
+    i0 = np.ascontiguousarray(a[:B, 4:-4, 4:-4]).astype(np.uint8)
+    i1 = np.ascontiguousarray(a[1:, 3:-5, 6:-2]).astype(np.uint8)
+    flow = (rng.normal(size=(B + 2, H, W, 2)) * 1.5).astype(np.float32)
+    flow[rng.random((B + 2, H, W)) < 0.02] = 25.0
+    want = [np_ops.variational_refinement(i0[b], i1[b], flow[1 + b]) for b in range(B)]
+    vr = tf.VariationalRefinement.create()
+    d0, d1 = torch.from_numpy(i0).cuda(), torch.from_numpy(i1).cuda()
+    for rounds in (32, 0):                                   # all images in one group / one image per group
+        big = torch.from_numpy(flow).cuda()
+        view = big[1:1 + B]                                  # frames 1 .. B of a larger array
+        vr.calc_batch_dev(d0, d1, view, rounds=rounds)
+        got = big.cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(got[1 + b], want[b]), (rounds, b, float(np.abs(got[1 + b] - want[b]).max()))
+        assert np.array_equal(got[0], flow[0]) and np.array_equal(got[-1], flow[-1])       # the neighbours are untouched
+    # a stride between the images that is larger than a frame: every second frame of the array
+    big = torch.from_numpy(np.repeat(flow[1:1 + B], 2, axis=0)).cuda()
+    L = _lib.lib()
+    p = vr._params()
+    ws = _lib.workspace(L.tf_varref_workspace_bytes_batch(B, H, W), "varref_test")
+    _lib.check(L.tf_varref_batch(_lib.ptr(d0), _lib.ptr(d1), B, H * W, H, W, ctypes.byref(p), _lib.ptr(big), 2 * H * W * 2, 0,
+                                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "tf_varref_batch")
+    got = big.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[2 * b], want[b]) and np.array_equal(got[2 * b + 1], flow[1 + b])
+    # a workspace for ONE image: the library refines the images one after the other
+    big = torch.from_numpy(flow[1:1 + B].copy()).cuda()
+    one = L.tf_varref_workspace_bytes(H, W)
+    _lib.check(L.tf_varref_batch(_lib.ptr(d0), _lib.ptr(d1), B, H * W, H, W, ctypes.byref(p), _lib.ptr(big), H * W * 2, 0,
+                                 _lib.ptr(ws), one, _lib.stream_ptr()), "tf_varref_batch")
+    assert all(np.array_equal(big[b].cpu().numpy(), want[b]) for b in range(B))
+    assert L.tf_varref_batch(_lib.ptr(d0), _lib.ptr(d1), B, H * W, H, W, ctypes.byref(p), _lib.ptr(big), H * W * 2, 0, _lib.ptr(ws), one - 4096 - 1024, _lib.stream_ptr()) == -1
+    assert L.tf_varref_batch(_lib.ptr(d0), _lib.ptr(d1), B, H * W - 1, H, W, ctypes.byref(p), _lib.ptr(big), H * W * 2, 0, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()) == -1
+    # parameters the fused SOR kernel does not cover (7 sweeps > its halo): per-image fallback inside the library, same bits
+    vr.fixedPointIterations, vr.sorIterations, vr.alpha, vr.omega = 2, 7, 5.0, 1.2
+    big = torch.from_numpy(flow[1:1 + B].copy()).cuda()
+    vr.calc_batch_dev(d0, d1, big)
+    for b in range(B):
+        assert np.array_equal(big[b].cpu().numpy(), np_ops.variational_refinement(i0[b], i1[b], flow[1 + b], 2, 7, alpha=5.0, omega=1.2))
+
+
 def test_vr_steps_refine_once_per_direction_like_the_reference(tf):
     """flow.py:513-519: any vr_steps > 0 runs exactly ONE VariationalRefinement.calc per direction, before the
     smoothing; create_flow / calculate_flow / calculate_flow_frame agree with each other and with the oracle pipeline

@@ -69,6 +69,9 @@ _PROTOS = {
     "tf_varref_workspace_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     "tf_varref": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.POINTER(VarRefParams), _P, _P, _c.c_size_t, _P]),
     "tf_varref_ex": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.POINTER(VarRefParams), _P, _c.c_int, _P, _c.c_size_t, _P]),
+    "tf_varref_workspace_bytes_batch": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64]),
+    "tf_varref_batch": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.POINTER(VarRefParams), _P, _c.c_int64, _c.c_int,
+                                   _P, _c.c_size_t, _P]),
     "tf_smooth_flow_step": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P, _P]),
     "tf_smooth_flow_step_clip": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P, _c.c_float, _P]),
     "tf_warp_flow": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int, _P, _P]),

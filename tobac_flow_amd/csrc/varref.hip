@@ -25,6 +25,9 @@
 #include <stdlib.h>
 
 struct VrP { float alpha2, delta2, gamma2, omega, zeta2, eps2; };
+// strides between the images of a batch (tf_varref_batch; all zero-cost for one image): frames in pixels, the caller's flow
+// array in float2, the workspace planes in elements
+struct VrB { int64_t img, flow, plane; };
 
 __device__ __forceinline__ int vr_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
@@ -35,9 +38,13 @@ __device__ __forceinline__ int vr_clampi(int v, int hi) { return v < 0 ? 0 : (v 
 
 __global__ void __launch_bounds__(256)
 k_vr_prepare(const uint8_t *__restrict__ I0, const uint8_t *__restrict__ I1, const float2 *__restrict__ flow,
-             int H, int W, float4 *__restrict__ D1, float4 *__restrict__ D2)
+             int H, int W, float4 *__restrict__ D1, float4 *__restrict__ D2, VrB bs)
 {
     __shared__ float s_avg[VR_LH][VR_LW], s_iz[VR_LH][VR_LW], s_ix[VR_LH][VR_LW], s_iy[VR_LH][VR_LW];
+    {   // image blockIdx.z of a batch (tf_varref_batch): the same tile code on that image's arrays
+        const int64_t b = blockIdx.z;
+        I0 += b * bs.img; I1 += b * bs.img; flow += b * bs.flow; D1 += b * bs.plane; D2 += b * bs.plane;
+    }
     const int x0 = blockIdx.x * VR_TW - 2, y0 = blockIdx.y * VR_TH - 2;
     // warped / averaged image and Iz on the tile + 2 halo (in-image positions only; neighbours are clamped later).
     // Three stages so that a thread's loads are in flight together: flow + I0 of all its positions, then the four I1
@@ -195,9 +202,16 @@ template <bool WEIGHTS, bool FAST = false>
 __global__ void __launch_bounds__(256)
 k_vr_system(const float4 *__restrict__ D1, const float4 *__restrict__ D2, const float2 *__restrict__ Wf,
             const float2 *__restrict__ dW, const float *wt_in, int H, int W, VrP P,
-            float4 *__restrict__ S, float *__restrict__ A12o, float *wt_out)
+            float4 *__restrict__ S, float *__restrict__ A12o, float *wt_out, VrB bs)
 {
     __shared__ float s_w[4][64];
+    {
+        const int64_t b = blockIdx.z;
+        D1 += b * bs.plane; D2 += b * bs.plane; Wf += b * bs.flow; S += b * bs.plane; A12o += b * bs.plane;
+        if (dW) dW += b * bs.plane;
+        if (wt_in) wt_in += b * bs.plane;
+        if (wt_out) wt_out += b * bs.plane;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wv;
     const bool in = x < W && y < H;
@@ -360,9 +374,16 @@ static_assert(VRT_PW == 64 && VRT_RH % VRT_WAVES == 0, "one wave per region row,
 template <bool FAST>
 __global__ void __launch_bounds__(VRT_THREADS, 2)
 k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
-              int n_half, float omega, const float2 *__restrict__ dW_in, const float2 *Wadd, float2 *dW_out)
+              int n_half, float omega, const float2 *__restrict__ dW_in, const float2 *Wadd, float2 *dW_out, VrB bs)
 {
     extern __shared__ __align__(16) unsigned char vr_lds[];
+    {
+        const int64_t b = blockIdx.z;
+        S += b * bs.plane; A12 += b * bs.plane; wt += b * bs.plane;
+        if (dW_in) dW_in += b * bs.plane;
+        // the last fixed-point iteration writes the refined flow into the caller's array (its stride), the others dW into a plane
+        if (Wadd) { Wadd += b * bs.flow; dW_out += b * bs.flow; } else dW_out += b * bs.plane;
+    }
     float2 *l_dw = (float2 *)vr_lds;                                   // [2][VRT_RH][VRT_PW]
     float *l_wt = (float *)(vr_lds + 2 * VRT_RH * VRT_PW * 8);         // [2][VRT_RH][VRT_PW]
     const int x0 = blockIdx.x * VRT_W - VRT_HALO, y0 = blockIdx.y * VRT_H - VRT_HALO;
@@ -486,49 +507,70 @@ extern "C" void tf_varref_default_params(tf_varref_params *p)
     p->alpha = 20.f; p->delta = 5.f; p->gamma = 10.f; p->omega = 1.6f;
 }
 
-extern "C" size_t tf_varref_workspace_bytes(int64_t H, int64_t W)
+static size_t vr_plane(int64_t n, int64_t B) { return B > 1 ? tf_align_up((size_t)n, 64) : (size_t)n; }
+
+extern "C" size_t tf_varref_workspace_bytes_batch(int64_t B, int64_t H, int64_t W)
 {
-    if (H <= 0 || W <= 0) return 0;
-    const size_t n = (size_t)H * W;
+    if (H <= 0 || W <= 0 || B <= 0) return 0;
+    const size_t n = vr_plane(H * W, B) * (size_t)B;
     // D1, D2, S (float4), A12, wt (float), dW and its ping-pong partner (float2)
     return 3 * tf_align_up(n * 16, 256) + 2 * tf_align_up(n * 4, 256) + 2 * tf_align_up(n * 8, 256) + 4096;
 }
+extern "C" size_t tf_varref_workspace_bytes(int64_t H, int64_t W) { return tf_varref_workspace_bytes_batch(1, H, W); }
 
-extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
-                            float *flow, int flags, void *ws, size_t ws_bytes, void *stream)
+// the refinement of B images in one set of launches (grid z = image): I0 + b * img_stride, I1 + b * img_stride, flow +
+// b * flow_stride (floats).  Per tile the code is the single image's, so the bits are too; what changes is the launch: at
+// 1500 x 2500 a k_vr_sor_tile launch for ONE image is 282 tiles on 256 CUs -- one full round and a second one that is 10 %
+// full -- and a frame pair costs 2 x 11 launches; 23 pairs at once are 6486 tiles (25.3 rounds) in 11 launches per direction.
+static int vr_run(const uint8_t *I0, const uint8_t *I1, int64_t B, int64_t img_stride, int64_t H, int64_t W, const tf_varref_params *params,
+                  float *flow, int64_t flow_stride, int flags, void *ws, size_t ws_bytes, void *stream)
 {
     TF_REQUIRE((flags & ~(TF_VR_FAST_DIVIDE | TF_VR_FAST_SOR)) == 0, "tf_varref_ex: unknown flag");
     const bool fast = (flags & TF_VR_FAST_DIVIDE) != 0;                  // system assembly AND the sweeps
     const bool fast_sor = fast || (flags & TF_VR_FAST_SOR) != 0;        // the sweeps only
     TF_REQUIRE(I0 && I1 && flow && ws, "tf_varref: null pointer");
     TF_REQUIRE(H > 0 && W > 0 && H < 32768 && W < 32768, "tf_varref: bad shape");
+    TF_REQUIRE(B >= 1 && B <= 65535, "tf_varref: bad batch size");
+    TF_REQUIRE(B == 1 || (img_stride >= H * W && flow_stride >= 2 * H * W && flow_stride % 2 == 0), "tf_varref_batch: strides smaller than one image / odd flow stride");
     tf_varref_params dp;
     if (!params) { tf_varref_default_params(&dp); params = &dp; }
     TF_REQUIRE(params->fixed_point_iterations >= 0 && params->sor_iterations >= 0, "tf_varref: bad iteration counts");
     hipStream_t s = (hipStream_t)stream;
+    // the fused SOR kernel covers up to VRT_HALO half sweeps; TF_VR_SOR_SWEEPS=1 selects the one-launch-per-half-sweep
+    // form (same results, kept as the reference for the fused one and for larger sorIterations)
+    static const bool force_sweeps = getenv("TF_VR_SOR_SWEEPS") != nullptr;
+    static const bool weights_pass_env = getenv("TF_VR_WEIGHTS_PASS") != nullptr;   // development aid: separate pass
+    const bool tiled = !force_sweeps && 2 * params->sor_iterations <= VRT_HALO;
+    const bool tile_path = tiled && params->sor_iterations > 0;
+    if (B > 1 && (!tile_path || weights_pass_env)) {
+        // the forms without a batch dimension (per-half-sweep kernels, the separate weights pass): image by image
+        for (int64_t b = 0; b < B; b++)
+            if (const int rc = vr_run(I0 + b * img_stride, I1 + b * img_stride, 1, 0, H, W, params, flow + b * flow_stride, 0, flags, ws, ws_bytes, stream)) return rc;
+        return TF_OK;
+    }
     const int64_t n = H * W;
+    const int64_t np = (int64_t)vr_plane(n, B);
     TfArena ar(ws, ws_bytes);
-    float4 *D1 = ar.take<float4>(n), *D2 = ar.take<float4>(n), *S = ar.take<float4>(n);
-    float *A12 = ar.take<float>(n), *wt = ar.take<float>(n);
-    float2 *dW = ar.take<float2>(n), *dW2 = ar.take<float2>(n);
+    float4 *D1 = ar.take<float4>(np * B), *D2 = ar.take<float4>(np * B), *S = ar.take<float4>(np * B);
+    float *A12 = ar.take<float>(np * B), *wt = ar.take<float>(np * B);
+    float2 *dW = ar.take<float2>(np * B), *dW2 = ar.take<float2>(np * B);
     if (!ar.ok()) { tf_set_error("tf_varref: workspace too small"); return TF_ENOMEM; }
     VrP P;
     P.alpha2 = params->alpha / 4; P.delta2 = params->delta / 2; P.gamma2 = params->gamma / 2; P.omega = params->omega;
     P.zeta2 = 0.1f * 0.1f; P.eps2 = 0.001f * 0.001f;
+    const VrB bs = {B > 1 ? img_stride : 0, B > 1 ? flow_stride / 2 : 0, B > 1 ? np : 0};
+    const unsigned Z = (unsigned)B;
+    const double nb = (double)n * (double)B;
     // W is the caller's flow array itself: it is only read until the last kernel replaces it by W + dW
     const float2 *Wf = (const float2 *)flow;
     const int iH = (int)H, iW = (int)W;
     {
-        TfProfScope ps(TFK_VR_PREPARE, (1.0 + 1.0 + 8.0 + 32.0) * (double)n, s);
-        hipLaunchKernelGGL(k_vr_prepare, dim3((iW + VR_TW - 1) / VR_TW, (iH + VR_TH - 1) / VR_TH), dim3(256), 0, s,
-                           I0, I1, Wf, iH, iW, D1, D2);
+        TfProfScope ps(TFK_VR_PREPARE, (1.0 + 1.0 + 8.0 + 32.0) * nb, s);
+        hipLaunchKernelGGL(k_vr_prepare, dim3((iW + VR_TW - 1) / VR_TW, (iH + VR_TH - 1) / VR_TH, Z), dim3(256), 0, s,
+                           I0, I1, Wf, iH, iW, D1, D2, bs);
     }
     TF_CHECK_LAUNCH();
-    const dim3 g1((iW + 63) / 64, (iH + 3) / 4), g2(((iW + 1) / 2 + 63) / 64, (iH + 3) / 4);
-    // the fused SOR kernel covers up to VRT_HALO half sweeps; TF_VR_SOR_SWEEPS=1 selects the one-launch-per-half-sweep
-    // form (same results, kept as the reference for the fused one and for larger sorIterations)
-    static const bool force_sweeps = getenv("TF_VR_SOR_SWEEPS") != nullptr;
-    const bool tiled = !force_sweeps && 2 * params->sor_iterations <= VRT_HALO;
+    const dim3 g1((iW + 63) / 64, (iH + 3) / 4, Z), g2(((iW + 1) / 2 + 63) / 64, (iH + 3) / 4);
     if (tiled) {
         static TfDeviceOnce once;                  // function attributes are per device
         TfDeviceOnce::Guard guard(once);
@@ -538,7 +580,6 @@ extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int
             guard.done();
         }
     }
-    const bool tile_path = tiled && params->sor_iterations > 0;
     // dW = 0 at the start: the tiled path passes "no dW" to the first iteration's kernels, the sweep path needs the array
     const float2 *dW_cur = nullptr;
     if (!tile_path) { TF_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)n * 8, s)); dW_cur = dW; }
@@ -546,35 +587,35 @@ extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int
     for (int it = 0; it < params->fixed_point_iterations; it++) {
         {
             // algorithmic bytes: D1 + D2 32, W 8, dW 8 read; S 16, A12 4, weight 4 written (no dW in the first iteration)
-            static const bool weights_pass_env = getenv("TF_VR_WEIGHTS_PASS") != nullptr;   // development aid: separate pass
             const bool weights_pass = weights_pass_env && !fast;
-            TfProfScope ps(TFK_VR_SYSTEM, (32.0 + 8.0 + (dW_cur ? 8.0 : 0.0) + 16.0 + 4.0 + 4.0) * (double)n, s);
+            TfProfScope ps(TFK_VR_SYSTEM, (32.0 + 8.0 + (dW_cur ? 8.0 : 0.0) + 16.0 + 4.0 + 4.0) * nb, s);
             if (weights_pass) {
                 hipLaunchKernelGGL(k_vr_weights, g1, dim3(256), 0, s, Wf, dW_cur, iH, iW, P, wt);
                 hipLaunchKernelGGL((k_vr_system<false, false>), g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
-                                   dW_cur, (const float *)wt, iH, iW, P, S, A12, (float *)nullptr);
+                                   dW_cur, (const float *)wt, iH, iW, P, S, A12, (float *)nullptr, bs);
             } else if (fast)
                 hipLaunchKernelGGL((k_vr_system<true, true>), g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
-                                   dW_cur, (const float *)nullptr, iH, iW, P, S, A12, wt);
+                                   dW_cur, (const float *)nullptr, iH, iW, P, S, A12, wt, bs);
             else
                 hipLaunchKernelGGL((k_vr_system<true, false>), g1, dim3(256), 0, s, (const float4 *)D1, (const float4 *)D2, Wf,
-                                   dW_cur, (const float *)nullptr, iH, iW, P, S, A12, wt);
+                                   dW_cur, (const float *)nullptr, iH, iW, P, S, A12, wt, bs);
         }
         TF_CHECK_LAUNCH();
         if (tile_path) {
             // algorithmic bytes: system 20 + weight 4 + dW 8 read, dW 8 written, once per fixed-point iteration (no dW
             // to read in the first; W 8 more to read in the last, which writes the refined flow)
             const bool last = it == params->fixed_point_iterations - 1;
-            TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + (dW_cur ? 8.0 : 0.0) + (last ? 8.0 : 0.0) + 8.0) * (double)n, s);
+            TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + (dW_cur ? 8.0 : 0.0) + (last ? 8.0 : 0.0) + 8.0) * nb, s);
             float2 *dst = last ? (float2 *)flow : (dW_cur == dW ? dW2 : dW);
+            const dim3 gt((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H, Z);
             if (fast_sor)
-                hipLaunchKernelGGL(k_vr_sor_tile<true>, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
+                hipLaunchKernelGGL(k_vr_sor_tile<true>, gt, dim3(VRT_THREADS),
                                    VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
-                                   2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);
+                                   2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst, bs);
             else
-                hipLaunchKernelGGL(k_vr_sor_tile<false>, dim3((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H), dim3(VRT_THREADS),
+                hipLaunchKernelGGL(k_vr_sor_tile<false>, gt, dim3(VRT_THREADS),
                                    VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
-                                   2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst);
+                                   2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst, bs);
             dW_cur = dst;
             flow_done = last;
         } else {
@@ -587,18 +628,40 @@ extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int
         TF_CHECK_LAUNCH();
     }
     if (!flow_done) {
-        // no tiled last iteration (sweep path, or no iterations at all): flow = W + dW, with dW = 0 if nothing ran
-        if (!dW_cur) { TF_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)n * 8, s)); dW_cur = dW; }
-        hipLaunchKernelGGL(k_vr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wf, dW_cur, n, (float2 *)flow);
-        TF_CHECK_LAUNCH();
+        // no tiled last iteration (sweep path, or no iterations at all; B == 1 here): flow = W + dW, with dW = 0 if nothing ran
+        for (int64_t b = 0; b < B; b++) {
+            if (!dW_cur) { TF_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)n * 8, s)); dW_cur = dW; }
+            hipLaunchKernelGGL(k_vr_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Wf + b * bs.flow, dW_cur + b * bs.plane, n, (float2 *)flow + b * bs.flow);
+            TF_CHECK_LAUNCH();
+        }
     }
     return TF_OK;
+}
+
+extern "C" int tf_varref_ex(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
+                            float *flow, int flags, void *ws, size_t ws_bytes, void *stream)
+{
+    return vr_run(I0, I1, 1, 0, H, W, params, flow, 0, flags, ws, ws_bytes, stream);
 }
 
 extern "C" int tf_varref(const uint8_t *I0, const uint8_t *I1, int64_t H, int64_t W, const tf_varref_params *params,
                          float *flow, void *ws, size_t ws_bytes, void *stream)
 {
     return tf_varref_ex(I0, I1, H, W, params, flow, 0, ws, ws_bytes, stream);
+}
+
+extern "C" int tf_varref_batch(const uint8_t *I0, const uint8_t *I1, int64_t B, int64_t img_stride, int64_t H, int64_t W,
+                               const tf_varref_params *params, float *flow, int64_t flow_stride, int flags,
+                               void *ws, size_t ws_bytes, void *stream)
+{
+    if (ws_bytes < tf_varref_workspace_bytes_batch(B, H, W)) {
+        // (a caller that sized for one image still gets its images refined -- one after the other)
+        TF_REQUIRE(B >= 1 && ws_bytes >= tf_varref_workspace_bytes(H, W), "tf_varref_batch: workspace too small");
+        for (int64_t b = 0; b < B; b++)
+            if (const int rc = vr_run(I0 + b * img_stride, I1 + b * img_stride, 1, 0, H, W, params, flow + b * flow_stride, 0, flags, ws, ws_bytes, stream)) return rc;
+        return TF_OK;
+    }
+    return vr_run(I0, I1, B, img_stride, H, W, params, flow, flow_stride, flags, ws, ws_bytes, stream);
 }
 
 // development aid: number of operand pairs (out of `count`, drawn from the range vr_div_shared is used in) for which the

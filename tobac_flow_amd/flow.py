@@ -329,6 +329,33 @@ class VariationalRefinement:
                                   _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "tf_varref")
         return flow
 
+    def calc_batch_dev(self, i0, i1, flow, rounds=32):
+        """The refinement of B images at once (tf_varref_batch: the grid gains an image dimension, the bits are calc_dev's):
+        i0, i1 (B, H, W) uint8 device tensors, flow (B, H, W, 2) float32 refined in place -- frames with contiguous rows, any
+        stride between them (views into the stack's flow arrays).  Images go out in groups that fill ~`rounds` rounds of the
+        fused SOR kernel's tiles on the device's CUs: at 1500 x 2500 (282 tiles) all 23 pairs of BASELINE config C in one set
+        of 11 launches; at 5424^2 (2279 tiles, 8.9 rounds by itself) 4 images, whose scratch is 8.5 GB."""
+        L = _lib.lib()
+        t = _lib.torch()
+        B, H, W = i0.shape
+        assert tuple(i1.shape) == (B, H, W) and tuple(flow.shape) == (B, H, W, 2)
+        assert i0.is_contiguous() and i1.is_contiguous() and flow[0].is_contiguous()
+        if B == 1:
+            self.calc_dev(i0[0], i1[0], flow[0])
+            return flow
+        tiles = -(-W // 108) * -(-H // 84)
+        cus = t.cuda.get_device_properties(i0.device).multi_processor_count
+        group = int(max(1, min(B, -(-rounds * cus // tiles))))
+        ws = _lib.workspace(L.tf_varref_workspace_bytes_batch(group, H, W), "varref")
+        p = self._params()
+        flags = (1 if self.fastDivide else 0) | (2 if self.fastSor else 0)
+        for b0 in range(0, B, group):
+            n = min(group, B - b0)
+            _lib.check(L.tf_varref_batch(_lib.ptr(i0[b0]), _lib.ptr(i1[b0]), n, H * W, H, W, ctypes.byref(p), _lib.ptr(flow[b0]),
+                                         flow.stride(0) if B > 1 else H * W * 2, flags, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                       "tf_varref_batch")
+        return flow
+
     def calc(self, I0, I1, flow):
         t = _lib.torch()
         i0, i1 = _lib.to_dev(I0), _lib.to_dev(I1)
@@ -551,9 +578,9 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
 
         def refine_and_smooth(i0=i0, B=B, prev8=prev8, next8=next8, f=f, bk=bk):
             if vr_steps > 0:                     # flow.py:513-519, before the smoothing (flow.py:521-525)
-                for b in range(B):
-                    vr_model.calc_dev(prev8[b], next8[b], f[b])
-                    vr_model.calc_dev(next8[b], prev8[b], bk[b])
+                # (round 6: all pairs of the batch per set of launches, one direction after the other -- tf_varref_batch)
+                vr_model.calc_batch_dev(prev8, next8, f)
+                vr_model.calc_batch_dev(next8, prev8, bk)
             for b in range(B if smoothing_passes > 0 else 0):
                 fi, bi = f[b], bk[b]
                 for k in range(smoothing_passes):
