@@ -582,7 +582,9 @@ int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
  * tf_host_alloc / tf_host_free: PINNED host blocks from a pool kept by size class (hipHostMalloc costs hundreds of ms per GB:
  *   a freed block is handed out again, tf_host_pool_trim(keep_bytes) returns cached blocks to the system).  A result is
  *   downloaded straight into such a block, which the caller wraps as the array it returns: no second host copy.
- *   tf_host_is_pinned: 1 if [ptr, ptr + bytes) lies inside a block that is handed out.
+ *   tf_host_is_pinned: 1 if [ptr, ptr + bytes) lies inside a block that is handed out.  tf_host_pool_spare: how many free
+ *   blocks of a size class the pool holds (the Python layer keeps one or two ahead, allocated on a background thread while
+ *   the device computes, so that a result's download does not wait for hipHostMalloc).
  * tf_upload(dst, src_host, bytes, hash_out_host, stream): host -> device on `stream`.  A pageable source is copied by host
  *   threads (<= 16, TF_STAGING_THREADS) chunk by chunk (8 MiB, TF_STAGING_CHUNK_MB) into a ring of pinned slots, each chunk's
  *   DMA enqueued as soon as it is staged; returns when the SOURCE has been read completely (the caller may free or change it),
@@ -601,6 +603,7 @@ int tf_host_alloc(size_t bytes, void **ptr_out_host);
 int tf_host_free(void *ptr_host);
 int tf_host_is_pinned(const void *ptr_host, size_t bytes);
 int tf_host_pool_stats(int64_t *live_bytes, int64_t *cached_bytes);
+int tf_host_pool_spare(size_t bytes);      /* free blocks of the size class of `bytes` in the pool */
 int tf_host_pool_trim(size_t keep_bytes);
 int tf_upload(void *dst, const void *src_host, size_t bytes, uint64_t *hash_out_host, void *stream);
 int tf_download(void *dst_host, const void *src, size_t bytes, void *stream);

@@ -137,6 +137,7 @@ _PROTOS = {
     "tf_host_free": (_c.c_int, [_P]),
     "tf_host_is_pinned": (_c.c_int, [_P, _c.c_size_t]),
     "tf_host_pool_stats": (_c.c_int, [_P, _P]),
+    "tf_host_pool_spare": (_c.c_int, [_c.c_size_t]),
     "tf_host_pool_trim": (_c.c_int, [_c.c_size_t]),
     "tf_upload": (_c.c_int, [_P, _P, _c.c_size_t, _P, _P]),
     "tf_download": (_c.c_int, [_P, _P, _c.c_size_t, _P]),

@@ -20,6 +20,7 @@ going to be written."""
 import ctypes
 import os
 import threading
+import time
 from collections import OrderedDict
 
 import numpy as np
@@ -30,19 +31,22 @@ _MIN_CACHED = 1 << 20                     # arrays below 1 MiB are not worth a c
 _LOCK = threading.Lock()
 _CACHE = OrderedDict()                    # (nbytes, dtype str, shape, device, h0, h1) -> (device tensor, event behind its last write)
 _cache_bytes = 0
-stats = {"uploads": 0, "upload_bytes": 0, "hits": 0, "hit_bytes": 0, "downloads": 0, "download_bytes": 0}
+stats = {"uploads": 0, "upload_bytes": 0, "hits": 0, "hit_bytes": 0, "downloads": 0, "download_bytes": 0,
+         "hash_s": 0.0, "upload_s": 0.0, "download_s": 0.0, "pinned_alloc_s": 0.0}      # (host seconds spent in each part)
 
 
 def _budget():
     return int(float(os.environ.get("TF_HOST_CACHE_GB", "32")) * 1e9)
 
 
-def clear():
-    """drop every cached device twin (their HBM goes back to torch's allocator) and trim the pinned pool's free blocks"""
+def clear(trim=True):
+    """drop every cached device twin (their HBM goes back to torch's allocator) and, with trim, the pinned pool's free blocks"""
     global _cache_bytes
     with _LOCK:
         _CACHE.clear()
         _cache_bytes = 0
+    if not trim:
+        return
     try:
         _lib.lib().tf_host_pool_trim(0)
     except Exception:                     # noqa: BLE001 -- library not built: nothing to trim
@@ -89,6 +93,56 @@ def _have_candidates(nbytes, dtype, shape, dev):
         return any(k[:4] == (nbytes, dtype, shape, dev) for k in _CACHE)
 
 
+# ---- pinned blocks ahead of need ---------------------------------------------------------------------------------------
+# hipHostMalloc pins page by page: 120 ms for a 1.88 GB label volume -- four times its DMA.  A script that runs once per
+# process (scripts/dcc_detect_goes.py: one file group per process) would pay that for every result it keeps.  So whenever a
+# large array passes through (an upload or a download of N bytes: the results of the entry points have the inputs' shape),
+# a background thread makes sure the pool holds TF_PINNED_SPARE (default 2) free blocks of that size class -- allocated while
+# the device computes.
+_SPARE_Q = None
+_SPARE_MIN = 32 << 20
+
+
+def _spare_worker(q):
+    L = _lib.lib()
+    t = _lib.torch()
+    while True:
+        dev, nbytes, want = q.get()
+        try:
+            t.cuda.set_device(dev)
+            while L.tf_host_pool_spare(nbytes) < want:
+                p = ctypes.c_void_p()
+                if L.tf_host_alloc(nbytes, ctypes.byref(p)) != 0:
+                    break
+                L.tf_host_free(p)
+        except Exception:                  # noqa: BLE001 -- a convenience: the foreground path allocates what is missing
+            pass
+        finally:
+            q.task_done()
+
+
+def wait_idle():
+    """wait until the background thread has nothing left to allocate (tests; a caller about to measure host memory)"""
+    if _SPARE_Q is not None:
+        _SPARE_Q.join()
+
+
+def _keep_spare(nbytes):
+    global _SPARE_Q
+    want = int(os.environ.get("TF_PINNED_SPARE", "2"))
+    if want <= 0 or nbytes < _SPARE_MIN:
+        return
+    if _lib.lib().tf_host_pool_spare(nbytes) >= want:
+        return
+    with _LOCK:
+        if _SPARE_Q is None:
+            import queue
+            _SPARE_Q = queue.Queue()
+            threading.Thread(target=_spare_worker, args=(_SPARE_Q,), name="tf-pinned-spare", daemon=True).start()
+    if _SPARE_Q.qsize() < 2:
+        _SPARE_Q.put((_lib.torch().cuda.current_device(), int(nbytes), want))
+
+
 def _as_bytes_view(a):
     """C-contiguous array with a plain dtype -> (array to keep alive, address, nbytes, dtype tag)"""
     a = np.asarray(a)
@@ -124,16 +178,22 @@ def upload(array, fresh=False):
     known = False
     if cacheable and _have_candidates(nbytes, tag, shape, dev.index):
         # something of this shape is cached: a read-only pass over the host buffer (no PCIe) decides
+        t0 = time.perf_counter()
         _lib.check(L.tf_hash_host(ctypes.c_void_p(addr), nbytes, hp), "tf_hash_host")
+        stats["hash_s"] += time.perf_counter() - t0
         known = True
         hit = _lookup((nbytes, tag, shape, dev.index, int(h[0]), int(h[1])))
         if hit is not None:
+            _keep_spare(nbytes)
             stats["hits"] += 1
             stats["hit_bytes"] += nbytes
             return hit
     out = t.empty(shape, dtype=td, device=dev)
+    t0 = time.perf_counter()
     _lib.check(L.tf_upload(_lib.ptr(out), ctypes.c_void_p(addr), nbytes, hp if (cacheable and not known) else None, _lib.stream_ptr()),
                "tf_upload")
+    stats["upload_s"] += time.perf_counter() - t0
+    _keep_spare(nbytes)
     stats["uploads"] += 1
     stats["upload_bytes"] += nbytes
     if cacheable:
@@ -183,14 +243,19 @@ def download(tensor, remember=True):
     if np_dtype is None or nbytes < _MIN_CACHED:
         return src.cpu().numpy()
     L = _lib.lib()
+    t0 = time.perf_counter()
     try:
         out = empty_pinned(tuple(src.shape), np_dtype)
     except MemoryError:                    # no pinned memory to be had: the runtime's pageable path
         return src.cpu().numpy()
+    stats["pinned_alloc_s"] += time.perf_counter() - t0
     with t.cuda.device(src.device):
+        t0 = time.perf_counter()
         _lib.check(L.tf_download(ctypes.c_void_p(out.ctypes.data), _lib.ptr(src), nbytes, _lib.stream_ptr()), "tf_download")
+        stats["download_s"] += time.perf_counter() - t0      # (includes waiting for the kernels that produce the result)
         stats["downloads"] += 1
         stats["download_bytes"] += nbytes
+        _keep_spare(nbytes)
         if remember and _budget() > 0:
             h = np.zeros(2, np.uint64)
             _lib.check(L.tf_hash_dev(_lib.ptr(src), nbytes, h.ctypes.data_as(_lib._P), _lib.stream_ptr()), "tf_hash_dev")

@@ -295,6 +295,15 @@ extern "C" int tf_host_pool_stats(int64_t *live_bytes, int64_t *cached_bytes)
     return TF_OK;
 }
 
+// cached (free) blocks of the size class `bytes` falls into
+extern "C" int tf_host_pool_spare(size_t bytes)
+{
+    if (!bytes) return 0;
+    HostPool &hp = pool();
+    std::lock_guard<std::mutex> lk(hp.mu);
+    return (int)hp.cached.count(size_class(bytes));
+}
+
 extern "C" int tf_host_pool_trim(size_t keep_bytes)
 {
     HostPool &hp = pool();
