@@ -332,6 +332,16 @@ def main():
                          "the flow and one channel: the timed steps are ONE detect_stack_sequence call over the rotated stacks -- the end "
                          "of a stack, i.e. its last windows' host replays, root phases and the stitch, runs beside the next stack's flow, "
                          "as in a sweep over many days; `step_ms` are then the intervals between the stacks' completions)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank holds its own T-frame segment of one sequence.  strong: ONE T-frame stack -- the "
+                         "configuration as BASELINE.json words V and F3 (\"288 frames, frame-sharded across 8 x MI355X\") -- whose windows "
+                         "are dealt out to the ranks (rank r: windows [r W / N, (r + 1) W / N) and the frames they cover; "
+                         "tobac_flow_amd.parallel.rank_windows); value = T H W per step over the wall time, whatever N")
+    ap.add_argument("--no-hand-out", dest="hand_out", action="store_false",
+                    help="several channels (config F3): keep every channel's stitched windows resident until `consume` (round 5) instead of "
+                         "handing each window out as it is finished, with window-local ids and the relabelling tables at the end "
+                         "(detect_stack_windows(on_window=...): the reference's own product structure -- one file per window job + linking.py "
+                         "-- and what lets the windows of all three channels be begun during the flow on one device)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: do not record HIP events around the library's launches in the timed region "
                          "(roofline = null); the difference to a default run is what the instrumentation costs")
@@ -360,7 +370,7 @@ def main():
 
     import tobac_flow_amd.flow as tf
     from tobac_flow_amd import _lib
-    from tobac_flow_amd.parallel import detect_stack_sequence, detect_stack_windows, window_bounds
+    from tobac_flow_amd.parallel import detect_stack_sequence, detect_stack_windows, rank_windows, window_bounds
     from tools.synth import anvil_seeds, blob_stack
 
     cT, cH, cW, cN, C = CONFIGS[a.config]
@@ -368,6 +378,13 @@ def main():
     n_windows = a.n_windows or (cN if T == cT else max(1, round(T / 12)))
     full_size = (T, H, W, n_windows) == (cT, cH, cW, cN)
     bounds = window_bounds(T, n_windows, a.overlap) if n_windows > 1 else [(0, T)]
+    # weak scaling: rank r holds frames r (T - overlap) ... of one sequence.  strong: ONE T-frame stack, rank r its share of the windows
+    T_glob, bounds_glob, strong = T, bounds, a.scaling == "strong"
+    frame0 = rank * (T - a.overlap)
+    if strong:
+        frame0, f_hi, bounds = rank_windows(bounds_glob, rank, world)
+        T = f_hi - frame0
+        n_windows = len(bounds)
     # rank r holds frames r * (T - overlap) ... of ONE sequence: its last `overlap` frames are rank r + 1's first ones.
     # Resident in HBM before the timed region: the brightness-temperature stack (generated in blocks of frames: torch's
     # own kernels index in 32 bits, tools/synth.py).  Everything else -- seeds included -- is computed inside the step.
@@ -378,7 +395,7 @@ def main():
     bt_all = torch.empty((T_all, H, W), dtype=torch.float32, device="cuda")
     for f0 in range(0, T_all, 12):
         f1 = min(f0 + 12, T_all)
-        bt_all[f0:f1] = blob_stack(f1 - f0, H, W, seed=20240601, t0=rank * (T - a.overlap) + f0)
+        bt_all[f0:f1] = blob_stack(f1 - f0, H, W, seed=20240601, t0=frame0 + f0)
     ws_stats = []                                            # tf_watershed stats of every window of every step (warmup included)
     ref_order = []                                           # reference order: (detour microseconds, replay form, replay us, export us) per flood that needed it
     tie_mode = {"order": a.tie_order}
@@ -414,15 +431,27 @@ def main():
             if c == C - 1:
                 keep[:] = [wins]                             # (one channel's labels resident at a time: only the last one's are kept)
             return None
-        detect_stack_windows(bt, bounds, seeds_of, channels=C, consume=consume, overlap=a.overlap,
-                             vr_steps=a.vr_steps if vr_steps is None else vr_steps, smoothing_passes=1, interp_method="cubic",
-                             connectivity=1, chain_depth=a.chain_depth,
-                             on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore",
-                             max_in_flight=a.inflight, stream_windows=a.stream_windows,
-                             flow_workspace_gb=float(os.environ["TF_BENCH_FLOW_GB"]) if "TF_BENCH_FLOW_GB" in os.environ else None,
-                             info=info, mark=mark if timeline else None)
+        hand_out = C > 1 and a.hand_out
+        res, _ = detect_stack_windows(bt, bounds, seeds_of, channels=C, consume=consume, overlap=a.overlap,
+                                      vr_steps=a.vr_steps if vr_steps is None else vr_steps, smoothing_passes=1, interp_method="cubic",
+                                      connectivity=1, chain_depth=a.chain_depth,
+                                      on_ambiguous="reference" if tie_mode["order"] == "reference" else "ignore",
+                                      max_in_flight=a.inflight, stream_windows=a.stream_windows,
+                                      flow_workspace_gb=float(os.environ["TF_BENCH_FLOW_GB"]) if "TF_BENCH_FLOW_GB" in os.environ else None,
+                                      info=info, mark=mark if timeline else None,
+                                      on_window=(lambda c, k, lab: None) if hand_out else None)
         inflight["n"] = info.get("floods_in_flight", 1)
         inflight["flow_workspace_gb"] = info.get("flow_workspace_gb")
+        inflight["channels_begun_during_the_flow"] = info.get("channels_begun_during_the_flow")
+        if hand_out:                                         # the windows have left one by one; objects = the largest consistent id
+            for r_ in res:
+                n_obj = int(max(int(l.max()) for l in r_["luts"]))
+                if dist is not None:
+                    tn = torch.tensor([n_obj], dtype=torch.int64, device="cpu" if a.backend == "gloo" else bt_all.device)
+                    dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                    n_obj = int(tn.item())
+                objects.append(n_obj)
+            return None, objects
         return keep[0], objects
 
     def barrier():
@@ -450,7 +479,7 @@ def main():
     t0 = time.perf_counter()
     n_objects, step_ms = [], []
     objects_per_step = []
-    pipelined = bool(a.pipeline_stacks and a.stream_windows and C == 1 and n_windows > 1 and a.steps > 1)
+    pipelined = bool(a.pipeline_stacks and a.stream_windows and C == 1 and len(bounds) > 1 and a.steps > 1)
     if pipelined:
         # THE TIMED STEPS AS ONE SWEEP (round 5): detect_stack_sequence over the a.steps rotated stacks -- every stack is processed
         # exactly as a detect_stack_windows step is (same windows, same labels: tests/test_gpu_windows.py), but the calling thread
@@ -479,6 +508,7 @@ def main():
                               info=info, mark=mark if timeline else None)
         inflight["n"] = info.get("floods_in_flight", 1)
         inflight["flow_workspace_gb"] = info.get("flow_workspace_gb")
+        inflight["channels_begun_during_the_flow"] = info.get("channels_begun_during_the_flow")
         out_labels = kept[0]
         kept.clear()                                         # (out_labels is the one reference: released with it)
         n_objects = [objects_per_step[-1]]
@@ -546,7 +576,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
-        frames_computed = sum(hi - lo for lo, hi in bounds)
+        frames_computed = sum(hi - lo for lo, hi in bounds) if not strong else sum(hi - lo for lo, hi in bounds_glob) / world     # (per rank, on average)
         dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
         roof = None
         if dom:
@@ -620,7 +650,9 @@ def main():
         names = {"F": "BASELINE config F: GOES-16 ABI full-disk-sized stack", "V": "BASELINE config V: SEVIRI full-disk-sized stack",
                  "F3": "BASELINE config F3: full-disk-sized stack, three channels sharing one Flow",
                  "C": "BASELINE config C: GOES-16 CONUS-sized stack", "window": "sub-report: ONE window per step"}
-        what = (f"{names[a.config]}: {T}x{H}x{W} float32 frames per GPU per step" + (f" x {C} channels" if C > 1 else "") +
+        what = ((f"{names[a.config]}: ONE {T_glob}x{H}x{W} float32 stack per step, its {len(bounds_glob)} windows dealt out to {world} GPU(s) "
+                 f"(strong sharding: rank r holds the windows [r W / N, (r + 1) W / N) and the {T} or so frames they cover)" if strong else
+                 f"{names[a.config]}: {T}x{H}x{W} float32 frames per GPU per step") + (f" x {C} channels" if C > 1 else "") +
                 (f" ({n_rot} different stacks of the synthetic sequence visited in turn)" if n_rot > 1 else "") +
                 (f", processed as {n_windows} time windows sharing {a.overlap} frames: flow of the {T - 1} frame pairs once for the stack, "
                  f"then per window Sobel edge field + seeds + watershed ({frames_computed} window frames for {T} delivered) + stitch of "
@@ -628,7 +660,8 @@ def main():
         if not full_size:
             what = "REDUCED rehearsal of " + what
         out = {"metric": "Mpix/s end-to-end flow+sobel+watershed, 5424^2 frames" if (H, W) == (5424, 5424)
-               else f"Mpix/s end-to-end flow+sobel+watershed, {H}x{W} frames", "value": round(world * a.steps * T * H * W / dt / 1e6, 2),
+               else f"Mpix/s end-to-end flow+sobel+watershed, {H}x{W} frames",
+               "value": round((T_glob if strong else world * T) * a.steps * H * W / dt / 1e6, 2),
                "unit": "Mpix/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist is not None else 1,
                "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt / a.steps * 1e3, 2), "step_ms": step_ms,
@@ -637,16 +670,21 @@ def main():
                                     "between the stacks' completions, the first one from the start of the timed region; --no-pipeline-stacks times them one by one"}
                                    if pipelined else {"on": False}),
                "one_stack_by_itself_ms": None if alone_ms is None else round(alone_ms, 1),
-               "higher_is_better": True, "scaling": "weak",
+               "higher_is_better": True, "scaling": a.scaling,
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": what,
-                          "frames_delivered_per_step": T, "window_frames_computed_per_step": frames_computed, "channels": C,
+                          "frames_delivered_per_step": T_glob if strong else T, "window_frames_computed_per_step": frames_computed, "channels": C,
+                          "delivery": ("every window handed out as it is finished, with window-local ids; relabelling tables (local id -> id consistent over all "
+                                       "windows and ranks) at the end of the step -- the reference's product structure: one file per window job + linking.py"
+                                       if (C > 1 and a.hand_out) else "stitched label windows resident at the end of the step"),
                           "seeds": ("every positive seed = 1 (detect_anvils(markers=None))" if a.single_label_seeds else
                                     "SURVEY 8(d): label(binary_erosion(field_lin >= 1)) per window on the device (component ids), "
                                     "-1 where get_watershed_mask(field_lin); computed inside the timed region"),
                           "stages": f"create_flow(Farneback, vr_steps={a.vr_steps}, smoothing_passes=1, cubic) + Flow.window_view + seeds + Flow.sobel(uphill, cubic, f64) "
                                     "+ edge field + Flow.watershed(connectivity 1)" + (" + stitch" if n_windows > 1 or world > 1 else ""),
-                          "sharding": f"one {T}-frame segment per GPU cut from one sequence, consecutive segments share {a.overlap} frames; "
+                          "sharding": (f"STRONG: one {T_glob}-frame stack, rank r floods the windows [r W / N, (r + 1) W / N) and computes the flow of the frames they cover "
+                                       f"(consecutive ranks share {a.overlap} frames); " if strong else
+                                       f"one {T}-frame segment per GPU cut from one sequence, consecutive segments share {a.overlap} frames; ") +
                                       "label IDs stitched over all windows of all ranks by the reference's overlap rule "
                                       "(>= 5 px and >= 0.5, linking.py:49-161): one neighbour message per rank boundary + all-gathers of pair lists",
                           "input_rotation": f"{n_rot} stacks at frame offsets {[k * a.rotate_shift for k in range(n_rot)]} of the sequence, visited in turn (warm-up steps first)",
@@ -668,7 +706,8 @@ def main():
                             "tie_order": a.tie_order,
                             "labels_bit_exact_with_the_reference": a.tie_order == "reference" and int(timed[:, 11].sum()) == 0,
                             "floods_in_flight": inflight.get("n", 1), "flow_workspace_GB_chosen_by_the_scheduler": inflight.get("flow_workspace_gb"),
-                            "windows_begun_during_the_flow": bool(a.stream_windows and C == 1 and n_windows > 1)}
+                            "windows_begun_during_the_flow": bool(a.stream_windows and n_windows > 1 and (inflight.get("channels_begun_during_the_flow") or 0) > 0),
+                            "channels_begun_during_the_flow": inflight.get("channels_begun_during_the_flow")}
         if a.tie_order == "reference":
             ro = ref_order                                                          # warm-up floods included
             out["watershed"]["reference_order"] = {
@@ -683,7 +722,7 @@ def main():
                 "note": "host replays run on worker threads beside the next windows' device work (tf_watershed_begin / _replay / _finish)"}
             if raster_ms is not None:
                 out["watershed"]["raster_order_subreport"] = {
-                    "ms_per_step": round(raster_ms, 1), "Mpix_per_s": round(world * T * H * W / (raster_ms * 1e-3) / 1e6, 1),
+                    "ms_per_step": round(raster_ms, 1), "Mpix_per_s": round((T_glob if strong else world * T) * H * W / (raster_ms * 1e-3) / 1e6, 1),
                     "labels_bit_exact_with_the_reference": False,
                     "note": "one extra step outside the timed region with on_ambiguous='ignore' (equal-valued markers in raster order)"}
         # per-stage rates, and the measured device-to-device copy rate as the practical HBM ceiling

@@ -583,8 +583,9 @@ int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
  *   a freed block is handed out again, tf_host_pool_trim(keep_bytes) returns cached blocks to the system).  A result is
  *   downloaded straight into such a block, which the caller wraps as the array it returns: no second host copy.
  *   tf_host_is_pinned: 1 if [ptr, ptr + bytes) lies inside a block that is handed out.  tf_host_pool_spare: how many free
- *   blocks of a size class the pool holds (the Python layer keeps one or two ahead, allocated on a background thread while
- *   the device computes, so that a result's download does not wait for hipHostMalloc).
+ *   blocks of a size class the pool holds.  (Allocating blocks AHEAD on a background thread, while the device computes, was
+ *   measured in round 6 and dropped: hipHostMalloc holds up the launching thread's runtime calls -- the first pass of the
+ *   script sequence got slower, 3.02 s against 2.70 s.)
  * tf_upload(dst, src_host, bytes, hash_out_host, stream): host -> device on `stream`.  A pageable source is copied by host
  *   threads (<= 16, TF_STAGING_THREADS) chunk by chunk (8 MiB, TF_STAGING_CHUNK_MB) into a ring of pinned slots, each chunk's
  *   DMA enqueued as soon as it is staged; returns when the SOURCE has been read completely (the caller may free or change it),

@@ -49,6 +49,26 @@ def test_two_ranks_on_one_device_equal_the_one_process_run():
     assert len(two_p["step_ms"]) == 2 and two_p["n_gpus"] == 2
 
 
+def test_strong_sharding_of_one_stack_equals_the_one_process_run():
+    """bench.py --scaling strong (BASELINE configs 4 - 5 as worded: ONE stack "frame-sharded" over the GPUs; the reference's
+    analogue: one window job per process, scripts/dcc_detect_seviri_nat.py:152 + scripts/linking_parallel.py:26-27): a 44-frame
+    stack of four windows, rank r taking two of them and the 24 frames they cover -- the same objects after the stitch as the
+    one-process run of the same stack, `value` = the ONE stack's pixels over the wall time (not times N), and N = 1 under
+    --scaling strong is the plain run."""
+    one = _bench("--frames", "44", "--n-windows", "4")
+    two = _bench("--frames", "44", "--n-windows", "4", "--gpus", "2", "--single-device", "--backend", "gloo", "--scaling", "strong")
+    solo = _bench("--frames", "44", "--n-windows", "4", "--scaling", "strong")
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2 and solo["scaling"] == "strong" and one["scaling"] == "weak"
+    assert two["config"]["frames_delivered_per_step"] == 44 == solo["config"]["frames_delivered_per_step"]
+    assert two["config"]["objects_after_stitch"] == one["config"]["objects_after_stitch"] == solo["config"]["objects_after_stitch"] > 10
+    assert abs(two["value"] - 44 * 1500 * 2500 / (two["ms_per_step"] * 1e-3) / 1e6) < 0.02 * two["value"]
+    assert "STRONG" in two["config"]["sharding"] and "ONE 44x1500x2500" in two["config"]["workload"]
+    # two steps: every rank's share of the stack goes through detect_stack_sequence, the stitch of each step a collective
+    two_p = _bench("--frames", "44", "--n-windows", "4", "--gpus", "2", "--single-device", "--backend", "gloo", "--scaling", "strong", "--steps", "2")
+    n_obj = one["config"]["objects_after_stitch"]
+    assert two_p["config"]["objects_after_stitch_per_step"] == [n_obj, n_obj] and two_p["steps_pipelined"]["on"]
+
+
 def test_bench_pipeline_equals_the_plain_calls():
     """bench.py's step -- windows begun from create_flow's callback while the later frames' flow is computed, floods in parts
     with their replays on worker threads, finished on a second stream, stitched in place -- against the same stack processed

@@ -134,39 +134,61 @@ def test_two_gloo_ranks_on_one_device_equal_the_one_process_run_voxel_for_voxel(
 
 def test_several_channels_share_the_flow_and_equal_the_plain_calls():
     """BASELINE config F3's shape of the problem at a small size: several detections (channels: the same stack at offsets 0 / -2
-    K) share ONE Flow and are processed one after the other, all windows of a channel after the stack's flow (no streaming with
-    more than one channel), `consume` called per channel.  Every channel's stitched windows equal the serial plain calls on
-    that channel, voxel for voxel."""
+    K) share ONE Flow.  Round 6: the windows of EVERY channel whose labels fit are begun during the flow, on the one flood
+    thread and stream (or from the calling thread), sharing the flood slots; `consume` is called per channel, in order.  In
+    hand-out mode (on_window) every window leaves as soon as it is finished, with window-local ids, and the call returns the
+    relabelling tables: tables applied to the handed-out windows == the stitched windows.  Every channel's stitched windows
+    equal the serial plain calls on that channel, voxel for voxel, in every form."""
     import torch
     import tobac_flow_amd.flow as tf
     from tobac_flow_amd.detection import get_combined_edge_field
-    from tobac_flow_amd.parallel import detect_stack_windows, stitch_window_list, window_bounds
+    from tobac_flow_amd.parallel import apply_global_lut, detect_stack_windows, stitch_window_list, window_bounds
     from tools.synth import anvil_seeds, blob_stack
-    t_, h_, w_ = 26, 400, 600
+    t_, h_, w_ = 38, 400, 600
     bt = blob_stack(t_, h_, w_, seed=20240601, t0=5)
-    bounds = window_bounds(t_, 2, 4)
+    bounds = window_bounds(t_, 3, 4)
     offsets = (0.0, -2.0)
 
     def seeds_fn(w, c):
         return anvil_seeds(w + offsets[c] if c else w)
-    seen = []
-
-    def consume(c, wins):
-        seen.append(c)
-        return [w.clone() for w in wins]
-    got, info = detect_stack_windows(bt, bounds, seeds_fn, channels=2, consume=consume, overlap=4)
-    assert seen == [0, 1] and len(got) == 2 and info["floods_in_flight"] >= 1 and "flood_thread" not in info
     flow = tf.create_flow(bt, model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    want = []
     for c in range(2):
         labs = []
         for a, b in bounds:
             fl = flow.window(a, b)
             lin, seeds = seeds_fn(bt[a:b], c)
             labs.append(fl.watershed(get_combined_edge_field(fl, lin, dtype=np.float32), seeds, connectivity=1))
-        want = stitch_window_list(labs, overlap=4)
-        for k, (g, w) in enumerate(zip(got[c], want)):
-            assert torch.equal(g, w), (c, k, int((g != w).sum()))
-    assert not torch.equal(got[0][0], got[1][0])                        # the channels do differ
+        want.append(stitch_window_list(labs, overlap=4))
+    del flow
+    assert not torch.equal(want[0][0], want[1][0])                      # the channels do differ
+    for stream, thread in ((True, True), (True, False), (False, None)):
+        seen = []
+
+        def consume(c, wins):
+            seen.append(c)
+            return [w.clone() for w in wins]
+        got, info = detect_stack_windows(bt, bounds, seeds_fn, channels=2, consume=consume, overlap=4, stream_windows=stream, flood_thread=thread)
+        assert seen == [0, 1] and len(got) == 2 and info["floods_in_flight"] >= 1
+        assert info["channels_begun_during_the_flow"] == (2 if stream else 0), info          # (a small stack: both channels fit)
+        for c in range(2):
+            for k, (g, w) in enumerate(zip(got[c], want[c])):
+                assert torch.equal(g, w), (stream, thread, c, k, int((g != w).sum()))
+        # hand-out mode: window-local labels leave one by one, the tables make them consistent
+        handed = {}
+
+        def on_window(c, k, lab):
+            assert lab.dtype == torch.int32 and (c, k) not in handed
+            handed[(c, k)] = lab.clone()
+            return int(lab.max())
+        res, info = detect_stack_windows(bt, bounds, seeds_fn, channels=2, on_window=on_window, overlap=4, stream_windows=stream, flood_thread=thread)
+        assert len(handed) == 6 and info["channels_begun_during_the_flow"] == (2 if stream else 0)
+        for c in range(2):
+            assert set(res[c]) == {"windows", "luts"} and len(res[c]["luts"]) == 3
+            assert res[c]["windows"] == [int(handed[(c, k)].max()) for k in range(3)]
+            for k in range(3):
+                g = apply_global_lut(handed[(c, k)], res[c]["luts"][k])
+                assert torch.equal(g, want[c][k]), ("hand-out", stream, thread, c, k, int((g != want[c][k]).sum()))
 
 
 def test_a_sequence_of_stacks_equals_the_per_stack_calls_voxel_for_voxel():
@@ -255,3 +277,79 @@ def test_a_window_that_ends_at_a_hand_over_waits_for_the_next_one_on_the_flood_t
         first_setup = next(i for i, m in enumerate(marks) if m.startswith("begin:"))
         assert marks.index("flow enqueued for 30 frames") < first_setup, marks
         del on_thread
+
+
+def _strong_worker(rank, world, port, out_dir, hand_out):
+    import torch
+    import torch.distributed as dist
+    from tobac_flow_amd.parallel import detect_stack_windows, rank_windows, window_bounds
+    from tools.synth import anvil_seeds, blob_stack
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t_all, h_, w_ = 54, 700, 900
+    lo, hi, local = rank_windows(window_bounds(t_all, 5, OVERLAP), rank, world)
+    bt = blob_stack(hi - lo, h_, w_, seed=20240601, t0=lo)              # this rank's frames of the ONE stack
+
+    def seeds_fn(w, c):
+        return anvil_seeds(w - 2.0 * c if c else w)
+    if hand_out:
+        kept = {}
+
+        def on_window(c, k, lab):
+            kept[(c, k)] = lab.cpu().numpy()
+        res, info = detect_stack_windows(bt, local, seeds_fn, channels=2, overlap=OVERLAP, on_window=on_window)
+        assert info["channels_begun_during_the_flow"] == 2
+        for c in range(2):
+            for k in range(len(local)):
+                lut = np.asarray(res[c]["luts"][k])
+                lab = kept[(c, k)]
+                np.save(os.path.join(out_dir, f"r{rank}_c{c}_w{k}.npy"), np.where(lab > 0, lut[np.maximum(lab, 0)], lab).astype(np.int32))
+    else:
+        got, _ = detect_stack_windows(bt, local, seeds_fn, channels=2, overlap=OVERLAP)
+        for c in range(2):
+            for k, g in enumerate(got[c]):
+                np.save(os.path.join(out_dir, f"r{rank}_c{c}_w{k}.npy"), g.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hand_out", [False, True])
+def test_strong_sharding_two_ranks_on_one_device_equal_the_one_process_run_voxel_for_voxel(tmp_path, hand_out):
+    """ONE 54-frame stack of five windows, two channels; rank 0 takes windows 0 - 1 (round(5 / 2) = 2), rank 1
+    windows 2 - 4, each the frames its windows cover (parallel.rank_windows); stitched over both ranks (stitched windows, or
+    hand-out mode's tables applied to the window-local labels) == the one-process run over all five windows, voxel for
+    voxel, both channels."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from tobac_flow_amd.parallel import detect_stack_windows, rank_windows, window_bounds
+    from tools.synth import anvil_seeds, blob_stack
+    t_all, h_, w_ = 54, 700, 900
+    bounds = window_bounds(t_all, 5, OVERLAP)
+    shares = [rank_windows(bounds, r, 2) for r in range(2)]
+    assert [len(s[2]) for s in shares] == [2, 3] and shares[0][0] == 0 and shares[1][1] == t_all
+    assert shares[0][1] - shares[1][0] == OVERLAP                       # consecutive ranks share the frames two windows share
+    bt = blob_stack(t_all, h_, w_, seed=20240601, t0=0)
+
+    def seeds_fn(w, c):
+        return anvil_seeds(w - 2.0 * c if c else w)
+    got, _ = detect_stack_windows(bt, bounds, seeds_fn, channels=2, overlap=OVERLAP)
+    want = [[w.cpu().numpy() for w in got[c]] for c in range(2)]
+    assert max(int(w.max()) for w in want[0]) > 5
+    del got, bt
+    torch.cuda.empty_cache()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_strong_worker, args=(2, port, str(tmp_path), hand_out), nprocs=2, join=True)
+    for c in range(2):
+        k_glob = 0
+        for r in range(2):
+            for k in range(len(shares[r][2])):
+                have = np.load(tmp_path / f"r{r}_c{c}_w{k}.npy")
+                assert np.array_equal(have, want[c][k_glob]), (hand_out, c, r, k, int((have != want[c][k_glob]).sum()))
+                k_glob += 1

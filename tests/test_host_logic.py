@@ -888,3 +888,27 @@ def test_flood_thread_never_begins_a_window_whose_last_frame_is_the_handovers_la
     del views[:]
     wf = make(False, [None, None])                                       # calling thread: ordered by the stream, begun at once
     assert len(wf.setup_up_to(FakeFlow(), 16)) == 1 and views == [(0, 16)]
+
+
+def test_rank_windows_deals_the_windows_of_one_stack_out_to_the_ranks():
+    """parallel.rank_windows (strong sharding, BASELINE configs 4 - 5): every window goes to exactly one rank, in order;
+    a rank's frames run from its first window's start to its last window's stop; consecutive ranks share exactly the
+    frames two consecutive windows share; one rank = the whole stack."""
+    import pytest
+    from tobac_flow_amd.parallel import rank_windows, window_bounds
+    for T, n, overlap in ((288, 24, 4), (144, 12, 4), (54, 5, 4), (40, 3, 2)):
+        bounds = window_bounds(T, n, overlap)
+        assert rank_windows(bounds, 0, 1) == (0, T, bounds)
+        for world in (2, 3, min(n, 8)):
+            shares = [rank_windows(bounds, r, world) for r in range(world)]
+            glob = [(lo + s[0], hi + s[0]) for s in shares for lo, hi in s[2]]
+            assert glob == bounds
+            assert shares[0][0] == 0 and shares[-1][1] == T
+            for a, b in zip(shares[:-1], shares[1:]):
+                assert a[1] - b[0] == overlap and len(a[2]) >= 1
+            assert max(len(s[2]) for s in shares) - min(len(s[2]) for s in shares) <= 1
+            assert all(s[2][0][0] == 0 and s[2][-1][1] == s[1] - s[0] for s in shares)
+    with pytest.raises(ValueError):
+        rank_windows(window_bounds(40, 3, 2), 0, 4)
+    with pytest.raises(ValueError):
+        rank_windows(window_bounds(40, 3, 2), 3, 3)

@@ -93,56 +93,6 @@ def _have_candidates(nbytes, dtype, shape, dev):
         return any(k[:4] == (nbytes, dtype, shape, dev) for k in _CACHE)
 
 
-# ---- pinned blocks ahead of need ---------------------------------------------------------------------------------------
-# hipHostMalloc pins page by page: 120 ms for a 1.88 GB label volume -- four times its DMA.  A script that runs once per
-# process (scripts/dcc_detect_goes.py: one file group per process) would pay that for every result it keeps.  So whenever a
-# large array passes through (an upload or a download of N bytes: the results of the entry points have the inputs' shape),
-# a background thread makes sure the pool holds TF_PINNED_SPARE (default 2) free blocks of that size class -- allocated while
-# the device computes.
-_SPARE_Q = None
-_SPARE_MIN = 32 << 20
-
-
-def _spare_worker(q):
-    L = _lib.lib()
-    t = _lib.torch()
-    while True:
-        dev, nbytes, want = q.get()
-        try:
-            t.cuda.set_device(dev)
-            while L.tf_host_pool_spare(nbytes) < want:
-                p = ctypes.c_void_p()
-                if L.tf_host_alloc(nbytes, ctypes.byref(p)) != 0:
-                    break
-                L.tf_host_free(p)
-        except Exception:                  # noqa: BLE001 -- a convenience: the foreground path allocates what is missing
-            pass
-        finally:
-            q.task_done()
-
-
-def wait_idle():
-    """wait until the background thread has nothing left to allocate (tests; a caller about to measure host memory)"""
-    if _SPARE_Q is not None:
-        _SPARE_Q.join()
-
-
-def _keep_spare(nbytes):
-    global _SPARE_Q
-    want = int(os.environ.get("TF_PINNED_SPARE", "2"))
-    if want <= 0 or nbytes < _SPARE_MIN:
-        return
-    if _lib.lib().tf_host_pool_spare(nbytes) >= want:
-        return
-    with _LOCK:
-        if _SPARE_Q is None:
-            import queue
-            _SPARE_Q = queue.Queue()
-            threading.Thread(target=_spare_worker, args=(_SPARE_Q,), name="tf-pinned-spare", daemon=True).start()
-    if _SPARE_Q.qsize() < 2:
-        _SPARE_Q.put((_lib.torch().cuda.current_device(), int(nbytes), want))
-
-
 def _as_bytes_view(a):
     """C-contiguous array with a plain dtype -> (array to keep alive, address, nbytes, dtype tag)"""
     a = np.asarray(a)
@@ -184,8 +134,7 @@ def upload(array, fresh=False):
         known = True
         hit = _lookup((nbytes, tag, shape, dev.index, int(h[0]), int(h[1])))
         if hit is not None:
-            _keep_spare(nbytes)
-            stats["hits"] += 1
+                    stats["hits"] += 1
             stats["hit_bytes"] += nbytes
             return hit
     out = t.empty(shape, dtype=td, device=dev)
@@ -193,7 +142,6 @@ def upload(array, fresh=False):
     _lib.check(L.tf_upload(_lib.ptr(out), ctypes.c_void_p(addr), nbytes, hp if (cacheable and not known) else None, _lib.stream_ptr()),
                "tf_upload")
     stats["upload_s"] += time.perf_counter() - t0
-    _keep_spare(nbytes)
     stats["uploads"] += 1
     stats["upload_bytes"] += nbytes
     if cacheable:
@@ -255,12 +203,50 @@ def download(tensor, remember=True):
         stats["download_s"] += time.perf_counter() - t0      # (includes waiting for the kernels that produce the result)
         stats["downloads"] += 1
         stats["download_bytes"] += nbytes
-        _keep_spare(nbytes)
-        if remember and _budget() > 0:
+            if remember and _budget() > 0:
             h = np.zeros(2, np.uint64)
             _lib.check(L.tf_hash_dev(_lib.ptr(src), nbytes, h.ctypes.data_as(_lib._P), _lib.stream_ptr()), "tf_hash_dev")
             _remember((nbytes, np.dtype(np_dtype).str, tuple(src.shape), src.device.index, int(h[0]), int(h[1])), src)
     return out
+
+
+_COPY_STREAMS = {}
+
+
+class Prefetch:
+    """upload(a) for every array of `arrays` on a background thread and a copy stream of its own, while the calling thread goes
+    on enqueuing kernels that do not need them: detect_cores starts on BT while WVD and SWD cross PCIe.  `get(i)` joins,
+    makes the caller's current stream wait for the copies and returns the tensor."""
+
+    def __init__(self, arrays):
+        t = _lib.torch()
+        self.dev = t.cuda.current_device()
+        if self.dev not in _COPY_STREAMS:
+            _COPY_STREAMS[self.dev] = t.cuda.Stream(device=self.dev)
+        self.stream, self.out, self.err, self.ev = _COPY_STREAMS[self.dev], [None] * len(arrays), None, None
+        self.thread = threading.Thread(target=self._run, args=(list(arrays),), name="tf-prefetch", daemon=True)
+        self.thread.start()
+
+    def _run(self, arrays):
+        t = _lib.torch()
+        try:
+            t.cuda.set_device(self.dev)
+            with t.cuda.stream(self.stream):
+                for i, a in enumerate(arrays):
+                    self.out[i] = upload(a)
+                self.ev = t.cuda.Event()
+                self.ev.record()
+        except BaseException as exc:       # noqa: BLE001 -- re-raised by get() on the calling thread
+            self.err = exc
+
+    def get(self, i):
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+        cur = _lib.torch().cuda.current_stream()
+        cur.wait_event(self.ev)
+        self.out[i].record_stream(cur)
+        return self.out[i]
 
 
 def to_device(*fields):

@@ -95,6 +95,32 @@ def _to_device(a):
     return _lib.to_dev(_values(a), share=True)
 
 
+def _to_device_later(*fields):
+    """one zero-argument callable per field that returns it as a device tensor: device input at once, HOST input uploaded on
+    a background thread and a copy stream (_staging.Prefetch) while the caller enqueues the kernels that do not need it --
+    resolved by calling, at the point of first use"""
+    from tobac_flow_amd import _staging
+    host = [i for i, f in enumerate(fields) if not _is_device(f)]
+    if not host:
+        return [(lambda f=f: _to_device(f)) for f in fields]
+    pre = _staging.Prefetch([_values(fields[i]) for i in host])
+    slot = {i: k for k, i in enumerate(host)}
+    memo = {}
+
+    def getter(i):
+        def get():
+            if i not in memo:
+                memo[i] = pre.get(slot[i]).contiguous() if i in slot else _to_device(fields[i])
+            return memo[i]
+        return get
+    return [getter(i) for i in range(len(fields))]
+
+
+def _now(x):
+    """a tensor, or a callable that returns one (_to_device_later)"""
+    return x() if callable(x) and not isinstance(x, _lib.torch().Tensor) else x
+
+
 def _deliver(result_dev, like):
     """device result in the container kind of the input `like`: tensor for device input, numpy for host input"""
     return result_dev if _is_device(like) else _lib.to_host(result_dev, remember=True)
@@ -323,9 +349,9 @@ def get_combined_filters(flow, bt, wvd, swd, use_wvd=True):
 
         combined = channel_dev(bt, "positive") != 0
         if use_wvd:
-            combined = combined | (channel_dev(wvd, "negative") != 0)
+            combined = combined | (channel_dev(_now(wvd), "negative") != 0)
         combined = nd.binary_opening(nd.binary_fill_holes(combined, s), s)
-        return combined.to(t.float64) * (1 - nd.linearise_field(swd, 2.5, 7.5))
+        return combined.to(t.float64) * (1 - nd.linearise_field(_now(swd), 2.5, 7.5))     # (wvd / swd may arrive late: _to_device_later)
 
     def channel(field, direction):
         seed = np.logical_or(get_curvature_filter(field, direction=direction),
@@ -350,8 +376,10 @@ def detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overl
     exactly as in the reference (their float32 means feed a threshold).  Same result as _detect_cores_host."""
     from tobac_flow_amd import ndimage_dev as nd
     t = _lib.torch()
-    bt_d, wvd_d, swd_d = (_to_device(x) for x in (bt, wvd, swd))
-    combined_filter = get_combined_filters(flow, bt_d, wvd_d, swd_d, use_wvd=use_wvd)
+    # BT first (usually in HBM already: create_flow has just been handed the same array); WVD and SWD cross PCIe on a copy
+    # stream while the kernels that need BT alone -- its growth rate, its curvature and peak filters -- are enqueued and run
+    bt_d = _to_device(bt)
+    wvd_get, swd_get = _to_device_later(wvd, swd)
     s = ndi.generate_binary_structure(3, 1)
     s *= np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
 
@@ -360,7 +388,11 @@ def detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overl
         rate = flow.diff(field_d, method="cubic") / dt
         return flow.convolve(rate, structure=_plane_struct(), func=_nanmean0, method="cubic")
 
-    bt_markers = (growth(-bt_d, bt.t) * combined_filter) > bt_threshold
+    bt_growth = growth(-bt_d, bt.t)
+    combined_filter = get_combined_filters(flow, bt_d, wvd_get, swd_get, use_wvd=use_wvd)
+    wvd_d = wvd_get()
+    bt_markers = (bt_growth * combined_filter) > bt_threshold
+    del bt_growth
     if use_wvd:
         wvd_markers = (growth(wvd_d, wvd.t) * combined_filter) > wvd_threshold
         combined_markers = nd.binary_opening(wvd_markers | bt_markers, s)

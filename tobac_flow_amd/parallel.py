@@ -27,6 +27,23 @@ def window_bounds(T, world, overlap=1):
     return [(edges[i], edges[i + 1] + overlap) for i in range(world)]
 
 
+def rank_windows(bounds, rank, world):
+    """STRONG sharding of ONE stack over the ranks of a node (BASELINE configs 4 - 5: "288 frames, frame-sharded across 8 x
+    MI355X"; the reference's analogue is one window job per process, scripts/dcc_detect_seviri_nat.py:152 +
+    scripts/linking_parallel.py:26-27): rank r takes the windows [r W / N, (r + 1) W / N) of `bounds` and with them the frames
+    from its first window's start to its last window's stop -- `overlap` of which it shares with each neighbour, exactly
+    the frames two consecutive windows share.  Returns (frame_start, frame_stop, bounds relative to frame_start): what
+    detect_stack_windows(stack[frame_start:frame_stop], local_bounds, ..., group=...) is called with on that rank; the
+    stitch over the ranks (stitch_rank_windows) then equals the stitch of the one-process run over all windows."""
+    n = len(bounds)
+    if not (0 <= rank < world) or n < world:
+        raise ValueError("rank_windows: need 0 <= rank < world <= number of windows")
+    edges = [round(i * n / world) for i in range(world + 1)]
+    mine = [(int(lo), int(hi)) for lo, hi in bounds[edges[rank]:edges[rank + 1]]]
+    start, stop = mine[0][0], mine[-1][1]
+    return start, stop, [(lo - start, hi - start) for lo, hi in mine]
+
+
 def stitch_lut(counts, pairs_per_boundary):
     """Global relabelling tables from per-rank label counts and per-boundary (id_left, id_right) pairs.
 
@@ -224,6 +241,21 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
         raise ValueError("stitch_rank_windows: rank %d: %s" % (r_bad, {1: "every rank must hold at least one window", 2: "window shorter than the overlap",
                                                                        3: "windows must share their spatial shape"}[codes[r_bad]]))
     atol, rtol, sel = _rule(min_overlap, overlap, atol, rtol, short_overlap_ok)
+    first = windows[0][:overlap][sel].contiguous()
+    last = windows[-1]
+    luts = _stitch_tables([_count(w) for w in windows], _local_pairs(windows, overlap, sel, atol, rtol), first,
+                          last[last.shape[0] - overlap:][sel], group, atol, rtol, dev)
+    return [apply_global_lut(w, luts[k], inplace) for k, w in enumerate(windows)]
+
+
+def _stitch_tables(counts_local, internal_pairs, first_head, last_tail, group, atol, rtol, dev):
+    """The collective part of stitch_rank_windows on what it needs of this rank's windows -- their label counts, the pairs of its
+    INTERNAL boundaries, the compared frames of its first window (`first_head`) and of its last one (`last_tail`) -- so that
+    a caller that hands its windows out one by one (detect_stack_windows(on_window=...)) never holds them together.  Returns
+    the relabelling table of every local window (index = local id -> global id)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
 
     def gather_i64(vec):
         """all_gather of variable-length int64 vectors -> list of 1-D CPU tensors (length exchange, then padded payload)"""
@@ -238,11 +270,11 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
         dist.all_gather(got, padded, group=group)
         return [g[:k].cpu() for g, k in zip(got, ns)]
 
-    counts = gather_i64(torch.tensor([_count(w) for w in windows], dtype=torch.int64))
+    counts = gather_i64(torch.tensor(list(counts_local), dtype=torch.int64))
     n_win = [int(c.numel()) for c in counts]
     first_window = np.concatenate([[0], np.cumsum(n_win)])             # global index of each rank's first window
     # neighbour exchange of the compared frames of my first window
-    first = windows[0][:overlap][sel].contiguous()
+    first = first_head.to(dev).contiguous()
     right_first = torch.empty_like(first)
     ops = []
     if rank > 0:
@@ -251,10 +283,9 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
         ops.append(dist.P2POp(dist.irecv, right_first, rank + 1, group))
     for req in dist.batch_isend_irecv(ops) if ops else []:
         req.wait()
-    mine = _local_pairs(windows, overlap, sel, atol, rtol)             # my internal boundaries ...
+    mine = list(internal_pairs)                                        # my internal boundaries ...
     if rank < world - 1:                                               # ... and the one to my right neighbour
-        last = windows[-1]
-        mine.append(overlap_pairs(last[last.shape[0] - overlap:][sel], right_first, atol, rtol))
+        mine.append(overlap_pairs(last_tail.to(dev), right_first, atol, rtol))
     triples = [np.concatenate([np.full((len(p), 1), first_window[rank] + k, np.int64), np.asarray(p, np.int64).reshape(-1, 2)], 1)
                for k, p in enumerate(mine)]
     flat = np.concatenate(triples, 0).reshape(-1) if triples else np.zeros(0, np.int64)
@@ -266,7 +297,7 @@ def stitch_rank_windows(windows, group=None, min_overlap=None, overlap=DEFAULT_O
     pairs = [p.reshape(-1, 2) for p in np.split(triples_all[:, 1:], cuts)] if n_total > 1 else []
     all_counts = [int(v) for c in counts for v in c.tolist()]
     luts = stitch_lut(all_counts, pairs)
-    return [apply_global_lut(w, luts[first_window[rank] + k], inplace) for k, w in enumerate(windows)]
+    return [luts[first_window[rank] + k] for k in range(len(counts_local))]
 
 
 def stitch_labels(labels, group=None, min_overlap=None, overlap=DEFAULT_OVERLAP, atol=LINK_ATOL, rtol=LINK_RTOL,
@@ -357,6 +388,51 @@ class _WindowFloods:
         self.next = 0                                        # next window to begin
         self.family = None                                   # detect_stack_sequence: the stacks in flight share the flood slots
         self.own_stream = False                              # True: driven from a flood thread on a stream of its own (_ready)
+        # hand-out mode (detect_stack_windows(on_window=...)): every window leaves as soon as it is finished, with window-local
+        # ids; what stays are its label count and the pairs it forms with its neighbours (computed as soon as both exist)
+        self.on_window = None
+        n = len(owner.bounds)
+        self.handed, self.counts, self.pairs = [None] * n, [0] * n, [None] * max(n - 1, 0)
+        self._heads, self._tails, self.first_head, self.last_tail = {}, {}, None, None
+
+    def _hand_out(self, k, lab):
+        """the finished window k leaves: its count and the label pairs it forms with windows k - 1 / k + 1 on the frames the
+        linking compares (linking.py:55-56; computed now if that neighbour is done, else the compared frames -- two of the
+        four shared ones -- are kept until it is) stay; on_window(channel, k, labels) gets the window-local labels"""
+        o = self.o
+        n, ov, sel = len(o.bounds), o.overlap, o.sel
+        self.counts[k] = _count(lab)
+        head, tail = lab[:ov][sel], lab[lab.shape[0] - ov:][sel]
+        if k > 0:
+            if (k - 1) in self._tails:
+                self.pairs[k - 1] = overlap_pairs(self._tails.pop(k - 1), head, o.atol, o.rtol)
+            else:
+                self._heads[k] = head.clone()
+        elif o.multi:
+            self.first_head = head.clone()
+        if k < n - 1:
+            if (k + 1) in self._heads:
+                self.pairs[k] = overlap_pairs(tail, self._heads.pop(k + 1), o.atol, o.rtol)
+            else:
+                self._tails[k] = tail.clone()
+        elif o.multi:
+            self.last_tail = tail.clone()
+        self.handed[k] = self.on_window(self.c, k, lab)
+        self.wins[k] = None
+        o.mark("window %d of channel %d handed out" % (k, self.c))
+
+    def tables(self):
+        """hand-out mode, every window finished: the relabelling table of every window (index = window-local id -> id that is
+        consistent over all windows, and over all ranks of the group: the collective of stitch_rank_windows on counts, pairs
+        and the two outer windows' compared frames)"""
+        import torch
+        import torch.distributed as dist
+        o = self.o
+        if o.multi:
+            gloo = dist.get_backend(o.group) == "gloo"
+            dev = torch.device("cpu") if gloo else torch.device("cuda", torch.cuda.current_device())
+            return _stitch_tables(self.counts, self.pairs, self.first_head, self.last_tail, o.group, o.atol, o.rtol, dev)
+        return stitch_lut(self.counts, self.pairs)
 
     def _ready(self, n_frames):
         """may the next window be begun now that the flow of the stack's first n_frames frames is enqueued?  Its last frame
@@ -437,6 +513,8 @@ class _WindowFloods:
             return True
         self.wins[done[4]] = lab
         self.pieces.append(done[3])
+        if self.on_window is not None:
+            self._hand_out(done[4], lab)
         return True
 
     def setup_up_to(self, flow, n_frames, wait_for=None):
@@ -507,10 +585,42 @@ class _StackRun:
     pass
 
 
+class _ChannelGroup:
+    """The window floods of several channels of ONE stack driven together (BASELINE config F3: channels are independent
+    detections that share the Flow, detection.py:203-254): a hand-over of frames sets up that window for every channel -- all
+    on the one thread and stream that drives the floods, sharing the flood slots -- then sweeps them; whoever waits for a slot
+    finishes whichever channel's flood is ready."""
+
+    def __init__(self, floods):
+        self.floods = list(floods)
+        if len(self.floods) > 1:
+            fam = _SequenceFloods(lambda wf: None)           # (nothing is delivered from inside: the caller collects per channel)
+            fam.active = list(self.floods)
+            for wf in self.floods:
+                wf.family = fam
+
+    def begin_up_to(self, flow, n_frames, wait_for=None):
+        begun = [(wf, wf.setup_up_to(flow, n_frames, wait_for)) for wf in self.floods]
+        for wf, jobs in begun:
+            wf.sweep(jobs)
+
+    def finish_all(self):
+        for wf in self.floods:
+            wf.finish_all()
+
+    def abandon_all(self):
+        for wf in self.floods:
+            wf.abandon_all()
+
+    def set_own_stream(self, flag):
+        for wf in self.floods:
+            wf.own_stream = flag
+
+
 def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap=DEFAULT_OVERLAP, stitch=True, group=None,
                          model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic", connectivity=1,
                          chain_depth=3, on_ambiguous="reference", max_in_flight=12, stream_windows=True,
-                         flow_workspace_gb=None, flood_thread=None, info=None, mark=None):
+                         flow_workspace_gb=None, flood_thread=None, info=None, mark=None, on_window=None):
     """Flow -> edge field -> marker-controlled watershed over a stack processed as overlapping time windows, on this device.
 
     bt: (T, H, W) float32 device tensor (the stack, resident).  bounds: [(start, stop), ...] consecutive windows sharing
@@ -526,8 +636,19 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
     info["floods"] = per flood the library's sweep counts and tie statistics, info["reference_order"] = per flood that
     needed it the host replay's figures, info["floods_in_flight"], info["flow_batches"].
 
-    Scheduling (no effect on results): stream_windows -- begin a window as soon as its flow is enqueued (one channel only;
-    otherwise all windows after the stack's flow, their scratch borrowed from the then idle Farneback workspace);
+    on_window(channel, k, labels) (round 6) -- HAND-OUT mode, the reference's own product structure (one file of window-local
+    labels per window job, scripts/dcc_detect_goes.py:316-330, made consistent afterwards by linking.py:49-161): every window is
+    handed out as soon as its flood is finished -- int32 labels with WINDOW-LOCAL ids, on the thread and stream that finished
+    it; the callee stores, reduces or downloads them and must not keep the tensor unless it clones it -- and nothing of it
+    stays resident but its label count and the pairs it forms with its neighbours.  results[c] is then {"windows": [what
+    on_window returned per window], "luts": [per window the table local id -> consistent id (numpy int64; index 0 = 0)]}
+    (`tf_apply_lut` / apply_global_lut(labels, lut) gives the stitched window).  `consume` is not called.  With the labels of
+    no channel resident, the windows of ALL channels are begun during the flow (config F3 on one device: 3 x 45 GB of labels
+    beside 136 GB of flow vectors would not fit).
+
+    Scheduling (no effect on results): stream_windows -- begin a window as soon as its flow is enqueued -- for every channel
+    whose labels fit beside the flow (round 6; the others after the stack's flow, their scratch borrowed from the then idle
+    Farneback workspace);
     max_in_flight -- floods in flight at most; flood_thread -- drive the windows from a thread of their own on the second stream
     (default since the end of round 5: the calling thread then only enqueues the flow, whose batches no longer wait for the begins
     between them) or from create_flow's callback on the calling thread (False); flow_workspace_gb -- scratch budget of the Farneback batches while floods run
@@ -559,17 +680,39 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
     n_windows = len(bounds)
     longest = max(hi - lo for lo, hi in bounds)
     per_job = 18 * longest * H * W                           # scratch of a flood in flight (~17 B per window voxel)
-    stream = bool(stream_windows) and C == 1 and n_windows > 1
+    import torch.distributed as dist_
+    o.overlap, o.group = int(overlap), group
+    o.atol, o.rtol, o.sel = LINK_ATOL, LINK_RTOL, compare_frames(int(overlap))
+    o.multi = dist_.is_available() and dist_.is_initialized() and dist_.get_world_size(group) > 1
     flow_kw = dict(model=model, vr_steps=vr_steps, smoothing_passes=smoothing_passes, interp_method=interp_method)
     total = torch.cuda.mem_get_info()[1]
     first = None
+    sum_win = sum(hi - lo for lo, hi in bounds)
+    label_bytes = 4 * sum_win * H * W                        # the windows of ONE channel
+    # How many channels have their windows begun DURING the flow: with on_window no labels stay resident -- all of them; else
+    # one channel always (round 4/5), and more only if their labels fit beside the flow vectors, the floods in flight and a
+    # Farneback scratch worth having (40 GB).  Same labels either way.
+    n_fly = int(max(1, min(max_in_flight, n_windows * C, 5)))
+
+    def room_for(cs):
+        free = torch.cuda.mem_get_info()[0] + (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
+        held = sum(int(v.numel()) for k, v in list(_lib._WS.items()) if v is not None and k[1] == torch.cuda.current_device())
+        resident = 0 if on_window is not None else cs * label_bytes
+        return free + held - (2 * T * H * W * 8 + resident + (n_fly + 1) * (3 * per_job // 2))
+    if not (bool(stream_windows) and n_windows > 1):
+        Cs = 0
+    elif on_window is not None or C == 1:
+        Cs = C
+    else:
+        Cs = max([cs for cs in range(1, C + 1) if room_for(cs) >= 40e9] or [0])
+    stream = Cs > 0
+    o.info["channels_begun_during_the_flow"] = Cs
     if not stream and T * H * W * (1 + 4 + C) * 4 > 0.6 * total:
         # a stack that takes most of the device: the flood slots of the previous call go back to the allocator's cache before
         # the flow is sized (held, they cost the Farneback batches a third of their pairs); the floods take them again afterwards
         for k in range(64):
             _lib.release_workspaces("watershed_job%d" % k)
     if stream:
-        n_fly = int(max(1, min(max_in_flight, n_windows, 5)))
         if flow_workspace_gb is None:
             # floods in flight beside the flow need scratch of their own (the Farneback workspace is busy): the Farneback batches
             # get what is left after the flow vectors, the labels of all windows, the floods (scratch + field + seeds ~ 1.5 x
@@ -579,14 +722,15 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             # 6.4 s instead of 4.6).  Memoised per stack shape: the batches of every call of a sweep are then the same, whatever
             # an earlier call left cached.  Config F (144 x 5424^2, 12 windows) on 288 GB: 86 GB -- any budget from 65 to 98 GB
             # gives the library's batch hint 21 full-resolution pairs, i.e. 42-pair batches finished in two parts of 21.
-            key = (torch.cuda.current_device(), T, H, W, tuple(bounds), n_fly)
+            key = (torch.cuda.current_device(), T, H, W, tuple(bounds), n_fly, Cs, on_window is not None)
             if key not in _BUDGET_MEMO:
-                free = torch.cuda.mem_get_info()[0] + (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
-                held = sum(int(v.numel()) for k, v in list(_lib._WS.items()) if v is not None and k[1] == torch.cuda.current_device())
-                need = 2 * T * H * W * 8 + 4 * sum(hi - lo for lo, hi in bounds) * H * W + (n_fly + 1) * (3 * per_job // 2)
-                _BUDGET_MEMO[key] = max(4.0, 0.7 * (free + held - need) / 1e9)
+                _BUDGET_MEMO[key] = max(4.0, 0.7 * room_for(Cs) / 1e9)
             flow_workspace_gb = _BUDGET_MEMO[key]
-        first = _WindowFloods(o, bt, 0, [None] * n_fly, n_fly)
+        slots = [None] * n_fly                               # the flood slots, shared by the channels begun during the flow
+        streamed = [_WindowFloods(o, bt, c, slots, n_fly) for c in range(Cs)]
+        for wf_ in streamed:
+            wf_.on_window = on_window
+        first = _ChannelGroup(streamed)
         o.info["floods_in_flight"] = n_fly
         o.side = _side_stream()
 
@@ -622,7 +766,7 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             handover = queue.Queue()
             failure = []
             flood_stream, dev_index = o.side, torch.cuda.current_device()
-            first.own_stream = True
+            first.set_own_stream(True)
             o.side = None                                      # (the thread's CURRENT stream is the second stream: floods are finished on it)
 
             def flood_loop():
@@ -685,10 +829,13 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
         _lib.release_workspaces("farneback")
         flow_released = True
     results = []
-    for c in range(C):                                       # channels one after the other: one channel's labels resident
+    if first is not None:
+        first.begin_up_to(flow_all, T)                       # (every window has been begun by the last hand-over: a no-op then)
+        first.finish_all()
+    for c in range(C):                                       # channels one after the other: their labels leave in that order
         wq = None
-        if first is not None:
-            wq = first
+        if first is not None and c < Cs:
+            wq = first.floods[c]
         else:
             # Every flood in flight owns ~17 B of scratch per window voxel until it is finished.  The Farneback scratch of
             # create_flow (up to 115 GB) is idle from here to the next create_flow: the floods take their scratch from it,
@@ -710,8 +857,15 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
                 pieces = [None] * n_fly
             o.info["floods_in_flight"] = n_fly
             wq = _WindowFloods(o, bt, c, pieces, n_fly)
+            wq.on_window = on_window
         wq.begin_up_to(flow_all, T)
         wins = wq.finish_all()
+        if on_window is not None:
+            # hand-out mode: the windows have left one by one; what is returned are the callee's values and the tables
+            results.append({"windows": wq.handed, "luts": wq.tables() if stitch else None})
+            o.mark("channel %d: tables" % c)
+            del wins, wq
+            continue
         if o.info.get("flood_thread"):
             # the flood thread allocated the labels under ITS stream; from here on they are the caller's, used on the caller's
             # stream: tell the caching allocator, or a later allocation of the flood stream could take a block the caller has
@@ -719,7 +873,6 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             for w_ in wins:
                 if w_ is not None and w_.is_cuda:
                     w_.record_stream(torch.cuda.current_stream())
-        first = None
         o.mark("all windows finished")
         # label ids of all windows (of all ranks) made consistent: pair counting on the GPU, one union-find, one LUT pass
         import torch.distributed as dist
@@ -806,6 +959,7 @@ def detect_stack_sequence(stacks, bounds, seeds_fn, consume=None, overlap=DEFAUL
     main_stream = torch.cuda.current_stream()
     flood_stream = _side_stream()
     info["floods_in_flight"], info["flood_thread"], info["stacks_pipelined"] = n_fly, True, True
+    info["channels_begun_during_the_flow"] = 1
 
     def deliver(wf):
         wins = wf.wins
