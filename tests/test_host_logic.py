@@ -912,3 +912,14 @@ def test_rank_windows_deals_the_windows_of_one_stack_out_to_the_ranks():
         rank_windows(window_bounds(40, 3, 2), 0, 4)
     with pytest.raises(ValueError):
         rank_windows(window_bounds(40, 3, 2), 3, 3)
+
+
+def test_every_module_of_the_package_imports():
+    """(a syntax error in a module the CPU suite does not otherwise touch must not wait for the GPU box)"""
+    import importlib
+    import pkgutil
+    import tobac_flow_amd
+    names = [m.name for m in pkgutil.walk_packages(tobac_flow_amd.__path__, "tobac_flow_amd.")]
+    assert "tobac_flow_amd._staging" in names and "tobac_flow_amd.parallel" in names
+    for name in names:
+        importlib.import_module(name)

@@ -134,7 +134,7 @@ def upload(array, fresh=False):
         known = True
         hit = _lookup((nbytes, tag, shape, dev.index, int(h[0]), int(h[1])))
         if hit is not None:
-                    stats["hits"] += 1
+            stats["hits"] += 1
             stats["hit_bytes"] += nbytes
             return hit
     out = t.empty(shape, dtype=td, device=dev)
@@ -203,7 +203,7 @@ def download(tensor, remember=True):
         stats["download_s"] += time.perf_counter() - t0      # (includes waiting for the kernels that produce the result)
         stats["downloads"] += 1
         stats["download_bytes"] += nbytes
-            if remember and _budget() > 0:
+        if remember and _budget() > 0:
             h = np.zeros(2, np.uint64)
             _lib.check(L.tf_hash_dev(_lib.ptr(src), nbytes, h.ctypes.data_as(_lib._P), _lib.stream_ptr()), "tf_hash_dev")
             _remember((nbytes, np.dtype(np_dtype).str, tuple(src.shape), src.device.index, int(h[0]), int(h[1])), src)

@@ -23,6 +23,7 @@
 // S = float4 {A11, A22, b1, b2}, A12 float, wt float, W float2 (the input flow), dW float2.
 #include "tf_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 struct VrP { float alpha2, delta2, gamma2, omega, zeta2, eps2; };
 // strides between the images of a batch (tf_varref_batch; all zero-cost for one image): frames in pixels, the caller's flow
@@ -360,23 +361,37 @@ k_vr_sor(const float4 *__restrict__ S, const float *__restrict__ A12, const floa
 // the new u, so they cannot be paired, and a per-pixel reciprocal kept across the ten half sweeps would need 52 more
 // registers than the 229 the kernel has.
 #define VRT_W 108
-#define VRT_H 84
 #define VRT_HALO 10
 #define VRT_RW (VRT_W + 2 * VRT_HALO)
-#define VRT_RH (VRT_H + 2 * VRT_HALO)
 #define VRT_PW (VRT_RW / 2)
-#define VRT_THREADS 512
-#define VRT_WAVES (VRT_THREADS / 64)
-#define VRT_K (VRT_RH / VRT_WAVES)
-#define VRT_LDS_BYTES (2 * VRT_RH * VRT_PW * 12)
-static_assert(VRT_PW == 64 && VRT_RH % VRT_WAVES == 0, "one wave per region row, whole rows per wave");
+static_assert(VRT_PW == 64, "one lane per pixel pair of a region row");
+// Tile HEIGHT and workgroup size are template parameters since round 6: <84, 512> is the kernel described
+// above -- one 8-wave workgroup per CU, whose load phase (HBM-bound) and sweep phase (VALU-bound) alternate with nothing
+// resident to overlap them; <32, 256> is the same code on half-height tiles (region 128 x 52, 78 KB of LDS, 4 waves x 13 rows:
+// the same registers per thread), TWO workgroups per CU, so that one loads while the other sweeps -- at the price of more halo
+// (region / tile = 1.93 instead of 1.47).  Measured: profiles/round6_vr_sor_notes.txt.
+template <int TH, int NT> struct VrTile {
+    static constexpr int H = TH, RH = TH + 2 * VRT_HALO, THREADS = NT, WAVES = NT / 64, K = RH / WAVES;
+    static constexpr int LDS_BYTES = 2 * RH * VRT_PW * 12;
+    static_assert(RH % WAVES == 0, "whole rows per wave");
+};
+typedef VrTile<84, 512> VrTileFull;
+typedef VrTile<32, 256> VrTileHalf;
+#define VRT_H (TILE::H)
+#define VRT_RH (TILE::RH)
+#define VRT_THREADS (TILE::THREADS)
+#define VRT_WAVES (TILE::WAVES)
+#define VRT_K (TILE::K)
 
-template <bool FAST>
-__global__ void __launch_bounds__(VRT_THREADS, 2)
+template <bool FAST, typename TILE>
+__global__ void __launch_bounds__(TILE::THREADS, 2)
 k_vr_sor_tile(const float4 *__restrict__ S, const float *__restrict__ A12, const float *__restrict__ wt, int H, int W,
-              int n_half, float omega, const float2 *__restrict__ dW_in, const float2 *Wadd, float2 *dW_out, VrB bs)
+              int n_half, float omega, const float2 *__restrict__ dW_in, const float2 *Wadd, float2 *dW_out, VrB bs, int stagger)
 {
     extern __shared__ __align__(16) unsigned char vr_lds[];
+    if (stagger > 0 && (blockIdx.x & 1)) {                 // (experiment: odd workgroups start `stagger` x 64 clocks late)
+        for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(1);
+    }
     {
         const int64_t b = blockIdx.z;
         S += b * bs.plane; A12 += b * bs.plane; wt += b * bs.plane;
@@ -575,8 +590,10 @@ static int vr_run(const uint8_t *I0, const uint8_t *I1, int64_t B, int64_t img_s
         static TfDeviceOnce once;                  // function attributes are per device
         TfDeviceOnce::Guard guard(once);
         if (guard.first) {
-            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, VRT_LDS_BYTES));
-            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, VRT_LDS_BYTES));
+            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile<false, VrTileFull>, hipFuncAttributeMaxDynamicSharedMemorySize, VrTileFull::LDS_BYTES));
+            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile<true, VrTileFull>, hipFuncAttributeMaxDynamicSharedMemorySize, VrTileFull::LDS_BYTES));
+            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile<false, VrTileHalf>, hipFuncAttributeMaxDynamicSharedMemorySize, VrTileHalf::LDS_BYTES));
+            TF_CHECK_HIP(hipFuncSetAttribute((const void *)k_vr_sor_tile<true, VrTileHalf>, hipFuncAttributeMaxDynamicSharedMemorySize, VrTileHalf::LDS_BYTES));
             guard.done();
         }
     }
@@ -607,15 +624,18 @@ static int vr_run(const uint8_t *I0, const uint8_t *I1, int64_t B, int64_t img_s
             const bool last = it == params->fixed_point_iterations - 1;
             TfProfScope ps(TFK_VR_SOR, (20.0 + 4.0 + (dW_cur ? 8.0 : 0.0) + (last ? 8.0 : 0.0) + 8.0) * nb, s);
             float2 *dst = last ? (float2 *)flow : (dW_cur == dW ? dW2 : dW);
-            const dim3 gt((iW + VRT_W - 1) / VRT_W, (iH + VRT_H - 1) / VRT_H, Z);
-            if (fast_sor)
-                hipLaunchKernelGGL(k_vr_sor_tile<true>, gt, dim3(VRT_THREADS),
-                                   VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
-                                   2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst, bs);
-            else
-                hipLaunchKernelGGL(k_vr_sor_tile<false>, gt, dim3(VRT_THREADS),
-                                   VRT_LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt, iH, iW,
-                                   2 * params->sor_iterations, P.omega, dW_cur, last ? Wf : (const float2 *)nullptr, dst, bs);
+            // TF_VR_TILE=half: half-height tiles, two 4-wave workgroups per CU (VrTileHalf); TF_VR_STAGGER=<n>: odd workgroups
+            // start n x 64 clocks late (development switches of the round-6 experiment; default: the full tile, no stagger)
+            static const bool half_env = getenv("TF_VR_TILE") && !strcmp(getenv("TF_VR_TILE"), "half");
+            static const int stagger_env = getenv("TF_VR_STAGGER") ? atoi(getenv("TF_VR_STAGGER")) : 0;
+            const float2 *wadd = last ? Wf : (const float2 *)nullptr;
+#define VR_LAUNCH_TILE(FASTV, TILET)                                                                                              \
+            hipLaunchKernelGGL((k_vr_sor_tile<FASTV, TILET>), dim3((iW + VRT_W - 1) / VRT_W, (iH + TILET::H - 1) / TILET::H, Z),      \
+                               dim3(TILET::THREADS), TILET::LDS_BYTES, s, (const float4 *)S, (const float *)A12, (const float *)wt,  \
+                               iH, iW, 2 * params->sor_iterations, P.omega, dW_cur, wadd, dst, bs, stagger_env)
+            if (half_env) { if (fast_sor) VR_LAUNCH_TILE(true, VrTileHalf); else VR_LAUNCH_TILE(false, VrTileHalf); }
+            else { if (fast_sor) VR_LAUNCH_TILE(true, VrTileFull); else VR_LAUNCH_TILE(false, VrTileFull); }
+#undef VR_LAUNCH_TILE
             dW_cur = dst;
             flow_done = last;
         } else {
