@@ -35,7 +35,7 @@ def test_two_ranks_on_one_device_equal_the_one_process_run():
     one = _bench("--frames", "44", "--n-windows", "4")
     assert two["n_gpus"] == 2 and two["rccl_world_size"] == 2 and one["n_gpus"] == 1
     assert two["config"]["frames_delivered_per_step"] == 24 and two["scaling"] == "weak"
-    assert two["watershed"]["tie_order"] == "reference" and two["watershed"]["labels_bit_exact_with_the_reference"]
+    assert two["watershed"]["tie_order"] == "reference" and two["watershed"]["labels_bit_exact_with_the_reference_by_construction"]
     assert two["config"]["objects_after_stitch"] == one["config"]["objects_after_stitch"] > 10
     # whole-job value: both ranks' frames over the slower rank's time
     assert two["value"] > 0 and abs(two["value"] - 2 * 24 * 1500 * 2500 / (two["ms_per_step"] * 1e-3) / 1e6) < 0.02 * two["value"]

@@ -923,3 +923,17 @@ def test_every_module_of_the_package_imports():
     assert "tobac_flow_amd._staging" in names and "tobac_flow_amd.parallel" in names
     for name in names:
         importlib.import_module(name)
+
+
+def test_select_peaks_grid_form_equals_the_all_pairs_form():
+    """utils.peak_utils.select_peaks (round 6: accepted points kept in a grid of cells) against the all-pairs statement of the
+    same greedy rule: 2-D and 3-D candidates, integer and fractional min_distance, ties in intensity, num_peaks"""
+    from tobac_flow_amd.utils.peak_utils import _select_peaks_all_pairs, select_peaks
+    rng = np.random.default_rng(4)
+    for ndim, n, span in ((2, 0, 50), (2, 1, 50), (2, 400, 60), (2, 3000, 400), (3, 800, 30), (1, 200, 100)):
+        coords = rng.integers(0, span, size=(n, ndim)).astype(np.int64)
+        vals = np.round(rng.normal(size=n), 1)                          # (ties in intensity: the order is argsort's, in both forms)
+        for d in (0, 1, 2, 3, 10, 2.5):
+            for num in (np.inf, 7):
+                a, b = select_peaks(coords, vals, d, num), _select_peaks_all_pairs(coords, vals, d, num)
+                assert a.shape == b.shape and np.array_equal(a, b), (ndim, n, d, num)

@@ -531,16 +531,20 @@ k_fb_polyexp(const float *__restrict__ I, int H, int W, FbPoly pp, float *__rest
 // columns of one row (14 values of each moment, fetched as three 16-byte and one 8-byte LDS reads from rows padded to
 // a multiple of four floats).  LDS reads per output drop from 11 + 33 to 3.5 + 10.5; every output is still formed by the
 // expressions of k_fb_polyexp in the same order (bit-identical, tests compare the two).
+// Round 6: the tile HEIGHT is a template parameter (16 = rounds 1 - 5; 32: the halo rows, the vertical pass' 10 extra rows and
+// the two barriers are paid once per 32 output rows -- image reads 1.88 x -> 1.52 x the tile, 3 instead of 5 workgroups of LDS
+// per CU; TF_FB_POLYEXP_TH picks, profiles/round6_polyexp_notes.txt has the measurement).
 #define FBP5_TS (FBP_W + 2 * 5 + 2)      /* row stride of the moment tiles: 76 floats, 16-byte aligned rows */
+template <int FBP5_H>
 __global__ void __launch_bounds__(256)
 k_fb_polyexp5(const float *__restrict__ I, int H, int W, FbPoly pp, float *__restrict__ R, int64_t plane,
               int64_t bs_I, int64_t bs_R)
 {
-    constexpr int n = 5, tw = FBP_W + 2 * n, th = FBP_H + 2 * n;
+    constexpr int n = 5, tw = FBP_W + 2 * n, th = FBP5_H + 2 * n;
     __shared__ float tI[th * tw];
-    __shared__ __attribute__((aligned(16))) float tT[3][FBP_H * FBP5_TS];
+    __shared__ __attribute__((aligned(16))) float tT[3][FBP5_H * FBP5_TS];
     I += (int64_t)blockIdx.z * bs_I; R += (int64_t)blockIdx.z * bs_R;
-    const int bx = blockIdx.x * FBP_W, by = blockIdx.y * FBP_H;
+    const int bx = blockIdx.x * FBP_W, by = blockIdx.y * FBP5_H;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     {
         // all loads of a thread first, the LDS stores afterwards: a store right behind its load makes every trip of the
@@ -559,7 +563,7 @@ k_fb_polyexp5(const float *__restrict__ I, int H, int W, FbPoly pp, float *__res
     float g[n + 1], xg[n + 1], xxg[n + 1];
 #pragma unroll
     for (int k = 0; k <= n; k++) { g[k] = pp.g[k]; xg[k] = pp.xg[k]; xxg[k] = pp.xxg[k]; }
-    for (int i = tid; i < tw * (FBP_H / 4); i += 256) {
+    for (int i = tid; i < tw * (FBP5_H / 4); i += 256) {
         const int rg = i / tw, tx = i - rg * tw;
         float v[14];
 #pragma unroll
@@ -580,8 +584,12 @@ k_fb_polyexp5(const float *__restrict__ I, int H, int W, FbPoly pp, float *__res
         }
     }
     __syncthreads();
-    const int oy = tid >> 4, x4 = (tid & 15) * 4, y = by + oy;
-    if (y >= H || bx + x4 >= W) return;
+    const int x4 = (tid & 15) * 4;
+    if (bx + x4 >= W) return;
+#pragma unroll
+    for (int part = 0; part < FBP5_H / 16; part++) {
+    const int oy = (tid >> 4) + 16 * part, y = by + oy;
+    if (y >= H) break;
     float a[14], b[14], c[14];
     {
         const float *pa = tT[0] + oy * FBP5_TS + x4, *pb = tT[1] + oy * FBP5_TS + x4, *pc = tT[2] + oy * FBP5_TS + x4;
@@ -619,6 +627,19 @@ k_fb_polyexp5(const float *__restrict__ I, int H, int W, FbPoly pp, float *__res
                                        (float)(b1 * pp.ig03 + b5 * pp.ig33), (float)(b1 * pp.ig03 + b4 * pp.ig33));
         R[4 * plane + o] = (float)(b6 * pp.ig55);
     }
+    }
+}
+
+static void fb_launch_polyexp(const float *I, int h, int w, const FbPoly &pp, float *R, int64_t plane, int64_t bs_I, int64_t bs_R, int B, hipStream_t s)
+{
+    static const int th_env = getenv("TF_FB_POLYEXP_TH") ? atoi(getenv("TF_FB_POLYEXP_TH")) : 0;      // development switch: 16 / 32
+    const dim3 block(64, 4);
+    if (pp.n != 5 || fb_polyexp_generic())
+        hipLaunchKernelGGL(k_fb_polyexp, dim3((w + FBP_W - 1) / FBP_W, (h + FBP_H - 1) / FBP_H, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);
+    else if (th_env == 32)
+        hipLaunchKernelGGL(k_fb_polyexp5<32>, dim3((w + FBP_W - 1) / FBP_W, (h + 31) / 32, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);
+    else
+        hipLaunchKernelGGL(k_fb_polyexp5<16>, dim3((w + FBP_W - 1) / FBP_W, (h + 15) / 16, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);
 }
 
 // ---- FarnebackUpdateMatrices ---------------------------------------------------------------------
@@ -1975,8 +1996,7 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
             }
             {
                 TfProfScope ps(TFK_FB_POLYEXP, 24.0 * plane * B, s);   // fused-ideal: 4 r + 20 w per level pixel
-                hipLaunchKernelGGL(pp.n == 5 && !fb_polyexp_generic() ? k_fb_polyexp5 : k_fb_polyexp, dim3((w + FBP_W - 1) / FBP_W, (h + FBP_H - 1) / FBP_H, B), block, 0, s,
-                                   Ik, h, w, pp, R[i], plane, bs_Ik, bs_R);
+                fb_launch_polyexp(Ik, h, w, pp, R[i], plane, bs_Ik, bs_R, B, s);
             }
         }
         TF_CHECK_LAUNCH();
@@ -2302,8 +2322,7 @@ extern "C" int tf_farneback_expansion(const uint8_t *img, int64_t H64, int64_t W
     if (!blur) TF_CHECK_HIP(hipMallocAsync((void **)&blur, (size_t)H * W * sizeof(float), s));
     const dim3 block(64, 4);
     hipLaunchKernelGGL(k_fb_blur3_fused<uint8_t>, dim3((W + 255) / 256, (H + 3) / 4, 1), block, 0, s, img, H, W, hk, blur, (int64_t)H * W, (int64_t)H * W);
-    hipLaunchKernelGGL(pp.n == 5 && !fb_polyexp_generic() ? k_fb_polyexp5 : k_fb_polyexp, dim3((W + FBP_W - 1) / FBP_W, (H + FBP_H - 1) / FBP_H, 1), block, 0, s,
-                       (const float *)blur, H, W, pp, R_out, (int64_t)H * W, (int64_t)H * W, (int64_t)5 * H * W);
+    fb_launch_polyexp((const float *)blur, H, W, pp, R_out, (int64_t)H * W, (int64_t)H * W, (int64_t)5 * H * W, 1, s);
     TF_CHECK_LAUNCH();
     if (!blur_out) TF_CHECK_HIP(hipFreeAsync(blur, s));
     return TF_OK;

@@ -36,13 +36,78 @@ def peak_local_max(image, min_distance=1, threshold_abs=None, threshold_rel=None
 
 def select_peaks(coords, intensities, min_distance, num_peaks=np.inf):
     """Second half of peak_local_max (scikit-image 0.18 `_get_high_intensity_peaks` + `ensure_spacing`): candidates
-    in C order with their intensities -> highest first, greedily dropping anything closer than min_distance."""
+    in C order with their intensities -> highest first, greedily dropping anything closer than min_distance.
+
+    The greedy pass keeps the candidates it has accepted in a grid of cells of edge `min_distance`: two points closer than
+    min_distance (Chebyshev) lie in the same or in neighbouring cells, so a candidate is compared with the accepted points of
+    3^ndim cells instead of with all of them (round 6: the all-pairs form rebuilt an array of the accepted points per
+    candidate -- 70 ms of host time for the 16 frames of a 5424^2 window, a twelfth of the drop-in sequence's wall time).
+    Same order, same decisions."""
+    coords = np.asarray(coords)
+    if len(coords) == 0:
+        return coords
+    coords = coords[np.argsort(-np.asarray(intensities))]
+    d = min_distance
+    if d > 0:
+        import itertools
+        ndim = coords.shape[1]
+        around = list(itertools.product((-1, 0, 1), repeat=ndim))
+        cells = {}
+        keep = np.ones(len(coords), bool)
+        pts = coords.tolist()
+        step = int(np.ceil(d))
+        if ndim == 2:                          # (the case of the recipes, written out: a third of the generic form's time)
+            get = cells.get
+            for i, (y, x) in enumerate(pts):
+                hy, hx = y // step, x // step
+                near = False
+                for cy in (hy - 1, hy, hy + 1):
+                    for cx in (hx - 1, hx, hx + 1):
+                        lst = get((cy, cx))
+                        if lst:
+                            for qy, qx in lst:
+                                if abs(qy - y) < d and abs(qx - x) < d:
+                                    near = True
+                                    break
+                        if near:
+                            break
+                    if near:
+                        break
+                if near:
+                    keep[i] = False
+                else:
+                    lst = get((hy, hx))
+                    if lst is None:
+                        cells[(hy, hx)] = [(y, x)]
+                    else:
+                        lst.append((y, x))
+            pts = ()
+        for i, c in enumerate(pts):            # highest first; drop anything closer than min_distance (Chebyshev)
+            home = tuple(v // step for v in c)
+            near = False
+            for off in around:
+                for q in cells.get(tuple(h + o for h, o in zip(home, off)), ()):
+                    if max(abs(a - b) for a, b in zip(q, c)) < d:
+                        near = True
+                        break
+                if near:
+                    break
+            if near:
+                keep[i] = False
+            else:
+                cells.setdefault(home, []).append(c)
+        coords = coords[keep]
+    return coords[:int(num_peaks)] if len(coords) > num_peaks else coords
+
+
+def _select_peaks_all_pairs(coords, intensities, min_distance, num_peaks=np.inf):
+    """the all-pairs form of select_peaks (rounds 2 - 5), kept as the statement the grid form is tested against"""
     coords = np.asarray(coords)
     if len(coords) == 0:
         return coords
     coords = coords[np.argsort(-np.asarray(intensities))]
     keep, kept = np.ones(len(coords), bool), []
-    for i, c in enumerate(coords):            # highest first; drop anything closer than min_distance (Chebyshev)
+    for i, c in enumerate(coords):
         if kept and np.min(np.max(np.abs(np.array(kept) - c), axis=1)) < min_distance:
             keep[i] = False
         else:
