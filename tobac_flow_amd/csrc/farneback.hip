@@ -636,7 +636,7 @@ static void fb_launch_polyexp(const float *I, int h, int w, const FbPoly &pp, fl
     const dim3 block(64, 4);
     if (pp.n != 5 || fb_polyexp_generic())
         hipLaunchKernelGGL(k_fb_polyexp, dim3((w + FBP_W - 1) / FBP_W, (h + FBP_H - 1) / FBP_H, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);
-    else if (th_env == 32)
+    else if (th_env != 16)                                   // 64 x 32 tiles: the default since round 6 (0.667 -> 0.645 ms per 5424^2 pair, same bits)
         hipLaunchKernelGGL(k_fb_polyexp5<32>, dim3((w + FBP_W - 1) / FBP_W, (h + 31) / 32, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);
     else
         hipLaunchKernelGGL(k_fb_polyexp5<16>, dim3((w + FBP_W - 1) / FBP_W, (h + 15) / 16, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);
