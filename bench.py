@@ -476,6 +476,7 @@ def main():
     n_warm = len(ws_stats)
     _lib.profile_enable(not a.no_kernel_events)
     _lib.profile_collect()
+    retries_t0 = torch.cuda.memory_stats().get("num_alloc_retries", 0)
     t0 = time.perf_counter()
     n_objects, step_ms = [], []
     objects_per_step = []
@@ -527,6 +528,7 @@ def main():
                 ms_.get("num_alloc_retries", -1), torch.cuda.memory_reserved() / 1e9), file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
+    retries_timed = torch.cuda.memory_stats().get("num_alloc_retries", 0) - retries_t0
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
     del out_labels
@@ -692,6 +694,7 @@ def main():
                           "objects_after_stitch_per_step": objects_per_step},
                "rate_over_computed_window_frames_Mpix_s": round(world * a.steps * frames_computed * H * W / dt / 1e6, 2),
                "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+               "allocator_retries_in_the_timed_region": int(retries_timed),      # (> 0: the device ran out and the caching allocator flushed its cache -- seconds)
                "roofline": roof}
         # which watershed schedule the timed windows ran: stats[5] = 1 / 0 probe (speculative root phase + conflict test,
         # conflict found / not found), -1 = root phase skipped on the conflict memo of watershed.py (identical labels)

@@ -557,7 +557,10 @@ def detect_anvils(flow, field, markers=None, upper_threshold=-5, lower_threshold
     # recipe with the reference's own SciPy glue; the two agree bit for bit, tests/test_gpu_detection.py)
     if markers is not None and hasattr(markers, "values") and not _is_device(markers):
         markers = markers.values
-    labels = _detect_anvils_dev(flow, _to_device(field), None if markers is None else _to_device(markers),
+    # the field first; the markers -- usually a label volume an earlier call returned: recognised by content, 7 - 18 ms of host
+    # checksum per 1.88 GB -- on a background thread while the field's first kernels are enqueued (_to_device_later)
+    field_d = _to_device(field)
+    labels = _detect_anvils_dev(flow, field_d, None if markers is None else _to_device_later(markers)[0],
                                 upper_threshold, lower_threshold, erode_distance, min_length)
     return _deliver(labels, field)
 
@@ -591,13 +594,16 @@ def _detect_anvils_dev(flow, field, markers, upper_threshold, lower_threshold, e
     t = _lib.torch()
     field = nd.linearise_field(field, lower_threshold, upper_threshold)
     s = ndi.generate_binary_structure(3, 1) * np.array([0, 1, 0])[:, np.newaxis, np.newaxis].astype(bool)
+    background = get_watershed_mask(field, erode_distance=erode_distance)      # (needs the field only: enqueued before the markers are waited for)
+    edges = get_combined_edge_field(flow, field, dtype=np.float32)
+    markers = _now(markers)
     if markers is None:
         markers = field >= 1
     markers = _lib.to_dev(markers)
     markers_i = markers.to(t.int32)
     seeds = markers_i * nd.binary_erosion(markers_i != 0, s).to(t.int32)
-    seeds[get_watershed_mask(field, erode_distance=erode_distance)] = -1
-    edges = get_combined_edge_field(flow, field, dtype=np.float32)
+    seeds[background] = -1
+    del background
     fw, bw = flow._dev_flows()
     labels = watershed_dev(fw, bw, edges, seeds, None, neighbour_offsets(ndi.generate_binary_structure(3, 1)))
     labels = t.where(labels < 0, t.zeros_like(labels), labels)
@@ -661,11 +667,12 @@ def relabel_anvils(flow, anvil_labels, markers=None, overlap: float = 0.5, absol
     if hasattr(anvil_labels, "values") and not _is_device(anvil_labels):
         anvil_labels = anvil_labels.values
     labels_d = _to_device(anvil_labels)
+    if markers is not None and hasattr(markers, "values") and not _is_device(markers):
+        markers = markers.values
+    markers_get = None if markers is None else _to_device_later(markers)[0]      # (recognised / uploaded beside the linking)
     linked = flow.link_overlap(_label.make_step_labels_dev(labels_d), overlap=overlap, absolute_overlap=absolute_overlap)
     if markers is not None:
-        if hasattr(markers, "values") and not _is_device(markers):
-            markers = markers.values
-        lengths, touches = nd.label_extent(linked, _to_device(markers) != 0)
+        lengths, touches = nd.label_extent(linked, markers_get() != 0)
         keep = np.logical_and(lengths > min_length, touches)
     else:
         keep = nd.label_extent(linked)[0] > min_length

@@ -334,7 +334,7 @@ class VariationalRefinement:
         i0, i1 (B, H, W) uint8 device tensors, flow (B, H, W, 2) float32 refined in place -- frames with contiguous rows, any
         stride between them (views into the stack's flow arrays).  Images go out in groups that fill ~`rounds` rounds of the
         fused SOR kernel's tiles on the device's CUs: at 1500 x 2500 (282 tiles) all 23 pairs of BASELINE config C in one set
-        of 11 launches; at 5424^2 (2279 tiles, 8.9 rounds by itself) 4 images, whose scratch is 8.5 GB."""
+        of 11 launches; at 5424^2 (2279 tiles, 8.9 rounds by itself) 3 images, whose scratch is 6.4 GB."""
         L = _lib.lib()
         t = _lib.torch()
         B, H, W = i0.shape
@@ -346,6 +346,8 @@ class VariationalRefinement:
         tiles = -(-W // 108) * -(-H // 84)
         cus = t.cuda.get_device_properties(i0.device).multi_processor_count
         group = int(max(1, min(B, -(-rounds * cus // tiles))))
+        # ... within 6.5 GB of scratch (72 B per pixel and image): three images at 5424^2, where a launch fills the chip anyway
+        group = int(max(1, min(group, 6.5e9 // max(1, L.tf_varref_workspace_bytes(H, W)))))
         ws = _lib.workspace(L.tf_varref_workspace_bytes_batch(group, H, W), "varref")
         p = self._params()
         flags = (1 if self.fastDivide else 0) | (2 if self.fastSor else 0)

@@ -712,6 +712,8 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
         # the flow is sized (held, they cost the Farneback batches a third of their pairs); the floods take them again afterwards
         for k in range(64):
             _lib.release_workspaces("watershed_job%d" % k)
+    retries_before = torch.cuda.memory_stats().get("num_alloc_retries", 0)
+    budget_key = None
     if stream:
         if flow_workspace_gb is None:
             # floods in flight beside the flow need scratch of their own (the Farneback workspace is busy): the Farneback batches
@@ -726,6 +728,7 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
             if key not in _BUDGET_MEMO:
                 _BUDGET_MEMO[key] = max(4.0, 0.7 * room_for(Cs) / 1e9)
             flow_workspace_gb = _BUDGET_MEMO[key]
+            budget_key = key
         slots = [None] * n_fly                               # the flood slots, shared by the channels begun during the flow
         streamed = [_WindowFloods(o, bt, c, slots, n_fly) for c in range(Cs)]
         for wf_ in streamed:
@@ -886,6 +889,13 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
     # flow's last launch) -- a starved chain of the iteration kernel (NaN rows, TF_ESTARVED) is reported here at the latest
     flow_all.check()
     del flow_all
+    # The budget above is an estimate.  If the device ran out during this call -- the caching allocator had to hand its cache
+    # back to the driver and retry, which synchronises everything: seconds, measured on config F3 (three channels beside 136 GB
+    # of flow vectors: a 4.4 s hole in a 14.6 s step) -- the next call of this shape gives the Farneback batches a quarter less.
+    retries = torch.cuda.memory_stats().get("num_alloc_retries", 0) - retries_before
+    o.info["allocator_retries"] = int(retries)
+    if retries > 0 and budget_key is not None:
+        _BUDGET_MEMO[budget_key] = max(4.0, 0.75 * _BUDGET_MEMO[budget_key])
     return results, o.info
 
 
