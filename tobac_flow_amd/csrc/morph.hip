@@ -92,8 +92,17 @@ __global__ void __launch_bounds__(256)
 k_binary_morph16(const uint4 *__restrict__ in, int64_t T, int H, int W16, MorphRows rw, int op, int border,
                  uint4 *__restrict__ out)
 {
-    const int x16 = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    const int64_t t = blockIdx.z;
+    // Round 6: a 1-D grid whose workgroup -> (tile, t) mapping is XCD-aware.  Workgroup L runs on XCD L % 8 (round-robin
+    // dispatch); within an XCD consecutive workgroups take consecutive time steps t of ONE (x, y) tile, so the up to three
+    // planes a tap row reads (t - 1, t, t + 1) are requested by workgroups that share an L2 and run back to back.  With the
+    // (x, y, t) grid of rounds 2 - 5 a plane was read again a whole plane's worth of workgroups later -- from the fabric:
+    // 2.18 x the algorithmic bytes by FETCH_SIZE for the 3 x 3 x 3 structure.
+    const int tiles_x = (W16 + 63) / 64, tiles_y = (H + 3) / 4;
+    const int64_t n_tiles = (int64_t)tiles_x * tiles_y, L = blockIdx.x;
+    const int64_t slot = L >> 3, tile = (slot / T) * 8 + (L & 7);
+    const int64_t t = slot % T;
+    if (tile >= n_tiles) return;
+    const int x16 = (int)(tile % tiles_x) * 64 + threadIdx.x, y = (int)(tile / tiles_x) * 4 + threadIdx.y;
     if (x16 >= W16 || y >= H) return;
     const int64_t plane16 = (int64_t)H * W16;
     const uint32_t bw = border ? 0x01010101u : 0u, bb = border ? 1u : 0u;
@@ -159,13 +168,16 @@ extern "C" int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t 
     const bool words = W % 4 == 0 && ((uintptr_t)in % 4 == 0) && ((uintptr_t)out % 4 == 0) && (!tmp || (uintptr_t)tmp % 4 == 0);
     const dim3 grid4((unsigned)((W / 4 + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
     const bool quads = W % 16 == 0 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!tmp || (uintptr_t)tmp % 16 == 0);
-    const dim3 grid16((unsigned)((W / 16 + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)T);
+    // tiles rounded up to a multiple of 8 (one per XCD and slot group), times T time steps
+    const int64_t tiles16 = (int64_t)((W / 16 + 63) / 64) * ((H + 3) / 4);
+    TF_REQUIRE(!quads || ((tiles16 + 7) / 8) * 8 * T < (1ll << 31), "tf_binary_morph: volume too large for the 1-D grid");
+    const dim3 grid16((unsigned)(((tiles16 + 7) / 8) * 8 * T), 1, 1);
     const uint8_t *src = in;
     for (int it = 0; it < iterations; it++) {
         // ping-pong so that the last iteration writes `out`
         uint8_t *dst = ((iterations - 1 - it) % 2 == 0) ? out : tmp;
         TfProfScope ps(TFK_MORPH, 2.0 * (double)T * H * W, s);
-        if (quads) hipLaunchKernelGGL(k_binary_morph16, grid16, block, 0, s, (const uint4 *)src, T, (int)H, (int)(W / 16), rw, op, border_value, (uint4 *)dst);
+        if (quads) hipLaunchKernelGGL(k_binary_morph16, grid16, block, 0, s, (const uint4 *)src, T, (int)H, (int)(W / 16), rw, op, border_value, (uint4 *)dst);   // (grid16: 1-D, XCD-aware mapping inside)
         else if (words) hipLaunchKernelGGL(k_binary_morph4, grid4, block, 0, s, (const uint32_t *)src, T, (int)H, (int)(W / 4), rw, op, border_value, (uint32_t *)dst);
         else hipLaunchKernelGGL(k_binary_morph, grid, block, 0, s, src, T, (int)H, (int)W, tp, op, border_value, dst);
         src = dst;

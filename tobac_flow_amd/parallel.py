@@ -804,6 +804,11 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
                 if failure:                                    # the flood thread has failed: stop the flow here, not after the
                     raise failure[0]                           # rest of the stack has been enqueued
                 o.mark("flow enqueued for %d frames" % n)
+                if os.environ.get("TF_WINDOWS_MEMDEBUG"):      # development aid: who holds the device's memory at this point
+                    ws = sorted(((int(v.numel()), k[0], k[2]) for k, v in list(_lib._WS.items()) if v is not None), reverse=True)
+                    print("  mem: allocated %.1f GB, reserved %.1f GB; workspaces %s" % (
+                        torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9,
+                        ", ".join("%s@%x %.1f" % (t_, s_ & 0xffff, b_ / 1e9) for b_, t_, s_ in ws[:14])), flush=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 handover.put((fl, n, ev))
