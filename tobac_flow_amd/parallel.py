@@ -694,17 +694,25 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
     # Farneback scratch worth having (40 GB).  Same labels either way.
     n_fly = int(max(1, min(max_in_flight, n_windows * C, 5)))
 
-    def room_for(cs):
+    def room_for(cs, slots=None):
         free = torch.cuda.mem_get_info()[0] + (torch.cuda.memory_reserved() - torch.cuda.memory_allocated())
         held = sum(int(v.numel()) for k, v in list(_lib._WS.items()) if v is not None and k[1] == torch.cuda.current_device())
         resident = 0 if on_window is not None else cs * label_bytes
-        return free + held - (2 * T * H * W * 8 + resident + (n_fly + 1) * (3 * per_job // 2))
+        # several channels: what the single-channel estimate leaves out is no longer small beside what is left -- the raw flow
+        # vectors and 8-bit frames of a batch, the refinement's and the labelling's scratch, the flood stream's cached transients
+        # (measured on config F3: 25 GB; the device ran out, the allocator flushed its cache -- a 4.4 s hole in the step)
+        other = int(0.08 * total) if C > 1 else 0
+        return free + held - (2 * T * H * W * 8 + resident + ((n_fly if slots is None else slots) + 1) * (3 * per_job // 2) + other)
     if not (bool(stream_windows) and n_windows > 1):
         Cs = 0
     elif on_window is not None or C == 1:
         Cs = C
     else:
         Cs = max([cs for cs in range(1, C + 1) if room_for(cs) >= 40e9] or [0])
+    if C > 1 and Cs > 0:
+        # fewer flood slots before a starved flow: the floods run one after the other on the one flood stream anyway, the
+        # slots beyond the third only keep more host replays in flight
+        n_fly = next((nf for nf in range(n_fly, 2, -1) if room_for(Cs, nf) >= 50e9), min(n_fly, 3))
     stream = Cs > 0
     o.info["channels_begun_during_the_flow"] = Cs
     if not stream and T * H * W * (1 + 4 + C) * 4 > 0.6 * total:
