@@ -48,8 +48,8 @@ def _latest(*names):
     return names[-1]
 
 
-_TRAFFIC_FILE = _latest("profiles/round5_pmc_traffic_bench.json", "profiles/round4_pmc_traffic_bench.json")
-_VALU_FILE = _latest("profiles/round5_pmc_valu_bench.json", "profiles/round4_pmc_valu_bench.json")
+_TRAFFIC_FILE = _latest("profiles/round6_pmc_traffic_bench.json", "profiles/round5_pmc_traffic_bench.json", "profiles/round4_pmc_traffic_bench.json")
+_VALU_FILE = _latest("profiles/round6_pmc_valu_bench.json", "profiles/round5_pmc_valu_bench.json", "profiles/round4_pmc_valu_bench.json")
 _CLOCK_GHZ_DEFAULT = 2.1       # GRBM_GUI_ACTIVE / 8 / duration under k_fb_iter; used when a pass has no timestamps
 
 

@@ -3,7 +3,7 @@
 # The counter passes use a 62-frame stack (61 pairs = 3 Farneback batches of 20 / 21 pairs, the batch size of the full
 # 144-frame run): rocprofiler's counter collection does not survive ~10^4 dispatches per process on this stack
 # (profiles/README.md), a full config-F step has ~10.5 k.  Usage: bash tools/round_evidence.sh <tag>
-tag=${1:-r5}
+tag=${1:-r6}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${tag}_smoke.txt 2>&1; tail -1 gpurun_out/${tag}_smoke.txt
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 400 gpurun_out/${tag}_bench.json; echo
