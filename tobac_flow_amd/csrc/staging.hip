@@ -1,9 +1,9 @@
 // Host containers <-> HBM (include/tobac_flow_hip.h, "host staging"): what the reference's numpy / xarray containers cost a
 // drop-in caller is PCIe time, and pageable memory moves at a third of the link's rate.  This file is the plumbing that keeps
 // the link busy:
-//   * a pool of PINNED host blocks (hipHostMalloc is slow -- hundreds of ms per GB -- so blocks are kept by size class and
-//     handed out again): results are downloaded straight into such a block, which the Python layer wraps as the numpy array it
-//     returns (no second host copy);
+//   * a pool of PINNED host blocks -- made from huge pages touched by the host threads and registered with the runtime (22 ms
+//     for 1.88 GB where hipHostMalloc takes 250 ms), kept by size class and handed out again: results are downloaded straight
+//     into such a block, which the Python layer wraps as the numpy array it returns (no second host copy);
 //   * tf_upload: a pageable source is copied by a pool of host threads, chunk by chunk, into a ring of pinned slots, each chunk
 //     followed at once by its own asynchronous DMA -- host memcpy and DMA pipelined, the call returns when the source has been
 //     read; a pinned source (a block of the pool) goes out in one DMA;
@@ -24,6 +24,7 @@
 #include <thread>
 #include <vector>
 #include <sched.h>
+#include <sys/mman.h>
 
 typedef unsigned long long u64;
 
@@ -170,6 +171,58 @@ struct HostPool {
     size_t live_bytes = 0, cached_bytes = 0;
 };
 HostPool &pool() { static HostPool *p = new HostPool(); return *p; }
+// A pinned block is made by mmap + MADV_HUGEPAGE, touched by the host threads, then registered with the runtime
+// (hipHostRegister).  hipHostMalloc of 1.88 GB takes 250 - 275 ms on the box this was measured on (tools/microbench/pin_cost.hip:
+// it faults and pins 460 000 4-KiB pages on one thread); the same block from 2-MiB pages, touched by 16 threads, takes 19 ms and
+// registers in 3 ms, and the DMA engine writes it at the same 57 GB/s.  Without transparent huge pages the pages are still
+// touched in parallel (137 + 33 ms).  If any step fails the block comes from hipHostMalloc as before.
+struct PinnedHow { void *raw; size_t raw_len; bool registered; };
+std::mutex g_how_mu;
+std::map<uintptr_t, PinnedHow> g_how;
+void *pinned_new(size_t cap)
+{
+    static const bool plain_env = getenv("TF_STAGING_HIPHOSTMALLOC") != nullptr;      // development switch: the runtime's own allocation
+    const size_t huge = (size_t)2 << 20, len = cap + huge;
+    if (!plain_env) {
+        void *raw = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (raw != MAP_FAILED) {
+            unsigned char *q = (unsigned char *)(((uintptr_t)raw + huge - 1) & ~(uintptr_t)(huge - 1));
+            (void)madvise(q, cap, MADV_HUGEPAGE);
+            const size_t piece = (size_t)8 << 20;
+            std::atomic<size_t> next(0);
+            workers().run([&](int) {
+                for (;;) {
+                    const size_t o = next.fetch_add(piece);
+                    if (o >= cap) break;
+                    for (size_t i = o, e = std::min(cap, o + piece); i < e; i += 4096) q[i] = 0;
+                }
+            });
+            if (hipHostRegister(q, cap, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(g_how_mu);
+                g_how[(uintptr_t)q] = PinnedHow{raw, len, true};
+                return q;
+            }
+            (void)hipGetLastError();
+            munmap(raw, len);
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_how_mu);
+    g_how[(uintptr_t)p] = PinnedHow{nullptr, 0, false};
+    return p;
+}
+void pinned_delete(void *p)
+{
+    PinnedHow how{nullptr, 0, false};
+    {
+        std::lock_guard<std::mutex> lk(g_how_mu);
+        auto it = g_how.find((uintptr_t)p);
+        if (it != g_how.end()) { how = it->second; g_how.erase(it); }
+    }
+    if (how.registered) { (void)hipHostUnregister(p); munmap(how.raw, how.raw_len); }
+    else (void)hipHostFree(p);
+}
 size_t size_class(size_t bytes)
 {
     // small: powers of two from 64 KiB; large (> 64 MiB): multiples of 32 MiB (a 1.88 GB volume wastes < 2 %)
@@ -199,9 +252,8 @@ int ring_prepare(Ring &r, int dev)
         const char *e = getenv("TF_STAGING_CHUNK_MB");
         r.slot_bytes = (size_t)std::max(1, e ? atoi(e) : 8) << 20;
         r.n_slots = 32;
-        void *p = nullptr;
-        if (hipHostMalloc(&p, r.slot_bytes * r.n_slots, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
+        void *p = pinned_new(r.slot_bytes * r.n_slots);
+        if (!p) {
             tf_set_error("tf_upload: no pinned memory for the staging ring (%zu MiB)", (r.slot_bytes * r.n_slots) >> 20);
             return TF_EHIP;
         }
@@ -233,11 +285,9 @@ extern "C" int tf_host_alloc(size_t bytes, void **ptr_out)
             return TF_OK;
         }
     }
-    void *p = nullptr;
-    hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
-    if (e != hipSuccess) {
+    void *p = pinned_new(cap);
+    if (!p) {
         // the cache may hold what is missing: give it back and try once more
-        (void)hipGetLastError();
         std::vector<void *> drop;
         {
             std::lock_guard<std::mutex> lk(hp.mu);
@@ -245,12 +295,11 @@ extern "C" int tf_host_alloc(size_t bytes, void **ptr_out)
             hp.cached.clear();
             hp.cached_bytes = 0;
         }
-        for (void *q : drop) (void)hipHostFree(q);
-        e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+        for (void *q : drop) pinned_delete(q);
+        p = pinned_new(cap);
     }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        tf_set_error("tf_host_alloc: hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    if (!p) {
+        tf_set_error("tf_host_alloc: no pinned block of %zu bytes (mmap + hipHostRegister and hipHostMalloc both failed)", cap);
         return TF_ENOMEM;
     }
     std::lock_guard<std::mutex> lk(hp.mu);
@@ -317,7 +366,7 @@ extern "C" int tf_host_pool_trim(size_t keep_bytes)
             hp.cached.erase(it);
         }
     }
-    for (void *q : drop) (void)hipHostFree(q);
+    for (void *q : drop) pinned_delete(q);
     return TF_OK;
 }
 
