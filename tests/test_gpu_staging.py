@@ -191,3 +191,52 @@ def test_to_device_and_to_host_helpers():
     d = b - b
     assert isinstance(d, DeviceField) and float(d.data.abs().max()) == 0.0
     tobac_flow_amd.clear_device_cache()
+
+
+def test_the_script_sequence_gives_the_same_labels_whatever_the_container_and_the_cache(monkeypatch):
+    """The drop-in script's call sequence (scripts/dcc_detect_goes.py:164-303) on one scene, four ways: host containers with
+    recognition by content switched off (every array uploaded), switched on (twice in a row: the second pass finds results of
+    the first still remembered), and device-resident (tobac_flow_amd.to_device).  Every result equal, array for array --
+    in particular no recipe writes into a device twin that a later call is served."""
+    import warnings
+    import torch
+    import tobac_flow_amd
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd import _staging
+    from tobac_flow_amd.detection import detect_anvils, detect_cores, get_anvil_markers, relabel_anvils
+    from tools.script_sequence import scene
+    from tools.synth import field_with_time
+    T, H, W, minutes = 10, 300, 420, 5
+    bt_d, wvd_d, swd_d = scene(T, H, W, minutes, torch.device("cuda", 0))
+    host = [field_with_time(x.cpu().numpy(), minutes=minutes) for x in (bt_d, wvd_d, swd_d)]
+    assert host[0].nbytes >= 1 << 20                                    # (large enough to be remembered)
+
+    def sequence(bt, wvd, swd):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            flow = tf.create_flow(bt, model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+            core = detect_cores(flow, bt, wvd, swd, wvd_threshold=0.25, bt_threshold=0.5, overlap=0.5, absolute_overlap=4,
+                                subsegment_shrink=0.0, min_length=2, use_wvd=False)
+            markers = get_anvil_markers(flow, wvd - swd, threshold=-5, overlap=0.5, absolute_overlap=4, subsegment_shrink=0.0, min_length=2)
+            thick0 = detect_anvils(flow, wvd - swd, markers=markers, upper_threshold=-5, lower_threshold=-12.5, erode_distance=2, min_length=2)
+            thick = relabel_anvils(flow, thick0, markers=markers, overlap=0.5, absolute_overlap=4, min_length=2)
+            thin = detect_anvils(flow, wvd + swd, markers=thick, upper_threshold=0, lower_threshold=-7.5, erode_distance=2, min_length=2)
+        return [tobac_flow_amd.to_host(x) if isinstance(x, torch.Tensor) else np.asarray(x) for x in (core, markers, thick0, thick, thin)]
+
+    def host_fields():                                                   # (arithmetic on the plain arrays: a fresh temporary per evaluation, like the script's)
+        return [field_with_time(np.asarray(h).copy(), minutes=minutes) for h in host]
+    monkeypatch.setenv("TF_HOST_CACHE_GB", "0")
+    _staging.clear()
+    plain = sequence(*host_fields())
+    assert int(plain[1].max()) >= 1 and int(plain[4].max()) >= 1, [int(p.max()) for p in plain]
+    monkeypatch.delenv("TF_HOST_CACHE_GB")
+    before = dict(_staging.stats)
+    first = sequence(*host_fields())
+    hits_first = _staging.stats["hits"] - before["hits"]
+    second = sequence(*host_fields())
+    assert hits_first >= 6                                               # bt, wvd - swd, the markers twice, the two anvil volumes
+    assert _staging.stats["hits"] - before["hits"] >= 2 * hits_first     # (the second pass finds at least as much)
+    device = sequence(*tobac_flow_amd.to_device(*host_fields()))
+    for name, a, b, c, d in zip(("core", "markers", "thick0", "thick", "thin"), plain, first, second, device):
+        assert a.dtype == b.dtype == c.dtype == d.dtype and np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d), name
+    _staging.clear()

@@ -353,3 +353,24 @@ def test_strong_sharding_two_ranks_on_one_device_equal_the_one_process_run_voxel
                 have = np.load(tmp_path / f"r{r}_c{c}_w{k}.npy")
                 assert np.array_equal(have, want[c][k_glob]), (hand_out, c, r, k, int((have != want[c][k_glob]).sum()))
                 k_glob += 1
+
+
+def test_hand_out_mode_with_one_window_and_without_stitching():
+    """on_window with a single window (no pair to form: the table is the identity on 1 .. count) and with stitch=False (no tables)"""
+    import torch
+    import tobac_flow_amd.flow as tf
+    from tobac_flow_amd.detection import get_combined_edge_field
+    from tobac_flow_amd.parallel import apply_global_lut, detect_stack_windows, window_bounds
+    from tools.synth import anvil_seeds, blob_stack
+    bt = blob_stack(14, 400, 600, seed=20240601, t0=5)
+    fl = tf.create_flow(bt, model="Farneback", vr_steps=1, smoothing_passes=1, interp_method="cubic")
+    lin, seeds = anvil_seeds(bt)
+    want = fl.watershed(get_combined_edge_field(fl, lin, dtype=np.float32), seeds, connectivity=1)
+    got = {}
+    res, _ = detect_stack_windows(bt, [(0, 14)], lambda w, c: anvil_seeds(w), on_window=lambda c, k, lab: got.setdefault(k, lab.clone()))
+    assert list(got) == [0] and torch.equal(got[0], want)
+    lut = np.asarray(res[0]["luts"][0])
+    assert lut[0] == 0 and np.array_equal(lut[1:], np.arange(1, int(want.max()) + 1))
+    assert torch.equal(apply_global_lut(got[0], lut), want)
+    res, _ = detect_stack_windows(bt, window_bounds(14, 2, 4), lambda w, c: anvil_seeds(w), stitch=False, on_window=lambda c, k, lab: int(lab.max()))
+    assert res[0]["luts"] is None and len(res[0]["windows"]) == 2 and all(isinstance(v, int) for v in res[0]["windows"])
