@@ -579,8 +579,9 @@ int tf_profile_collect(int64_t *calls, double *ms, double *bytes);
  * pageable memory moves at a third of the link's rate.  These entry points are what the Python layer moves host containers
  * with ("pinned-host staging to HBM"); pointers named *_host are HOST pointers.
  *
- * tf_host_alloc / tf_host_free: PINNED host blocks from a pool kept by size class (a freed block is handed out again,
- *   tf_host_pool_trim(keep_bytes) returns cached blocks to the system).  A new block is mmap'ed with MADV_HUGEPAGE, touched by
+ * tf_host_alloc / tf_host_free: PINNED host blocks from a pool kept by size class (a freed block is handed out again; the
+ *   pool keeps at most TF_PINNED_CACHE_GB = 16 GB of free blocks, tf_host_pool_trim(keep_bytes) returns more of them to the
+ *   system).  A new block is mmap'ed with MADV_HUGEPAGE, touched by
  *   the host threads and registered (hipHostRegister): 22 ms for 1.88 GB where hipHostMalloc takes 250 ms
  *   (tools/microbench/pin_cost.hip); hipHostMalloc is the fallback.  A result is
  *   downloaded straight into such a block, which the caller wraps as the array it returns: no second host copy.

@@ -313,7 +313,7 @@ extern "C" int tf_host_free(void *ptr)
 {
     if (!ptr) return TF_OK;
     HostPool &hp = pool();
-    std::lock_guard<std::mutex> lk(hp.mu);
+    std::unique_lock<std::mutex> lk(hp.mu);
     auto it = hp.live.find((uintptr_t)ptr);
     TF_REQUIRE(it != hp.live.end(), "tf_host_free: not a block of tf_host_alloc");
     const size_t cap = it->second;
@@ -321,6 +321,18 @@ extern "C" int tf_host_free(void *ptr)
     hp.live_bytes -= cap;
     hp.cached.emplace(cap, ptr);
     hp.cached_bytes += cap;
+    // the pool keeps at most TF_PINNED_CACHE_GB (default 16) of FREE blocks: a process that once returned a 15 GB flow array
+    // does not hold it pinned for ever; the largest go first (a block is cheap to make again: 14 ms per 1.88 GB)
+    static const size_t keep = (size_t)((getenv("TF_PINNED_CACHE_GB") ? atof(getenv("TF_PINNED_CACHE_GB")) : 16.0) * 1e9);
+    std::vector<void *> drop;
+    while (hp.cached_bytes > keep && !hp.cached.empty()) {
+        auto last = std::prev(hp.cached.end());
+        drop.push_back(last->second);
+        hp.cached_bytes -= last->first;
+        hp.cached.erase(last);
+    }
+    lk.unlock();
+    for (void *q : drop) pinned_delete(q);
     return TF_OK;
 }
 
