@@ -531,9 +531,10 @@ k_fb_polyexp(const float *__restrict__ I, int H, int W, FbPoly pp, float *__rest
 // columns of one row (14 values of each moment, fetched as three 16-byte and one 8-byte LDS reads from rows padded to
 // a multiple of four floats).  LDS reads per output drop from 11 + 33 to 3.5 + 10.5; every output is still formed by the
 // expressions of k_fb_polyexp in the same order (bit-identical, tests compare the two).
-// Round 6: the tile HEIGHT is a template parameter (16 = rounds 1 - 5; 32: the halo rows, the vertical pass' 10 extra rows and
+// Round 6: the tile HEIGHT is a template parameter (16 = the default; 32: the halo rows, the vertical pass' 10 extra rows and
 // the two barriers are paid once per 32 output rows -- image reads 1.88 x -> 1.52 x the tile, 3 instead of 5 workgroups of LDS
-// per CU; TF_FB_POLYEXP_TH picks, profiles/round6_polyexp_notes.txt has the measurement).
+// per CU: 3 % faster with nothing beside it, 30 % slower in the timed region of bench.py, where the floods' kernels share the
+// CUs -- TF_FB_POLYEXP_TH=32 opts in, profiles/round6_polyexp_notes.txt has the measurements).
 #define FBP5_TS (FBP_W + 2 * 5 + 2)      /* row stride of the moment tiles: 76 floats, 16-byte aligned rows */
 template <int FBP5_H>
 __global__ void __launch_bounds__(256)
@@ -636,7 +637,7 @@ static void fb_launch_polyexp(const float *I, int h, int w, const FbPoly &pp, fl
     const dim3 block(64, 4);
     if (pp.n != 5 || fb_polyexp_generic())
         hipLaunchKernelGGL(k_fb_polyexp, dim3((w + FBP_W - 1) / FBP_W, (h + FBP_H - 1) / FBP_H, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);
-    else if (th_env != 16)                                   // 64 x 32 tiles: the default since round 6 (0.667 -> 0.645 ms per 5424^2 pair, same bits)
+    else if (th_env == 32)                                   // 64 x 32 tiles: 3 % faster alone, 30 % SLOWER beside the floods (round 6, measured): opt-in
         hipLaunchKernelGGL(k_fb_polyexp5<32>, dim3((w + FBP_W - 1) / FBP_W, (h + 31) / 32, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);
     else
         hipLaunchKernelGGL(k_fb_polyexp5<16>, dim3((w + FBP_W - 1) / FBP_W, (h + 15) / 16, B), block, 0, s, I, h, w, pp, R, plane, bs_I, bs_R);

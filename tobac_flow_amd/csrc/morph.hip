@@ -7,6 +7,8 @@
 // All are one-pass HBM-bound stencils / reductions on uint8 / int32 volumes.
 #include "tf_common.h"
 #include <initializer_list>
+#include <string.h>
+#include <stdlib.h>
 
 struct MorphTaps { int n; int8_t dt[27], dy[27], dx[27]; };
 
@@ -99,8 +101,12 @@ k_binary_morph16(const uint4 *__restrict__ in, int64_t T, int H, int W16, MorphR
     // 2.18 x the algorithmic bytes by FETCH_SIZE for the 3 x 3 x 3 structure.
     const int tiles_x = (W16 + 63) / 64, tiles_y = (H + 3) / 4;
     const int64_t n_tiles = (int64_t)tiles_x * tiles_y, L = blockIdx.x;
-    const int64_t slot = L >> 3, tile = (slot / T) * 8 + (L & 7);
-    const int64_t t = slot % T;
+    int64_t slot = L >> 3, tile = (slot / T) * 8 + (L & 7), t = slot % T;
+    if (border & 2) {                                 // (A/B switch TF_MORPH_GRID=plane: the (x, y, t) order of rounds 2 - 5)
+        const int64_t padded = (n_tiles + 7) / 8 * 8;
+        tile = L % padded; t = L / padded;
+        border &= 1;
+    }
     if (tile >= n_tiles) return;
     const int x16 = (int)(tile % tiles_x) * 64 + threadIdx.x, y = (int)(tile / tiles_x) * 4 + threadIdx.y;
     if (x16 >= W16 || y >= H) return;
@@ -177,7 +183,8 @@ extern "C" int tf_binary_morph(const uint8_t *in, int64_t T, int64_t H, int64_t 
         // ping-pong so that the last iteration writes `out`
         uint8_t *dst = ((iterations - 1 - it) % 2 == 0) ? out : tmp;
         TfProfScope ps(TFK_MORPH, 2.0 * (double)T * H * W, s);
-        if (quads) hipLaunchKernelGGL(k_binary_morph16, grid16, block, 0, s, (const uint4 *)src, T, (int)H, (int)(W / 16), rw, op, border_value, (uint4 *)dst);   // (grid16: 1-D, XCD-aware mapping inside)
+        static const bool plane_grid = getenv("TF_MORPH_GRID") && !strcmp(getenv("TF_MORPH_GRID"), "plane");
+        if (quads) hipLaunchKernelGGL(k_binary_morph16, grid16, block, 0, s, (const uint4 *)src, T, (int)H, (int)(W / 16), rw, op, (border_value ? 1 : 0) | (plane_grid ? 2 : 0), (uint4 *)dst);   // (grid16: 1-D, XCD-aware mapping inside)
         else if (words) hipLaunchKernelGGL(k_binary_morph4, grid4, block, 0, s, (const uint32_t *)src, T, (int)H, (int)(W / 4), rw, op, border_value, (uint32_t *)dst);
         else hipLaunchKernelGGL(k_binary_morph, grid, block, 0, s, src, T, (int)H, (int)W, tp, op, border_value, dst);
         src = dst;

@@ -334,7 +334,7 @@ class VariationalRefinement:
         i0, i1 (B, H, W) uint8 device tensors, flow (B, H, W, 2) float32 refined in place -- frames with contiguous rows, any
         stride between them (views into the stack's flow arrays).  Images go out in groups that fill ~`rounds` rounds of the
         fused SOR kernel's tiles on the device's CUs: at 1500 x 2500 (282 tiles) all 23 pairs of BASELINE config C in one set
-        of 11 launches; at 5424^2 (2279 tiles, 8.9 rounds by itself) 3 images, whose scratch is 6.4 GB."""
+        of 11 launches; at 5424^2 (2279 tiles, 8.9 rounds by itself) one image per launch, as before round 6."""
         L = _lib.lib()
         t = _lib.torch()
         B, H, W = i0.shape
@@ -346,7 +346,11 @@ class VariationalRefinement:
         tiles = -(-W // 108) * -(-H // 84)
         cus = t.cuda.get_device_properties(i0.device).multi_processor_count
         group = int(max(1, min(B, -(-rounds * cus // tiles))))
-        # ... within 6.5 GB of scratch (72 B per pixel and image): three images at 5424^2, where a launch fills the chip anyway
+        # ... but only where ONE image does not fill the chip for several rounds by itself (fewer tiles than 4 x the CUs) and within
+        # 6.5 GB of scratch (72 B per pixel and image).  At 5424^2 an image is 8.9 rounds; three per launch were measured 3 %
+        # slower in bench.py's timed region (vr_sor 925 -> 952 ms per step: longer launches interleave worse with the floods' kernels)
+        if tiles >= 4 * cus and rounds > 0:
+            group = 1
         group = int(max(1, min(group, 6.5e9 // max(1, L.tf_varref_workspace_bytes(H, W)))))
         ws = _lib.workspace(L.tf_varref_workspace_bytes_batch(group, H, W), "varref")
         p = self._params()
