@@ -59,8 +59,26 @@ def main():
     t0 = time.perf_counter()
     pinned = _staging.empty_pinned((n,), np.uint8)
     print("%-46s %8.1f ms" % ("tf_host_alloc (pooled)", (time.perf_counter() - t0) * 1e3), flush=True)
-    for threads in (4, 8):
-        pass
+    # fresh arrays every time (nothing the runtime could have pinned before): what a script's one upload per array sees
+    def fresh_upload():
+        b = np.empty(n, np.uint8)
+        b[:] = 5
+        t0 = time.perf_counter()
+        _lib.check(L.tf_upload(_lib.ptr(d), b.ctypes.data_as(_lib._P), n, None, _lib.stream_ptr()), "up")
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    ts = [fresh_upload() for _ in range(4)]
+    print("%-46s %s ms" % ("tf_upload, a FRESH pageable array each time", [round(t * 1e3, 1) for t in ts]), flush=True)
+
+    def fresh_torch():
+        b = np.empty(n, np.uint8)
+        b[:] = 5
+        t0 = time.perf_counter()
+        d.copy_(torch.from_numpy(b))
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    ts = [fresh_torch() for _ in range(4)]
+    print("%-46s %s ms" % ("torch copy_, a FRESH pageable array each time", [round(t * 1e3, 1) for t in ts]), flush=True)
 
 
 if __name__ == "__main__":
