@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak (MI355X_MICROARCH.md); the library
 
 
 # library profile name -> kernel symbol prefix in the rocprofv3 counter files
-_KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<", "vr_sor": "void k_vr_sor_tile<false>", "vr_system": "void k_vr_system<true, false>",
+_KERNEL_SYMBOL = {"fb_iteration_fused": "void k_fb_iter<", "vr_sor": "void k_vr_sor_tile<false", "vr_system": "void k_vr_system<true, false>",
                   "sobel": "void k_sobel27<2, double, 2, true>", "fb_polyexp": "k_fb_polyexp", "vr_prepare": "k_vr_prepare",
                   "smooth_flow": "void k_smooth<", "ws_relax_sweep": "k_ws_sweep", "fb_gaussian_blur": "k_fb_blur", "fb_resize": "k_fb_resize",
                   "binary_morph": "k_binary_morph", "ws_labels": "k_ws_labels", "to8bit_pair": ("k_minmax", "k_to8bit"),
