@@ -71,13 +71,9 @@ def create_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_pas
     if on_frames_ready is not None:
         holder = {}
 
-        phase_log = []
-        extra["_phase_log"] = phase_log
-
         def on_batch(forward, backward, pairs_done, n_pairs):
             if "flow" not in holder:
                 holder["flow"] = Flow(forward, backward)
-                holder["flow"]._iter_phases = phase_log      # (events around the iteration launches of the parts enqueued so far)
             on_frames_ready(holder["flow"], pairs_done + 1 if pairs_done < n_pairs else n_pairs + 1)
         extra["_on_batch"] = on_batch
     # host (numpy / DataArray) input: the flow stays in HBM, where every Flow method works, and the object's numpy arrays
@@ -439,7 +435,7 @@ def _side_stream(main):
 
 def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_passes, interp_method,
                          norm_name, norm_method, normalisation_kwargs, on_device, max_value=float("inf"), on_batch=None,
-                         workspace_gb=None, split_parts=None, check_out=None, phase_log=None):
+                         workspace_gb=None, split_parts=None, check_out=None):
     t = _lib.torch()
     L = _lib.lib()
     H, W = shape
@@ -606,18 +602,7 @@ def _calculate_flow_impl(frame_pairs, T, shape, of_model, vr_steps, smoothing_pa
         if by_part:
             for b0 in range(0, B, per):
                 b1 = min(B, b0 + per)
-                # (phase_log: events around the finest levels' iteration launches -- where the device is busy with k_fb_iter; a
-                # caller that runs other work beside the flow can look: parallel.detect_stack_windows, TF_WINDOWS_GATE)
-                ev_a = ev_b = None
-                if phase_log is not None:
-                    ev_a = t.cuda.Event()
-                    ev_a.record()
                 of_model.calc_phase_dev(prev8[b0:b1], next8[b0:b1], f[b0:b1], bk[b0:b1], 2, (B, per))
-                if phase_log is not None:
-                    ev_b = t.cuda.Event()
-                    ev_b.record()
-                    phase_log.append((ev_a, ev_b))
-                    del phase_log[:-8]
                 if vr_steps > 0 or smoothing_passes > 0:
                     refine_and_smooth(i0 + b0, b1 - b0, prev8[b0:b1], next8[b0:b1], f[b0:b1], bk[b0:b1])
                 yield i0 + b1
@@ -730,7 +715,6 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     workspace_gb = normalisation_kwargs.pop("_workspace_gb", None)
     split_parts = normalisation_kwargs.pop("_split_parts", None)
     check_out = normalisation_kwargs.pop("_check_out", None)
-    phase_log = normalisation_kwargs.pop("_phase_log", None)
     of_model = select_of_model(model)
     norm_method = select_normalisation_method(normalisation_method)
     t = _lib.torch()
@@ -744,7 +728,7 @@ def calculate_flow(data, model: str = "Farneback", vr_steps: int = 0, smoothing_
     T = d.shape[0]
     return _calculate_flow_impl(lambda i: (d[i], d[i + 1]), T, tuple(d.shape[1:]), of_model, vr_steps,
                                 smoothing_passes, interp_method, normalisation_method, norm_method,
-                                normalisation_kwargs, on_device, max_value, on_batch, workspace_gb, split_parts, check_out, phase_log)
+                                normalisation_kwargs, on_device, max_value, on_batch, workspace_gb, split_parts, check_out)
 
 
 def calculate_flow_2(a, b, model: str = "Farneback", vr_steps: int = 0, smoothing_passes: int = 0,

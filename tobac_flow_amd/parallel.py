@@ -545,27 +545,11 @@ class _WindowFloods:
             self.next += 1
         return begun
 
-    def _gate(self):
-        """TF_WINDOWS_GATE=1 (experiment, round 6): hold the sweeps back while the device is inside an iteration phase of the flow
-        (k_fb_iter at the two finest levels: the kernel that loses most to a neighbour, +9 %), so that they run beside the
-        refinement instead; at most 0.4 s, finishing ready floods meanwhile"""
-        import time
-        phases = getattr(self, "iter_phases", None)
-        if not phases:
-            return
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 0.4:
-            if not any(a.query() and not b.query() for a, b in list(phases)):
-                return
-            if not self._finish_any(block=False):
-                time.sleep(0.0005)
-
     def sweep(self, begun):
         """second pass: phase A and the chain levels of the windows set up by setup_up_to -- all their host replays are running
         by now (at the end of a stack, where nothing else is left to do, the last window's replay so starts one window's
         sweeps earlier)"""
         for job in begun:
-            self._gate()
             job.sweeps()                                     # (a no-op for a job finish_one has completed meanwhile)
             self.o.mark("begin: swept")
         while self._finish_any(block=False):
@@ -804,9 +788,6 @@ def detect_stack_windows(bt, bounds, seeds_fn, channels=1, consume=None, overlap
                             item = handover.get()
                             if item is None:
                                 break
-                            if os.environ.get("TF_WINDOWS_GATE") == "1":
-                                for wf_ in first.floods:
-                                    wf_.iter_phases = getattr(item[0], "_iter_phases", None)
                             first.begin_up_to(item[0], item[1], wait_for=item[2])
                         first.finish_all()
                         flood_stream.synchronize()
@@ -1036,8 +1017,6 @@ def detect_stack_sequence(stacks, bounds, seeds_fn, consume=None, overlap=DEFAUL
                     if what == "new":
                         fam.active.append(wf)
                     elif what == "frames":
-                        if os.environ.get("TF_WINDOWS_GATE") == "1":
-                            wf.iter_phases = getattr(item[2], "_iter_phases", None)
                         begun = wf.setup_up_to(item[2], item[3], wait_for=item[4])
                         item = None                              # (the hand-over holds the stack's Flow: 68 GB at config F)
                         if wf.next == n_windows and not wf.setups_done.is_set():
