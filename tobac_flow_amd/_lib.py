@@ -295,6 +295,11 @@ def workspace(nbytes, tag="default"):
             with _WS_LOCK:
                 for k in [k for k in _WS if k[1] == key[1] and k[2] == key[2] and k != key]:
                     del _WS[k]
+            try:                                # ... and the device twins remembered for host arrays (they are a convenience)
+                from tobac_flow_amd import _staging
+                _staging.clear(trim=False)
+            except Exception:                   # noqa: BLE001
+                pass
             t.cuda.empty_cache()
             cur = t.empty(int(nbytes), dtype=t.uint8, device=dev)
     with _WS_LOCK:
