@@ -350,7 +350,12 @@ class VariationalRefinement:
         # 6.5 GB of scratch (72 B per pixel and image).  At 5424^2 an image is 8.9 rounds; three per launch were measured 3 %
         # slower in bench.py's timed region (vr_sor 925 -> 952 ms per step: longer launches interleave worse with the floods' kernels)
         if tiles >= 4 * cus and rounds > 0:
-            group = 1
+            # ... unless its last round is poorly filled: the smallest group of up to four images that wastes < 3 % of its rounds
+            # (3712^2: 1575 tiles = 6.15 rounds, 14 % of 7 rounds idle by itself, 5 % of 13 in pairs, 3 % of 19 in threes)
+            def waste(g):
+                r = g * tiles / cus
+                return -(-g * tiles // cus) / r - 1.0
+            group = next((g for g in range(1, min(B, 4) + 1) if waste(g) < 0.03), min(range(1, min(B, 4) + 1), key=waste))
         group = int(max(1, min(group, 6.5e9 // max(1, L.tf_varref_workspace_bytes(H, W)))))
         ws = _lib.workspace(L.tf_varref_workspace_bytes_batch(group, H, W), "varref")
         p = self._params()
