@@ -357,6 +357,8 @@ class VariationalRefinement:
                 return -(-g * tiles // cus) / r - 1.0
             group = next((g for g in range(1, min(B, 4) + 1) if waste(g) < 0.03), min(range(1, min(B, 4) + 1), key=waste))
         group = int(max(1, min(group, 6.5e9 // max(1, L.tf_varref_workspace_bytes(H, W)))))
+        if os.environ.get("TF_VR_GROUP"):                    # development switch: images per launch
+            group = max(1, min(B, int(os.environ["TF_VR_GROUP"])))
         ws = _lib.workspace(L.tf_varref_workspace_bytes_batch(group, H, W), "varref")
         p = self._params()
         flags = (1 if self.fastDivide else 0) | (2 if self.fastSor else 0)
