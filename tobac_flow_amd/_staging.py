@@ -160,8 +160,15 @@ def upload(array, fresh=False):
             return hit
     out = t.empty(shape, dtype=td, device=dev)
     t0 = time.perf_counter()
-    _lib.check(L.tf_upload(_lib.ptr(out), ctypes.c_void_p(addr), nbytes, hp if (cacheable and not known) else None, _lib.stream_ptr()),
-               "tf_upload")
+    rc = L.tf_upload(_lib.ptr(out), ctypes.c_void_p(addr), nbytes, hp if (cacheable and not known) else None, _lib.stream_ptr())
+    if rc == -3:
+        # no pinned staging ring to be had on this system (TF_EHIP: neither hipHostRegister nor hipHostMalloc gave 256 MiB): the
+        # runtime's own pageable copy moves the array -- slower, never wrong
+        out.copy_(t.from_numpy(a).view(td) if a.dtype != np.bool_ else t.from_numpy(a))
+        if cacheable and not known:
+            _lib.check(L.tf_hash_host(ctypes.c_void_p(addr), nbytes, hp), "tf_hash_host")
+    else:
+        _lib.check(rc, "tf_upload")
     stats["upload_s"] += time.perf_counter() - t0
     stats["uploads"] += 1
     stats["upload_bytes"] += nbytes
