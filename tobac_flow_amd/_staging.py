@@ -164,7 +164,7 @@ def upload(array, fresh=False):
     if rc == -3:
         # no pinned staging ring to be had on this system (TF_EHIP: neither hipHostRegister nor hipHostMalloc gave 256 MiB): the
         # runtime's own pageable copy moves the array -- slower, never wrong
-        out.copy_(t.from_numpy(a).view(td) if a.dtype != np.bool_ else t.from_numpy(a))
+        out.copy_(t.from_numpy(a))
         if cacheable and not known:
             _lib.check(L.tf_hash_host(ctypes.c_void_p(addr), nbytes, hp), "tf_hash_host")
     else:
