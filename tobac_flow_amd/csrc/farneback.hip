@@ -273,7 +273,41 @@ k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKern
     const float *k = kk.k;
     const TIn *S = src + (int64_t)y * W;
     float2 out;
-    if (ksize > 5 && sx1 == sx + 1 && sx - r >= 0 && sx1 + r < W) {
+    if (sizeof(TIn) == 1 && ksize > 5 && sx1 == sx + 1 && sx - r >= 0 && sx1 + r + 4 < W) {
+        // interior, 8-bit source (round 6): the ksize + 1 bytes of the two overlapping windows come as ALIGNED 32-bit words --
+        // one load and one v_alignbyte per four taps instead of four byte loads (the kernel was bound by its memory
+        // instructions, a byte each) -- and feed the same two accumulation chains in the same order.  (The last word may reach
+        // up to three bytes past the window: still inside the row, hence `+ 4` in the condition.)
+        const uint8_t *P = (const uint8_t *)S + sx - r;
+        const unsigned sh = (unsigned)((uintptr_t)P & 3);
+        const unsigned *wp = (const unsigned *)((uintptr_t)P & ~(uintptr_t)3);
+        unsigned lo = wp[0], hi = wp[1];
+        unsigned q = __builtin_amdgcn_alignbyte(hi, lo, sh);             // bytes P[0 .. 3]
+        float s0 = k[0] * (float)(q & 0xffu), cur = (float)((q >> 8) & 0xffu);
+        float s1 = k[0] * cur;
+        // from here on the NEXT values P[i + 1 ..] are fetched in quads that start at byte sh + 2 of the word stream
+        const unsigned sh2 = (sh + 2) & 3;
+        int j = (int)((sh + 2) >> 2);                                      // word that holds P[2]
+        lo = j ? hi : lo;
+        int i = 1;
+        for (; i + 3 < ksize; i += 4) {
+            hi = wp[j + 1];
+            q = __builtin_amdgcn_alignbyte(hi, lo, sh2);                   // bytes P[i + 1 .. i + 4]
+            const float n0 = (float)(q & 0xffu), n1 = (float)((q >> 8) & 0xffu), n2 = (float)((q >> 16) & 0xffu), n3 = (float)(q >> 24);
+            s0 += k[i] * cur;     s1 += k[i] * n0;
+            s0 += k[i + 1] * n0;  s1 += k[i + 1] * n1;
+            s0 += k[i + 2] * n1;  s1 += k[i + 2] * n2;
+            s0 += k[i + 3] * n2;  s1 += k[i + 3] * n3;
+            cur = n3; lo = hi; j++;
+        }
+        for (; i < ksize; i++) {
+            const float nxt = (float)P[i + 1];
+            s0 += k[i] * cur;
+            s1 += k[i] * nxt;
+            cur = nxt;
+        }
+        out.x = s0; out.y = s1;
+    } else if (ksize > 5 && sx1 == sx + 1 && sx - r >= 0 && sx1 + r < W) {
         // interior: the two windows overlap in ksize - 1 pixels -> one pass over ksize + 1 pixels feeding two
         // independent accumulation chains (each chain keeps the reference's left-to-right order)
         const TIn *P = S + sx - r;
@@ -338,7 +372,7 @@ k_fb_blur_rows_sampled(const TIn *__restrict__ src, FbResizeGeom g, const FbKern
 #define FBL_ROW_WORDS (FBL_ROW_BYTES / 4 + FBL_ROW_BYTES / 32 + 8)
 __global__ void __launch_bounds__(256)
 k_fb_blur_rows_sampled_lds(const uint8_t *__restrict__ src, FbResizeGeom g, const FbKernel kk, float2 *__restrict__ rowf,
-                           int64_t bs_src, int64_t bs_dst, int unit_shift)
+                           int64_t bs_src, int64_t bs_dst, int unit_shift, int word_env)
 {
     __shared__ unsigned s_row[4][FBL_ROW_WORDS];
     src += (int64_t)blockIdx.z * bs_src; rowf += (int64_t)blockIdx.z * bs_dst;
@@ -384,11 +418,42 @@ k_fb_blur_rows_sampled_lds(const uint8_t *__restrict__ src, FbResizeGeom g, cons
     if (dx >= g.dw || y >= g.sh) return;
     const float *k = kk.k;
     const uint8_t *L = (const uint8_t *)s_row[ry];
+    // the word reads may touch the word after the last staged one (its value is never used: alignbyte drops it for the bytes
+    // that matter, but the index must be inside the LDS row); TF_FB_BLUR_BYTES=1: the byte reads of rounds 2 - 5
+    const bool word_reads = word_env && (((span + 3) >> 2) + 2 + (((span + 3) & ~3) >> unit_shift) < FBL_ROW_WORDS);
     // byte a of the segment lives at a + 4 * (a >> unit_shift)
     auto at = [&](int a) { return (float)L[a + ((a >> unit_shift) << 2)]; };
     const int b0 = sx - r - lo, b1 = sx1 - r - lo;
     float s0, s1;
-    if (b1 == b0 + 1) {
+    static_assert(FBL_ROW_WORDS > 0, "");
+    if (b1 == b0 + 1 && (word_reads)) {
+        // (round 6) the same two chains fed from 32-bit LDS reads: byte a of the segment lives in word (a >> 2) + (a >> unit_shift),
+        // a quad that starts at an arbitrary byte is v_alignbyte of two neighbouring words -- one LDS read per four taps
+        // instead of four byte reads (the kernel was bound by its LDS instructions)
+        const unsigned *Lw = s_row[ry];
+        auto word = [&](int a4) { return Lw[(a4 >> 2) + (a4 >> unit_shift)]; };     // a4: a multiple of four
+        const int a0 = b0 & ~3;
+        const unsigned sh = (unsigned)(b0 & 3);
+        unsigned lo = word(a0), hi = word(a0 + 4);
+        unsigned q = __builtin_amdgcn_alignbyte(hi, lo, sh);               // bytes b0 .. b0 + 3
+        float cur = (float)((q >> 8) & 0xffu);
+        s0 = k[0] * (float)(q & 0xffu); s1 = k[0] * cur;
+        const unsigned sh2 = (sh + 2) & 3;
+        int a = a0 + (int)((sh + 2) & ~3u);                                  // word that holds byte b0 + 2
+        lo = (sh + 2) >= 4 ? hi : lo;
+        int i = 1;
+        for (; i + 3 < ksize; i += 4) {
+            hi = word(a + 4);
+            q = __builtin_amdgcn_alignbyte(hi, lo, sh2);                     // bytes b0 + i + 1 .. b0 + i + 4
+            const float n0 = (float)(q & 0xffu), n1 = (float)((q >> 8) & 0xffu), n2 = (float)((q >> 16) & 0xffu), n3 = (float)(q >> 24);
+            s0 += k[i] * cur;     s1 += k[i] * n0;
+            s0 += k[i + 1] * n0;  s1 += k[i + 1] * n1;
+            s0 += k[i + 2] * n1;  s1 += k[i + 2] * n2;
+            s0 += k[i + 3] * n2;  s1 += k[i + 3] * n3;
+            cur = n3; lo = hi; a += 4;
+        }
+        for (; i < ksize; i++) { const float nxt = at(b0 + i + 1); s0 += k[i] * cur; s1 += k[i] * nxt; cur = nxt; }
+    } else if (b1 == b0 + 1) {
         float cur = at(b0 + 1);
         s0 = k[0] * at(b0); s1 = k[0] * cur;
         int i = 1;
@@ -1987,8 +2052,9 @@ static int fb_run_levels(const uint8_t *prev, const uint8_t *next, int B, int64_
                     int unit_shift = 2;                                 // pad unit = largest power of two <= stride, >= 8 bytes;
                     while ((2 << unit_shift) <= (int)rsx) unit_shift++; // unit 4 (shift 2) would pad every word: then no padding
                     if (unit_shift < 3) unit_shift = 30;
+                    static const int word_env = getenv("TF_FB_BLUR_BYTES") ? 0 : 1;                // development aid: byte reads
                     hipLaunchKernelGGL(k_fb_blur_rows_sampled_lds, dim3((w + 63) / 64, (H + 3) / 4, B), block, 0, s, img[i], rg, hk,
-                                       (float2 *)tmp, img_stride, bs_tmp / 2, unit_shift);
+                                       (float2 *)tmp, img_stride, bs_tmp / 2, unit_shift, word_env);
                 } else
                     hipLaunchKernelGGL(k_fb_blur_rows_sampled<uint8_t>, dim3((w + 63) / 64, (H + 3) / 4, B), block, 0, s, img[i], rg, hk,
                                        (float2 *)tmp, img_stride, bs_tmp / 2);
