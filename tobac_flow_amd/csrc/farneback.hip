@@ -391,17 +391,20 @@ k_fb_blur_rows_sampled_lds(const uint8_t *__restrict__ src, FbResizeGeom g, cons
     const int n_words = (span + 3) >> 2;
     const bool inside = lo >= 0 && lo + 4 * n_words <= W && ((W & 3) == 0) && ((bs_src & 3) == 0) && ((((uintptr_t)src) & 3) == 0);
     {
-        const int tid = ry * 64 + lane;
-        unsigned v[(4 * (FBL_ROW_BYTES / 4 + 1) + 255) / 256];
+        // every wave stages the row it is going to read (round 6: the first form dealt the 4 x n_words words out over the 256
+        // threads with `i / n_words` -- two runtime integer divisions per word and thread, 34 of them unrolled: more VALU work
+        // than the 95-tap sums themselves, SQ_INSTS_VALU said); all loads of a thread first, the LDS stores afterwards
+        constexpr int NV = (FBL_ROW_BYTES / 4 + 1 + 63) / 64;
+        unsigned v[NV];
+        const int yy = min(y0 + ry, g.sh - 1);
+        const uint8_t *S = src + (int64_t)yy * W;
 #pragma unroll
-        for (int j = 0; j < (int)(sizeof(v) / sizeof(v[0])); j++) {
-            const int i = tid + 256 * j, row = i / n_words, wd = i - row * n_words;
-            const int yy = min(y0 + row, g.sh - 1);
+        for (int j = 0; j < NV; j++) {
+            const int wd = lane + 64 * j;
             v[j] = 0;
-            if (i < 4 * n_words) {
-                if (inside) v[j] = *(const unsigned *)(src + (int64_t)yy * W + lo + 4 * wd);
+            if (wd < n_words) {
+                if (inside) v[j] = *(const unsigned *)(S + lo + 4 * wd);
                 else {
-                    const uint8_t *S = src + (int64_t)yy * W;
                     const int c = lo + 4 * wd;
                     v[j] = (unsigned)S[fb_reflect101(c, W)] | ((unsigned)S[fb_reflect101(c + 1, W)] << 8) |
                            ((unsigned)S[fb_reflect101(c + 2, W)] << 16) | ((unsigned)S[fb_reflect101(c + 3, W)] << 24);
@@ -409,9 +412,9 @@ k_fb_blur_rows_sampled_lds(const uint8_t *__restrict__ src, FbResizeGeom g, cons
             }
         }
 #pragma unroll
-        for (int j = 0; j < (int)(sizeof(v) / sizeof(v[0])); j++) {
-            const int i = tid + 256 * j, row = i / n_words, wd = i - row * n_words;
-            if (i < 4 * n_words) s_row[row][wd + ((4 * wd) >> unit_shift)] = v[j];
+        for (int j = 0; j < NV; j++) {
+            const int wd = lane + 64 * j;
+            if (wd < n_words) s_row[ry][wd + ((4 * wd) >> unit_shift)] = v[j];
         }
     }
     __syncthreads();
