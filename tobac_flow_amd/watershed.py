@@ -369,13 +369,35 @@ def watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHA
 
 def watershed_dev(fwd, bwd, field, markers, mask, nbr, chain_depth=DEFAULT_CHAIN_DEPTH, stats=None,
                   expect_conflict=None, max_chain_depth=MAX_CHAIN_DEPTH, on_ambiguous="reference", return_ambiguous=False):
-    """Device-resident core: torch tensors in, labels out (`watershed_begin(...).finish()`, which see)."""
+    """Device-resident core: torch tensors in, labels out (`watershed_begin(...).finish()`, which see).  Round 6: when the job was
+    begun with a guessed tie value, its host replay of the reference heap's order (sequential host work, 20 - 35 ms per
+    16 x 5424^2 window) runs on a worker thread beside the device's phase A and chain levels instead of after them --
+    what the window scheduler does for many floods, done for the one flood of a plain call."""
+    def run(**kw):
+        job = watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth, stats, expect_conflict, max_chain_depth,
+                              on_ambiguous, return_ambiguous, defer_sweeps=True, **kw)
+        fut = _replay_worker().submit(job.replay) if job.needs_replay else None
+        try:
+            job.sweeps()
+        finally:
+            if fut is not None:
+                fut.result()
+        return job
     try:
-        return watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth, stats, expect_conflict, max_chain_depth,
-                               on_ambiguous, return_ambiguous).finish(_deepen=True)
+        return run().finish(_deepen=True)
     except _DepthRetry:
-        return watershed_begin(fwd, bwd, field, markers, mask, nbr, chain_depth, stats, expect_conflict, max_chain_depth,
-                               on_ambiguous, return_ambiguous, _all_levels=True).finish()
+        return run(_all_levels=True).finish()
+
+
+_REPLAY_WORKER = None
+
+
+def _replay_worker():
+    global _REPLAY_WORKER
+    if _REPLAY_WORKER is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _REPLAY_WORKER = ThreadPoolExecutor(max_workers=2, thread_name_prefix="tf-ws-replay1")
+    return _REPLAY_WORKER
 
 
 def watershed(
